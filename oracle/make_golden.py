@@ -1,0 +1,281 @@
+"""TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+Generates tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (/root/reference, CPU, fp32) on the
+deterministic synthetic weights/inputs of oracle/synth.py, and asserts on the way that the oracle
+restatement (oracle/vol_oracle.py) reproduces every reference output.  Run in the build container:
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+
+The fixtures hold REFERENCE outputs (not oracle outputs); big tensors are stored as strided
+sub-samples (the stride is stored too).  Inputs/weights are regenerated from seeds at test time.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import ref_loader, spec, synth
+from . import vol_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _maxrel(a, b):
+    a = a.double(); b = b.double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def _check(name, ours, ref, tol):
+    e = _maxrel(torch.as_tensor(ours), torch.as_tensor(ref))
+    print("  oracle-vs-reference %-28s max|d|/max|ref| = %.3e (tol %.1e)" % (name, e, tol))
+    assert e <= tol, (name, e)
+    return e
+
+
+def _cameras(mvn, K, R, t, B):
+    """batch['cameras']: list[NV] of list[B] of reference Camera objects (datasets/utils.py:26)."""
+    Cam = mvn.utils.multiview.Camera
+    return [[Cam(R[v], t[v], K[v]) for _ in range(B)] for v in range(K.shape[0])]
+
+
+def sub(t, stride):
+    """Strided sub-sample over the trailing spatial dims of a (N, C, spatial...) tensor."""
+    sl = (slice(None), slice(None)) + tuple(slice(None, None, stride) for _ in range(t.dim() - 2))
+    return t[sl].contiguous().numpy()
+
+
+def gen_ops(mvn):
+    op, mv, vol = mvn.utils.op, mvn.utils.multiview, mvn.utils.volumetric
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    # --- unprojection: non-square heatmaps (exercises the h/w swap), camera 0 inside the cube
+    B, NV, h, w, V = 2, 3, 12, 20, 7
+    K, R, t = synth.ring_cameras(NV, 64, inside=True)
+    P = torch.from_numpy(O.resized_projection(K, R, t, (64, 64), (h, w))).float()
+    P = P[None].repeat(B, 1, 1, 1).contiguous()
+    P[1, 1] *= 1.01
+    base = np.array([[30.0, -20.0, 10.0], [-100.0, 50.0, 80.0]])
+    cv = torch.stack([O.coord_volume(base[b], 2500.0, V, theta=0.3 * b) for b in range(B)])
+    for C in (32, 8, 5):
+        hm = torch.randn(B, NV, C, h, w, generator=g)
+        conf = torch.rand(B, NV, C, generator=g)
+        out["unproj_hm_C%d" % C] = hm.numpy()
+        out["unproj_cin_C%d" % C] = conf.numpy()
+        for method in ("sum", "max", "softmax", "conf"):
+            ref = op.unproject_heatmaps(hm, P, cv, method, conf)
+            _check("unproject/%s/C%d" % (method, C), O.unproject_heatmaps(hm, P, cv, method, conf), ref, 2e-6)
+            out["unproj_%s_C%d" % (method, C)] = ref.numpy()
+    out["unproj_P"] = P.numpy(); out["unproj_cv"] = cv.numpy()
+    try:
+        op.unproject_heatmaps(hm, P, cv, "bogus")
+        raise AssertionError("expected ValueError")
+    except ValueError as e:
+        out["unproj_bad_method_msg"] = np.array(str(e))
+    # --- 3D soft-argmax
+    vols = torch.randn(2, 5, 6, 7, 8, generator=g) * 3
+    cvs = torch.randn(2, 6, 7, 8, 3, generator=g) * 100
+    for sm in (True, False):
+        rc, rv = op.integrate_tensor_3d_with_coordinates(vols, cvs, softmax=sm)
+        oc, ov = O.integrate_tensor_3d_with_coordinates(vols, cvs, softmax=sm)
+        _check("integrate3d/softmax=%s" % sm, oc, rc, 2e-6); _check("integrate3d vols", ov, rv, 2e-6)
+        out["int3d_coords_%d" % sm] = rc.numpy(); out["int3d_vols_%d" % sm] = rv.numpy()
+    out["int3d_in"] = vols.numpy(); out["int3d_cv"] = cvs.numpy()
+    # --- 2D soft-argmax
+    hm2 = torch.randn(3, 4, 9, 11, generator=g) * 4
+    for sm in (True, False):
+        rc, rh = op.integrate_tensor_2d(hm2, softmax=sm)
+        oc, oh = O.integrate_tensor_2d(hm2, softmax=sm)
+        _check("integrate2d/softmax=%s" % sm, oc, rc, 2e-6); _check("integrate2d hm", oh, rh, 2e-6)
+        out["int2d_coords_%d" % sm] = rc.numpy(); out["int2d_hm_%d" % sm] = rh.numpy()
+    out["int2d_in"] = hm2.numpy()
+    # --- DLT: project a known point, triangulate back (SURVEY.md section 4 known-answer)
+    K4, R4, t4 = synth.ring_cameras(4, 256)
+    P4 = torch.from_numpy(K4 @ np.concatenate([R4, t4], -1)).float()
+    X = torch.tensor([[100.0, -50.0, 300.0], [-400.0, 20.0, -100.0], [0.0, 0.0, 0.0]])
+    pts = torch.stack([mv.project_3d_points_to_image_plane_without_distortion(P4[v], X) for v in range(4)])  # (NV,J,2)
+    pts = pts[None].repeat(2, 1, 1, 1).contiguous()
+    pts[1] += torch.randn(pts[1].shape, generator=g) * 2.0
+    conf = torch.rand(2, 4, 3, generator=g) + 0.1
+    Pb = P4[None].repeat(2, 1, 1, 1).contiguous()
+    rt = mv.triangulate_batch_of_points(Pb, pts, conf)
+    _check("triangulate", O.triangulate_batch_of_points(Pb, pts, conf), rt, 1e-5)
+    assert float((rt[0] - X).abs().max()) < 1e-2, rt[0]
+    rt_nc = mv.triangulate_batch_of_points(Pb, pts)
+    out.update(dlt_P=Pb.numpy(), dlt_pts=pts.numpy(), dlt_conf=conf.numpy(), dlt_out=rt.numpy(),
+               dlt_out_noconf=rt_nc.numpy(), dlt_X=X.numpy())
+    # --- geometry helpers
+    for i, (axis, th) in enumerate([((0, 0, 1), 0.0), ((0, 0, 1), 1.234), ((0, 1, 0), -2.5), ((1, 2, 3), 0.7)]):
+        rr = vol.get_rotation_matrix(axis, th)
+        assert np.abs(rr - O.rotation_matrix(axis, th)).max() < 1e-15
+        out["rot_%d" % i] = rr; out["rot_%d_arg" % i] = np.array(list(axis) + [th], dtype=np.float64)
+    cam = mv.Camera(R4[1], t4[1], K4[1])
+    cam.update_after_crop((10, 20, 200, 220))
+    cam.update_after_resize((200, 190), (96, 96))
+    out["cam_K_after"] = cam.K.copy(); out["cam_P_after"] = cam.projection.copy()
+    out["cam_in"] = np.concatenate([R4[1].ravel(), t4[1].ravel(), K4[1].ravel()])
+    Kc = K4[1].copy(); Kc[0, 2] -= 10; Kc[1, 2] -= 20
+    assert np.abs(O.resized_projection(Kc, R4[1], t4[1], (200, 190), (96, 96)) - cam.projection).max() < 1e-9
+    cvr = O.coord_volume(base[0], 2500.0, 8, theta=0.9)
+    # reference coord-volume arithmetic, triangulation.py:306-333, executed verbatim on its pieces
+    pos = base[0] - 2500.0 / 2
+    xxx, yyy, zzz = torch.meshgrid(torch.arange(8), torch.arange(8), torch.arange(8))
+    grid = torch.stack([xxx, yyy, zzz], dim=-1).type(torch.float).reshape((-1, 3))
+    gc = torch.zeros_like(grid)
+    for i in range(3):
+        gc[:, i] = pos[i] + (2500.0 / (8 - 1)) * grid[:, i]
+    center = torch.from_numpy(base[0]).type(torch.float)
+    ref_cv = vol.rotate_coord_volume(gc.reshape(8, 8, 8, 3) - center, 0.9, [0, 0, 1]) + center
+    _check("coord_volume(theta=0.9)", cvr, ref_cv, 1e-7)
+    out["cv_ref"] = ref_cv.numpy(); out["cv_base"] = base[0]
+    np.savez_compressed(os.path.join(GOLD, "ops.npz"), **out)
+
+
+def gen_nets(mvn):
+    out = {}
+    g = torch.Generator().manual_seed(9)
+    # --- V2V on a 32^3 volume
+    sp = spec.v2v_spec(32, 17, "")
+    ref = mvn.models.v2v.V2VModel(32, 17)
+    rsd = ref.state_dict()
+    assert list(rsd.keys()) == list(sp.keys()), "v2v key order"
+    assert all(tuple(rsd[k].shape) == sp[k][0] for k in sp)
+    sd = synth.make_state_dict(sp, seed=3)
+    ref.load_state_dict(sd, strict=True); ref.eval()
+    x = torch.randn(1, 32, 32, 32, 32, generator=g)
+    with torch.no_grad():
+        y = ref(x)
+    _check("v2v 32^3", O.v2v(sd, x, prefix=""), y, 2e-5)
+    out["v2v_out_s3"] = sub(y, 3); out["v2v_out_absmean"] = y.abs().mean(dim=(2, 3, 4)).numpy()
+    out["v2v_sd_digest"] = np.array(synth.state_dict_checksum(sd))
+    print("  v2v logits std %.4f" % float(y.std()))
+    assert 1e-3 < float(y.std()) < 1.0
+    # --- pose resnets
+    for nl, hw, algc, volc in ((152, 128, False, False), (50, 128, True, True), (18, 64, False, False)):
+        sp = spec.pose_resnet_spec(nl, 17, algc, volc, "")
+        cfg = synth.AttrDict(num_layers=nl, style="simple", num_joints=17, alg_confidences=algc,
+                             vol_confidences=volc, init_weights=False, checkpoint="")
+        ref = mvn.models.pose_resnet.get_pose_net(cfg, device="cpu")
+        rsd = ref.state_dict()
+        assert list(rsd.keys()) == list(sp.keys()), "resnet%d key order" % nl
+        assert all(tuple(rsd[k].shape) == sp[k][0] for k in sp)
+        sd = synth.make_state_dict(sp, seed=nl, basic_block=(nl < 50))
+        ref.load_state_dict(sd, strict=True); ref.eval()
+        x = torch.randn(2, 3, hw, hw, generator=g)
+        with torch.no_grad():
+            hm, ft, ac, vc = ref(x)
+        ohm, oft, oac, ovc = O.pose_resnet(sd, x, nl, prefix="")
+        _check("resnet%d features" % nl, oft, ft, 2e-5); _check("resnet%d heatmaps" % nl, ohm, hm, 2e-5)
+        print("  resnet%d features absmean %.4f max %.3f" % (nl, float(ft.abs().mean()), float(ft.abs().max())))
+        out["rn%d_feat_s2" % nl] = sub(ft, 2); out["rn%d_hm" % nl] = hm.numpy()
+        out["rn%d_sd_digest" % nl] = np.array(synth.state_dict_checksum(sd))
+        if algc:
+            _check("resnet%d alg conf" % nl, oac, ac, 2e-5); _check("resnet%d vol conf" % nl, ovc, vc, 2e-5)
+            out["rn%d_algc" % nl] = ac.numpy(); out["rn%d_volc" % nl] = vc.numpy()
+    np.savez_compressed(os.path.join(GOLD, "nets.npz"), **out)
+
+
+def run_vol_case(mvn, tag, num_layers, B, NV, H, V, method="softmax", multiplier=1.0, sharpen=False,
+                 inside=False, rotate=False, kind="mpii", seed=0, stride=4, cmu=False):
+    cfg = synth.vol_config(num_layers, V, method, multiplier, kind)
+    if cmu:
+        cfg.model.transfer_cmu_to_human36m = True
+    sp = spec.vol_net_spec(num_layers, 17, method.startswith("conf"))
+    sd = synth.make_state_dict(sp, seed=seed, sharpen=sharpen, basic_block=(num_layers < 50))
+    inp = synth.make_inputs(B, NV, H, seed=seed, inside=inside)
+    ref = mvn.models.triangulation.VolumetricTriangulationNet(cfg, device="cpu")
+    rsd = ref.state_dict()
+    assert list(rsd.keys()) == list(sp.keys()), "vol key order"
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    thetas = None
+    if rotate:  # random theta of triangulation.py:318-319 without putting BN into train mode
+        ref.training = True
+        np.random.seed(seed + 100)
+        thetas = np.random.uniform(0.0, 2 * np.pi, size=B)
+        np.random.seed(seed + 100)
+    batch = {"cameras": _cameras(mvn, inp["K"], inp["R"], inp["t"], B), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+    t0 = time.time()
+    with torch.no_grad():
+        kp, feats, vols, volc, cuboids, cvs, bps = ref(inp["images"], torch.zeros(B, NV, 3, 4), batch)
+    dt = time.time() - t0
+    o = O.volumetric_forward(sd, cfg, inp["images"], inp["K"], inp["R"], inp["t"], inp["pred_keypoints_3d"],
+                             thetas=thetas, stages=True)
+    print(" case %s: reference forward %.2fs; logits std %.3f, max prob %.2e, kp spread %.1f mm" % (
+        tag, dt, float(o["logits"].std() * multiplier), float(vols.max()), float(kp.std(dim=1).mean())))
+    _check(tag + " coord_volumes", o["coord_volumes"], cvs, 1e-7)
+    _check(tag + " features", o["features"], feats, 2e-5)
+    _check(tag + " volumes", o["volumes"], vols, 1e-3)
+    _check(tag + " base_points", o["base_points"], bps, 1e-7)
+    d = (o["keypoints_3d"] - kp).abs() / kp.abs().clamp(min=1.0)
+    print("  oracle-vs-reference %-28s max rel (|ref| floor 1mm) = %.3e" % (tag + " keypoints_3d", float(d.max())))
+    assert float(d.max()) < 1e-4
+    res = {
+        "kp": kp.numpy(), "base_points": bps.numpy(), "proj": o["proj"].numpy(),
+        "feat_sub": sub(feats.reshape(B * NV, *feats.shape[2:]), stride), "vol_sub": sub(vols, stride),
+        "unproj_sub": sub(o["unprojected"], stride), "logits_sub": sub(o["logits"], stride),
+        "cv_sub": cvs[:, ::stride, ::stride, ::stride].contiguous().numpy(), "stride": np.array(stride),
+        "sd_digest": np.array(synth.state_dict_checksum(sd)),
+        "images_digest": np.array([float(inp["images"].double().sum()), float((inp["images"].double() ** 2).sum())]),
+        "cuboid_pos": np.stack([c.position for c in cuboids]), "cuboid_sides": np.stack([c.sides for c in cuboids]),
+    }
+    if thetas is not None:
+        res["thetas"] = thetas
+    if volc is not None:
+        res["vol_conf"] = volc.numpy()
+    np.savez_compressed(os.path.join(GOLD, "vol_%s.npz" % tag), **res)
+    return float(o["logits"].std())
+
+
+def gen_alg(mvn):
+    cfg = synth.alg_config(50, True)
+    sp = spec.alg_net_spec(50, 17, True)
+    sd = synth.make_state_dict(sp, seed=50)
+    inp = synth.make_inputs(2, 4, 256, seed=1)
+    ref = mvn.models.triangulation.AlgebraicTriangulationNet(cfg, device="cpu")
+    assert list(ref.state_dict().keys()) == list(sp.keys())
+    ref.load_state_dict(sd, strict=True); ref.eval()
+    P = torch.from_numpy(inp["K"] @ np.concatenate([inp["R"], inp["t"]], -1)).float()[None].repeat(2, 1, 1, 1)
+    with torch.no_grad():
+        kp3, kp2, hm, conf = ref(inp["images"], P, {})
+    o = O.algebraic_forward(sd, cfg, inp["images"], inp["K"], inp["R"], inp["t"])
+    _check("alg keypoints_2d", o["keypoints_2d"], kp2, 1e-4)
+    _check("alg confidences", o["alg_confidences"], conf, 1e-4)
+    _check("alg keypoints_3d", o["keypoints_3d"], kp3, 1e-3)
+    np.savez_compressed(os.path.join(GOLD, "alg_c1.npz"), kp3=kp3.numpy(), kp2=kp2.numpy(), conf=conf.numpy(),
+                        hm_sub=sub(hm.reshape(8, 17, 64, 64), 4), sd_digest=np.array(synth.state_dict_checksum(sd)))
+
+
+def main():
+    torch.manual_seed(0)
+    os.makedirs(GOLD, exist_ok=True)
+    mvn = ref_loader.load()
+    which = sys.argv[1:] or ["ops", "nets", "vol", "alg"]
+    if "ops" in which:
+        print("[ops]"); gen_ops(mvn)
+    if "nets" in which:
+        print("[nets]"); gen_nets(mvn)
+    if "vol" in which:
+        print("[vol]")
+        # small whole-pipeline cases (fast on CPU, exercise every branch)
+        run_vol_case(mvn, "small_softmax", 18, 2, 3, 128, 32, "softmax", sharpen=True, inside=True, rotate=True, seed=2, stride=2)
+        run_vol_case(mvn, "small_sum_coco", 18, 1, 2, 128, 32, "sum", multiplier=100.0, sharpen=False, kind="coco", rotate=True, seed=3, stride=2, cmu=True)
+        run_vol_case(mvn, "small_conf", 50, 2, 4, 128, 32, "conf_norm", sharpen=True, seed=4, stride=2)
+        run_vol_case(mvn, "small_max", 18, 1, 3, 128, 32, "max", sharpen=True, seed=5, stride=2)
+        # BASELINE config 2 shape, B=1: default and sharpened weights
+        run_vol_case(mvn, "c2_default", 152, 1, 4, 384, 64, "softmax", sharpen=False, seed=0, stride=4)
+        std = run_vol_case(mvn, "c2_sharp", 152, 1, 4, 384, 64, "softmax", sharpen=True, seed=0, stride=4)
+        print("  (calibration) sharpened logit std = %.3f with SHARPEN_GAIN=%.1f" % (std, synth.SHARPEN_GAIN))
+    if "alg" in which:
+        print("[alg]"); gen_alg(mvn)
+    digest = {k: [list(v[0]), v[1]] for k, v in spec.vol_net_spec(152, 17).items()}
+    with open(os.path.join(GOLD, "spec_digest.json"), "w") as f:
+        json.dump({"n_keys": len(digest), "n_params": int(sum(int(np.prod(v[0])) for v in digest.values())),
+                   "first": list(digest)[:3], "last": list(digest)[-3:]}, f)
+    print("golden fixtures written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()
