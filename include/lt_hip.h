@@ -1,0 +1,188 @@
+/*
+ * lt_hip.h -- flat C ABI of liblt_hip.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * volumetric-triangulation forward path of karfly/learnable-triangulation-pytorch.
+ *
+ * The reference has no FFI/operator registry: the boundary it offers is a set
+ * of Python callables whose arithmetic is done by ATen kernels.  Each entry point below replaces the
+ * ATen kernels behind one of those callables; the Python host in
+ * learnable-triangulation-pytorch_amd/mvn/ keeps the callables' names and signatures and binds
+ * these symbols with ctypes (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is enqueued on
+ *     it and nothing synchronises, allocates or frees: every call is hipGraph-capturable;
+ *   - return value: 0 = LT_OK, negative = error; lt_last_error() holds a message (thread local);
+ *   - activations are channels-last: 2D maps N,H,W,C and volumes N,D,H,W,C, element type `dtype`
+ *     (LT_F32, or LT_BF16 with fp32 accumulation); 2D tensors are the D == 1 case of 3D;
+ *   - thread-safe for distinct streams.
+ */
+#ifndef LT_HIP_H
+#define LT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_ABI_VERSION 1
+
+enum { LT_F32 = 0, LT_BF16 = 1 };
+enum { LT_OK = 0, LT_ERR_INVALID = -1, LT_ERR_UNSUPPORTED = -2, LT_ERR_LAUNCH = -3 };
+
+/* view-aggregation modes of op.unproject_heatmaps (mvn/utils/op.py:149-164) */
+enum { LT_AGG_SUM = 0, LT_AGG_MAX = 1, LT_AGG_SOFTMAX = 2, LT_AGG_CONF = 3,
+       LT_AGG_CONF_NORM = 4 /* 'conf_norm': confidences divided by their sum over views first (triangulation.py:268-269) */ };
+
+/* epilogue flags of lt_conv_fwd */
+enum {
+    LT_EPI_RELU_PRE = 1,  /* ReLU before the residual add  (Upsample3DBlock + skip, v2v.py:121-136) */
+    LT_EPI_RELU_POST = 2, /* ReLU after the residual add   (Bottleneck / Res3DBlock, pose_resnet.py:92-93, v2v.py:42) */
+    LT_EPI_STORE_F32 = 4, /* store fp32 even when dtype is bf16 (V2V logits feeding the soft-argmax) */
+    LT_EPI_SIGMOID = 8    /* v = 1/(1+exp(-v)) last (GlobalAveragePoolingHead, pose_resnet.py:160) */
+};
+
+const char* lt_last_error(void);
+int lt_abi_version(void);
+/* fills CU count, LDS bytes per CU and the gcn arch name (e.g. "gfx950") of the current device */
+int lt_device_info(int* cu_count, int* lds_per_cu, char* arch, int arch_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generalised convolution = implicit GEMM on MFMA (fp32: v_mfma_f32_32x32x2_f32 / 16x16x4_f32,
+ * exact fp32; bf16: v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16, fp32 accumulate).
+ * Replaces F.conv2d / F.conv3d / F.conv_transpose2d / F.conv_transpose3d + eval BatchNorm + ReLU +
+ * residual add as used by PoseResNet.forward (mvn/models/pose_resnet.py:293-318, :75-95),
+ * process_features (mvn/models/triangulation.py:238-240) and V2VModel.forward (mvn/models/v2v.py:7-66,
+ * :164-169).
+ *
+ *   for every phase p, every point o = (n, od, oh, ow) of the iteration space N x Do x Ho x Wo and
+ *   every output channel co:
+ *     acc = sum_{tap t, ci} x[n, od*sd - pd + dd_t, oh*sh - ph + dh_t, ow*sw - pw + dw_t, ci]
+ *                           * w_p[co][t*Cin + ci]                      (out-of-range taps read 0)
+ *     v   = acc * scale[co] + shift[co]                 (folded BN / bias; NULL = 1 / 0)
+ *     if RELU_PRE v = max(v,0);  if residual v += residual[same place as y];  if RELU_POST v = max(v,0)
+ *     y[n, od*osd + ood_p, oh*osh + ooh_p, ow*osw + oow_p, co] = v
+ *
+ * A plain convolution is one phase with out_stride 1 / out_off 0; a stride-2 transposed convolution
+ * is 2^nd phases (one per output parity) with out_stride 2.
+ * -------------------------------------------------------------------------------------------*/
+#define LT_CONV_MAX_PHASES 8
+
+typedef struct lt_conv_phase {
+    const void* weight;  /* [cout_pad][k_pad] elements of `dtype`, k = tap*Cin + ci, zero padded      */
+    const int32_t* taps; /* ntaps x 4 int32: dd, dh, dw, element offset ((dd*H + dh)*W + dw)*Cin     */
+    int32_t ntaps;
+    int32_t out_off[3];  /* ood, ooh, oow                                                            */
+} lt_conv_phase;
+
+typedef struct lt_conv_desc {
+    int32_t dtype;              /* LT_F32 | LT_BF16                                                  */
+    int32_t N, D, H, W, Cin;    /* input tensor (Cin a power of two, >= 16 bytes per pixel)           */
+    int32_t Do, Ho, Wo;         /* iteration space per sample                                        */
+    int32_t stride[3], pad[3];  /* sd,sh,sw / pd,ph,pw                                               */
+    int32_t OD, OH, OW;         /* output tensor spatial dims                                        */
+    int32_t out_stride[3];      /* osd, osh, osw                                                     */
+    int32_t Cout, ldc;          /* real output channels; output pixel stride in elements (>= Cout)   */
+    int32_t cout_pad, k_pad;    /* padded weight dims: cout_pad % tile_n == 0, k_pad % (128 B) == 0  */
+    int32_t nphase;
+    int32_t flags;              /* LT_EPI_*                                                          */
+    int32_t tile;               /* 0 = choose; else one of LT_TILE_* (tests / tuning)                */
+    int32_t reserved;
+    lt_conv_phase phase[LT_CONV_MAX_PHASES];
+} lt_conv_desc;
+
+enum { LT_TILE_AUTO = 0, LT_TILE_128x128 = 1, LT_TILE_128x64 = 2, LT_TILE_256x32 = 3, LT_TILE_256x16 = 4,
+       LT_TILE_64x64 = 5, LT_TILE_DIRECT = 99 /* scalar fp32 VALU kernel, debug cross-check only */ };
+
+int lt_conv_fwd(const lt_conv_desc* desc, const void* x, const float* scale, const float* shift,
+                const void* residual, void* y, void* stream);
+/* weight padding rule (every tile's N divides it): cout_pad = 16 if Cout <= 16, 32 if <= 32, 64 if <= 64,
+ * else Cout rounded up to a multiple of 128; scale/shift arrays hold cout_pad floats. */
+int lt_conv_cout_pad(int32_t cout);
+
+/* max pooling, channels-last, window k / stride s / zero-size padding p per dim (padding never wins):
+ * F.max_pool2d(x,3,2,1) (pose_resnet.py:297) and F.max_pool3d(x,2,2) (v2v.py:51) */
+int lt_maxpool_fwd(int32_t dtype, const void* x, void* y, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
+                   const int32_t k[3], const int32_t s[3], const int32_t p[3], void* stream);
+
+/* x.mean over all pixels per channel (GlobalAveragePoolingHead.forward, pose_resnet.py:168-170):
+ * x N,HW,C channels-last -> y N,C */
+int lt_global_avgpool(int32_t dtype, const void* x, void* y, int32_t N, int32_t HW, int32_t C, void* stream);
+
+/* images N,C,H,W fp32 (the reference's input layout, datasets/utils.py:45-52) -> N,H,W,c_pad `dtype`,
+ * channels >= C zero filled */
+int lt_nchw_to_nhwc(int32_t dtype, const float* x, void* y, int32_t N, int32_t C, int32_t HW, int32_t c_pad, void* stream);
+/* channels-last `dtype` (pixel stride ld) -> N,C,HW fp32 (API outputs) */
+int lt_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32_t N, int32_t C, int32_t HW, int32_t ld, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Voxel-grid construction: mvn/models/triangulation.py:298-339 + volumetric.rotate_coord_volume
+ * (mvn/utils/volumetric.py:102-114), fp32 in the reference's operation order:
+ *   X = R_b * ((pos_b + step*idx) - center_b) + center_b        idx = (i,j,k), 'ij' meshgrid
+ * pos/center: B x 3 fp32, rot: B x 9 fp32 row-major.  coords: B,V,V,V,3 fp32.
+ * cmu_transfer != 0 applies permute(0,2,1,3) + flip(axis 1) (triangulation.py:336-339).
+ * -------------------------------------------------------------------------------------------*/
+int lt_coord_volumes(const float* pos, const float* center, const float* rot, float step, int32_t B, int32_t V,
+                     int32_t cmu_transfer, float* coords, void* stream);
+/* volumetric.rotate_coord_volume (mvn/utils/volumetric.py:102-114) for an arbitrary point set:
+ * y[i] = rot (3x3 row-major, device) * x[i], i < n; x, y: n x 3 fp32 */
+int lt_rotate_points(const float* x, const float* rot, float* y, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * op.unproject_heatmaps (mvn/utils/op.py:99-166) fused with
+ * multiview.project_3d_points_to_image_plane_without_distortion (mvn/utils/multiview.py:89-110):
+ * per voxel and view: project, z<=0 mask, perspective divide, the reference's (h,w)-swapped
+ * normalisation, bilinear sample (zeros padding, align_corners=True), then aggregate over views.
+ *   feats : B,NV,h,w,C channels-last `dtype`     proj: B,NV,3,4 fp32
+ *   coords: B,v0,v1,v2,3 fp32 (any grid; arbitrary point sets use v0 = v1 = 1)
+ *   conf  : B,NV,C fp32 (LT_AGG_CONF*)           out : B,v0,v1,v2,C channels-last `dtype`
+ * One 16-byte channel vector per lane (a voxel's C channels = consecutive lanes -> every bilinear tap
+ * and every output voxel is one contiguous run); 4x4x16 voxel bricks per workgroup keep the projected
+ * footprint compact in L1/L2; with B % 8 == 0 sample b is pinned to XCD b % 8 (private L2).
+ * -------------------------------------------------------------------------------------------*/
+int lt_unproject_fwd(int32_t dtype, const void* feats, const float* proj, const float* coords, const float* conf,
+                     void* out, int32_t B, int32_t NV, int32_t C, int32_t h, int32_t w, int32_t v0, int32_t v1,
+                     int32_t v2, int32_t agg, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * op.integrate_tensor_3d_with_coordinates (mvn/utils/op.py:84-96):
+ *   p = softmax_over_voxels(mult * logits[b,j,:])  (or relu(mult*logits) when softmax == 0)
+ *   kp[b,j,:] = sum_vox p * coords[b,vox,:]
+ * logits: fp32, element (b,j,vox) at b*J*nvox + vox*ld + j when channels_last (ld >= J) else
+ * b*J*nvox.. (b*J + j)*nvox + vox.  probs: B,J,nvox fp32 (always joint-major, the API layout) or
+ * NULL.  workspace: lt_softargmax3d_workspace() bytes.
+ * -------------------------------------------------------------------------------------------*/
+size_t lt_softargmax3d_workspace(int32_t B, int32_t J, int64_t nvox);
+int lt_softargmax3d_fwd(const float* logits, const float* coords, float mult, int32_t softmax, int32_t channels_last,
+                        int32_t ld, float* kp, float* probs, int32_t B, int32_t J, int64_t nvox, void* workspace,
+                        void* stream);
+
+/* op.integrate_tensor_2d (mvn/utils/op.py:11-47) on N,J,h,w fp32 heatmaps (joint-major): 2D
+ * soft-argmax; writes coords N,J,2 (x,y) and the normalised heatmaps (or NULL). */
+int lt_softargmax2d_fwd(const float* heatmaps, float mult, int32_t softmax, float* coords, float* probs, int32_t NJ,
+                        int32_t h, int32_t w, void* stream);
+
+/* multiview.triangulate_batch_of_points (mvn/utils/multiview.py:141-183): confidence-weighted DLT.
+ * proj B,NV,3,4; points B,NV,J,2; conf B,NV,J or NULL; out B,J,3.  Smallest right singular vector
+ * of the (2NV x 4) system by Jacobi eigen-iteration on A^T A in fp64. */
+int lt_triangulate_dlt(const float* proj, const float* points, const float* conf, float* out, int32_t B, int32_t NV,
+                       int32_t J, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * hipGraph + event helpers (the forward is ~230 launches: replay it as one graph)
+ * -------------------------------------------------------------------------------------------*/
+int lt_graph_begin(void* stream);
+int lt_graph_end(void* stream, void** graph_exec_out);
+int lt_graph_launch(void* graph_exec, void* stream);
+int lt_graph_destroy(void* graph_exec);
+int lt_event_create(void** ev_out);
+int lt_event_record(void* ev, void* stream);
+int lt_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
+int lt_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LT_HIP_H */

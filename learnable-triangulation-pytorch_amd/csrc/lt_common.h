@@ -1,0 +1,67 @@
+// Shared host/device helpers for liblt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/lt_hip.h"
+
+namespace lt {
+
+void set_error(const char* fmt, ...);
+
+#define LT_REQUIRE(cond, code, ...)        \
+    do {                                   \
+        if (!(cond)) {                     \
+            lt::set_error(__VA_ARGS__);    \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+// Checks the launch that was just enqueued (no synchronisation).
+#define LT_CHECK_LAUNCH(what)                                                            \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) {                                                          \
+            lt::set_error("%s: launch failed: %s", (what), hipGetErrorString(e_));       \
+            return LT_ERR_LAUNCH;                                                        \
+        }                                                                                \
+    } while (0)
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// round-to-nearest-even, NaN preserved (same rounding as torch's float -> bfloat16)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct elt;
+template <> struct elt<float> {
+    static constexpr int bytes = 4;
+    static constexpr int vec = 4;  // elements per 16 B
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct elt<bf16_t> {
+    static constexpr int bytes = 2;
+    static constexpr int vec = 8;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+static inline int ilog2_exact(int v) {  // -1 when v is not a power of two
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace lt

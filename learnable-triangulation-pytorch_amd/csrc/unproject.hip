@@ -1,0 +1,312 @@
+// Voxel-grid construction and the fused unprojection (projective bilinear gather + view aggregation).
+//
+// Unprojection is HBM/L2-bound: per sample it must read the NV feature maps once and write the
+// C x V^3 volume once (38.27 MB fp32 at config 2); everything else (projection,
+// 4-tap weights, view softmax) lives in registers.  Layout choices that make it stream:
+//   * feature maps are channels-last, so ONE bilinear tap of ONE voxel is a contiguous C-vector
+//     (128 B fp32 / 64 B bf16 at C=32): the C/CH lanes of a voxel issue one coalesced 16-byte load each;
+//   * the volume is written channels-last too (what the V2V implicit GEMM wants): 16 B per lane, a
+//     brick's 16 consecutive voxels form one 2 KiB run;
+//   * a workgroup owns a 4x4x16 voxel brick: its projection into every view is a ~10-px patch that
+//     stays L1/L2 resident across the brick's 1024 taps per view (8x reuse);
+//   * with B % 8 == 0, sample b is processed only by workgroups dispatched to XCD b % 8, so a sample's
+//     feature maps occupy one private L2 instead of being replicated into all eight.
+#include "lt_common.h"
+
+using namespace lt;
+
+namespace {
+
+__global__ void coord_volumes_kernel(const float* __restrict__ pos, const float* __restrict__ center,
+                                     const float* __restrict__ rot, float step, int B, int V, int cmu, float* __restrict__ out) {
+    const long long total = (long long)B * V * V * V;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        long long r = g;
+        const int k = (int)(r % V); r /= V;
+        const int j = (int)(r % V); r /= V;
+        const int i = (int)(r % V);
+        const int b = (int)(r / V);
+        // triangulation.py:336-339: permute(0,2,1,3) then flip axis 1  ==> out[i][j][k] = cv[i][k][V-1-j]
+        const int a0 = i, a1 = cmu ? k : j, a2 = cmu ? (V - 1 - j) : k;
+        const float* p = pos + 3 * b;
+        const float* c = center + 3 * b;
+        const float* R = rot + 9 * b;
+        // f32(position) + f32(step) * idx, two roundings as in triangulation.py:311-313 (no FMA contraction)
+        const float x0 = __fadd_rn(p[0], __fmul_rn(step, (float)a0));
+        const float x1 = __fadd_rn(p[1], __fmul_rn(step, (float)a1));
+        const float x2 = __fadd_rn(p[2], __fmul_rn(step, (float)a2));
+        const float d0 = __fsub_rn(x0, c[0]), d1 = __fsub_rn(x1, c[1]), d2 = __fsub_rn(x2, c[2]);
+        // rot.mm(d): k-ordered multiply-adds (exact for theta = 0, where R is the identity)
+        const float r0 = fmaf(R[2], d2, fmaf(R[1], d1, __fmul_rn(R[0], d0)));
+        const float r1 = fmaf(R[5], d2, fmaf(R[4], d1, __fmul_rn(R[3], d0)));
+        const float r2 = fmaf(R[8], d2, fmaf(R[7], d1, __fmul_rn(R[6], d0)));
+        float* o = out + g * 3;
+        o[0] = __fadd_rn(r0, c[0]);
+        o[1] = __fadd_rn(r1, c[1]);
+        o[2] = __fadd_rn(r2, c[2]);
+    }
+}
+
+template <typename T, int CH> struct ChVec;  // CH channels of one pixel <-> CH floats
+template <> struct ChVec<float, 4> {
+    static __device__ __forceinline__ void ld(const float* p, float (&f)[4]) {
+        const float4 v = *(const float4*)p;
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float (&f)[4]) { *(float4*)p = make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <> struct ChVec<float, 1> {
+    static __device__ __forceinline__ void ld(const float* p, float (&f)[1]) { f[0] = *p; }
+    static __device__ __forceinline__ void st(float* p, const float (&f)[1]) { *p = f[0]; }
+};
+template <> struct ChVec<bf16_t, 8> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float (&f)[8]) {
+        const uint4 v = *(const uint4*)p;
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(u[i] << 16);
+            f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float (&f)[8]) {
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = (unsigned)f32_to_bf16(f[2 * i]) | ((unsigned)f32_to_bf16(f[2 * i + 1]) << 16);
+        *(uint4*)p = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+};
+template <> struct ChVec<bf16_t, 1> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float (&f)[1]) { f[0] = bf16_to_f32(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, const float (&f)[1]) { *p = f32_to_bf16(f[0]); }
+};
+
+struct UnprojArgs {
+    const void* feats;
+    const float* proj;
+    const float* coords;
+    const float* conf;
+    void* out;
+    int B, NV, C, h, w, v0, v1, v2, agg;
+    int bricked;        // 4x4x16 bricks (v0%4 == v1%4 == v2%16 == 0) or linear 256-voxel chunks
+    int chunks;         // workgroups per sample
+    int xcd_pin;        // B % 8 == 0
+};
+
+// Bilinear sample of CH channels for one voxel in one view; mirrors ATen's CPU grid_sampler_2d
+// (bilinear, zeros padding, align_corners=True) and op.py:116-141.
+template <typename T, int CH>
+__device__ __forceinline__ void sample_view(const T* __restrict__ fmap, const float* __restrict__ P, float X0, float X1,
+                                            float X2, int h, int w, int C, int c0, float (&val)[CH]) {
+    // multiview.py:105: [X,1] @ P^T, k-ordered
+    const float px = __fadd_rn(fmaf(X2, P[2], fmaf(X1, P[1], __fmul_rn(X0, P[0]))), P[3]);
+    const float py = __fadd_rn(fmaf(X2, P[6], fmaf(X1, P[5], __fmul_rn(X0, P[4]))), P[7]);
+    float pz = __fadd_rn(fmaf(X2, P[10], fmaf(X1, P[9], __fmul_rn(X0, P[8]))), P[11]);
+    const bool invalid = pz <= 0.0f;  // op.py:123
+    if (pz == 0.0f) pz = 1.0f;        // op.py:125
+    const float u = __fdiv_rn(px, pz), v = __fdiv_rn(py, pz);
+    // op.py:128-129: x normalised by heatmap_shape[0] (= h), y by heatmap_shape[1] (= w)
+    const float gx = __fmul_rn(2.0f, __fsub_rn(__fdiv_rn(u, (float)h), 0.5f));
+    const float gy = __fmul_rn(2.0f, __fsub_rn(__fdiv_rn(v, (float)w), 0.5f));
+    // grid_sample, align_corners=True: pixel = (g + 1) * (size - 1) / 2
+    const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), 0.5f * (float)(w - 1));
+    const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), 0.5f * (float)(h - 1));
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float we = __fsub_rn(ix, xw), ww = __fsub_rn(1.0f, we);
+    const float ws = __fsub_rn(iy, yn), wn = __fsub_rn(1.0f, ws);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) val[e] = 0.f;
+    if (invalid) return;  // op.py:141 (the sample is computed, then zeroed)
+    // in-range tests in float (huge / NaN coordinates never convert to int)
+    const bool xw_ok = xw >= 0.f && xw <= (float)(w - 1), xe_ok = xw >= -1.f && xw <= (float)(w - 2);
+    const bool yn_ok = yn >= 0.f && yn <= (float)(h - 1), ys_ok = yn >= -1.f && yn <= (float)(h - 2);
+    if (!((xw_ok || xe_ok) && (yn_ok || ys_ok))) return;
+    const int x0 = (int)xw, y0 = (int)yn;
+    float t00[CH], t01[CH], t10[CH], t11[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) t00[e] = t01[e] = t10[e] = t11[e] = 0.f;
+    const T* base = fmap + ((long long)y0 * w + x0) * C + c0;
+    if (yn_ok && xw_ok) ChVec<T, CH>::ld(base, t00);
+    if (yn_ok && xe_ok) ChVec<T, CH>::ld(base + C, t01);
+    if (ys_ok && xw_ok) ChVec<T, CH>::ld(base + (long long)w * C, t10);
+    if (ys_ok && xe_ok) ChVec<T, CH>::ld(base + (long long)w * C + C, t11);
+    const float nw = __fmul_rn(wn, ww), ne = __fmul_rn(wn, we), sw = __fmul_rn(ws, ww), se = __fmul_rn(ws, we);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) val[e] = t00[e] * nw + t01[e] * ne + t10[e] * sw + t11[e] * se;
+}
+
+template <typename T, int CH, bool SMALL_NV>
+__global__ __launch_bounds__(256) void unproject_kernel(const UnprojArgs a) {
+    const int tpv = a.C / CH;  // lanes per voxel
+    // workgroup -> (sample, chunk); XCD-pinned when B % 8 == 0 (block b runs on XCD b % 8)
+    int b, chunk;
+    if (a.xcd_pin) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        b = xcd + 8 * (j / a.chunks);
+        chunk = j % a.chunks;
+    } else {
+        b = blockIdx.x / a.chunks;
+        chunk = blockIdx.x % a.chunks;
+    }
+    const long long nvox = (long long)a.v0 * a.v1 * a.v2;
+    const T* feats = (const T*)a.feats + (long long)b * a.NV * a.h * a.w * a.C;
+    const float* P = a.proj + (long long)b * a.NV * 12;
+    const float* coords = a.coords + (long long)b * nvox * 3;
+    T* out = (T*)a.out + (long long)b * nvox * a.C;
+    int bi = 0, bj = 0, bk = 0;
+    if (a.bricked) {
+        const int nk = a.v2 >> 4, nj = a.v1 >> 2;
+        bk = (chunk % nk) << 4;
+        bj = ((chunk / nk) % nj) << 2;
+        bi = (chunk / (nk * nj)) << 2;
+    }
+    const int items = 256 * tpv;
+    for (int q = threadIdx.x; q < items; q += 256) {
+        const int vb = q / tpv;            // voxel within the chunk, 0..255
+        const int c0 = (q - vb * tpv) * CH;
+        long long vox;
+        if (a.bricked) vox = ((long long)(bi + (vb >> 6)) * a.v1 + bj + ((vb >> 4) & 3)) * a.v2 + bk + (vb & 15);
+        else vox = (long long)chunk * 256 + vb;
+        if (vox >= nvox) continue;
+        const float X0 = coords[vox * 3], X1 = coords[vox * 3 + 1], X2 = coords[vox * 3 + 2];
+        float res[CH];
+        if (SMALL_NV) {  // NV <= 8: keep every view's sample in registers (two-pass softmax like torch)
+            float vals[8][CH];
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+                if (v < a.NV) sample_view<T, CH>(feats + (long long)v * a.h * a.w * a.C, P + v * 12, X0, X1, X2, a.h, a.w, a.C, c0, vals[v]);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                float r;
+                if (a.agg == LT_AGG_SOFTMAX) {
+                    float m = vals[0][e];
+#pragma unroll
+                    for (int v = 1; v < 8; ++v) if (v < a.NV) m = fmaxf(m, vals[v][e]);
+                    float s = 0.f, ex[8];
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) if (v < a.NV) { ex[v] = expf(vals[v][e] - m); s += ex[v]; }
+                    r = 0.f;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) if (v < a.NV) r += vals[v][e] * __fdiv_rn(ex[v], s);
+                } else if (a.agg == LT_AGG_MAX) {
+                    r = vals[0][e];
+#pragma unroll
+                    for (int v = 1; v < 8; ++v) if (v < a.NV) r = fmaxf(r, vals[v][e]);
+                } else if (a.agg == LT_AGG_CONF || a.agg == LT_AGG_CONF_NORM) {
+                    float cs = 1.f;
+                    if (a.agg == LT_AGG_CONF_NORM) {
+                        cs = 0.f;
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) if (v < a.NV) cs += a.conf[((long long)b * a.NV + v) * a.C + c0 + e];
+                    }
+                    r = 0.f;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) if (v < a.NV) r += vals[v][e] * __fdiv_rn(a.conf[((long long)b * a.NV + v) * a.C + c0 + e], cs);
+                } else {
+                    r = 0.f;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) if (v < a.NV) r += vals[v][e];
+                }
+                res[e] = r;
+            }
+        } else {  // any NV: recompute the samples instead of storing them (softmax needs the max first)
+            float m[CH], s[CH], acc[CH], val[CH], cs[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                m[e] = -INFINITY; s[e] = 0.f; acc[e] = 0.f; cs[e] = 1.f;
+                if (a.agg == LT_AGG_CONF_NORM) {
+                    cs[e] = 0.f;
+                    for (int v = 0; v < a.NV; ++v) cs[e] += a.conf[((long long)b * a.NV + v) * a.C + c0 + e];
+                }
+            }
+            if (a.agg == LT_AGG_SOFTMAX || a.agg == LT_AGG_MAX)
+                for (int v = 0; v < a.NV; ++v) {
+                    sample_view<T, CH>(feats + (long long)v * a.h * a.w * a.C, P + v * 12, X0, X1, X2, a.h, a.w, a.C, c0, val);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) m[e] = fmaxf(m[e], val[e]);
+                }
+            if (a.agg != LT_AGG_MAX)
+                for (int v = 0; v < a.NV; ++v) {
+                    sample_view<T, CH>(feats + (long long)v * a.h * a.w * a.C, P + v * 12, X0, X1, X2, a.h, a.w, a.C, c0, val);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) {
+                        if (a.agg == LT_AGG_SOFTMAX) { const float ex = expf(val[e] - m[e]); s[e] += ex; acc[e] += val[e] * ex; }
+                        else if (a.agg == LT_AGG_CONF || a.agg == LT_AGG_CONF_NORM)
+                            acc[e] += val[e] * __fdiv_rn(a.conf[((long long)b * a.NV + v) * a.C + c0 + e], cs[e]);
+                        else acc[e] += val[e];
+                    }
+                }
+#pragma unroll
+            for (int e = 0; e < CH; ++e)
+                res[e] = a.agg == LT_AGG_MAX ? m[e] : (a.agg == LT_AGG_SOFTMAX ? __fdiv_rn(acc[e], s[e]) : acc[e]);
+        }
+        ChVec<T, CH>::st(out + vox * a.C + c0, res);
+    }
+}
+
+template <typename T, int CH>
+int launch_unproject(const UnprojArgs& a, hipStream_t st) {
+    const unsigned grid = (unsigned)((long long)a.B * a.chunks);
+    if (a.NV <= 8) hipLaunchKernelGGL((unproject_kernel<T, CH, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((unproject_kernel<T, CH, false>), dim3(grid), dim3(256), 0, st, a);
+    LT_CHECK_LAUNCH("lt_unproject_fwd");
+    return LT_OK;
+}
+
+}  // namespace
+
+extern "C" int lt_coord_volumes(const float* pos, const float* center, const float* rot, float step, int32_t B, int32_t V,
+                                int32_t cmu_transfer, float* coords, void* stream) {
+    LT_REQUIRE(pos && center && rot && coords && B >= 1 && V >= 2, LT_ERR_INVALID, "lt_coord_volumes: bad argument");
+    const long long total = (long long)B * V * V * V;
+    const long long blocks = cdiv(total, 256);
+    hipLaunchKernelGGL(coord_volumes_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, pos,
+                       center, rot, step, B, V, cmu_transfer, coords);
+    LT_CHECK_LAUNCH("lt_coord_volumes");
+    return LT_OK;
+}
+
+extern "C" int lt_unproject_fwd(int32_t dtype, const void* feats, const float* proj, const float* coords, const float* conf,
+                                void* out, int32_t B, int32_t NV, int32_t C, int32_t h, int32_t w, int32_t v0, int32_t v1,
+                                int32_t v2, int32_t agg, void* stream) {
+    LT_REQUIRE(feats && proj && coords && out, LT_ERR_INVALID, "lt_unproject_fwd: null argument");
+    LT_REQUIRE(dtype == LT_F32 || dtype == LT_BF16, LT_ERR_INVALID, "lt_unproject_fwd: bad dtype %d", dtype);
+    LT_REQUIRE(agg >= LT_AGG_SUM && agg <= LT_AGG_CONF_NORM, LT_ERR_INVALID, "lt_unproject_fwd: unknown aggregation %d", agg);
+    LT_REQUIRE((agg != LT_AGG_CONF && agg != LT_AGG_CONF_NORM) || conf, LT_ERR_INVALID, "lt_unproject_fwd: LT_AGG_CONF* needs confidences");
+    LT_REQUIRE(B >= 1 && NV >= 1 && C >= 1 && h >= 2 && w >= 2 && v0 >= 1 && v1 >= 1 && v2 >= 1, LT_ERR_INVALID, "lt_unproject_fwd: bad shape");
+    LT_REQUIRE((long long)NV * h * w * C < (1ll << 31), LT_ERR_UNSUPPORTED, "lt_unproject_fwd: feature maps too large");
+    UnprojArgs a;
+    a.feats = feats; a.proj = proj; a.coords = coords; a.conf = conf; a.out = out;
+    a.B = B; a.NV = NV; a.C = C; a.h = h; a.w = w; a.v0 = v0; a.v1 = v1; a.v2 = v2; a.agg = agg;
+    const long long nvox = (long long)v0 * v1 * v2;
+    a.bricked = (v0 % 4 == 0 && v1 % 4 == 0 && v2 % 16 == 0) ? 1 : 0;
+    a.chunks = (int)cdiv(nvox, 256);
+    a.xcd_pin = (B % 8 == 0) ? 1 : 0;
+    LT_REQUIRE((long long)B * a.chunks < (1ll << 31), LT_ERR_UNSUPPORTED, "lt_unproject_fwd: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LT_F32) {
+        if (C % 4 == 0) return launch_unproject<float, 4>(a, st);
+        return launch_unproject<float, 1>(a, st);
+    }
+    if (C % 8 == 0) return launch_unproject<bf16_t, 8>(a, st);
+    return launch_unproject<bf16_t, 1>(a, st);
+}
+
+namespace {
+__global__ void rotate_points_kernel(const float* __restrict__ x, const float* __restrict__ R, float* __restrict__ y, long long n) {
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (long long)gridDim.x * blockDim.x) {
+        const float a = x[g * 3], b = x[g * 3 + 1], c = x[g * 3 + 2];
+        y[g * 3] = fmaf(R[2], c, fmaf(R[1], b, __fmul_rn(R[0], a)));
+        y[g * 3 + 1] = fmaf(R[5], c, fmaf(R[4], b, __fmul_rn(R[3], a)));
+        y[g * 3 + 2] = fmaf(R[8], c, fmaf(R[7], b, __fmul_rn(R[6], a)));
+    }
+}
+}  // namespace
+
+extern "C" int lt_rotate_points(const float* x, const float* rot, float* y, int64_t n, void* stream) {
+    LT_REQUIRE(x && rot && y && n >= 1, LT_ERR_INVALID, "lt_rotate_points: bad argument");
+    const long long blocks = cdiv(n, 256);
+    hipLaunchKernelGGL(rotate_points_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, x, rot, y, (long long)n);
+    LT_CHECK_LAUNCH("lt_rotate_points");
+    return LT_OK;
+}

@@ -1,0 +1,337 @@
+"""Host-side execution engine: turns the reference-shaped nn.Module trees (parameter containers only)
+into a flat list of liblt_hip launches over preallocated channels-last buffers, captured once per
+input shape into a hipGraph and replayed.
+
+Everything numerical happens in liblt_hip.so.  This module only
+  * re-packs weights once per plan (k = tap*Cin + ci, zero padded), folds eval-mode BatchNorm and the
+    conv bias into per-channel scale/shift, and splits stride-2 transposed convs into parity phases;
+  * allocates activations (torch is the device allocator) with size-keyed reuse;
+  * issues the C-ABI calls on an explicit stream and owns the hipGraph.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+import lt_hip as H
+
+BN_EPS = 1e-5
+
+
+def cout_pad_of(cout):
+    """lt_conv_cout_pad (include/lt_hip.h) restated so that specs can be built without the library."""
+    if cout <= 16:
+        return 16
+    if cout <= 32:
+        return 32
+    if cout <= 64:
+        return 64
+    return (cout + 127) // 128 * 128
+
+
+def k_step_of(dtype):
+    return 32 if dtype == torch.float32 else 64  # elements per 128-byte K step
+
+
+def min_cin_of(dtype):
+    return 4 if dtype == torch.float32 else 8   # one 16-byte vector per pixel
+
+
+@dataclass
+class ConvPhaseSpec:
+    weight: torch.Tensor            # fp32 [cout_pad, k_pad]
+    taps: torch.Tensor              # int32 [ntaps, 4] = dd, dh, dw, element offset
+    out_off: Tuple[int, int, int]
+
+
+@dataclass
+class ConvSpec:
+    N: int; D: int; H: int; W: int; Cin: int
+    Do: int; Ho: int; Wo: int
+    stride: Tuple[int, int, int]; pad: Tuple[int, int, int]
+    OD: int; OH: int; OW: int
+    out_stride: Tuple[int, int, int]
+    Cout: int; cout_pad: int; k_pad: int
+    flags: int
+    scale: torch.Tensor             # fp32 [cout_pad]
+    shift: torch.Tensor             # fp32 [cout_pad]
+    phases: List[ConvPhaseSpec] = field(default_factory=list)
+
+
+def fold_bn(cout, bias, bn, cout_pad):
+    """Eval-mode BatchNorm (F.batch_norm, eps 1e-5) and conv bias -> y = acc*scale + shift.
+
+    bn = (gamma, beta, running_mean, running_var) or None.  fp64 on the host, stored fp32.
+    """
+    scale = torch.ones(cout, dtype=torch.float64)
+    shift = torch.zeros(cout, dtype=torch.float64)
+    if bias is not None:
+        shift = shift + bias.detach().double().cpu()
+    if bn is not None:
+        g, b, m, v = (t.detach().double().cpu() for t in bn)
+        s = g / torch.sqrt(v + BN_EPS)
+        shift = (shift - m) * s + b
+        scale = s
+    sc = torch.zeros(cout_pad, dtype=torch.float32); sc[:cout] = scale.float()
+    sh = torch.zeros(cout_pad, dtype=torch.float32); sh[:cout] = shift.float()
+    return sc, sh
+
+
+def _pad_k(wk, cout_pad, k_pad):
+    out = torch.zeros(cout_pad, k_pad, dtype=torch.float32)
+    out[:wk.shape[0], :wk.shape[1]] = wk
+    return out
+
+
+def make_conv_spec(weight, bias, bn, in_shape, stride, pad, dtype, transposed=False, flags=0):
+    """Build the lt_conv_fwd description of one (transposed) convolution layer.
+
+    weight: Conv{2,3}d [Cout,Cin,*k] or ConvTranspose{2,3}d [Cin,Cout,*k] (stride 2 only);
+    in_shape: (N, D, H, W, Cin_buffer) of the channels-last input (D = 1 for 2D; Cin_buffer >= Cin,
+    extra input channels get zero weights); stride/pad: ints or 3-tuples (d,h,w).
+    """
+    w = weight.detach().float().cpu()
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    N, D, Hh, W, cin_buf = in_shape
+    st = (stride,) * 3 if isinstance(stride, int) else tuple(stride)
+    pd = (pad,) * 3 if isinstance(pad, int) else tuple(pad)
+    if weight.dim() == 4:
+        st = (1, st[1], st[2]); pd = (0, pd[1], pd[2])
+    kstep = k_step_of(dtype)
+    if not transposed:
+        cout, cin, kd, kh, kw = w.shape
+        assert cin <= cin_buf
+        if cin < cin_buf:
+            w = torch.cat([w, torch.zeros(cout, cin_buf - cin, kd, kh, kw)], dim=1)
+        Do = (D + 2 * pd[0] - kd) // st[0] + 1
+        Ho = (Hh + 2 * pd[1] - kh) // st[1] + 1
+        Wo = (W + 2 * pd[2] - kw) // st[2] + 1
+        cp = cout_pad_of(cout)
+        K = kd * kh * kw * cin_buf
+        k_pad = (K + kstep - 1) // kstep * kstep
+        wk = w.permute(0, 2, 3, 4, 1).reshape(cout, K)
+        taps = [(a, b, c, ((a * Hh + b) * W + c) * cin_buf) for a in range(kd) for b in range(kh) for c in range(kw)]
+        sc, sh = fold_bn(cout, bias, bn, cp)
+        spec = ConvSpec(N, D, Hh, W, cin_buf, Do, Ho, Wo, st, pd, Do, Ho, Wo, (1, 1, 1), cout, cp, k_pad, flags, sc, sh)
+        spec.phases.append(ConvPhaseSpec(_pad_k(wk, cp, k_pad), torch.tensor(taps, dtype=torch.int32).reshape(-1, 4), (0, 0, 0)))
+        return spec
+    # ---- stride-2 transposed conv: one phase per output parity --------------------------------
+    cin, cout, kd, kh, kw = w.shape
+    assert cin == cin_buf, "transposed conv input may not be channel padded"
+    nd3 = weight.dim() == 5
+    assert all(s == 2 for s in (st if nd3 else st[1:])), "only stride-2 transposed convolutions"
+    ks = (kd, kh, kw)
+    dims = (D, Hh, W)
+    outs = []
+    for i in range(3):
+        if not nd3 and i == 0:
+            outs.append(1)
+        else:
+            o = (dims[i] - 1) * 2 - 2 * pd[i] + ks[i]
+            assert o == 2 * dims[i], "transposed conv must exactly double the size (k=4,p=1 or k=2,p=0)"
+            outs.append(o)
+    cp = cout_pad_of(cout)
+
+    def dim_phases(i):
+        if not nd3 and i == 0:
+            return [(0, [(0, 0)])]
+        res = []
+        for phi in (0, 1):  # o = 2q + phi = 2*i_in - p + kk  ->  kk = phi + p (mod 2), i_in = q + (phi + p - kk)/2
+            res.append((phi, [(kk, (phi + pd[i] - kk) // 2) for kk in range(ks[i]) if (phi + pd[i] - kk) % 2 == 0]))
+        return res
+
+    phase_list = []
+    ntaps_max = 0
+    for pa, ta in dim_phases(0):
+        for pb, tb in dim_phases(1):
+            for pc, tc in dim_phases(2):
+                taps, cols = [], []
+                for (ka, da) in ta:
+                    for (kb, db) in tb:
+                        for (kc, dc) in tc:
+                            taps.append((da, db, dc, ((da * Hh + db) * W + dc) * cin))
+                            cols.append(w[:, :, ka, kb, kc].t())  # [cout, cin]
+                wk = torch.cat(cols, dim=1)
+                phase_list.append((wk, taps, (pa, pb, pc)))
+                ntaps_max = max(ntaps_max, len(taps))
+    K = ntaps_max * cin
+    k_pad = (K + kstep - 1) // kstep * kstep
+    sc, sh = fold_bn(cout, bias, bn, cp)
+    ostr = (2 if nd3 else 1, 2, 2)
+    spec = ConvSpec(N, D, Hh, W, cin, D, Hh, W, (1, 1, 1), (0, 0, 0), outs[0], outs[1], outs[2], ostr, cout, cp, k_pad, flags, sc, sh)
+    for wk, taps, off in phase_list:
+        spec.phases.append(ConvPhaseSpec(_pad_k(wk, cp, k_pad), torch.tensor(taps, dtype=torch.int32).reshape(-1, 4), off))
+    assert len(spec.phases) <= H.MAX_PHASES
+    return spec
+
+
+class Act:
+    """A channels-last activation: tensor [N, D, H, W, C] (D == 1 for 2D maps)."""
+    __slots__ = ("t", "pooled")
+
+    def __init__(self, t):
+        self.t = t
+        self.pooled = True
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape)
+
+
+class PlanBuilder:
+    """Records liblt_hip launches; buffers are reused by exact byte size once released."""
+
+    def __init__(self, device, dtype, tile_override=0):
+        H.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("liblt_hip plans run on the GPU only (device=%s); there is no CPU fallback" % device)
+        self.dtype = dtype
+        self.code = H.dtype_code(dtype)
+        self.ops = []          # (callable, args)
+        self.keep = []         # tensors / ctypes objects that must outlive the plan
+        self.pool = {}         # nbytes -> [tensor]
+        self.tile_override = tile_override
+        self.flops = 0         # 2*MAC of the recorded convolutions
+        self.bytes_alloc = 0
+
+    # ---- memory ---------------------------------------------------------------------------
+    def alloc(self, shape, dtype=None):
+        dtype = dtype or self.dtype
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        lst = self.pool.get((n, dtype))
+        if lst:
+            t = lst.pop().view(*shape)
+        else:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.bytes_alloc += n
+        self.keep.append(t)
+        return Act(t)
+
+    def release(self, act):
+        """Hand a dead activation's storage back (stream order makes the reuse safe)."""
+        if act is None or not act.pooled:
+            return
+        t = act.t
+        n = t.numel() * t.element_size()
+        self.pool.setdefault((n, t.dtype), []).append(t.reshape(-1))
+
+    def const(self, t, dtype=None):
+        t = t.to(device=self.device, dtype=dtype or t.dtype).contiguous()
+        self.keep.append(t)
+        return t
+
+    # ---- ops ------------------------------------------------------------------------------
+    def _add(self, fn, kind="op", label="", flops=0, nbytes=0):
+        self.ops.append((fn, {"kind": kind, "label": label, "flops": flops, "bytes": nbytes}))
+
+    def conv(self, x, weight, bias=None, bn=None, stride=1, pad=0, transposed=False, relu=False, relu_pre=False,
+             residual=None, out_f32=False, out=None, sigmoid=False):
+        """x: Act.  Returns the output Act [N, OD, OH, OW, Cout]."""
+        flags = ((H.EPI_RELU_POST if relu else 0) | (H.EPI_RELU_PRE if relu_pre else 0) | (H.EPI_STORE_F32 if out_f32 else 0)
+                 | (H.EPI_SIGMOID if sigmoid else 0))
+        spec = make_conv_spec(weight, bias, bn, x.shape, stride, pad, self.dtype, transposed, flags)
+        y = out or self.alloc((spec.N, spec.OD, spec.OH, spec.OW, spec.Cout), torch.float32 if out_f32 else self.dtype)
+        if residual is not None:
+            assert residual.shape == y.shape and residual.t.dtype == self.dtype, (residual.shape, y.shape)
+        d = H.ConvDesc()
+        d.dtype = self.code
+        d.N, d.D, d.H, d.W, d.Cin = spec.N, spec.D, spec.H, spec.W, spec.Cin
+        d.Do, d.Ho, d.Wo = spec.Do, spec.Ho, spec.Wo
+        d.stride = H.i3(spec.stride); d.pad = H.i3(spec.pad)
+        d.OD, d.OH, d.OW = spec.OD, spec.OH, spec.OW
+        d.out_stride = H.i3(spec.out_stride)
+        d.Cout, d.ldc, d.cout_pad, d.k_pad = spec.Cout, spec.Cout, spec.cout_pad, spec.k_pad
+        d.nphase, d.flags, d.tile = len(spec.phases), spec.flags, self.tile_override
+        for i, ph in enumerate(spec.phases):
+            wdev = self.const(ph.weight, self.dtype)
+            tdev = self.const(ph.taps)
+            d.phase[i].weight = wdev.data_ptr(); d.phase[i].taps = tdev.data_ptr()
+            d.phase[i].ntaps = ph.taps.shape[0]; d.phase[i].out_off = H.i3(ph.out_off)
+        sc, sh = self.const(spec.scale), self.const(spec.shift)
+        self.keep.append(d)
+        macs = spec.N * spec.Do * spec.Ho * spec.Wo * spec.Cout * sum(int(p.taps.shape[0]) for p in spec.phases) * (
+            weight.shape[1] if not transposed else weight.shape[0])
+        self.flops += 2 * macs
+        lib = H.lib()
+        ksz = "x".join(str(k) for k in weight.shape[2:])
+        label = "%s%s %d->%d @%s" % ("deconv" if transposed else "conv", ksz, spec.Cin, spec.Cout,
+                                     "x".join(str(v) for v in (spec.N, spec.Do, spec.Ho, spec.Wo)))
+        esz = torch.empty((), dtype=self.dtype).element_size()
+        nbytes = (x.t.numel() + y.t.numel() + (residual.t.numel() if residual is not None else 0)) * esz + \
+            sum(p.weight.numel() for p in spec.phases) * esz
+        self._add(lambda s, d=d, xp=x.t.data_ptr(), scp=sc.data_ptr(), shp=sh.data_ptr(),
+                  rp=H.ptr(residual.t) if residual is not None else None, yp=y.t.data_ptr():
+                  H.check(lib.lt_conv_fwd(C.byref(d), xp, scp, shp, rp, yp, s), "lt_conv_fwd"),
+                  "conv", label, 2 * macs, nbytes)
+        return y
+
+    def maxpool(self, x, k, s, p, nd):
+        N, D, Hh, W, Cc = x.shape
+        kk = (1, k, k) if nd == 2 else (k, k, k)
+        ss = (1, s, s) if nd == 2 else (s, s, s)
+        pp = (0, p, p) if nd == 2 else (p, p, p)
+        od = [(dim + 2 * pp[i] - kk[i]) // ss[i] + 1 for i, dim in enumerate((D, Hh, W))]
+        y = self.alloc((N, od[0], od[1], od[2], Cc))
+        lib = H.lib()
+        self._add(lambda st, xp=x.t.data_ptr(), yp=y.t.data_ptr(), a=(N, D, Hh, W, Cc), kk=H.i3(kk), ss=H.i3(ss), pp=H.i3(pp):
+                  H.check(lib.lt_maxpool_fwd(self.code, xp, yp, a[0], a[1], a[2], a[3], a[4], kk, ss, pp, st), "lt_maxpool_fwd"),
+                  "maxpool", "maxpool%dd k%d @%s" % (nd, k, "x".join(map(str, x.shape))), 0,
+                  (x.t.numel() + y.t.numel()) * x.t.element_size())
+        return y
+
+    def global_avgpool(self, x):
+        """x: Act [N,1,H,W,C] -> Act [1,1,1,N,C] (a one-row 'image' of N pixels: feeds 1x1 convs = linears)."""
+        N, D, Hh, W, Cc = x.shape
+        y = self.alloc((1, 1, 1, N, Cc))
+        lib = H.lib()
+        self._add(lambda st, xp=x.t.data_ptr(), yp=y.t.data_ptr(), a=(N, D * Hh * W, Cc):
+                  H.check(lib.lt_global_avgpool(self.code, xp, yp, a[0], a[1], a[2], st), "lt_global_avgpool"), "avgpool", "global_avgpool")
+        return y
+
+    def custom(self, fn, kind="op", label="", flops=0, nbytes=0):
+        """fn(stream) -> None: any other liblt_hip launch; nbytes = its ALGORITHMIC HBM bytes (roofline numerator)."""
+        self._add(fn, kind, label or kind, flops, nbytes)
+
+    def finish(self):
+        return Plan(self.ops, self.keep, self.device, self.flops, self.bytes_alloc)
+
+
+class Plan:
+    def __init__(self, ops, keep, device, flops, bytes_alloc):
+        self.ops, self.keep, self.device = ops, keep, device
+        self.flops, self.bytes_alloc = flops, bytes_alloc
+        self.graph = None
+
+    def run_eager(self, stream):
+        for fn, _ in self.ops:
+            fn(stream)
+
+    def run_profiled(self, stream, reps=3):
+        """Eager launches with a hipEvent pair around EVERY op on `stream`; returns one record per op with the mean
+        duration in ms (kind, label, flops, bytes, ms).  Used by bench.py for the per-kernel roofline numbers."""
+        n = len(self.ops)
+        tot = [0.0] * n
+        for _ in range(reps):
+            evs = [(H.Event(), H.Event()) for _ in range(n)]
+            for (fn, _), (e0, e1) in zip(self.ops, evs):
+                e0.record(stream)
+                fn(stream)
+                e1.record(stream)
+            for i, (e0, e1) in enumerate(evs):
+                tot[i] += e0.elapsed_ms(e1)
+        return [dict(meta, ms=tot[i] / reps) for i, (_, meta) in enumerate(self.ops)]
+
+    def capture(self, stream):
+        g = H.Graph()
+        g.capture(stream, lambda: self.run_eager(stream))
+        self.graph = g
+
+    def run(self, stream):
+        if self.graph is not None:
+            self.graph.launch(stream)
+        else:
+            self.run_eager(stream)

@@ -1,0 +1,171 @@
+"""ctypes binding of liblt_hip.so (include/lt_hip.h).  PyTorch appears here only as the owner of device
+memory and streams: every function takes raw ``data_ptr()`` addresses and a ``hipStream_t``.
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "liblt_hip.so")
+
+LT_F32, LT_BF16 = 0, 1
+AGG = {"sum": 0, "max": 1, "softmax": 2, "conf": 3, "conf_norm": 4}
+EPI_RELU_PRE, EPI_RELU_POST, EPI_STORE_F32, EPI_SIGMOID = 1, 2, 4, 8
+TILE_AUTO, TILE_128x128, TILE_128x64, TILE_256x32, TILE_256x16, TILE_64x64, TILE_DIRECT = 0, 1, 2, 3, 4, 5, 99
+MAX_PHASES = 8
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class ConvPhase(C.Structure):
+    _fields_ = [("weight", vp), ("taps", vp), ("ntaps", i32), ("out_off", i32 * 3)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("N", i32), ("D", i32), ("H", i32), ("W", i32), ("Cin", i32),
+                ("Do", i32), ("Ho", i32), ("Wo", i32), ("stride", i32 * 3), ("pad", i32 * 3),
+                ("OD", i32), ("OH", i32), ("OW", i32), ("out_stride", i32 * 3),
+                ("Cout", i32), ("ldc", i32), ("cout_pad", i32), ("k_pad", i32),
+                ("nphase", i32), ("flags", i32), ("tile", i32), ("reserved", i32),
+                ("phase", ConvPhase * MAX_PHASES)]
+
+
+# symbol -> (restype, argtypes); must list every symbol include/lt_hip.h declares
+SIGNATURES = {
+    "lt_last_error": (C.c_char_p, []),
+    "lt_abi_version": (C.c_int, []),
+    "lt_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "lt_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
+    "lt_conv_cout_pad": (C.c_int, [i32]),
+    "lt_maxpool_fwd": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32 * 3, vp]),
+    "lt_global_avgpool": (C.c_int, [i32, vp, vp, i32, i32, i32, vp]),
+    "lt_nchw_to_nhwc": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, vp]),
+    "lt_nhwc_to_nchw_f32": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, vp]),
+    "lt_coord_volumes": (C.c_int, [vp, vp, vp, f32, i32, i32, i32, vp, vp]),
+    "lt_rotate_points": (C.c_int, [vp, vp, vp, i64, vp]),
+    "lt_unproject_fwd": (C.c_int, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "lt_softargmax3d_workspace": (C.c_size_t, [i32, i32, i64]),
+    "lt_softargmax3d_fwd": (C.c_int, [vp, vp, f32, i32, i32, i32, vp, vp, i32, i32, i64, vp, vp]),
+    "lt_softargmax2d_fwd": (C.c_int, [vp, f32, i32, vp, vp, i32, i32, i32, vp]),
+    "lt_triangulate_dlt": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "lt_graph_begin": (C.c_int, [vp]),
+    "lt_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
+    "lt_graph_launch": (C.c_int, [vp, vp]),
+    "lt_graph_destroy": (C.c_int, [vp]),
+    "lt_event_create": (C.c_int, [C.POINTER(vp)]),
+    "lt_event_record": (C.c_int, [vp, vp]),
+    "lt_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
+    "lt_event_destroy": (C.c_int, [vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it was never built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("liblt_hip.so is not built (%s): run `python __graft_entry__.py` (build()) first; "
+                               "there is no non-HIP fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        if l.lt_abi_version() != 1:
+            raise RuntimeError("liblt_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().lt_last_error()
+        raise RuntimeError("liblt_hip %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return LT_F32
+    if dt == torch.bfloat16:
+        return LT_BF16
+    raise TypeError("liblt_hip supports float32 and bfloat16 activations, got %s" % dt)
+
+
+def require_gpu(t, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: this package has no CPU path (device=%s)" % (name, t.device))
+
+
+def cur_stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def i3(a, b=None, c=None):
+    if b is None:
+        a, b, c = a
+    return (i32 * 3)(int(a), int(b), int(c))
+
+
+def device_info():
+    cu, lds = C.c_int(0), C.c_int(0)
+    buf = C.create_string_buffer(64)
+    check(lib().lt_device_info(C.byref(cu), C.byref(lds), buf, 64), "lt_device_info")
+    return {"cu_count": cu.value, "lds_per_cu": lds.value, "arch": buf.value.decode()}
+
+
+class Event:
+    """hipEvent on an explicit stream (torch.cuda.Event only sees torch's current stream)."""
+
+    def __init__(self):
+        h = vp()
+        check(lib().lt_event_create(C.byref(h)), "lt_event_create")
+        self.h = h
+
+    def record(self, stream=None):
+        check(lib().lt_event_record(self.h, cur_stream() if stream is None else stream), "lt_event_record")
+
+    def elapsed_ms(self, stop):
+        ms = f32(0)
+        check(lib().lt_event_elapsed_ms(self.h, stop.h, C.byref(ms)), "lt_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().lt_event_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Graph:
+    """A captured hipGraph of liblt_hip launches."""
+
+    def __init__(self):
+        self.exec = None
+
+    def capture(self, stream, fn):
+        check(lib().lt_graph_begin(stream), "lt_graph_begin")
+        try:
+            fn()
+        finally:
+            h = vp()
+            rc = lib().lt_graph_end(stream, C.byref(h))
+        check(rc, "lt_graph_end")
+        self.exec = h
+
+    def launch(self, stream):
+        check(lib().lt_graph_launch(self.exec, stream), "lt_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.exec is not None:
+                lib().lt_graph_destroy(self.exec)
+        except Exception:
+            pass

@@ -1,0 +1,277 @@
+"""Triangulation networks with the reference's surface (mvn/models/triangulation.py of the reference):
+
+    VolumetricTriangulationNet(config, device).forward(images, proj_matricies, batch)
+    AlgebraicTriangulationNet(config, device).forward(images, proj_matricies, batch)
+
+Same constructor side effects on ``config``, same ``state_dict()`` keys, same return tuples.  The whole
+forward is ONE recorded plan of liblt_hip launches per input shape, captured into a hipGraph:
+
+    images --lt_nchw_to_nhwc--> [graph: PoseResNet convs -> process_features 1x1 -> lt_coord_volumes ->
+    lt_unproject_fwd -> V2V convs -> lt_softargmax3d_fwd] --> outputs
+
+Host work per call is numpy fp64 camera algebra for B*NV 3x4 matrices (vectorised; the reference
+deep-copies B*NV Camera objects) and one small H2D copy of the geometry block.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import lt_engine as E
+import lt_hip as H
+from mvn.models import pose_resnet
+from mvn.models.v2v import V2VModel
+from mvn.utils import multiview, op, volumetric
+
+
+def _bn_in_train_mode(m):
+    return any(isinstance(c, nn.modules.batchnorm._BatchNorm) and c.training for c in m.modules())
+
+
+def _no_training(m):
+    if _bn_in_train_mode(m):
+        raise NotImplementedError("forward with BatchNorm in training mode (and backward) is not built yet "
+                                  "(SURVEY.md section 8f row 1); call model.eval()")
+
+
+class _PlannedNet(nn.Module):
+    """Shared plan cache: one recorded + graph-captured launch list per (shape, dtype, device)."""
+
+    def __init__(self):
+        super().__init__()
+        self.compute_dtype = torch.float32   # the reference's precision; torch.bfloat16 = throughput mode
+        self.use_graph = True
+        self.copy_outputs = True             # False: return views of plan-owned buffers (valid until the next forward)
+        self.tile_override = 0
+        self._plans = {}
+        self._stream = None
+        self.register_load_state_dict_post_hook(lambda m, k: m._plans.clear())
+
+    def set_compute_dtype(self, dtype):
+        H.dtype_code(dtype)
+        self.compute_dtype = dtype
+        return self
+
+    def invalidate_plans(self):
+        """Call after changing weights in place (load_state_dict does it automatically)."""
+        self._plans.clear()
+
+    def _side_stream(self, device):
+        if self._stream is None or self._stream.device != device:
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream
+
+
+class VolumetricTriangulationNet(_PlannedNet):
+    def __init__(self, config, device="cuda:0"):
+        super().__init__()
+        m = config.model
+        self.num_joints = m.backbone.num_joints
+        self.volume_aggregation_method = m.volume_aggregation_method
+        self.volume_softmax = m.volume_softmax
+        self.volume_multiplier = m.volume_multiplier
+        self.volume_size = m.volume_size
+        self.cuboid_side = m.cuboid_side
+        self.kind = m.kind
+        self.use_gt_pelvis = m.use_gt_pelvis
+        self.heatmap_softmax = m.heatmap_softmax
+        self.heatmap_multiplier = m.heatmap_multiplier
+        self.transfer_cmu_to_human36m = m.transfer_cmu_to_human36m if hasattr(m, "transfer_cmu_to_human36m") else False
+        if self.volume_aggregation_method not in H.AGG:
+            raise ValueError("Unknown volume_aggregation_method: {}".format(self.volume_aggregation_method))
+        # same config mutation as the reference (:228-231)
+        m.backbone.alg_confidences = False
+        m.backbone.vol_confidences = self.volume_aggregation_method.startswith("conf")
+        self.backbone = pose_resnet.get_pose_net(m.backbone, device=device)
+        for p in self.backbone.final_layer.parameters():
+            p.requires_grad = False
+        self.process_features = nn.Sequential(nn.Conv2d(256, 32, 1))
+        self.volume_net = V2VModel(32, self.num_joints)
+        if hasattr(m, "compute_dtype"):
+            self.compute_dtype = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+                                  "bfloat16": torch.bfloat16}[str(m.compute_dtype)]
+
+    # ---------------------------------------------------------------------------------------
+    def _build_plan(self, B, NV, Hh, W, device):
+        dt = self.compute_dtype
+        V, J = self.volume_size, self.num_joints
+        b = E.PlanBuilder(device, dt, self.tile_override)
+        lib = H.lib()
+        x_in = b.alloc((B * NV, 1, Hh, W, E.min_cin_of(dt)))
+        x_in.pooled = False
+        # the 1x1 heatmap head is dead in the volumetric path: only its SHAPE is used (reference :264)
+        _, feats256, _, volc = self.backbone.record(b, x_in, want_heatmaps=False)
+        pf = self.process_features[0]
+        feats = b.conv(feats256, pf.weight, pf.bias, None)
+        b.release(feats256)
+        feats.pooled = False
+        h, w = feats.shape[2], feats.shape[3]
+        # geometry block (fp32, one H2D copy per forward): proj B*NV*12 | pos B*3 | center B*3 | rot B*9
+        n_geo = B * NV * 12 + B * 15
+        geo = torch.zeros(n_geo, dtype=torch.float32, device=device)
+        geo_host = torch.zeros(n_geo, dtype=torch.float32).pin_memory()
+        o_pos, o_cen, o_rot = B * NV * 12, B * NV * 12 + 3 * B, B * NV * 12 + 6 * B
+        coords = torch.empty(B, V, V, V, 3, dtype=torch.float32, device=device)
+        step = float(np.float32(self.cuboid_side / (V - 1)))
+        gp = geo.data_ptr()
+        cmu = int(bool(self.transfer_cmu_to_human36m))
+        b.custom(lambda st: H.check(lib.lt_coord_volumes(gp + 4 * o_pos, gp + 4 * o_cen, gp + 4 * o_rot, step, B, V, cmu,
+                                                         coords.data_ptr(), st), "lt_coord_volumes"),
+                 "coord_volumes", nbytes=B * V ** 3 * 12)
+        conf = None
+        if volc is not None:
+            conf = volc.t.reshape(B, NV, 32)   # 'conf_norm' is normalised inside lt_unproject_fwd (LT_AGG_CONF_NORM)
+        vol = b.alloc((B, V, V, V, 32))
+        esz = torch.empty((), dtype=dt).element_size()
+        agg = H.AGG[self.volume_aggregation_method]
+        b.custom(lambda st: H.check(lib.lt_unproject_fwd(b.code, feats.t.data_ptr(), gp, coords.data_ptr(), H.ptr(conf), vol.t.data_ptr(),
+                                                         B, NV, 32, h, w, V, V, V, agg, st), "lt_unproject_fwd"),
+                 "unproject", nbytes=(B * NV * h * w * 32 + B * V ** 3 * 32) * esz)  # read feats once + write volume once
+        logits = self.volume_net.record(b, vol)
+        kp = torch.empty(B, J, 3, dtype=torch.float32, device=device)
+        probs = torch.empty(B, J, V, V, V, dtype=torch.float32, device=device)
+        ws = torch.empty(max(1, lib.lt_softargmax3d_workspace(B, J, V ** 3)), dtype=torch.uint8, device=device)
+        mult, sm = float(self.volume_multiplier), int(bool(self.volume_softmax))
+        b.custom(lambda st: H.check(lib.lt_softargmax3d_fwd(logits.t.data_ptr(), coords.data_ptr(), mult, sm, 1, J, kp.data_ptr(),
+                                                            probs.data_ptr(), B, J, V ** 3, ws.data_ptr(), st), "lt_softargmax3d_fwd"),
+                 "softargmax3d", nbytes=2 * B * J * V ** 3 * 4)  # read logits + write probabilities
+        plan = b.finish()
+        plan.keep += [geo, geo_host, coords, kp, probs, ws]
+        return {"plan": plan, "x_in": x_in, "feats": feats, "geo": geo, "geo_host": geo_host, "coords": coords, "kp": kp,
+                "probs": probs, "conf": conf, "logits": logits, "vol": vol, "hw": (h, w), "offs": (o_pos, o_cen, o_rot),
+                "captured": False}
+
+    # ---------------------------------------------------------------------------------------
+    def forward(self, images, proj_matricies, batch):
+        """images (B,NV,3,H,W) fp32 on the GPU; ``proj_matricies`` is ignored exactly as in the reference
+        (overwritten at :277); ``batch`` as built by datasets/utils.py:14-37 (``cameras``, and
+        ``pred_keypoints_3d`` or ``keypoints_3d``).  Returns the reference's 7-tuple (:355)."""
+        H.require_gpu(images, "images")
+        _no_training(self)
+        device = images.device
+        B, NV = images.shape[:2]
+        Hh, W = images.shape[3:]
+        key = (B, NV, Hh, W, self.compute_dtype, device, self.use_graph)
+        if key not in self._plans:
+            self._plans[key] = self._build_plan(B, NV, Hh, W, device)
+        P = self._plans[key]
+        h, w = P["hw"]
+        # ---- host geometry, numpy fp64 like the reference (:272-296, :318-328) ----
+        K, R, t = multiview.stack_cameras(batch["cameras"])
+        proj = multiview.resized_projections(K, R, t, (Hh, W), (h, w))
+        kp3d = batch["keypoints_3d"] if self.use_gt_pelvis else batch["pred_keypoints_3d"]
+        base = np.empty((B, 3), dtype=np.float64)
+        for i in range(B):
+            k3 = np.asarray(kp3d[i])
+            base[i] = (k3[11, :3] + k3[12, :3]) / 2 if self.kind == "coco" else k3[6, :3]
+        sides = np.array([self.cuboid_side] * 3)
+        position = base - sides / 2
+        axis = [0, 1, 0] if self.kind == "coco" else [0, 0, 1]
+        rot = np.empty((B, 9))
+        for i in range(B):
+            theta = np.random.uniform(0.0, 2 * np.pi) if self.training else 0.0
+            rot[i] = volumetric.get_rotation_matrix(axis, theta).reshape(-1)
+        o_pos, o_cen, o_rot = P["offs"]
+        gh = P["geo_host"]
+        gh[:o_pos] = torch.from_numpy(proj.astype(np.float32).reshape(-1))
+        gh[o_pos:o_cen] = torch.from_numpy(position.astype(np.float32).reshape(-1))
+        gh[o_cen:o_rot] = torch.from_numpy(base.astype(np.float32).reshape(-1))
+        gh[o_rot:] = torch.from_numpy(rot.astype(np.float32).reshape(-1))
+        # ---- device side ----
+        cur = torch.cuda.current_stream(device)
+        side = self._side_stream(device)
+        side.wait_stream(cur)
+        x = images.reshape(B * NV, 3, Hh, W)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        with torch.cuda.stream(side):
+            st = side.cuda_stream
+            P["geo"].copy_(gh, non_blocking=True)
+            H.check(H.lib().lt_nchw_to_nhwc(H.dtype_code(self.compute_dtype), x.data_ptr(), P["x_in"].t.data_ptr(), B * NV, 3, Hh * W,
+                                            P["x_in"].t.shape[-1], st), "lt_nchw_to_nhwc")
+            plan = P["plan"]
+            if self.use_graph and not P["captured"]:
+                plan.run_eager(st)          # warm-up launch outside capture (sets func attributes, loads code objects)
+                side.synchronize()
+                plan.capture(st)
+                P["captured"] = True
+            plan.run(st)
+            kp, probs, coords = P["kp"], P["probs"], P["coords"]
+            feats = P["feats"].t.reshape(B, NV, h, w, 32).permute(0, 1, 4, 2, 3)
+            conf = P["conf"]
+            if self.copy_outputs:
+                kp, probs, coords = kp.clone(), probs.clone(), coords.clone()
+                feats = feats.to(torch.float32, copy=True)
+                conf = None if conf is None else conf.clone()
+            if conf is not None and self.volume_aggregation_method == "conf_norm":
+                conf = conf / conf.sum(dim=1, keepdim=True)   # the RETURNED confidences are the normalised ones (reference :268-269, :355)
+        x.record_stream(side)
+        cur.wait_stream(side)
+        cuboids = [volumetric.Cuboid3D(position[i], sides) for i in range(B)]
+        base_points = torch.from_numpy(base.astype(np.float32)).to(device)
+        return kp, feats, probs, conf, cuboids, coords, base_points
+
+
+class AlgebraicTriangulationNet(_PlannedNet):
+    def __init__(self, config, device="cuda:0"):
+        super().__init__()
+        m = config.model
+        self.use_confidences = m.use_confidences
+        m.backbone.alg_confidences = bool(self.use_confidences)   # reference :137-141
+        m.backbone.vol_confidences = False
+        self.backbone = pose_resnet.get_pose_net(m.backbone, device=device)
+        self.heatmap_softmax = m.heatmap_softmax
+        self.heatmap_multiplier = m.heatmap_multiplier
+
+    def _build_plan(self, B, NV, Hh, W, device):
+        dt = self.compute_dtype
+        b = E.PlanBuilder(device, dt, self.tile_override)
+        lib = H.lib()
+        x_in = b.alloc((B * NV, 1, Hh, W, E.min_cin_of(dt)))
+        x_in.pooled = False
+        hm, feats, algc, _ = self.backbone.record(b, x_in, want_heatmaps=True)
+        b.release(feats)
+        N = B * NV
+        J, h, w = hm.shape[4], hm.shape[2], hm.shape[3]
+        hm_nchw = torch.empty(N, J, h, w, dtype=torch.float32, device=device)
+        b.custom(lambda st: H.check(lib.lt_nhwc_to_nchw_f32(H.LT_F32, hm.t.data_ptr(), hm_nchw.data_ptr(), N, J, h * w, J, st), "lt_nhwc_to_nchw_f32"))
+        kp2d = torch.empty(N, J, 2, dtype=torch.float32, device=device)
+        probs = torch.empty_like(hm_nchw)
+        mult, sm = float(self.heatmap_multiplier), int(bool(self.heatmap_softmax))
+        b.custom(lambda st: H.check(lib.lt_softargmax2d_fwd(hm_nchw.data_ptr(), mult, sm, kp2d.data_ptr(), probs.data_ptr(), N * J, h, w, st),
+                                    "lt_softargmax2d_fwd"))
+        plan = b.finish()
+        plan.keep += [hm_nchw, kp2d, probs]
+        return {"plan": plan, "x_in": x_in, "kp2d": kp2d, "probs": probs, "algc": algc, "hw": (h, w), "J": J}
+
+    def forward(self, images, proj_matricies, batch):
+        """Returns (keypoints_3d (B,J,3), keypoints_2d (B,NV,J,2) in image pixels, heatmaps (B,NV,J,h,w) after
+        softmax, alg_confidences (B,NV,J)) -- reference :149-200."""
+        H.require_gpu(images, "images")
+        _no_training(self)
+        device = images.device
+        B, NV = images.shape[:2]
+        Hh, W = images.shape[3:]
+        key = (B, NV, Hh, W, self.compute_dtype, device)
+        if key not in self._plans:
+            self._plans[key] = self._build_plan(B, NV, Hh, W, device)
+        P = self._plans[key]
+        h, w = P["hw"]; J = P["J"]
+        st = torch.cuda.current_stream(device).cuda_stream
+        x = images.reshape(B * NV, 3, Hh, W).float().contiguous()
+        H.check(H.lib().lt_nchw_to_nhwc(H.dtype_code(self.compute_dtype), x.data_ptr(), P["x_in"].t.data_ptr(), B * NV, 3, Hh * W,
+                                        P["x_in"].t.shape[-1], st), "lt_nchw_to_nhwc")
+        P["plan"].run_eager(st)
+        heatmaps = P["probs"].reshape(B, NV, J, h, w).clone()
+        kp2d = P["kp2d"].reshape(B, NV, J, 2)
+        if P["algc"] is not None:
+            conf = P["algc"].t.reshape(B, NV, J).float()
+        else:
+            conf = torch.ones(B, NV, J, dtype=torch.float32, device=device)
+        # tiny (B*NV*J) host-style glue, reference :173-184
+        conf = conf / conf.sum(dim=1, keepdim=True) + 1e-5
+        scale = torch.tensor([W / w, Hh / h], dtype=torch.float32, device=device)
+        kp2d = kp2d * scale
+        kp3d = multiview.triangulate_batch_of_points(proj_matricies.to(device), kp2d, confidences_batch=conf)
+        return kp3d, kp2d, heatmaps, conf

@@ -22,3 +22,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    try:
+        import gpu_util
+        if gpu_util.REPORT:
+            gpu_util.flush_report()
+    except Exception:
+        pass

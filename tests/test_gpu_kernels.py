@@ -1,0 +1,250 @@
+"""GPU (-m gpu): every liblt_hip kernel, called through the C ABI, against a plain torch-CPU fp32 statement of
+the same op (floating-point kernels) and against the committed reference outputs (tests/golden).
+
+Tolerances (max|d| / max|ref|): fp32 kernels 2e-5 (accumulation-order noise over K <= 11k terms); bf16 kernels are
+compared with the fp32 op evaluated on bf16-rounded operands, 1.5e-2 (output rounding 2^-8 + fp32 accumulation)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import lt_engine as E
+import lt_hip as H
+from gpu_util import bf16_round, check, from_cl, record, rel_err, to_cl
+from oracle import vol_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TILES = {"auto": 0, "128x128": 1, "128x64": 2, "256x32": 3, "256x16": 4, "64x64": 5, "direct": 99}
+
+
+def _bn(c, g):
+    return (0.5 + torch.rand(c, generator=g), torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1, 0.5 + torch.rand(c, generator=g))
+
+
+def _bn_ref(x, bn):
+    return F.batch_norm(x, bn[2], bn[3], bn[0], bn[1], False, 0.1, 1e-5)
+
+
+def run_conv(x, w, bias, bn, stride, pad, dtype, tile, transposed=False, relu=False, relu_pre=False, residual=None, cin_pad=None):
+    nd = x.dim() - 2
+    b = E.PlanBuilder(DEV, dtype, tile_override=tile)
+    xa = E.Act(to_cl(x, cin_pad, dtype))
+    ra = None if residual is None else E.Act(to_cl(residual, None, dtype))
+    y = b.conv(xa, w, bias, bn, stride=stride, pad=pad, transposed=transposed, relu=relu, relu_pre=relu_pre, residual=ra)
+    b.finish().run_eager(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return from_cl(y.t, nd)
+
+
+CONV_CASES = {
+    # name: (nd, N, cin, cout, k, stride, pad, spatial)
+    "c2d_3x3_64_128": (2, 2, 64, 128, 3, 1, 1, (20, 24)),
+    "c2d_1x1_256_64": (2, 2, 256, 64, 1, 1, 0, (17, 19)),
+    "c2d_3x3s2_32_192": (2, 1, 32, 192, 3, 2, 1, (23, 21)),
+    "c2d_1x1s2_64_256": (2, 2, 64, 256, 1, 2, 0, (16, 18)),
+    "c3d_3x3_16_32": (3, 1, 16, 32, 3, 1, 1, (9, 10, 12)),
+    "c3d_3x3_32_32": (3, 2, 32, 32, 3, 1, 1, (8, 8, 8)),
+    "c3d_7x7_32_16": (3, 1, 32, 16, 7, 1, 3, (10, 9, 12)),
+    "c3d_1x1_32_17": (3, 1, 32, 17, 1, 1, 0, (8, 9, 10)),
+    "c3d_3x3_128_128_tiny": (3, 1, 128, 128, 3, 1, 1, (2, 2, 2)),
+}
+
+
+def _tiles_for(cout):
+    cp = E.cout_pad_of(cout)
+    t = ["auto", "direct"]
+    if cp % 128 == 0:
+        t += ["128x128", "128x64", "64x64", "256x32", "256x16"]
+    elif cp == 64:
+        t += ["128x64", "64x64", "256x32", "256x16"]
+    elif cp == 32:
+        t += ["256x32", "256x16"]
+    else:
+        t += ["256x16"]
+    return t
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", list(CONV_CASES))
+def test_conv_all_tiles(case, dtype):
+    nd, N, cin, cout, k, s, p, sp = CONV_CASES[case]
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(N, cin, *sp, generator=g)
+    w = torch.randn(cout, cin, *([k] * nd), generator=g) * (1.0 / (cin * k ** nd) ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    bn = _bn(cout, g)
+    conv = F.conv2d if nd == 2 else F.conv3d
+    if dtype == torch.bfloat16:
+        xr, wr = bf16_round(x), bf16_round(w)
+    else:
+        xr, wr = x, w
+    pre = _bn_ref(conv(xr, wr, bias, s, p), bn)
+    res = torch.randn(pre.shape, generator=g)
+    resr = bf16_round(res) if dtype == torch.bfloat16 else res
+    ref = torch.relu(pre + resr)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    for tname in _tiles_for(cout):
+        out = run_conv(x, w, bias, bn, s, p, dtype, TILES[tname], relu=True, residual=res)
+        check("conv/%s/%s/%s" % (case, "f32" if dtype == torch.float32 else "bf16", tname), out, ref, tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_stem_conv_padded_channels(dtype):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 3, 37, 41, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    bn = _bn(64, g)
+    xr, wr = (bf16_round(x), bf16_round(w)) if dtype == torch.bfloat16 else (x, w)
+    ref = torch.relu(_bn_ref(F.conv2d(xr, wr, None, 2, 3), bn))
+    for tname in ("auto", "128x64", "64x64", "direct"):
+        out = run_conv(x, w, None, bn, 2, 3, dtype, TILES[tname], relu=True, cin_pad=E.min_cin_of(dtype))
+        check("stem/%s/%s" % ("f32" if dtype == torch.float32 else "bf16", tname), out, ref, 2e-5 if dtype == torch.float32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_transposed_convs(dtype):
+    g = torch.Generator().manual_seed(8)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    rd = (lambda t: bf16_round(t)) if dtype == torch.bfloat16 else (lambda t: t)
+    # ConvTranspose2d 4x4 s2 p1 + BN + ReLU (pose_resnet deconv_layers)
+    x = torch.randn(2, 64, 6, 7, generator=g); w = torch.randn(64, 256, 4, 4, generator=g) * 0.05; bn = _bn(256, g)
+    ref = torch.relu(_bn_ref(F.conv_transpose2d(rd(x), rd(w), None, 2, 1), bn))
+    for tname in ("auto", "128x128", "64x64", "direct"):
+        check("deconv2d/%s/%s" % (dtype, tname), run_conv(x, w, None, bn, 2, 1, dtype, TILES[tname], transposed=True, relu=True), ref, tol)
+    # ConvTranspose3d 2^3 s2 + BN + ReLU, then + skip (v2v Upsample3DBlock)
+    x = torch.randn(1, 128, 4, 4, 4, generator=g); w = torch.randn(128, 64, 2, 2, 2, generator=g) * 0.1
+    bias = torch.randn(64, generator=g) * 0.1; bn = _bn(64, g); skip = torch.randn(1, 64, 8, 8, 8, generator=g)
+    ref = torch.relu(_bn_ref(F.conv_transpose3d(rd(x), rd(w), bias, 2), bn)) + rd(skip)
+    for tname in ("auto", "128x64", "64x64", "direct"):
+        check("deconv3d/%s/%s" % (dtype, tname),
+              run_conv(x, w, bias, bn, 2, 0, dtype, TILES[tname], transposed=True, relu_pre=True, residual=skip), ref, tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_pool_layout_avgpool(dtype):
+    g = torch.Generator().manual_seed(9)
+    lib = H.lib(); st = torch.cuda.current_stream().cuda_stream; code = H.dtype_code(dtype)
+    rd = (lambda t: bf16_round(t)) if dtype == torch.bfloat16 else (lambda t: t)
+    b = E.PlanBuilder(DEV, dtype)
+    x = torch.randn(2, 64, 19, 23, generator=g)
+    y = b.maxpool(E.Act(to_cl(x, None, dtype)), 3, 2, 1, nd=2)
+    x3 = torch.randn(1, 32, 6, 8, 10, generator=g)
+    y3 = b.maxpool(E.Act(to_cl(x3, None, dtype)), 2, 2, 0, nd=3)
+    ga = b.global_avgpool(E.Act(to_cl(x, None, dtype)))
+    b.finish().run_eager(st); torch.cuda.synchronize()
+    check("maxpool2d/%s" % dtype, from_cl(y.t, 2), F.max_pool2d(rd(x), 3, 2, 1), 0.0)
+    check("maxpool3d/%s" % dtype, from_cl(y3.t, 3), F.max_pool3d(rd(x3), 2, 2), 0.0)
+    check("avgpool/%s" % dtype, ga.t.float().cpu().reshape(2, 64), rd(x).mean(dim=(2, 3)), 1e-6 if dtype == torch.float32 else 4e-3)
+    # image layout transform: N,3,H,W fp32 -> N,H,W,cpad
+    img = torch.randn(3, 3, 10, 12, generator=g).to(DEV)
+    cpad = E.min_cin_of(dtype)
+    out = torch.empty(3, 10, 12, cpad, dtype=dtype, device=DEV)
+    H.check(lib.lt_nchw_to_nhwc(code, img.data_ptr(), out.data_ptr(), 3, 3, 120, cpad, st))
+    torch.cuda.synchronize()
+    exp = torch.zeros(3, 10, 12, cpad); exp[..., :3] = rd(img.cpu()).permute(0, 2, 3, 1)
+    check("nchw_to_nhwc/%s" % dtype, out.float().cpu(), exp, 0.0)
+    src = torch.randn(2, 70, 17, generator=g).to(DEV, dtype)  # N,HW,C
+    dst = torch.empty(2, 17, 70, dtype=torch.float32, device=DEV)
+    H.check(lib.lt_nhwc_to_nchw_f32(code, src.data_ptr(), dst.data_ptr(), 2, 17, 70, 17, st))
+    torch.cuda.synchronize()
+    check("nhwc_to_nchw/%s" % dtype, dst.cpu(), src.float().cpu().permute(0, 2, 1), 0.0)
+
+
+def test_coord_volumes_bit_exact_and_rotated(golden_dir):
+    from mvn.utils import op, volumetric
+    base = np.array([[30.0, -20.0, 10.0], [-100.123, 50.5, 80.25], [1234.5, -987.6, 55.5]])
+    for V in (8, 64):
+        out = op.build_coord_volumes(base, 2500.0, V, device=DEV).cpu()
+        ref = torch.stack([O.coord_volume(base[b], 2500.0, V) for b in range(3)])
+        check("coord_volumes/eval/V%d (bit exact)" % V, out, ref, 0.0)
+    th = [0.3, 1.7, -2.2]
+    out = op.build_coord_volumes(base, 2500.0, 16, thetas=th, axis=(0, 1, 0), device=DEV).cpu()
+    ref = torch.stack([O.coord_volume(base[b], 2500.0, 16, th[b], (0, 1, 0)) for b in range(3)])
+    check("coord_volumes/rotated", out, ref, 2e-7)
+    out = op.build_coord_volumes(base, 2500.0, 8, cmu_transfer=True, device=DEV).cpu()
+    ref = torch.stack([O.coord_volume(base[b], 2500.0, 8, cmu_transfer=True) for b in range(3)])
+    check("coord_volumes/cmu (bit exact)", out, ref, 0.0)
+    g = np.load(os.path.join(golden_dir, "ops.npz"))
+    check("coord_volumes/golden theta=0.9", op.build_coord_volumes(g["cv_base"][None], 2500.0, 8, thetas=[0.9], device=DEV)[0].cpu(), g["cv_ref"], 2e-7)
+    x = torch.randn(5, 7, 3)
+    check("rotate_coord_volume", volumetric.rotate_coord_volume(x.to(DEV), 0.7, [1, 2, 3]).cpu(),
+          (torch.from_numpy(O.rotation_matrix([1, 2, 3], 0.7)).float() @ x.reshape(-1, 3).t()).t().reshape(5, 7, 3), 1e-6)
+
+
+@pytest.mark.parametrize("C", [32, 8, 5])
+@pytest.mark.parametrize("method", ["sum", "max", "softmax", "conf"])
+def test_unproject_vs_reference_golden(golden_dir, C, method):
+    """Reference outputs of op.unproject_heatmaps: non-square maps (h/w swap quirk), a camera inside the cube (z <= 0
+    mask), out-of-frame voxels (zero padding).  Gate 1e-5 * max|ref| (pixel coordinates ~50 carry fp32 rounding 4e-6)."""
+    from mvn.utils import op
+    g = np.load(os.path.join(golden_dir, "ops.npz"))
+    hm = torch.from_numpy(g["unproj_hm_C%d" % C]).to(DEV); conf = torch.from_numpy(g["unproj_cin_C%d" % C]).to(DEV)
+    P = torch.from_numpy(g["unproj_P"]).to(DEV); cv = torch.from_numpy(g["unproj_cv"]).to(DEV)
+    out = op.unproject_heatmaps(hm, P, cv, method, conf)
+    assert out.shape == (2, C, 7, 7, 7)
+    check("unproject/golden/%s/C%d" % (method, C), out.cpu(), g["unproj_%s_C%d" % (method, C)], 1e-5)
+    if C % 8 == 0:
+        outb = op.unproject_heatmaps(hm.bfloat16(), P, cv, method, conf)
+        refb = O.unproject_heatmaps(bf16_round(hm.cpu()), P.cpu(), cv.cpu(), method, conf.cpu())
+        check("unproject/bf16/%s/C%d" % (method, C), outb.float().cpu(), refb, 1e-2)
+
+
+def test_unproject_bricks_xcd_pin_many_views():
+    """Bricked voxel order (V=16), XCD-pinned sample mapping (B=8) and the NV>8 path, against the oracle."""
+    from mvn.utils import op
+    g = torch.Generator().manual_seed(11)
+    for B, NV, V in ((8, 3, 16), (3, 9, 16), (1, 4, 32)):
+        K, R, t = __import__("oracle.synth", fromlist=["x"]).ring_cameras(NV, 96, inside=(NV == 3))
+        P = torch.from_numpy(O.resized_projection(K, R, t, (96, 96), (24, 24))).float()[None].repeat(B, 1, 1, 1).contiguous()
+        hm = torch.randn(B, NV, 32, 24, 24, generator=g)
+        base = torch.randn(B, 3, generator=g).numpy() * 100
+        cv = torch.stack([O.coord_volume(base[b], 2500.0, V, 0.2 * b) for b in range(B)])
+        for method in ("softmax", "max"):
+            out = op.unproject_heatmaps(hm.to(DEV), P.to(DEV), cv.to(DEV), method)
+            check("unproject/B%d_NV%d_V%d/%s" % (B, NV, V, method), out.cpu(), O.unproject_heatmaps(hm, P, cv, method), 1e-5)
+    # raises like the reference for an unknown method (op.py:164)
+    with pytest.raises(ValueError, match="Unknown volume_aggregation_method: bogus"):
+        op.unproject_heatmaps(hm.to(DEV), P.to(DEV), cv.to(DEV), "bogus")
+
+
+def test_softargmax_and_dlt_vs_reference_golden(golden_dir):
+    from mvn.utils import multiview, op
+    g = np.load(os.path.join(golden_dir, "ops.npz"))
+    vols = torch.from_numpy(g["int3d_in"]).to(DEV); cvs = torch.from_numpy(g["int3d_cv"]).to(DEV)
+    for sm in (True, False):
+        for layout in ("joint_major", "channels_last"):
+            v = vols if layout == "joint_major" else vols.permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+            c, p = op.integrate_tensor_3d_with_coordinates(v, cvs, softmax=sm)
+            check("integrate3d/%s/softmax=%d/coords" % (layout, sm), c.cpu(), g["int3d_coords_%d" % sm], 5e-6)
+            check("integrate3d/%s/softmax=%d/volumes" % (layout, sm), p.cpu(), g["int3d_vols_%d" % sm], 5e-6)
+        c, h = op.integrate_tensor_2d(torch.from_numpy(g["int2d_in"]).to(DEV), softmax=sm)
+        check("integrate2d/softmax=%d/coords" % sm, c.cpu(), g["int2d_coords_%d" % sm], 5e-6)
+        check("integrate2d/softmax=%d/heatmaps" % sm, h.cpu(), g["int2d_hm_%d" % sm], 5e-6)
+    P, pts, conf = (torch.from_numpy(g[k]).to(DEV) for k in ("dlt_P", "dlt_pts", "dlt_conf"))
+    # the reference's own fp32 SVD carries ~1e-6*cond error: compare at 1e-3 like the oracle pin, and against the
+    # exactly known 3D points for the noise-free sample
+    check("dlt/conf", multiview.triangulate_batch_of_points(P, pts, conf).cpu(), g["dlt_out"], 1e-3)
+    check("dlt/noconf", multiview.triangulate_batch_of_points(P, pts).cpu(), g["dlt_out_noconf"], 1e-3)
+    check("dlt/known_answer", multiview.triangulate_batch_of_points(P, pts, conf)[0].cpu(), g["dlt_X"], 1e-5)
+
+
+def test_softargmax3d_large_sharp():
+    """64^3 volume, 17 joints, logits std 5 (the 'sharpened' regime), both layouts."""
+    from mvn.utils import op
+    g = torch.Generator().manual_seed(13)
+    lg = torch.randn(2, 17, 64, 64, 64, generator=g) * 5
+    cv = torch.stack([O.coord_volume(np.array([10.0 * b, -20.0, 30.0]), 2500.0, 64) for b in range(2)])
+    rc, rv = O.integrate_tensor_3d_with_coordinates(lg.double(), cv.double())
+    for layout in ("joint_major", "channels_last"):
+        v = lg.to(DEV)
+        if layout == "channels_last":
+            v = v.permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+        c, p = op.integrate_tensor_3d_with_coordinates(v, cv.to(DEV))
+        rel = ((c.cpu().double() - rc).abs() / rc.abs().clamp(min=1.0)).max()
+        record("integrate3d/64^3 sharp/%s coords max rel (1mm floor)" % layout, float(rel))
+        assert float(rel) < 2e-5
+        check("integrate3d/64^3 sharp/%s volumes" % layout, p.cpu(), rv, 1e-5)
+        assert float((p.sum(dim=(2, 3, 4)) - 1).abs().max()) < 1e-4

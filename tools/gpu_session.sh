@@ -1,0 +1,49 @@
+#!/bin/bash
+# One GPU-box session: parity tests, bench, rocprofv3 kernel trace.  Usage (from the repo root on the GPU box):
+#   bash tools/gpu_session.sh [tests] [bench] [prof] [pmc]
+# Everything is written under gpurun_out/ (merged back by gpurun); each stage is time-boxed.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd $R
+export PYTHONDONTWRITEBYTECODE=1
+STAGES="${@:-tests bench prof}"
+echo "== stages: $STAGES" | tee $OUT/session.log
+rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9" | head -4 | tee -a $OUT/session.log
+nproc | tee -a $OUT/session.log
+for s in $STAGES; do
+case $s in
+tests)
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider > $OUT/test_kernels.log 2>&1
+  echo "kernels rc=$?" | tee -a $OUT/session.log; tail -5 $OUT/test_kernels.log | tee -a $OUT/session.log
+  timeout 1200 python -m pytest tests/test_gpu_models.py -m gpu -q --tb=short -p no:cacheprovider > $OUT/test_models.log 2>&1
+  echo "models rc=$?" | tee -a $OUT/session.log; tail -5 $OUT/test_models.log | tee -a $OUT/session.log
+  ;;
+smoke)
+  timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/session.log; tail -3 $OUT/smoke.log | tee -a $OUT/session.log
+  ;;
+bench)
+  timeout 900 python bench.py --ops-json $OUT/bench_ops_bf16.json > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
+  echo "bench bf16 rc=$?" | tee -a $OUT/session.log; cat $OUT/bench_bf16.json | tee -a $OUT/session.log; tail -3 $OUT/bench_bf16.err
+  timeout 900 python bench.py --dtype fp32 --steps 5 --warmup 2 --no-cpu-baseline --ops-json $OUT/bench_ops_fp32.json > $OUT/bench_fp32.json 2> $OUT/bench_fp32.err
+  echo "bench fp32 rc=$?" | tee -a $OUT/session.log; cat $OUT/bench_fp32.json | tee -a $OUT/session.log; tail -3 $OUT/bench_fp32.err
+  ;;
+prof)
+  cd /tmp; export TMPDIR=/tmp
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $OUT/prof_bench.json 2> $OUT/prof.err
+  echo "prof rc=$?" | tee -a $OUT/session.log
+  cd $R
+  find $OUT/prof -name "*stats*" | head | tee -a $OUT/session.log
+  ;;
+pmc)
+  cd /tmp; export TMPDIR=/tmp
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-graph > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+  echo "pmc fetch rc=$?" | tee -a $OUT/session.log
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-graph > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+  echo "pmc write rc=$?" | tee -a $OUT/session.log
+  cd $R
+  ;;
+esac
+done
+ls -la $OUT | tee -a $OUT/session.log
