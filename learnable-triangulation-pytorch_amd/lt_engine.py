@@ -184,11 +184,15 @@ class Act:
 class PlanBuilder:
     """Records liblt_hip launches; buffers are reused by exact byte size once released."""
 
-    def __init__(self, device, dtype, tile_override=0):
-        H.lib()
+    def __init__(self, device, dtype, tile_override=0, dry_run=False):
+        """dry_run=True records the plan over CPU tensors WITHOUT being able to execute it (Plan.run raises): the CPU
+        test-suite uses it to check the recorded wiring / buffer reuse with an interpreter that lives in tests/."""
         self.device = torch.device(device)
-        if self.device.type != "cuda":
+        self.dry_run = dry_run
+        if self.device.type != "cuda" and not dry_run:
             raise RuntimeError("liblt_hip plans run on the GPU only (device=%s); there is no CPU fallback" % device)
+        if not dry_run:
+            H.lib()
         self.dtype = dtype
         self.code = H.dtype_code(dtype)
         self.ops = []          # (callable, args)
@@ -225,8 +229,11 @@ class PlanBuilder:
         return t
 
     # ---- ops ------------------------------------------------------------------------------
-    def _add(self, fn, kind="op", label="", flops=0, nbytes=0):
-        self.ops.append((fn, {"kind": kind, "label": label, "flops": flops, "bytes": nbytes}))
+    def _add(self, fn, kind="op", label="", flops=0, nbytes=0, info=None):
+        meta = {"kind": kind, "label": label, "flops": flops, "bytes": nbytes}
+        if self.dry_run:
+            meta["info"] = info or {}
+        self.ops.append((fn, meta))
 
     def conv(self, x, weight, bias=None, bn=None, stride=1, pad=0, transposed=False, relu=False, relu_pre=False,
              residual=None, out_f32=False, out=None, sigmoid=False):
@@ -256,7 +263,7 @@ class PlanBuilder:
         macs = spec.N * spec.Do * spec.Ho * spec.Wo * spec.Cout * sum(int(p.taps.shape[0]) for p in spec.phases) * (
             weight.shape[1] if not transposed else weight.shape[0])
         self.flops += 2 * macs
-        lib = H.lib()
+        lib = None if self.dry_run else H.lib()
         ksz = "x".join(str(k) for k in weight.shape[2:])
         label = "%s%s %d->%d @%s" % ("deconv" if transposed else "conv", ksz, spec.Cin, spec.Cout,
                                      "x".join(str(v) for v in (spec.N, spec.Do, spec.Ho, spec.Wo)))
@@ -266,7 +273,7 @@ class PlanBuilder:
         self._add(lambda s, d=d, xp=x.t.data_ptr(), scp=sc.data_ptr(), shp=sh.data_ptr(),
                   rp=H.ptr(residual.t) if residual is not None else None, yp=y.t.data_ptr():
                   H.check(lib.lt_conv_fwd(C.byref(d), xp, scp, shp, rp, yp, s), "lt_conv_fwd"),
-                  "conv", label, 2 * macs, nbytes)
+                  "conv", label, 2 * macs, nbytes, {"spec": spec, "x": x, "y": y, "res": residual})
         return y
 
     def maxpool(self, x, k, s, p, nd):
@@ -276,37 +283,41 @@ class PlanBuilder:
         pp = (0, p, p) if nd == 2 else (p, p, p)
         od = [(dim + 2 * pp[i] - kk[i]) // ss[i] + 1 for i, dim in enumerate((D, Hh, W))]
         y = self.alloc((N, od[0], od[1], od[2], Cc))
-        lib = H.lib()
+        lib = None if self.dry_run else H.lib()
         self._add(lambda st, xp=x.t.data_ptr(), yp=y.t.data_ptr(), a=(N, D, Hh, W, Cc), kk=H.i3(kk), ss=H.i3(ss), pp=H.i3(pp):
                   H.check(lib.lt_maxpool_fwd(self.code, xp, yp, a[0], a[1], a[2], a[3], a[4], kk, ss, pp, st), "lt_maxpool_fwd"),
                   "maxpool", "maxpool%dd k%d @%s" % (nd, k, "x".join(map(str, x.shape))), 0,
-                  (x.t.numel() + y.t.numel()) * x.t.element_size())
+                  (x.t.numel() + y.t.numel()) * x.t.element_size(), {"x": x, "y": y, "k": kk, "s": ss, "p": pp})
         return y
 
     def global_avgpool(self, x):
         """x: Act [N,1,H,W,C] -> Act [1,1,1,N,C] (a one-row 'image' of N pixels: feeds 1x1 convs = linears)."""
         N, D, Hh, W, Cc = x.shape
         y = self.alloc((1, 1, 1, N, Cc))
-        lib = H.lib()
+        lib = None if self.dry_run else H.lib()
         self._add(lambda st, xp=x.t.data_ptr(), yp=y.t.data_ptr(), a=(N, D * Hh * W, Cc):
-                  H.check(lib.lt_global_avgpool(self.code, xp, yp, a[0], a[1], a[2], st), "lt_global_avgpool"), "avgpool", "global_avgpool")
+                  H.check(lib.lt_global_avgpool(self.code, xp, yp, a[0], a[1], a[2], st), "lt_global_avgpool"), "avgpool", "global_avgpool",
+                  info={"x": x, "y": y})
         return y
 
-    def custom(self, fn, kind="op", label="", flops=0, nbytes=0):
+    def custom(self, fn, kind="op", label="", flops=0, nbytes=0, info=None):
         """fn(stream) -> None: any other liblt_hip launch; nbytes = its ALGORITHMIC HBM bytes (roofline numerator)."""
-        self._add(fn, kind, label or kind, flops, nbytes)
+        self._add(fn, kind, label or kind, flops, nbytes, info)
 
     def finish(self):
-        return Plan(self.ops, self.keep, self.device, self.flops, self.bytes_alloc)
+        return Plan(self.ops, self.keep, self.device, self.flops, self.bytes_alloc, self.dry_run)
 
 
 class Plan:
-    def __init__(self, ops, keep, device, flops, bytes_alloc):
+    def __init__(self, ops, keep, device, flops, bytes_alloc, dry_run=False):
         self.ops, self.keep, self.device = ops, keep, device
         self.flops, self.bytes_alloc = flops, bytes_alloc
         self.graph = None
+        self.dry_run = dry_run
 
     def run_eager(self, stream):
+        if self.dry_run:
+            raise RuntimeError("a dry-run plan cannot execute: liblt_hip runs on the GPU only")
         for fn, _ in self.ops:
             fn(stream)
 

@@ -93,11 +93,11 @@ class VolumetricTriangulationNet(_PlannedNet):
                                   "bfloat16": torch.bfloat16}[str(m.compute_dtype)]
 
     # ---------------------------------------------------------------------------------------
-    def _build_plan(self, B, NV, Hh, W, device):
+    def _build_plan(self, B, NV, Hh, W, device, dry_run=False):
         dt = self.compute_dtype
         V, J = self.volume_size, self.num_joints
-        b = E.PlanBuilder(device, dt, self.tile_override)
-        lib = H.lib()
+        b = E.PlanBuilder(device, dt, self.tile_override, dry_run=dry_run)
+        lib = None if dry_run else H.lib()
         x_in = b.alloc((B * NV, 1, Hh, W, E.min_cin_of(dt)))
         x_in.pooled = False
         # the 1x1 heatmap head is dead in the volumetric path: only its SHAPE is used (reference :264)
@@ -110,7 +110,9 @@ class VolumetricTriangulationNet(_PlannedNet):
         # geometry block (fp32, one H2D copy per forward): proj B*NV*12 | pos B*3 | center B*3 | rot B*9
         n_geo = B * NV * 12 + B * 15
         geo = torch.zeros(n_geo, dtype=torch.float32, device=device)
-        geo_host = torch.zeros(n_geo, dtype=torch.float32).pin_memory()
+        geo_host = torch.zeros(n_geo, dtype=torch.float32)
+        if not dry_run:
+            geo_host = geo_host.pin_memory()
         o_pos, o_cen, o_rot = B * NV * 12, B * NV * 12 + 3 * B, B * NV * 12 + 6 * B
         coords = torch.empty(B, V, V, V, 3, dtype=torch.float32, device=device)
         step = float(np.float32(self.cuboid_side / (V - 1)))
@@ -118,7 +120,7 @@ class VolumetricTriangulationNet(_PlannedNet):
         cmu = int(bool(self.transfer_cmu_to_human36m))
         b.custom(lambda st: H.check(lib.lt_coord_volumes(gp + 4 * o_pos, gp + 4 * o_cen, gp + 4 * o_rot, step, B, V, cmu,
                                                          coords.data_ptr(), st), "lt_coord_volumes"),
-                 "coord_volumes", nbytes=B * V ** 3 * 12)
+                 "coord_volumes", nbytes=B * V ** 3 * 12, info={"geo": geo, "offs": (o_pos, o_cen, o_rot), "step": step, "cmu": cmu, "coords": coords})
         conf = None
         if volc is not None:
             conf = volc.t.reshape(B, NV, 32)   # 'conf_norm' is normalised inside lt_unproject_fwd (LT_AGG_CONF_NORM)
@@ -127,39 +129,29 @@ class VolumetricTriangulationNet(_PlannedNet):
         agg = H.AGG[self.volume_aggregation_method]
         b.custom(lambda st: H.check(lib.lt_unproject_fwd(b.code, feats.t.data_ptr(), gp, coords.data_ptr(), H.ptr(conf), vol.t.data_ptr(),
                                                          B, NV, 32, h, w, V, V, V, agg, st), "lt_unproject_fwd"),
-                 "unproject", nbytes=(B * NV * h * w * 32 + B * V ** 3 * 32) * esz)  # read feats once + write volume once
+                 "unproject", nbytes=(B * NV * h * w * 32 + B * V ** 3 * 32) * esz,  # read feats once + write volume once
+                 info={"feats": feats, "geo": geo, "coords": coords, "conf": conf, "vol": vol, "agg": self.volume_aggregation_method, "NV": NV})
         logits = self.volume_net.record(b, vol)
         kp = torch.empty(B, J, 3, dtype=torch.float32, device=device)
         probs = torch.empty(B, J, V, V, V, dtype=torch.float32, device=device)
-        ws = torch.empty(max(1, lib.lt_softargmax3d_workspace(B, J, V ** 3)), dtype=torch.uint8, device=device)
+        ws = torch.empty(1 if dry_run else max(1, lib.lt_softargmax3d_workspace(B, J, V ** 3)), dtype=torch.uint8, device=device)
         mult, sm = float(self.volume_multiplier), int(bool(self.volume_softmax))
         b.custom(lambda st: H.check(lib.lt_softargmax3d_fwd(logits.t.data_ptr(), coords.data_ptr(), mult, sm, 1, J, kp.data_ptr(),
                                                             probs.data_ptr(), B, J, V ** 3, ws.data_ptr(), st), "lt_softargmax3d_fwd"),
-                 "softargmax3d", nbytes=2 * B * J * V ** 3 * 4)  # read logits + write probabilities
+                 "softargmax3d", nbytes=2 * B * J * V ** 3 * 4,  # read logits + write probabilities
+                 info={"logits": logits, "coords": coords, "mult": mult, "softmax": sm, "kp": kp, "probs": probs})
         plan = b.finish()
         plan.keep += [geo, geo_host, coords, kp, probs, ws]
         return {"plan": plan, "x_in": x_in, "feats": feats, "geo": geo, "geo_host": geo_host, "coords": coords, "kp": kp,
                 "probs": probs, "conf": conf, "logits": logits, "vol": vol, "hw": (h, w), "offs": (o_pos, o_cen, o_rot),
                 "captured": False}
 
-    # ---------------------------------------------------------------------------------------
-    def forward(self, images, proj_matricies, batch):
-        """images (B,NV,3,H,W) fp32 on the GPU; ``proj_matricies`` is ignored exactly as in the reference
-        (overwritten at :277); ``batch`` as built by datasets/utils.py:14-37 (``cameras``, and
-        ``pred_keypoints_3d`` or ``keypoints_3d``).  Returns the reference's 7-tuple (:355)."""
-        H.require_gpu(images, "images")
-        _no_training(self)
-        device = images.device
-        B, NV = images.shape[:2]
-        Hh, W = images.shape[3:]
-        key = (B, NV, Hh, W, self.compute_dtype, device, self.use_graph)
-        if key not in self._plans:
-            self._plans[key] = self._build_plan(B, NV, Hh, W, device)
-        P = self._plans[key]
+    def _host_geometry(self, batch, B, image_shape, P):
+        """numpy fp64 camera / cuboid algebra of the reference (:272-296, :318-328), vectorised; fills the plan's pinned
+        geometry block (fp32: projections, cuboid origins, centres, rotations).  Returns (position, base, sides)."""
         h, w = P["hw"]
-        # ---- host geometry, numpy fp64 like the reference (:272-296, :318-328) ----
         K, R, t = multiview.stack_cameras(batch["cameras"])
-        proj = multiview.resized_projections(K, R, t, (Hh, W), (h, w))
+        proj = multiview.resized_projections(K, R, t, image_shape, (h, w))
         kp3d = batch["keypoints_3d"] if self.use_gt_pelvis else batch["pred_keypoints_3d"]
         base = np.empty((B, 3), dtype=np.float64)
         for i in range(B):
@@ -178,6 +170,24 @@ class VolumetricTriangulationNet(_PlannedNet):
         gh[o_pos:o_cen] = torch.from_numpy(position.astype(np.float32).reshape(-1))
         gh[o_cen:o_rot] = torch.from_numpy(base.astype(np.float32).reshape(-1))
         gh[o_rot:] = torch.from_numpy(rot.astype(np.float32).reshape(-1))
+        return position, base, sides
+
+    # ---------------------------------------------------------------------------------------
+    def forward(self, images, proj_matricies, batch):
+        """images (B,NV,3,H,W) fp32 on the GPU; ``proj_matricies`` is ignored exactly as in the reference
+        (overwritten at :277); ``batch`` as built by datasets/utils.py:14-37 (``cameras``, and
+        ``pred_keypoints_3d`` or ``keypoints_3d``).  Returns the reference's 7-tuple (:355)."""
+        H.require_gpu(images, "images")
+        _no_training(self)
+        device = images.device
+        B, NV = images.shape[:2]
+        Hh, W = images.shape[3:]
+        key = (B, NV, Hh, W, self.compute_dtype, device, self.use_graph)
+        if key not in self._plans:
+            self._plans[key] = self._build_plan(B, NV, Hh, W, device)
+        P = self._plans[key]
+        h, w = P["hw"]
+        position, base, sides = self._host_geometry(batch, B, (Hh, W), P)
         # ---- device side ----
         cur = torch.cuda.current_stream(device)
         side = self._side_stream(device)
@@ -187,7 +197,7 @@ class VolumetricTriangulationNet(_PlannedNet):
             x = x.float().contiguous()
         with torch.cuda.stream(side):
             st = side.cuda_stream
-            P["geo"].copy_(gh, non_blocking=True)
+            P["geo"].copy_(P["geo_host"], non_blocking=True)
             H.check(H.lib().lt_nchw_to_nhwc(H.dtype_code(self.compute_dtype), x.data_ptr(), P["x_in"].t.data_ptr(), B * NV, 3, Hh * W,
                                             P["x_in"].t.shape[-1], st), "lt_nchw_to_nhwc")
             plan = P["plan"]

@@ -50,3 +50,55 @@ def emulate_conv(spec, x, residual=None):
         y[sl] = v
     assert not torch.isnan(y).any(), "phases do not cover the output"
     return y
+
+
+def run_plan_on_cpu(plan):
+    """Interpret a DRY-RUN plan (lt_engine.PlanBuilder(dry_run=True)) on the CPU: convolutions through emulate_conv,
+    the other ops through plain torch / the oracle.  Executes ops in recorded order over the recorded (aliasing!) buffers,
+    so wiring and buffer-reuse mistakes show up as wrong numbers."""
+    import torch.nn.functional as F
+    from oracle import vol_oracle as O
+    assert plan.dry_run
+    for _, meta in plan.ops:
+        kind, info = meta["kind"], meta["info"]
+        if kind == "conv":
+            res = None if info["res"] is None else info["res"].t.float().clone()
+            out = emulate_conv(info["spec"], info["x"].t.float().clone(), res)
+            info["y"].t.copy_(out)
+        elif kind == "maxpool":
+            x = info["x"].t.float().permute(0, 4, 1, 2, 3)
+            y = F.max_pool3d(x, tuple(info["k"]), tuple(info["s"]), tuple(info["p"]))
+            info["y"].t.copy_(y.permute(0, 2, 3, 4, 1))
+        elif kind == "avgpool":
+            x = info["x"].t.float()
+            info["y"].t.copy_(x.mean(dim=(1, 2, 3)).reshape(info["y"].t.shape))
+        elif kind == "coord_volumes":
+            o_pos, o_cen, o_rot = info["offs"]
+            geo = info["geo"]
+            B, V = info["coords"].shape[0], info["coords"].shape[1]
+            pos = geo[o_pos:o_cen].reshape(B, 3); cen = geo[o_cen:o_rot].reshape(B, 3); rot = geo[o_rot:].reshape(B, 3, 3)
+            idx = torch.arange(V, dtype=torch.float32)
+            for b in range(B):
+                ax = [pos[b, i] + torch.tensor(info["step"]) * idx for i in range(3)]
+                grid = torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1)
+                g = (rot[b] @ (grid - cen[b]).reshape(-1, 3).t()).t().reshape(V, V, V, 3) + cen[b]
+                if info["cmu"]:
+                    g = g.permute(0, 2, 1, 3).flip(1)
+                info["coords"][b] = g
+        elif kind == "unproject":
+            f = info["feats"].t.float()
+            NV = info["NV"]; B = f.shape[0] // NV
+            hm = f.reshape(B, NV, f.shape[2], f.shape[3], f.shape[4]).permute(0, 1, 4, 2, 3)
+            P = info["geo"][:B * NV * 12].reshape(B, NV, 3, 4)
+            conf = info["conf"]
+            agg = info["agg"]
+            if agg == "conf_norm":
+                conf = conf / conf.sum(dim=1, keepdim=True)
+            out = O.unproject_heatmaps(hm, P, info["coords"], "conf" if agg.startswith("conf") else agg, conf)
+            info["vol"].t.copy_(out.permute(0, 2, 3, 4, 1))
+        elif kind == "softargmax3d":
+            lg = info["logits"].t.float().permute(0, 4, 1, 2, 3) * info["mult"]
+            kp, pr = O.integrate_tensor_3d_with_coordinates(lg, info["coords"], bool(info["softmax"]))
+            info["kp"].copy_(kp); info["probs"].copy_(pr)
+        else:
+            raise KeyError(kind)

@@ -114,8 +114,7 @@ def test_volumetric_forward_vs_reference_golden(golden_dir, tag):
     if out2 is not None:
         assert torch.equal(out2[0], kp) and torch.equal(out2[2], vols)
     logits = P["logits"].t.permute(0, 4, 1, 2, 3).float().cpu()
-    if not c["rotate"]:
-        check(tag + "/v2v logits", _sub(logits, s), g["logits_sub"], 2e-4)
+    check(tag + "/v2v logits", _sub(logits, s), g["logits_sub"], 2e-4)
 
 
 @pytest.mark.parametrize("tag", ["small_softmax", "c2_sharp", "c2_default"])

@@ -1,0 +1,53 @@
+"""CPU: record the WHOLE volumetric forward as a dry-run plan (no GPU, nothing executes in liblt_hip) and interpret it
+with tests/emul.py: checks the recorded network wiring, residual/skip routing, transposed-conv phases, BN folding and the
+size-keyed buffer reuse against the oracle.  What remains for the GPU suite is kernel == contract."""
+import numpy as np
+import pytest
+import torch
+
+from emul import run_plan_on_cpu
+from oracle import spec, synth
+from oracle import vol_oracle as O
+
+
+def _cameras(inp, B):
+    from mvn.utils.multiview import Camera
+    return [[Camera(inp["R"][v], inp["t"][v], inp["K"][v]) for _ in range(B)] for v in range(inp["K"].shape[0])]
+
+
+@pytest.mark.parametrize("nl,method,kind,Himg", [(18, "softmax", "mpii", 64), (50, "conf_norm", "coco", 128)])
+def test_recorded_plan_matches_oracle(nl, method, kind, Himg):
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    B, NV, V = 2, 2, 32
+    cfg = synth.vol_config(nl, V, method, kind=kind)
+    sd = synth.make_state_dict(spec.vol_net_spec(nl, 17, method.startswith("conf")), seed=31, sharpen=True, basic_block=(nl < 50))
+    inp = synth.make_inputs(B, NV, Himg, seed=31)
+    m = VolumetricTriangulationNet(cfg, device="cpu")
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    P = m._build_plan(B, NV, Himg, Himg, "cpu", dry_run=True)
+    with pytest.raises(RuntimeError):
+        P["plan"].run_eager(None)
+    batch = {"cameras": _cameras(inp, B), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+    m.training = True            # random theta (children stay in eval mode)
+    np.random.seed(5)
+    thetas = np.random.uniform(0.0, 2 * np.pi, size=B)
+    np.random.seed(5)
+    position, base, sides = m._host_geometry(batch, B, (Himg, Himg), P)
+    P["geo"].copy_(P["geo_host"])
+    x = inp["images"].reshape(B * NV, 3, Himg, Himg).permute(0, 2, 3, 1)
+    P["x_in"].t.zero_()
+    P["x_in"].t[:, 0, :, :, :3] = x
+    run_plan_on_cpu(P["plan"])
+    o = O.volumetric_forward(sd, cfg, inp["images"], inp["K"], inp["R"], inp["t"], inp["pred_keypoints_3d"], thetas=thetas, stages=True)
+    h, w = P["hw"]
+    feats = P["feats"].t.reshape(B, NV, h, w, 32).permute(0, 1, 4, 2, 3)
+    rel = lambda a, r: float((a.double() - r.double()).abs().max() / r.double().abs().max())
+    assert rel(P["coords"], o["coord_volumes"]) < 1e-6
+    assert rel(feats, o["features"]) < 2e-5
+    assert rel(P["logits"].t.permute(0, 4, 1, 2, 3), o["logits"]) < 1e-4
+    assert rel(P["probs"], o["volumes"]) < 1e-3
+    d = (P["kp"] - o["keypoints_3d"]).abs() / o["keypoints_3d"].abs().clamp(min=1.0)
+    assert float(d.max()) < 1e-4, float(d.max())
+    assert np.allclose(base, O.base_points_from_batch(inp["pred_keypoints_3d"], kind))
+    assert P["plan"].flops > 0 and len(P["plan"].ops) > 50
