@@ -1,0 +1,86 @@
+// Shared pieces of the implicit-GEMM convolution kernels (conv_igemm.hip = register-staged v1,
+// conv_igemm2.hip = LDS-DMA staged v2 with the LDS-transposed vector epilogue).
+#pragma once
+#include "lt_common.h"
+
+namespace lt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct PhaseArg {
+    const void* w;
+    const int4* taps;
+    int ntaps;
+    int ood, ooh, oow;
+};
+
+struct ConvArgs {
+    const void* x;
+    void* y;
+    const void* res;
+    const float* scale;
+    const float* shift;
+    int N, D, H, W, Cin, log2Cin;
+    int Do, Ho, Wo;
+    int sd, sh, sw, pd, ph, pw;
+    int OD, OH, OW, osd, osh, osw;
+    int Cout, ldc, k_pad, flags;
+    int M;        // N*Do*Ho*Wo
+    int tiles_n;  // cout_pad / BN
+    PhaseArg phase[LT_CONV_MAX_PHASES];
+};
+
+union V16 {
+    uint4 u;
+    f32x4 f;
+    bf16x8 h;
+};
+
+template <typename T, int MF> struct Mma;
+template <> struct Mma<float, 32> {
+    typedef f32x16 acc_t;
+    static __device__ __forceinline__ void run(acc_t& c, const V16& a, const V16& b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[e], b.f[e], c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float, 16> {
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ void run(acc_t& c, const V16& a, const V16& b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[e], b.f[e], c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16_t, 32> {
+    typedef f32x16 acc_t;
+    static __device__ __forceinline__ void run(acc_t& c, const V16& a, const V16& b) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16_t, 16> {
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ void run(acc_t& c, const V16& a, const V16& b) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+    }
+};
+
+// decode a GEMM row into (sample, od, oh, ow)
+__device__ __forceinline__ void decode_row(const ConvArgs& a, int m, int& n, int& od, int& oh, int& ow) {
+    int hw = a.Ho * a.Wo;
+    int dhw = a.Do * hw;
+    n = m / dhw;
+    int r = m - n * dhw;
+    od = r / hw;
+    r -= od * hw;
+    oh = r / a.Wo;
+    ow = r - oh * a.Wo;
+}
+
+constexpr int ROW_BYTES = 128;  // K bytes per tile row per step
+
+// launchers implemented in conv_igemm2.hip, used by the dispatcher in conv_igemm.hip
+int conv2_dispatch(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile, hipStream_t s);
+
+}  // namespace lt

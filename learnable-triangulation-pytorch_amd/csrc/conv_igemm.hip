@@ -16,86 +16,14 @@
 // vectors for BOTH dtypes: bf16 feeds one v_mfma_f32_32x32x16_bf16 (16x16x32) per vector pair,
 // fp32 feeds four v_mfma_f32_32x32x2_f32 (16x16x4) from the vector's four lanes-worth of k (the k
 // order inside a step is permuted identically for A and B, which leaves the dot product unchanged).
-#include "lt_common.h"
+#include <stdlib.h>
+
+#include "conv_common.h"
 
 using namespace lt;
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-struct PhaseArg {
-    const void* w;
-    const int4* taps;
-    int ntaps;
-    int ood, ooh, oow;
-};
-
-struct ConvArgs {
-    const void* x;
-    void* y;
-    const void* res;
-    const float* scale;
-    const float* shift;
-    int N, D, H, W, Cin, log2Cin;
-    int Do, Ho, Wo;
-    int sd, sh, sw, pd, ph, pw;
-    int OD, OH, OW, osd, osh, osw;
-    int Cout, ldc, k_pad, flags;
-    int M;        // N*Do*Ho*Wo
-    int tiles_n;  // cout_pad / BN
-    PhaseArg phase[LT_CONV_MAX_PHASES];
-};
-
-union V16 {
-    uint4 u;
-    f32x4 f;
-    bf16x8 h;
-};
-
-template <typename T, int MF> struct Mma;
-template <> struct Mma<float, 32> {
-    typedef f32x16 acc_t;
-    static __device__ __forceinline__ void run(acc_t& c, const V16& a, const V16& b) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[e], b.f[e], c, 0, 0, 0);
-    }
-};
-template <> struct Mma<float, 16> {
-    typedef f32x4 acc_t;
-    static __device__ __forceinline__ void run(acc_t& c, const V16& a, const V16& b) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[e], b.f[e], c, 0, 0, 0);
-    }
-};
-template <> struct Mma<bf16_t, 32> {
-    typedef f32x16 acc_t;
-    static __device__ __forceinline__ void run(acc_t& c, const V16& a, const V16& b) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
-    }
-};
-template <> struct Mma<bf16_t, 16> {
-    typedef f32x4 acc_t;
-    static __device__ __forceinline__ void run(acc_t& c, const V16& a, const V16& b) {
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
-    }
-};
-
-// decode a GEMM row into (sample, od, oh, ow)
-__device__ __forceinline__ void decode_row(const ConvArgs& a, int m, int& n, int& od, int& oh, int& ow) {
-    int hw = a.Ho * a.Wo;
-    int dhw = a.Do * hw;
-    n = m / dhw;
-    int r = m - n * dhw;
-    od = r / hw;
-    r -= od * hw;
-    oh = r / a.Wo;
-    ow = r - oh * a.Wo;
-}
-
-constexpr int ROW_BYTES = 128;  // K bytes per row per step
 
 template <typename T, int BM, int BN, int WM, int WN, int MF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
@@ -334,12 +262,14 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
         LT_CHECK_LAUNCH("lt_conv_fwd(direct)");
         return LT_OK;
     }
+    static const bool force_v1 = getenv("LT_CONV_V1") != nullptr;   // A/B switch for profiling sessions
+    if ((tile == LT_TILE_AUTO && !force_v1) || (tile >= LT_TILE2_128x128 && tile <= LT_TILE2_64x64))
+        return conv2_dispatch(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, max_taps, tile, s);
     if (tile == LT_TILE_AUTO) {
         if (cout_pad <= 16) tile = LT_TILE_256x16;
         else if (cout_pad <= 32) tile = LT_TILE_256x32;
         else if (cout_pad <= 64) tile = LT_TILE_128x64;
         else tile = LT_TILE_128x128;
-        // small problems: more, smaller blocks
         if (cout_pad >= 64 && cdiv(a.M, 128) * cdiv(cout_pad, 128) < 192) tile = LT_TILE_64x64;
     }
     switch (tile) {

@@ -11,7 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liblt_hip.so")
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# -ffp-contract=off: a*b+c is two roundings unless the source says fmaf() -- HIP's __fmul_rn/__fadd_rn are plain operators that
+# the compiler would otherwise fuse, which breaks the bit-exact coordinate grid (and makes results depend on inlining)
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=off"]
 
 
 def _hipcc():
@@ -29,7 +31,7 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "lt_common.h"), os.path.join(HERE, "..", "include", "lt_hip.h")]
+    deps = sources() + [os.path.join(CSRC, "lt_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(HERE, "..", "include", "lt_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

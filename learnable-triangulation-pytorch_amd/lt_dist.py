@@ -1,0 +1,67 @@
+"""Multi-GPU plumbing: one process per GPU, launched by ``torch.distributed.run``; backend "nccl" (= RCCL over xGMI
+on ROCm) on GPUs, "gloo" in the CPU tests.
+
+The forward path shards by SAMPLE (one sample = NV views -> one skeleton): ranks own disjoint
+slices of the batch and exchange nothing on the data path.  The only collectives are the barrier that brackets the
+timed region and the MAX-reduce of the per-rank elapsed time.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (no-op for a single process).
+    Returns (world, rank, local_rank)."""
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC, needed by RCCL on this driver
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
+    return world, rank, local
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    """MAX of a python float over all ranks (the step time the job is judged on is the slowest rank's)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device="cpu"):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def shard_samples(n_samples, rank, world):
+    """Indices of the samples rank ``rank`` owns: r, r+world, r+2*world, ... (the reference's DistributedSampler
+    striding, train.py:68).  Shards are disjoint and cover range(n_samples)."""
+    return list(range(rank, n_samples, world))
+
+
+def job_throughput(samples_this_rank, elapsed_this_rank, device="cpu"):
+    """Whole-job samples/s = (samples processed by ALL ranks) / (MAX elapsed over ranks)."""
+    total = sum_over_ranks(samples_this_rank, device)
+    t = max_over_ranks(elapsed_this_rank, device)
+    return total / t, total, t
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

@@ -242,6 +242,9 @@ class PlanBuilder:
                  | (H.EPI_SIGMOID if sigmoid else 0))
         spec = make_conv_spec(weight, bias, bn, x.shape, stride, pad, self.dtype, transposed, flags)
         y = out or self.alloc((spec.N, spec.OD, spec.OH, spec.OW, spec.Cout), torch.float32 if out_f32 else self.dtype)
+        self.keep.append(x.t)   # the launch closure holds raw pointers only
+        if residual is not None:
+            self.keep.append(residual.t)
         if residual is not None:
             assert residual.shape == y.shape and residual.t.dtype == self.dtype, (residual.shape, y.shape)
         d = H.ConvDesc()
@@ -283,6 +286,7 @@ class PlanBuilder:
         pp = (0, p, p) if nd == 2 else (p, p, p)
         od = [(dim + 2 * pp[i] - kk[i]) // ss[i] + 1 for i, dim in enumerate((D, Hh, W))]
         y = self.alloc((N, od[0], od[1], od[2], Cc))
+        self.keep.append(x.t)
         lib = None if self.dry_run else H.lib()
         self._add(lambda st, xp=x.t.data_ptr(), yp=y.t.data_ptr(), a=(N, D, Hh, W, Cc), kk=H.i3(kk), ss=H.i3(ss), pp=H.i3(pp):
                   H.check(lib.lt_maxpool_fwd(self.code, xp, yp, a[0], a[1], a[2], a[3], a[4], kk, ss, pp, st), "lt_maxpool_fwd"),
@@ -294,6 +298,7 @@ class PlanBuilder:
         """x: Act [N,1,H,W,C] -> Act [1,1,1,N,C] (a one-row 'image' of N pixels: feeds 1x1 convs = linears)."""
         N, D, Hh, W, Cc = x.shape
         y = self.alloc((1, 1, 1, N, Cc))
+        self.keep.append(x.t)
         lib = None if self.dry_run else H.lib()
         self._add(lambda st, xp=x.t.data_ptr(), yp=y.t.data_ptr(), a=(N, D * Hh * W, Cc):
                   H.check(lib.lt_global_avgpool(self.code, xp, yp, a[0], a[1], a[2], st), "lt_global_avgpool"), "avgpool", "global_avgpool",

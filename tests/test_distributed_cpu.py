@@ -1,0 +1,63 @@
+"""CPU, world_size 2, gloo: the N > 1 path of bench.py -- sample sharding with no data-path collective, the barrier,
+and the MAX-over-ranks timing / whole-job aggregation (lt_dist.py)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "learnable-triangulation-pytorch_amd")
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, PKG)
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import lt_dist
+    w, r, l = lt_dist.init("gloo")
+    assert (w, r, l) == (world, rank, rank)
+    mine = lt_dist.shard_samples(11, r, w)
+    # every rank "processes" its own samples: the result of a sample must not depend on the rank that owns it
+    gen = lambda i: torch.Generator().manual_seed(100 + i)
+    res = {i: float(torch.randn(4, generator=gen(i)).sum()) for i in mine}
+    lt_dist.barrier()
+    elapsed = 0.5 + 0.25 * r                       # rank 1 is the slow one
+    thr, total, t = lt_dist.job_throughput(len(mine), elapsed)
+    q.put((r, mine, res, thr, total, t, lt_dist.max_over_ranks(r), lt_dist.sum_over_ranks(1)))
+    lt_dist.barrier()
+    lt_dist.shutdown()
+
+
+def test_two_rank_sharding_and_timing():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, m0, res0, thr0, tot0, t0, mx0, sm0), (r1, m1, res1, thr1, tot1, t1, mx1, sm1) = got
+    assert sorted(m0 + m1) == list(range(11)) and not set(m0) & set(m1)      # disjoint cover
+    assert m0 == [0, 2, 4, 6, 8, 10] and m1 == [1, 3, 5, 7, 9]
+    assert tot0 == tot1 == 11 and t0 == t1 == 0.75 and thr0 == thr1 == pytest.approx(11 / 0.75)   # whole job / slowest rank
+    assert mx0 == mx1 == 1.0 and sm0 == sm1 == 2.0
+    single = {i: float(torch.randn(4, generator=torch.Generator().manual_seed(100 + i)).sum()) for i in range(11)}
+    assert {**res0, **res1} == single                                                 # sharded == unsharded, sample by sample
+
+
+def test_single_process_is_a_noop():
+    sys.path.insert(0, PKG)
+    import lt_dist
+    assert lt_dist.max_over_ranks(3.5) == 3.5 and lt_dist.shard_samples(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert lt_dist.job_throughput(8, 2.0) == (4.0, 8.0, 2.0)
+    lt_dist.barrier()

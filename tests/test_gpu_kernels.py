@@ -17,7 +17,8 @@ from oracle import vol_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TILES = {"auto": 0, "128x128": 1, "128x64": 2, "256x32": 3, "256x16": 4, "64x64": 5, "direct": 99}
+TILES = {"auto": 0, "128x128": 1, "128x64": 2, "256x32": 3, "256x16": 4, "64x64": 5, "direct": 99,
+         "v2_128x128": 11, "v2_128x64": 12, "v2_256x32": 13, "v2_256x16": 14, "v2_64x64": 15}
 
 
 def _bn(c, g):
@@ -55,16 +56,15 @@ CONV_CASES = {
 
 def _tiles_for(cout):
     cp = E.cout_pad_of(cout)
-    t = ["auto", "direct"]
     if cp % 128 == 0:
-        t += ["128x128", "128x64", "64x64", "256x32", "256x16"]
+        t = ["128x128", "128x64", "64x64", "256x32", "256x16"]
     elif cp == 64:
-        t += ["128x64", "64x64", "256x32", "256x16"]
+        t = ["128x64", "64x64", "256x32", "256x16"]
     elif cp == 32:
-        t += ["256x32", "256x16"]
+        t = ["256x32", "256x16"]
     else:
-        t += ["256x16"]
-    return t
+        t = ["256x16"]
+    return ["auto", "direct"] + t + ["v2_" + n for n in t]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -99,7 +99,7 @@ def test_stem_conv_padded_channels(dtype):
     bn = _bn(64, g)
     xr, wr = (bf16_round(x), bf16_round(w)) if dtype == torch.bfloat16 else (x, w)
     ref = torch.relu(_bn_ref(F.conv2d(xr, wr, None, 2, 3), bn))
-    for tname in ("auto", "128x64", "64x64", "direct"):
+    for tname in ("auto", "128x64", "64x64", "v2_128x64", "v2_64x64", "v2_256x16", "direct"):
         out = run_conv(x, w, None, bn, 2, 3, dtype, TILES[tname], relu=True, cin_pad=E.min_cin_of(dtype))
         check("stem/%s/%s" % ("f32" if dtype == torch.float32 else "bf16", tname), out, ref, 2e-5 if dtype == torch.float32 else 1.5e-2)
 
@@ -112,13 +112,13 @@ def test_transposed_convs(dtype):
     # ConvTranspose2d 4x4 s2 p1 + BN + ReLU (pose_resnet deconv_layers)
     x = torch.randn(2, 64, 6, 7, generator=g); w = torch.randn(64, 256, 4, 4, generator=g) * 0.05; bn = _bn(256, g)
     ref = torch.relu(_bn_ref(F.conv_transpose2d(rd(x), rd(w), None, 2, 1), bn))
-    for tname in ("auto", "128x128", "64x64", "direct"):
+    for tname in ("auto", "128x128", "64x64", "v2_128x128", "v2_64x64", "v2_256x32", "direct"):
         check("deconv2d/%s/%s" % (dtype, tname), run_conv(x, w, None, bn, 2, 1, dtype, TILES[tname], transposed=True, relu=True), ref, tol)
     # ConvTranspose3d 2^3 s2 + BN + ReLU, then + skip (v2v Upsample3DBlock)
     x = torch.randn(1, 128, 4, 4, 4, generator=g); w = torch.randn(128, 64, 2, 2, 2, generator=g) * 0.1
     bias = torch.randn(64, generator=g) * 0.1; bn = _bn(64, g); skip = torch.randn(1, 64, 8, 8, 8, generator=g)
     ref = torch.relu(_bn_ref(F.conv_transpose3d(rd(x), rd(w), bias, 2), bn)) + rd(skip)
-    for tname in ("auto", "128x64", "64x64", "direct"):
+    for tname in ("auto", "128x64", "64x64", "v2_128x64", "v2_64x64", "v2_256x16", "direct"):
         check("deconv3d/%s/%s" % (dtype, tname),
               run_conv(x, w, bias, bn, 2, 0, dtype, TILES[tname], transposed=True, relu_pre=True, residual=skip), ref, tol)
 
@@ -130,7 +130,7 @@ def test_pool_layout_avgpool(dtype):
     rd = (lambda t: bf16_round(t)) if dtype == torch.bfloat16 else (lambda t: t)
     b = E.PlanBuilder(DEV, dtype)
     x = torch.randn(2, 64, 19, 23, generator=g)
-    y = b.maxpool(E.Act(to_cl(x, None, dtype)), 3, 2, 1, nd=2)
+    y = b.maxpool(E.Act(to_cl(x, None, dtype)), 3, 2, 1, nd=2)   # (the builder keeps the input tensors alive)
     x3 = torch.randn(1, 32, 6, 8, 10, generator=g)
     y3 = b.maxpool(E.Act(to_cl(x3, None, dtype)), 2, 2, 0, nd=3)
     ga = b.global_avgpool(E.Act(to_cl(x, None, dtype)))
@@ -248,3 +248,22 @@ def test_softargmax3d_large_sharp():
         assert float(rel) < 2e-5
         check("integrate3d/64^3 sharp/%s volumes" % layout, p.cpu(), rv, 1e-5)
         assert float((p.sum(dim=(2, 3, 4)) - 1).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_conv_epilogue_variants(dtype):
+    """fp32 store from bf16 compute (V2V logits), sigmoid head (linear as 1x1 conv over an N-pixel row), ragged Cout."""
+    g = torch.Generator().manual_seed(15)
+    rd = (lambda t: bf16_round(t)) if dtype == torch.bfloat16 else (lambda t: t)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    st = torch.cuda.current_stream().cuda_stream
+    for tile in (0, 4, 14, 3, 13):
+        b = E.PlanBuilder(DEV, dtype, tile_override=tile)
+        x = torch.randn(2, 32, 6, 7, 5, generator=g); w = torch.randn(17, 32, 1, 1, 1, generator=g) * 0.2; bias = torch.randn(17, generator=g)
+        y = b.conv(E.Act(to_cl(x, None, dtype)), w, bias, None, out_f32=True)
+        xl = torch.randn(6, 256, generator=g); wl = torch.randn(40, 256, generator=g) * 0.1; bl = torch.randn(40, generator=g)
+        yl = b.conv(E.Act(xl.reshape(1, 1, 1, 6, 256).to(DEV, dtype)), wl[:, :, None, None], bl, None, sigmoid=True, out_f32=True)
+        b.finish().run_eager(st); torch.cuda.synchronize()
+        assert y.t.dtype == torch.float32
+        check("conv1x1x1->17 fp32 store/%s/tile%d" % (dtype, tile), from_cl(y.t, 3), F.conv3d(rd(x), rd(w), bias), tol)
+        check("linear+sigmoid/%s/tile%d" % (dtype, tile), yl.t.reshape(6, 40).cpu(), torch.sigmoid(F.linear(rd(xl), rd(wl), bl)), tol)

@@ -31,16 +31,25 @@ bench)
   ;;
 prof)
   cd /tmp; export TMPDIR=/tmp
-  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $OUT/prof_bench.json 2> $OUT/prof.err
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $OUT/prof_bench.json 2> $OUT/prof.err
   echo "prof rc=$?" | tee -a $OUT/session.log
   cd $R
   find $OUT/prof -name "*stats*" | head | tee -a $OUT/session.log
   ;;
+ab)
+  # A/B: v1 (register staged) vs v2 (LDS-DMA) conv kernels, and batch-size sweep
+  LT_CONV_V1=1 timeout 600 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --ops-json $OUT/bench_ops_bf16_v1.json > $OUT/bench_bf16_v1.json 2> $OUT/bench_bf16_v1.err
+  echo "bench v1 rc=$?" | tee -a $OUT/session.log; cut -c1-400 $OUT/bench_bf16_v1.json | tee -a $OUT/session.log
+  for b in 1 4 16; do
+    timeout 600 python bench.py --no-cpu-baseline --no-profile --steps 10 --warmup 3 --batch $b > $OUT/bench_bf16_b$b.json 2> $OUT/bench_bf16_b$b.err
+    echo "bench B=$b rc=$?" | tee -a $OUT/session.log; cut -c1-330 $OUT/bench_bf16_b$b.json | tee -a $OUT/session.log
+  done
+  ;;
 pmc)
   cd /tmp; export TMPDIR=/tmp
-  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-graph > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-graph > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
   echo "pmc fetch rc=$?" | tee -a $OUT/session.log
-  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-graph > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-graph > $OUT/pmc_write.json 2> $OUT/pmc_write.err
   echo "pmc write rc=$?" | tee -a $OUT/session.log
   cd $R
   ;;
