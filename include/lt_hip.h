@@ -61,12 +61,16 @@ int lt_device_info(int* cu_count, int* lds_per_cu, char* arch, int arch_len);
  *   every output channel co:
  *     acc = sum_{tap t, ci} x[n, od*sd - pd + dd_t, oh*sh - ph + dh_t, ow*sw - pw + dw_t, ci]
  *                           * w_p[co][t*Cin + ci]                      (out-of-range taps read 0)
- *     v   = acc * scale[co] + shift[co]                 (folded BN / bias; NULL = 1 / 0)
+ *     v   = (acc + bias[co]) * scale[co] + shift[co]    (conv bias, then eval BatchNorm as ATen evaluates it:
+ *                                                         scale = weight/sqrt(var+eps), shift = bias_bn - mean*scale;
+ *                                                         NULL = 0 / 1 / 0; arrays hold cout_pad floats)
  *     if RELU_PRE v = max(v,0);  if residual v += residual[same place as y];  if RELU_POST v = max(v,0)
  *     y[n, od*osd + ood_p, oh*osh + ooh_p, ow*osw + oow_p, co] = v
  *
  * A plain convolution is one phase with out_stride 1 / out_off 0; a stride-2 transposed convolution
- * is 2^nd phases (one per output parity) with out_stride 2.
+ * is 2^nd phases (one per output parity) with out_stride 2.  A single one-tap phase with unit strides,
+ * zero pads and equal input / iteration / output extents IS a pointwise (1x1) convolution -- its tap must
+ * be (0,0,0,0) -- and takes a fast path without tap or bounds logic.
  * -------------------------------------------------------------------------------------------*/
 #define LT_CONV_MAX_PHASES 8
 
@@ -100,10 +104,10 @@ enum { LT_TILE_AUTO = 0,
        LT_TILE2_128x128 = 11, LT_TILE2_128x64 = 12, LT_TILE2_256x32 = 13, LT_TILE2_256x16 = 14, LT_TILE2_64x64 = 15,
        LT_TILE_DIRECT = 99 /* scalar fp32 VALU kernel, debug cross-check only */ };
 
-int lt_conv_fwd(const lt_conv_desc* desc, const void* x, const float* scale, const float* shift,
+int lt_conv_fwd(const lt_conv_desc* desc, const void* x, const float* bias, const float* scale, const float* shift,
                 const void* residual, void* y, void* stream);
 /* weight padding rule (every tile's N divides it): cout_pad = 16 if Cout <= 16, 32 if <= 32, 64 if <= 64,
- * else Cout rounded up to a multiple of 128; scale/shift arrays hold cout_pad floats. */
+ * else Cout rounded up to a multiple of 128; bias/scale/shift arrays hold cout_pad floats. */
 int lt_conv_cout_pad(int32_t cout);
 
 /* max pooling, channels-last, window k / stride s / zero-size padding p per dim (padding never wins):

@@ -20,6 +20,7 @@ struct ConvArgs {
     const void* x;
     void* y;
     const void* res;
+    const float* bias;
     const float* scale;
     const float* shift;
     int N, D, H, W, Cin, log2Cin;

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < SN; ++j) {
         const int col = n0 + wn * WN + j * MF + (lane & (MF - 1));
+        const float bi = a.bias ? a.bias[col] : 0.f;
         const float sc = a.scale ? a.scale[col] : 1.f;
         const float sf = a.shift ? a.shift[col] : 0.f;
         const bool col_ok = col < a.Cout;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 const int pix = s_rowpix[r];
                 if (pix >= 0 && col_ok) {
                     const size_t off = (size_t)pix * a.ldc + col;
-                    float val = acc[i][j][e] * sc + sf;
+                    float val = (acc[i][j][e] + bi) * sc + sf;
                     if (relu_pre) val = fmaxf(val, 0.f);
                     if (res) val += elt<T>::ld(res + off);
                     if (relu_post) val = fmaxf(val, 0.f);
@@ -226,7 +227,7 @@ __global__ void conv_direct_kernel(const ConvArgs a) {
     }
     const size_t pix = (((size_t)n * a.OD + od * a.osd + ph.ood) * a.OH + oh * a.osh + ph.ooh) * a.OW + ow * a.osw + ph.oow;
     const size_t off = pix * a.ldc + co;
-    float val = acc * (a.scale ? a.scale[co] : 1.f) + (a.shift ? a.shift[co] : 0.f);
+    float val = (acc + (a.bias ? a.bias[co] : 0.f)) * (a.scale ? a.scale[co] : 1.f) + (a.shift ? a.shift[co] : 0.f);
     if (a.flags & LT_EPI_RELU_PRE) val = fmaxf(val, 0.f);
     if (a.res) val += elt<T>::ld((const T*)a.res + off);
     if (a.flags & LT_EPI_RELU_POST) val = fmaxf(val, 0.f);
@@ -286,7 +287,7 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
 
 }  // namespace
 
-extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* scale, const float* shift,
+extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bias, const float* scale, const float* shift,
                            const void* residual, void* y, void* stream) {
     LT_REQUIRE(d && x && y, LT_ERR_INVALID, "lt_conv_fwd: null argument");
     LT_REQUIRE(d->dtype == LT_F32 || d->dtype == LT_BF16, LT_ERR_INVALID, "lt_conv_fwd: bad dtype %d", d->dtype);
@@ -303,7 +304,7 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* sc
     LT_REQUIRE(M > 0 && M < (1ll << 31) && in_elems < (1ll << 31) && out_pix < (1ll << 31), LT_ERR_UNSUPPORTED,
                "lt_conv_fwd: tensor too large for 32-bit indexing (M=%lld, in=%lld)", M, in_elems);
     ConvArgs a;
-    a.x = x; a.y = y; a.res = residual; a.scale = scale; a.shift = shift;
+    a.x = x; a.y = y; a.res = residual; a.bias = bias; a.scale = scale; a.shift = shift;
     a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.log2Cin = l2;
     a.Do = d->Do; a.Ho = d->Ho; a.Wo = d->Wo;
     a.sd = d->stride[0]; a.sh = d->stride[1]; a.sw = d->stride[2];

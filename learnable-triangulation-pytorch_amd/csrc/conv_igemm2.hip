@@ -3,16 +3,21 @@
 // Same GEMM view, tile shapes, swizzled 128-byte LDS rows and MFMA fragment scheme as conv_igemm.hip;
 // what changes is how bytes move:
 //   * global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write pass.  The DMA
-//     writes wave-linearly (base + lane*16), so the XOR swizzle is applied to the SOURCE: lane L of a
+//     writes wave-linearly (M0 base + lane*16), so the XOR swizzle is applied to the SOURCE: lane L of a
 //     wave-instruction owns physical slot L&7 of row L>>3 and fetches the logical 16-byte K vector
 //     (L&7) ^ ((row>>1)&7) of that row.  Out-of-image taps (zero padding) fetch from a 16-byte zero page.
-//   * tile k+1 is in flight while tile k feeds the MFMAs (2 LDS stages, one barrier per K step, 2
-//     workgroups per CU so one block's DMA wait overlaps the other's MFMAs).
-//   * epilogue: accumulators -> per-wave LDS sub-tile -> every lane owns 16 contiguous output bytes of one
-//     pixel: folded BN / bias on 4-8 channels at a time, 16-byte residual loads, 16-byte stores (a 64-channel
-//     row segment = one contiguous 128/256-byte run).  The v1 kernel stored 2-4 bytes per lane.
+//     The DMA is issued from inline asm: hipcc drains vmcnt(0) before the next ds_read after a builtin
+//     LDS-DMA (measured: the whole pipeline serialised), so the waits are counted by hand.
+//   * NST-stage ring (2 or 3): per K step  { s_waitcnt vmcnt(in-flight stages) ; s_barrier ; issue stage
+//     ks+NST-1 ; MFMAs on stage ks }  -- one barrier per step, NST-1 tiles of DMA in flight under the MFMAs.
+//   * epilogue: (acc + bias)*scale + shift on the accumulator (fp64 in fp32 mode), then accumulators ->
+//     per-wave LDS sub-tile -> every lane owns 16 contiguous output bytes of one pixel: 16-byte residual
+//     loads, 16-byte stores (a 64-channel row segment = one contiguous 128/256-byte run).
 //   * fp32 mode flushes the MFMA accumulators into fp64 registers every 2 K steps (64 products), which
 //     removes the long fp32 accumulation chain from the parity path (K up to 10976 in the 7^3 layer).
+//   * PW = pointwise fast path (1x1, stride 1, dense output): rows are contiguous, no tap/bounds logic.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 using namespace lt;
@@ -21,11 +26,44 @@ namespace {
 
 __device__ uint4 g_zero_page[2];  // source of out-of-image taps
 
-typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ void dma16(const void* src, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+// one LDS-DMA wave-instruction: 64 lanes x 16 B -> lds_base .. lds_base + 1 KiB (wave-uniform base)
+__device__ __forceinline__ void dma16(const void* src, unsigned lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_base)
+        : "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform n (the immediate must be a literal)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // conservative
+    }
+}
+
+__device__ __forceinline__ void block_barrier() {
+    // LDS reads of this wave are consumed (lgkmcnt(0)) before it releases the buffer to the next DMA
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <int VECO> struct OutVec;  // VECO output elements <-> 16 bytes
@@ -59,12 +97,12 @@ __device__ __forceinline__ float epi_act(float v, bool relu_pre, bool has_res, f
     return v;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int MF>
+template <typename T, int BM, int BN, int WM, int WN, int MF, int NST, bool PW>
 __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     constexpr bool ACC64 = sizeof(T) == 4;  // fp32 = parity mode
     constexpr int VEC = elt<T>::vec;
     constexpr int BK = 8 * VEC;
-    constexpr int A_IT = BM / 32;                  // DMA instructions per thread for the A tile
+    constexpr int A_IT = BM / 32;                  // DMA instructions per wave for the A tile
     constexpr int B_VECS = BN * 8;
     constexpr int B_IT = (B_VECS + 255) / 256;
     constexpr int SM = WM / MF, SN = WN / MF;
@@ -74,13 +112,14 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     constexpr int STAGE = (BM + BN) * ROW_BYTES;   // bytes per pipeline stage
     constexpr int EP_LD = WN + 4;                  // padded fp32 row of the per-wave epilogue tile
     constexpr int EP_WAVE = WM * EP_LD * 4;        // bytes
-    constexpr int REGION = (2 * STAGE > 4 * EP_WAVE) ? 2 * STAGE : 4 * EP_WAVE;
+    constexpr int REGION = (NST * STAGE > 4 * EP_WAVE) ? NST * STAGE : 4 * EP_WAVE;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves");
     typedef typename Mma<T, MF>::acc_t acc_t;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* s_rowpix = (int*)(smem + REGION);         // [BM]
+    int* s_rowpix = (int*)(smem + REGION);         // [BM]   (unused when PW)
     int4* s_taps = (int4*)(s_rowpix + BM);         // [ntaps]
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic region
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -93,57 +132,76 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     const T* __restrict__ x = (const T*)a.x;
     const T* __restrict__ w = (const T*)ph.w;
 
-    for (int i = t; i < ph.ntaps; i += 256) s_taps[i] = ph.taps[i];
-    for (int r = t; r < BM; r += 256) {
-        int m = m0 + r, pix = -1;
-        if (m < a.M) {
-            int n, od, oh, ow;
-            decode_row(a, m, n, od, oh, ow);
-            pix = ((n * a.OD + od * a.osd + ph.ood) * a.OH + oh * a.osh + ph.ooh) * a.OW + ow * a.osw + ph.oow;
-        }
-        s_rowpix[r] = pix;
-    }
-
     // DMA ownership: thread t fills physical slot t&7 of rows (t>>3) + 32*i; the logical K vector it must fetch is
     // v = (t&7) ^ ((row>>1)&7), the same for all its rows (32*i does not change (row>>1)&7)
     const int v = (t & 7) ^ ((t >> 4) & 7);
-    int id0[A_IT], ih0[A_IT], iw0[A_IT], baseC[A_IT];
+    int id0[PW ? 1 : A_IT], ih0[PW ? 1 : A_IT], iw0[PW ? 1 : A_IT], baseC[A_IT];
+    if (PW) {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        int m = m0 + (t >> 3) + 32 * i;
-        if (m < a.M) {
-            int n, od, oh, ow;
-            decode_row(a, m, n, od, oh, ow);
-            id0[i] = od * a.sd - a.pd;
-            ih0[i] = oh * a.sh - a.ph;
-            iw0[i] = ow * a.sw - a.pw;
-            baseC[i] = (((n * a.D + id0[i]) * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
-        } else {
-            id0[i] = -(1 << 24);
-            ih0[i] = iw0[i] = baseC[i] = 0;
+        for (int i = 0; i < A_IT; ++i) {
+            const int m = m0 + (t >> 3) + 32 * i;
+            baseC[i] = (m < a.M) ? m * a.Cin + v * VEC : -1;
+        }
+    } else {
+        for (int i = t; i < ph.ntaps; i += 256) s_taps[i] = ph.taps[i];
+        for (int r = t; r < BM; r += 256) {
+            int m = m0 + r, pix = -1;
+            if (m < a.M) {
+                int n, od, oh, ow;
+                decode_row(a, m, n, od, oh, ow);
+                pix = ((n * a.OD + od * a.osd + ph.ood) * a.OH + oh * a.osh + ph.ooh) * a.OW + ow * a.osw + ph.oow;
+            }
+            s_rowpix[r] = pix;
+        }
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            int m = m0 + (t >> 3) + 32 * i;
+            if (m < a.M) {
+                int n, od, oh, ow;
+                decode_row(a, m, n, od, oh, ow);
+                id0[i] = od * a.sd - a.pd;
+                ih0[i] = oh * a.sh - a.ph;
+                iw0[i] = ow * a.sw - a.pw;
+                baseC[i] = (((n * a.D + id0[i]) * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
+            } else {
+                id0[i] = -(1 << 24);
+                ih0[i] = iw0[i] = baseC[i] = 0;
+            }
         }
     }
     const T* wrow[B_IT];
+    int nb_wave = 0;  // B-tile DMA instructions this wave issues per stage
 #pragma unroll
-    for (int j = 0; j < B_IT; ++j) wrow[j] = w + (size_t)(n0 + ((t + 256 * j) >> 3)) * a.k_pad + v * VEC;
+    for (int j = 0; j < B_IT; ++j) {
+        wrow[j] = w + (size_t)(n0 + ((t + 256 * j) >> 3)) * a.k_pad + v * VEC;
+        if (B_VECS >= 256 * (j + 1) || 8 * wave + 32 * j < BN) ++nb_wave;
+    }
+    const int dps = A_IT + nb_wave;  // DMA instructions per stage per wave (wave-uniform)
     __syncthreads();
 
     const int nk = a.k_pad / BK;
-    // wave-uniform LDS destinations: rows 8*wave + 32*i (A) / 8*wave + 32*j (B) of the stage
     auto stage = [&](int ks, int buf) {
-        unsigned char* sA = smem + buf * STAGE;
-        unsigned char* sB = sA + BM * ROW_BYTES;
-        const int kel = ks * BK + v * VEC;
-        const int tap = kel >> a.log2Cin;
-        const int c = kel & (a.Cin - 1);
-        int4 tp = make_int4(-(1 << 24), 0, 0, 0);
-        if (tap < ph.ntaps) tp = s_taps[tap];
+        const unsigned sA = lds0 + buf * STAGE;
+        const unsigned sB = sA + BM * ROW_BYTES;
+        if (PW) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int id = id0[i] + tp.x, ih = ih0[i] + tp.y, iw = iw0[i] + tp.z;
-            const bool ok = ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-            const void* src = ok ? (const void*)(x + (baseC[i] + tp.w + c)) : (const void*)g_zero_page;
-            dma16(src, sA + (8 * wave + 32 * i) * ROW_BYTES);
+            for (int i = 0; i < A_IT; ++i) {
+                const void* src = baseC[i] >= 0 ? (const void*)(x + (baseC[i] + ks * BK)) : (const void*)g_zero_page;
+                dma16(src, sA + (8 * wave + 32 * i) * ROW_BYTES);
+            }
+        } else {
+            const int kel = ks * BK + v * VEC;
+            const int tap = kel >> a.log2Cin;
+            const int c = kel & (a.Cin - 1);
+            int4 tp = make_int4(-(1 << 24), 0, 0, 0);
+            if (tap < ph.ntaps) tp = s_taps[tap];
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int id = id0[i] + tp.x, ih = ih0[i] + tp.y, iw = iw0[i] + tp.z;
+                const bool ok = ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+                const void* src = ok ? (const void*)(x + (baseC[i] + tp.w + c)) : (const void*)g_zero_page;
+                dma16(src, sA + (8 * wave + 32 * i) * ROW_BYTES);
+            }
         }
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
@@ -175,13 +233,19 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                 if (ACC64) dacc[i][j][e] = 0.0;
             }
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // prologue: NST-1 stages in flight
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) stage(s, s);
 
     for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nk) stage(ks + 1, buf ^ 1);
+        // stage ks must have landed; the (up to NST-2) younger stages may stay in flight
+        int younger = nk - 1 - ks;
+        if (younger > NST - 2) younger = NST - 2;
+        wait_vmcnt(younger * dps);
+        block_barrier();   // everybody's stage-ks DMAs landed, everybody is done reading stage ks-1
+        if (ks + NST - 1 < nk) stage(ks + NST - 1, (ks + NST - 1) % NST);
+        const int buf = ks % NST;
         const unsigned char* pa = smem + buf * STAGE + a_base;
         const unsigned char* pb = smem + buf * STAGE + b_base;
 #pragma unroll
@@ -207,22 +271,29 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                         acc[i][j][e] = 0.f;
                     }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
+    block_barrier();   // all waves done with the last stage: the region is reused by the epilogue tiles
 
-    // ---- epilogue: accumulators -> this wave's LDS sub-tile (fp32, padded rows) -> 16-byte vectors ----------------
+    // ---- epilogue: (acc + bias)*scale + shift, then this wave's LDS sub-tile (fp32, padded rows) -> 16-byte vectors ---
     float* ep = (float*)(smem + wave * EP_WAVE);
 #pragma unroll
-    for (int i = 0; i < SM; ++i)
+    for (int j = 0; j < SN; ++j) {
+        const int colj = n0 + wn * WN + j * MF + (lane & (MF - 1));   // < cout_pad: the constant arrays are padded
+        const float bi = a.bias ? a.bias[colj] : 0.f;
+        const float sc = a.scale ? a.scale[colj] : 1.f;
+        const float sf = a.shift ? a.shift[colj] : 0.f;
 #pragma unroll
-        for (int j = 0; j < SN; ++j)
+        for (int i = 0; i < SM; ++i)
 #pragma unroll
             for (int e = 0; e < NACC; ++e) {
                 const int r = i * MF + ((MF == 32) ? ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) : ((lane >> 4) * 4 + e));
                 const int cc = j * MF + (lane & (MF - 1));
-                ep[r * EP_LD + cc] = ACC64 ? (float)dacc[i][j][e] : acc[i][j][e];
+                float val;
+                if (ACC64) val = (float)((dacc[i][j][e] + (double)bi) * (double)sc + (double)sf);
+                else val = (acc[i][j][e] + bi) * sc + sf;
+                ep[r * EP_LD + cc] = val;
             }
+    }
     __syncthreads();
 
     const bool relu_pre = a.flags & LT_EPI_RELU_PRE, relu_post = a.flags & LT_EPI_RELU_POST, sigm = a.flags & LT_EPI_SIGMOID;
@@ -231,21 +302,18 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     const int col0 = n0 + wn * WN;                 // first output channel of this wave's sub-tile
     const int veco = store_f32 ? 4 : 8;
     const bool vec_ok = (a.Cout % veco == 0) && (a.ldc % veco == 0);
+    auto row_pix = [&](int r) -> int {             // output pixel index of tile row r (or -1)
+        if (PW) { const int m = m0 + r; return m < a.M ? m : -1; }
+        return s_rowpix[r];
+    };
     if (vec_ok) {
-        // lanes_per_row = WN/veco; rows_per_pass = 64/lanes_per_row
-        const int lpr = WN / veco;
-        const int rpp = 64 / lpr;
+        const int lpr = WN / veco;                 // lanes per row
+        const int rpp = 64 / lpr;                  // rows per pass
         const int cq = (lane % lpr) * veco;        // channel offset inside the sub-tile
         const int col = col0 + cq;
         if (col < a.Cout) {
-            float sc[8], sf[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sc[e] = (e < veco && a.scale) ? a.scale[col + e] : 1.f;
-                sf[e] = (e < veco && a.shift) ? a.shift[col + e] : 0.f;
-            }
             for (int r = lane / lpr; r < WM; r += rpp) {
-                const int pix = s_rowpix[wm * WM + r];
+                const int pix = row_pix(wm * WM + r);
                 if (pix < 0) continue;
                 const size_t off = (size_t)pix * a.ldc + col;
                 const float* src = ep + r * EP_LD + cq;
@@ -261,7 +329,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                         }
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) vv[e] = epi_act(vv[e] * sc[e] + sf[e], relu_pre, has_res, rr[e], relu_post, sigm);
+                    for (int e = 0; e < 4; ++e) vv[e] = epi_act(vv[e], relu_pre, has_res, rr[e], relu_post, sigm);
                     OutVec<4>::st((float*)a.y + off, vv);
                 } else {
                     float vv[8], rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -269,7 +337,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                     vv[0] = q0.x; vv[1] = q0.y; vv[2] = q0.z; vv[3] = q0.w; vv[4] = q1.x; vv[5] = q1.y; vv[6] = q1.z; vv[7] = q1.w;
                     if (has_res) OutVec<8>::ld_res((const bf16_t*)a.res + off, rr);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) vv[e] = epi_act(vv[e] * sc[e] + sf[e], relu_pre, has_res, rr[e], relu_post, sigm);
+                    for (int e = 0; e < 8; ++e) vv[e] = epi_act(vv[e], relu_pre, has_res, rr[e], relu_post, sigm);
                     OutVec<8>::st((bf16_t*)a.y + off, vv);
                 }
             }
@@ -279,30 +347,28 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
         for (int idx = lane; idx < WM * WN; idx += 64) {
             const int r = idx / WN, cc = idx - r * WN;
             const int col = col0 + cc;
-            const int pix = s_rowpix[wm * WM + r];
+            const int pix = row_pix(wm * WM + r);
             if (pix < 0 || col >= a.Cout) continue;
             const size_t off = (size_t)pix * a.ldc + col;
-            float val = ep[r * EP_LD + cc] * (a.scale ? a.scale[col] : 1.f) + (a.shift ? a.shift[col] : 0.f);
             const float rr = has_res ? elt<T>::ld((const T*)a.res + off) : 0.f;
-            val = epi_act(val, relu_pre, has_res, rr, relu_post, sigm);
+            const float val = epi_act(ep[r * EP_LD + cc], relu_pre, has_res, rr, relu_post, sigm);
             if (store_f32) ((float*)a.y)[off] = val;
             else elt<T>::st((T*)a.y + off, val);
         }
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int MF>
+template <typename T, int BM, int BN, int WM, int WN, int MF, int NST, bool PW>
 int launch2(ConvArgs a, int cout_pad, int nphase, int max_taps, hipStream_t s) {
-    LT_REQUIRE(cout_pad % BN == 0, LT_ERR_INVALID, "lt_conv_fwd: cout_pad %d not a multiple of tile N %d", cout_pad, BN);
     a.tiles_n = cout_pad / BN;
     const long long nblk = cdiv(a.M, BM) * a.tiles_n;
     LT_REQUIRE(nblk < (1ll << 31), LT_ERR_INVALID, "lt_conv_fwd: grid too large");
     constexpr int STAGE = (BM + BN) * ROW_BYTES;
     constexpr int EP_WAVE = WM * (WN + 4) * 4;
-    constexpr int REGION = (2 * STAGE > 4 * EP_WAVE) ? 2 * STAGE : 4 * EP_WAVE;
+    constexpr int REGION = (NST * STAGE > 4 * EP_WAVE) ? NST * STAGE : 4 * EP_WAVE;
     const size_t lds = REGION + BM * sizeof(int) + (size_t)max_taps * sizeof(int4);
     LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: tile needs %zu B of LDS", lds);
-    auto kern = conv_igemm2_kernel<T, BM, BN, WM, WN, MF>;
+    auto kern = conv_igemm2_kernel<T, BM, BN, WM, WN, MF, NST, PW>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -311,6 +377,17 @@ int launch2(ConvArgs a, int cout_pad, int nphase, int max_taps, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, nphase), dim3(256), lds, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(v2)");
     return LT_OK;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int MF>
+int launch2_pick(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int nst, bool pw, hipStream_t s) {
+    LT_REQUIRE(cout_pad % BN == 0, LT_ERR_INVALID, "lt_conv_fwd: cout_pad %d not a multiple of tile N %d", cout_pad, BN);
+    if (nst == 3) {
+        if (pw) return launch2<T, BM, BN, WM, WN, MF, 3, true>(a, cout_pad, nphase, max_taps, s);
+        return launch2<T, BM, BN, WM, WN, MF, 3, false>(a, cout_pad, nphase, max_taps, s);
+    }
+    if (pw) return launch2<T, BM, BN, WM, WN, MF, 2, true>(a, cout_pad, nphase, max_taps, s);
+    return launch2<T, BM, BN, WM, WN, MF, 2, false>(a, cout_pad, nphase, max_taps, s);
 }
 
 template <typename T>
@@ -323,12 +400,21 @@ int dispatch2(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int til
         // small problems: more, smaller workgroups
         if (cout_pad >= 64 && cdiv(a.M, 128) * cdiv(cout_pad, 128) < 192) tile = LT_TILE2_64x64;
     }
+    // pointwise fast path: one tap at offset 0, unit strides, dense output rows
+    const PhaseArg& p0 = a.phase[0];
+    const bool pw = nphase == 1 && p0.ntaps == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.pd == 0 && a.ph == 0 && a.pw == 0 &&
+                    a.osd == 1 && a.osh == 1 && a.osw == 1 && p0.ood == 0 && p0.ooh == 0 && p0.oow == 0 && a.OD == a.Do && a.OH == a.Ho &&
+                    a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
+    static const int env_nst = getenv("LT_CONV_NST") ? atoi(getenv("LT_CONV_NST")) : 0;   // A/B switch for profiling sessions
+    int nst = (env_nst == 2 || env_nst == 3) ? env_nst : 3;
+    // 3 stages of a 256-row tile exceed what two resident workgroups can hold: keep those at 2 stages
+    if (env_nst == 0 && (tile == LT_TILE2_256x32 || tile == LT_TILE2_256x16)) nst = 2;
     switch (tile) {
-        case LT_TILE2_128x128: return launch2<T, 128, 128, 64, 64, 32>(a, cout_pad, nphase, max_taps, s);
-        case LT_TILE2_128x64: return launch2<T, 128, 64, 64, 32, 32>(a, cout_pad, nphase, max_taps, s);
-        case LT_TILE2_256x32: return launch2<T, 256, 32, 64, 32, 32>(a, cout_pad, nphase, max_taps, s);
-        case LT_TILE2_256x16: return launch2<T, 256, 16, 64, 16, 16>(a, cout_pad, nphase, max_taps, s);
-        case LT_TILE2_64x64: return launch2<T, 64, 64, 32, 32, 32>(a, cout_pad, nphase, max_taps, s);
+        case LT_TILE2_128x128: return launch2_pick<T, 128, 128, 64, 64, 32>(a, cout_pad, nphase, max_taps, nst, pw, s);
+        case LT_TILE2_128x64: return launch2_pick<T, 128, 64, 64, 32, 32>(a, cout_pad, nphase, max_taps, nst, pw, s);
+        case LT_TILE2_256x32: return launch2_pick<T, 256, 32, 64, 32, 32>(a, cout_pad, nphase, max_taps, nst, pw, s);
+        case LT_TILE2_256x16: return launch2_pick<T, 256, 16, 64, 16, 16>(a, cout_pad, nphase, max_taps, nst, pw, s);
+        case LT_TILE2_64x64: return launch2_pick<T, 64, 64, 32, 32, 32>(a, cout_pad, nphase, max_taps, nst, pw, s);
         default: break;
     }
     set_error("lt_conv_fwd: unknown tile id %d", tile);

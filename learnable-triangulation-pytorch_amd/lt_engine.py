@@ -55,28 +55,31 @@ class ConvSpec:
     out_stride: Tuple[int, int, int]
     Cout: int; cout_pad: int; k_pad: int
     flags: int
+    bias: torch.Tensor              # fp32 [cout_pad]   y = (acc + bias) * scale + shift
     scale: torch.Tensor             # fp32 [cout_pad]
     shift: torch.Tensor             # fp32 [cout_pad]
     phases: List[ConvPhaseSpec] = field(default_factory=list)
 
 
 def fold_bn(cout, bias, bn, cout_pad):
-    """Eval-mode BatchNorm (F.batch_norm, eps 1e-5) and conv bias -> y = acc*scale + shift.
+    """Epilogue constants of y = (acc + bias) * scale + shift, as fp32 arrays of cout_pad entries.
 
-    bn = (gamma, beta, running_mean, running_var) or None.  fp64 on the host, stored fp32.
+    Eval-mode BatchNorm is folded exactly the way ATen evaluates it (batch_norm_cpu_collect_linear_and_constant_terms):
+    fp32 invstd = 1/sqrt(var + eps), scale = invstd * weight, shift = bias_bn - mean * scale -- so the per-channel
+    constants carry the same roundings as the reference's.  bn = (gamma, beta, running_mean, running_var) or None.
     """
-    scale = torch.ones(cout, dtype=torch.float64)
-    shift = torch.zeros(cout, dtype=torch.float64)
+    bi = torch.zeros(cout_pad, dtype=torch.float32)
+    sc = torch.ones(cout_pad, dtype=torch.float32)
+    sh = torch.zeros(cout_pad, dtype=torch.float32)
     if bias is not None:
-        shift = shift + bias.detach().double().cpu()
+        bi[:cout] = bias.detach().float().cpu()
     if bn is not None:
-        g, b, m, v = (t.detach().double().cpu() for t in bn)
-        s = g / torch.sqrt(v + BN_EPS)
-        shift = (shift - m) * s + b
-        scale = s
-    sc = torch.zeros(cout_pad, dtype=torch.float32); sc[:cout] = scale.float()
-    sh = torch.zeros(cout_pad, dtype=torch.float32); sh[:cout] = shift.float()
-    return sc, sh
+        g, b, m, v = (t.detach().float().cpu() for t in bn)
+        invstd = 1.0 / torch.sqrt(v + BN_EPS)
+        alpha = invstd * g
+        sc[:cout] = alpha
+        sh[:cout] = b - m * alpha
+    return bi, sc, sh
 
 
 def _pad_k(wk, cout_pad, k_pad):
@@ -114,8 +117,8 @@ def make_conv_spec(weight, bias, bn, in_shape, stride, pad, dtype, transposed=Fa
         k_pad = (K + kstep - 1) // kstep * kstep
         wk = w.permute(0, 2, 3, 4, 1).reshape(cout, K)
         taps = [(a, b, c, ((a * Hh + b) * W + c) * cin_buf) for a in range(kd) for b in range(kh) for c in range(kw)]
-        sc, sh = fold_bn(cout, bias, bn, cp)
-        spec = ConvSpec(N, D, Hh, W, cin_buf, Do, Ho, Wo, st, pd, Do, Ho, Wo, (1, 1, 1), cout, cp, k_pad, flags, sc, sh)
+        bi, sc, sh = fold_bn(cout, bias, bn, cp)
+        spec = ConvSpec(N, D, Hh, W, cin_buf, Do, Ho, Wo, st, pd, Do, Ho, Wo, (1, 1, 1), cout, cp, k_pad, flags, bi, sc, sh)
         spec.phases.append(ConvPhaseSpec(_pad_k(wk, cp, k_pad), torch.tensor(taps, dtype=torch.int32).reshape(-1, 4), (0, 0, 0)))
         return spec
     # ---- stride-2 transposed conv: one phase per output parity --------------------------------
@@ -159,9 +162,9 @@ def make_conv_spec(weight, bias, bn, in_shape, stride, pad, dtype, transposed=Fa
                 ntaps_max = max(ntaps_max, len(taps))
     K = ntaps_max * cin
     k_pad = (K + kstep - 1) // kstep * kstep
-    sc, sh = fold_bn(cout, bias, bn, cp)
+    bi, sc, sh = fold_bn(cout, bias, bn, cp)
     ostr = (2 if nd3 else 1, 2, 2)
-    spec = ConvSpec(N, D, Hh, W, cin, D, Hh, W, (1, 1, 1), (0, 0, 0), outs[0], outs[1], outs[2], ostr, cout, cp, k_pad, flags, sc, sh)
+    spec = ConvSpec(N, D, Hh, W, cin, D, Hh, W, (1, 1, 1), (0, 0, 0), outs[0], outs[1], outs[2], ostr, cout, cp, k_pad, flags, bi, sc, sh)
     for wk, taps, off in phase_list:
         spec.phases.append(ConvPhaseSpec(_pad_k(wk, cp, k_pad), torch.tensor(taps, dtype=torch.int32).reshape(-1, 4), off))
     assert len(spec.phases) <= H.MAX_PHASES
@@ -261,7 +264,7 @@ class PlanBuilder:
             tdev = self.const(ph.taps)
             d.phase[i].weight = wdev.data_ptr(); d.phase[i].taps = tdev.data_ptr()
             d.phase[i].ntaps = ph.taps.shape[0]; d.phase[i].out_off = H.i3(ph.out_off)
-        sc, sh = self.const(spec.scale), self.const(spec.shift)
+        bi, sc, sh = self.const(spec.bias), self.const(spec.scale), self.const(spec.shift)
         self.keep.append(d)
         macs = spec.N * spec.Do * spec.Ho * spec.Wo * spec.Cout * sum(int(p.taps.shape[0]) for p in spec.phases) * (
             weight.shape[1] if not transposed else weight.shape[0])
@@ -273,9 +276,9 @@ class PlanBuilder:
         esz = torch.empty((), dtype=self.dtype).element_size()
         nbytes = (x.t.numel() + y.t.numel() + (residual.t.numel() if residual is not None else 0)) * esz + \
             sum(p.weight.numel() for p in spec.phases) * esz
-        self._add(lambda s, d=d, xp=x.t.data_ptr(), scp=sc.data_ptr(), shp=sh.data_ptr(),
+        self._add(lambda s, d=d, xp=x.t.data_ptr(), bip=bi.data_ptr(), scp=sc.data_ptr(), shp=sh.data_ptr(),
                   rp=H.ptr(residual.t) if residual is not None else None, yp=y.t.data_ptr():
-                  H.check(lib.lt_conv_fwd(C.byref(d), xp, scp, shp, rp, yp, s), "lt_conv_fwd"),
+                  H.check(lib.lt_conv_fwd(C.byref(d), xp, bip, scp, shp, rp, yp, s), "lt_conv_fwd"),
                   "conv", label, 2 * macs, nbytes, {"spec": spec, "x": x, "y": y, "res": residual})
         return y
 

@@ -39,7 +39,7 @@ SIGNATURES = {
     "lt_last_error": (C.c_char_p, []),
     "lt_abi_version": (C.c_int, []),
     "lt_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
-    "lt_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
+    "lt_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
     "lt_conv_cout_pad": (C.c_int, [i32]),
     "lt_maxpool_fwd": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32 * 3, vp]),
     "lt_global_avgpool": (C.c_int, [i32, vp, vp, i32, i32, i32, vp]),

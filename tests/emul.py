@@ -35,7 +35,7 @@ def emulate_conv(spec, x, residual=None):
             acc += g @ wt.t()
         # beyond the real K the packed weights must be zero
         assert float(ph.weight[:, ph.taps.shape[0] * Cin:].abs().sum()) == 0.0
-        v = acc * spec.scale + spec.shift
+        v = (acc + spec.bias) * spec.scale + spec.shift
         v = v[..., :spec.Cout]
         sl = (slice(None), slice(ph.out_off[0], None, spec.out_stride[0]), slice(ph.out_off[1], None, spec.out_stride[1]),
               slice(ph.out_off[2], None, spec.out_stride[2]))

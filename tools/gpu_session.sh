@@ -36,6 +36,13 @@ prof)
   cd $R
   find $OUT/prof -name "*stats*" | head | tee -a $OUT/session.log
   ;;
+nst)
+  # A/B: 2-stage vs 3-stage LDS-DMA ring in the v2 conv kernels
+  for n in 2 3; do
+    LT_CONV_NST=$n timeout 600 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --ops-json $OUT/bench_ops_bf16_nst$n.json > $OUT/bench_bf16_nst$n.json 2> $OUT/bench_bf16_nst$n.err
+    echo "bench nst=$n rc=$?" | tee -a $OUT/session.log; cut -c1-140 $OUT/bench_bf16_nst$n.json | tee -a $OUT/session.log
+  done
+  ;;
 ab)
   # A/B: v1 (register staged) vs v2 (LDS-DMA) conv kernels, and batch-size sweep
   LT_CONV_V1=1 timeout 600 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --ops-json $OUT/bench_ops_bf16_v1.json > $OUT/bench_bf16_v1.json 2> $OUT/bench_bf16_v1.err
