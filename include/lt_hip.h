@@ -93,7 +93,7 @@ typedef struct lt_conv_desc {
     int32_t nphase;
     int32_t flags;              /* LT_EPI_*                                                          */
     int32_t tile;               /* 0 = choose; else one of LT_TILE_* (tests / tuning)                */
-    int32_t reserved;
+    int32_t stages;             /* 0 = choose; 2 or 3 = LDS-DMA ring depth of the v2 kernels (tuning)       */
     lt_conv_phase phase[LT_CONV_MAX_PHASES];
 } lt_conv_desc;
 

@@ -30,6 +30,7 @@ struct ConvArgs {
     int Cout, ldc, k_pad, flags;
     int M;        // N*Do*Ho*Wo
     int tiles_n;  // cout_pad / BN
+    int stages;   // requested LDS-DMA ring depth (0 = auto)
     PhaseArg phase[LT_CONV_MAX_PHASES];
 };
 

@@ -311,7 +311,7 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bi
     a.pd = d->pad[0]; a.ph = d->pad[1]; a.pw = d->pad[2];
     a.OD = d->OD; a.OH = d->OH; a.OW = d->OW;
     a.osd = d->out_stride[0]; a.osh = d->out_stride[1]; a.osw = d->out_stride[2];
-    a.Cout = d->Cout; a.ldc = d->ldc; a.k_pad = d->k_pad; a.flags = d->flags; a.M = (int)M; a.tiles_n = 1;
+    a.Cout = d->Cout; a.ldc = d->ldc; a.k_pad = d->k_pad; a.flags = d->flags; a.M = (int)M; a.tiles_n = 1; a.stages = d->stages;
     int max_taps = 0;
     for (int p = 0; p < d->nphase; ++p) {
         const lt_conv_phase& ph = d->phase[p];

@@ -392,23 +392,34 @@ int launch2_pick(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int 
 
 template <typename T>
 int dispatch2(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile, hipStream_t s) {
+    // workgroups of each candidate tile; 256 CUs want >= ~2 resident workgroups each to hide the DMA latency of the
+    // 2-stage ring, so the largest tile that still gives >= 480 workgroups wins (measured: 288 workgroups of 128x128 on a
+    // M=18432, N=256 layer ran 1.6x slower than 576 of 128x64)
+    auto blocks = [&](int bm, int bn) { return cdiv(a.M, bm) * (long long)(cout_pad / bn) * nphase; };
     if (tile == LT_TILE_AUTO) {
         if (cout_pad <= 16) tile = LT_TILE2_256x16;
         else if (cout_pad <= 32) tile = LT_TILE2_256x32;
-        else if (cout_pad <= 64) tile = LT_TILE2_128x64;
-        else tile = LT_TILE2_128x128;
-        // small problems: more, smaller workgroups
-        if (cout_pad >= 64 && cdiv(a.M, 128) * cdiv(cout_pad, 128) < 192) tile = LT_TILE2_64x64;
+        else if (cout_pad <= 64) tile = blocks(128, 64) >= 480 ? LT_TILE2_128x64 : LT_TILE2_64x64;
+        else tile = blocks(128, 128) >= 480 ? LT_TILE2_128x128 : (blocks(128, 64) >= 480 ? LT_TILE2_128x64 : LT_TILE2_64x64);
     }
     // pointwise fast path: one tap at offset 0, unit strides, dense output rows
     const PhaseArg& p0 = a.phase[0];
     const bool pw = nphase == 1 && p0.ntaps == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.pd == 0 && a.ph == 0 && a.pw == 0 &&
                     a.osd == 1 && a.osh == 1 && a.osw == 1 && p0.ood == 0 && p0.ooh == 0 && p0.oow == 0 && a.OD == a.Do && a.OH == a.Ho &&
                     a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
-    static const int env_nst = getenv("LT_CONV_NST") ? atoi(getenv("LT_CONV_NST")) : 0;   // A/B switch for profiling sessions
-    int nst = (env_nst == 2 || env_nst == 3) ? env_nst : 3;
-    // 3 stages of a 256-row tile exceed what two resident workgroups can hold: keep those at 2 stages
-    if (env_nst == 0 && (tile == LT_TILE2_256x32 || tile == LT_TILE2_256x16)) nst = 2;
+    // ring depth: 3 stages cost a resident workgroup per CU on the big tiles, so they only pay when the grid leaves at most
+    // one workgroup per CU anyway (tiny layers: pure latency chains)
+    int nst = a.stages;
+    if (nst != 2 && nst != 3) {
+        long long nblk = 0;
+        switch (tile) {
+            case LT_TILE2_128x128: nblk = blocks(128, 128); break;
+            case LT_TILE2_128x64: nblk = blocks(128, 64); break;
+            case LT_TILE2_64x64: nblk = blocks(64, 64); break;
+            default: nblk = 1 << 20; break;
+        }
+        nst = nblk <= 256 ? 3 : 2;
+    }
     switch (tile) {
         case LT_TILE2_128x128: return launch2_pick<T, 128, 128, 64, 64, 32>(a, cout_pad, nphase, max_taps, nst, pw, s);
         case LT_TILE2_128x64: return launch2_pick<T, 128, 64, 64, 32, 32>(a, cout_pad, nphase, max_taps, nst, pw, s);

@@ -187,7 +187,7 @@ class Act:
 class PlanBuilder:
     """Records liblt_hip launches; buffers are reused by exact byte size once released."""
 
-    def __init__(self, device, dtype, tile_override=0, dry_run=False):
+    def __init__(self, device, dtype, tile_override=0, dry_run=False, stages=0):
         """dry_run=True records the plan over CPU tensors WITHOUT being able to execute it (Plan.run raises): the CPU
         test-suite uses it to check the recorded wiring / buffer reuse with an interpreter that lives in tests/."""
         self.device = torch.device(device)
@@ -202,6 +202,7 @@ class PlanBuilder:
         self.keep = []         # tensors / ctypes objects that must outlive the plan
         self.pool = {}         # nbytes -> [tensor]
         self.tile_override = tile_override
+        self.stages = stages
         self.flops = 0         # 2*MAC of the recorded convolutions
         self.bytes_alloc = 0
 
@@ -258,7 +259,7 @@ class PlanBuilder:
         d.OD, d.OH, d.OW = spec.OD, spec.OH, spec.OW
         d.out_stride = H.i3(spec.out_stride)
         d.Cout, d.ldc, d.cout_pad, d.k_pad = spec.Cout, spec.Cout, spec.cout_pad, spec.k_pad
-        d.nphase, d.flags, d.tile = len(spec.phases), spec.flags, self.tile_override
+        d.nphase, d.flags, d.tile, d.stages = len(spec.phases), spec.flags, self.tile_override, self.stages
         for i, ph in enumerate(spec.phases):
             wdev = self.const(ph.weight, self.dtype)
             tdev = self.const(ph.taps)

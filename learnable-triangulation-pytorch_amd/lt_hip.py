@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
                 ("Do", i32), ("Ho", i32), ("Wo", i32), ("stride", i32 * 3), ("pad", i32 * 3),
                 ("OD", i32), ("OH", i32), ("OW", i32), ("out_stride", i32 * 3),
                 ("Cout", i32), ("ldc", i32), ("cout_pad", i32), ("k_pad", i32),
-                ("nphase", i32), ("flags", i32), ("tile", i32), ("reserved", i32),
+                ("nphase", i32), ("flags", i32), ("tile", i32), ("stages", i32),
                 ("phase", ConvPhase * MAX_PHASES)]
 
 

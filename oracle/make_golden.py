@@ -262,7 +262,8 @@ def main():
         # small whole-pipeline cases (fast on CPU, exercise every branch)
         run_vol_case(mvn, "small_softmax", 18, 2, 3, 128, 32, "softmax", sharpen=True, inside=True, rotate=True, seed=2, stride=2)
         run_vol_case(mvn, "small_sum_coco", 18, 1, 2, 128, 32, "sum", multiplier=100.0, sharpen=False, kind="coco", rotate=True, seed=3, stride=2, cmu=True)
-        run_vol_case(mvn, "small_conf", 50, 2, 4, 128, 32, "conf_norm", sharpen=True, seed=4, stride=2)
+        # (multiplier 100 instead of the x250 sharpening: with it the reference deviates from ITSELF by 8.9e-5 between 1 and 8 threads)
+        run_vol_case(mvn, "small_conf", 50, 2, 4, 128, 32, "conf_norm", multiplier=100.0, sharpen=False, seed=4, stride=2)
         run_vol_case(mvn, "small_max", 18, 1, 3, 128, 32, "max", sharpen=True, seed=5, stride=2)
         # BASELINE config 2 shape, B=1: default and sharpened weights
         run_vol_case(mvn, "c2_default", 152, 1, 4, 384, 64, "softmax", sharpen=False, seed=0, stride=4)

@@ -145,9 +145,13 @@ def test_eager_equals_graph_and_batch_independence():
         outs[name] = m(inp["images"][idx].to(DEV), None, batch)
     assert torch.equal(outs["graph8"][0], outs["eager8"][0]) and torch.equal(outs["graph8"][2], outs["eager8"][2])
     assert torch.equal(outs["graph8"][0][2:3], outs["graph_2"][0]), "sample 2 differs between B=8 and B=1"
-    o = O.volumetric_forward(sd, cfg, inp["images"][:2], inp["K"], inp["R"], inp["t"], inp["pred_keypoints_3d"][:2])
+    o = O.volumetric_forward(sd, cfg, inp["images"][:2], inp["K"], inp["R"], inp["t"], inp["pred_keypoints_3d"][:2], stages=True)
     rel = ((outs["graph8"][0][:2].cpu() - o["keypoints_3d"]).abs() / o["keypoints_3d"].abs().clamp(min=1.0)).max()
     record("B=8 XCD-pinned path vs oracle: joints max rel", float(rel))
+    record("B=8 XCD-pinned path vs oracle: joints max abs (mm)", float((outs["graph8"][0][:2].cpu() - o["keypoints_3d"]).abs().max()))
+    record("B=8 XCD-pinned path vs oracle: features rel", rel_err(outs["graph8"][1][:2].cpu(), o["features"]))
+    record("B=8 XCD-pinned path vs oracle: volumes rel", rel_err(outs["graph8"][2][:2].cpu(), o["volumes"]))
+    record("B=8 XCD-pinned path vs oracle: coord rel", rel_err(outs["graph8"][5][:2].cpu(), o["coord_volumes"]))
     assert float(rel) <= 1e-4
     p = outs["graph8"][2]
     assert float((p.sum(dim=(2, 3, 4)) - 1).abs().max()) < 1e-4                      # probabilities sum to one

@@ -36,6 +36,16 @@ prof)
   cd $R
   find $OUT/prof -name "*stats*" | head | tee -a $OUT/session.log
   ;;
+convbench)
+  timeout 600 python tools/conv_bench.py --json $OUT/conv_bench_bf16.json > $OUT/conv_bench_bf16.log 2>&1
+  echo "convbench rc=$?" | tee -a $OUT/session.log; tail -3 $OUT/conv_bench_bf16.log
+  ;;
+pmcsq)
+  cd /tmp; export TMPDIR=/tmp
+  timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-graph > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+  echo "pmc sq rc=$?" | tee -a $OUT/session.log; ls $OUT/pmc_sq | head
+  cd $R
+  ;;
 nst)
   # A/B: 2-stage vs 3-stage LDS-DMA ring in the v2 conv kernels
   for n in 2 3; do
