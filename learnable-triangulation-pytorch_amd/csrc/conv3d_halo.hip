@@ -1,0 +1,358 @@
+// Stride-1 "same" 3D convolution (3^3 / 7^3) for the V2V hourglass: the input HALO TILE lives in LDS.
+//
+// The implicit-GEMM kernels stream one K step of the im2col matrix per barrier, i.e. every input voxel crosses
+// L2 -> LDS once per filter tap (27x / 343x).  At the 64^3 / 32^3 levels of V2V the GEMM is narrow (16..64 output
+// channels), so that stream -- not the MFMAs -- sets the time (measured: 3^3 32->32 at 64^3 = 350 TF/s, 7^3 = 330 TF/s).
+// Here a workgroup owns a TD x TH x TW block of output voxels (256 GEMM rows), DMAs the (T+K-1)^3 input halo into
+// LDS ONCE (zero filled outside the volume), and then walks the taps: the A fragment of tap (kd,kh,kw) is the same
+// LDS image read at a shifted voxel index, so the per-tap traffic is LDS -> VGPR only.  Weights stream through a
+// double-buffered LDS ring, a few taps per barrier.
+//
+// LDS images (both filled by LDS-DMA, so both are lane-linear and swizzled on the SOURCE side):
+//   halo   : voxel-major, CINB = Cin*sizeof(T) bytes per voxel = NVV 16-byte vectors; vector lv of voxel hv is stored in
+//            slot lv ^ ((hv / VPR) % NVV), VPR = 16/NVV voxels per 256-byte bank row: 16 consecutive voxels read the same
+//            logical vector from 16 different slots;
+//   weights: per tap a [cout_pad][CINB] slab with the same swizzle keyed by the output channel.
+#include "conv_common.h"
+
+using namespace lt;
+
+namespace {
+
+__device__ uint4 g_zero_page_h[2];
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void dma16h(const void* src, unsigned lds_base) {
+    unsigned keep;
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);   // wave-uniform by construction; make it provable
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_base)
+        : "memory");
+}
+
+__device__ __forceinline__ float epi_act_h(float v, bool relu_pre, bool has_res, float r, bool relu_post) {
+    if (relu_pre) v = fmaxf(v, 0.f);
+    if (has_res) v += r;
+    if (relu_post) v = fmaxf(v, 0.f);
+    return v;
+}
+
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC>
+struct HaloCfg {
+    static constexpr int ES = sizeof(T);
+    static constexpr int VEC = 16 / ES;
+    static constexpr int CINB = CIN * ES;
+    static constexpr int NVV = CINB / 16;          // 16-byte vectors per voxel
+    static constexpr int VPR = 16 / NVV;           // voxels per 256-byte bank row
+    static constexpr int HD = TD + KS - 1, HH = TH + KS - 1, HW = TW + KS - 1;
+    static constexpr int HV = HD * HH * HW;        // halo voxels
+    static constexpr int HALO_BYTES = ((HV * CINB + 1023) / 1024) * 1024;   // whole DMA wave-instructions
+    static constexpr int NTAPS = KS * KS * KS;
+    static constexpr int NCH = (NTAPS + TPC - 1) / TPC;
+    static constexpr int SLAB = CP * CINB;         // bytes of one tap's weights
+    static constexpr int WCH = ((TPC * SLAB + 1023) / 1024) * 1024;
+    static constexpr int MF = CP == 16 ? 16 : 32;
+    static constexpr int G = MF == 32 ? NVV / 2 : NVV / 4;   // fragment groups per tap (K = Cin)
+    static constexpr int SM = 64 / MF;             // sub-tiles per wave along M (wave = 64 rows)
+    static constexpr int SN = CP / MF;
+    static constexpr int NACC = MF == 32 ? 16 : 4;
+    static constexpr int EP_LD = CP + 4;
+    static constexpr int EP_BYTES = 4 * 64 * EP_LD * 4;
+    static constexpr int MAIN_BYTES = HALO_BYTES + 2 * WCH;
+    static constexpr int LDS_BYTES = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
+    static_assert(TD * TH * TW == 256, "256 rows per workgroup");
+    static_assert(NVV >= 1 && (MF == 32 ? NVV >= 2 : NVV >= 4), "Cin too small for the MFMA K");
+    static_assert((NVV & (NVV - 1)) == 0 && NVV <= 16, "NVV must be a power of two <= 16");
+};
+
+struct HaloArgs {
+    const void* x;
+    const void* w;      // [cout_pad][k_pad], k = tap*Cin + ci (the lt_conv_fwd packing)
+    void* y;
+    const void* res;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    int N, D, H, W, Cout, ldc, k_pad, flags;
+    int tiles_d, tiles_h, tiles_w;   // per sample
+    int xcd_pin;
+};
+
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC>
+__global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
+    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC> C;
+    constexpr bool ACC64 = sizeof(T) == 4;
+    constexpr int MF = C::MF, SM = C::SM, SN = C::SN, G = C::G, NACC = C::NACC, NVV = C::NVV, VPR = C::VPR, CINB = C::CINB;
+    typedef typename Mma<T, MF>::acc_t acc_t;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    unsigned char* s_halo = smem;
+    unsigned char* s_w = smem + C::HALO_BYTES;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    // ---- workgroup -> (sample, tile); with N % 8 == 0 sample n is pinned to XCD n % 8 (its d-slabs stay in that L2) ----
+    const int tps = a.tiles_d * a.tiles_h * a.tiles_w;
+    int n, tix;
+    if (a.xcd_pin) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        n = xcd + 8 * (j / tps);
+        tix = j % tps;
+    } else {
+        n = blockIdx.x / tps;
+        tix = blockIdx.x % tps;
+    }
+    const int w0 = (tix % a.tiles_w) * TW;
+    const int h0 = ((tix / a.tiles_w) % a.tiles_h) * TH;
+    const int d0 = (tix / (a.tiles_w * a.tiles_h)) * TD;
+    constexpr int P = KS / 2;
+
+    const T* __restrict__ x = (const T*)a.x + (size_t)n * a.D * a.H * a.W * CIN;
+    const T* __restrict__ w = (const T*)a.w;
+
+    // ---- halo DMA: vector q = hv*NVV + pv, wave-instruction i covers q in [64 i, 64 i + 64) ----
+    constexpr int NI_H = C::HALO_BYTES / 1024;
+    for (int i = wave; i < NI_H; i += 4) {
+        const int q = i * 64 + lane;
+        const int hv = q / NVV, pv = q % NVV;
+        const int lv = pv ^ ((hv / VPR) % NVV);
+        const int hw_ = hv % C::HW, hh_ = (hv / C::HW) % C::HH, hd_ = hv / (C::HW * C::HH);
+        const int id = d0 - P + hd_, ih = h0 - P + hh_, iw = w0 - P + hw_;
+        const bool ok = hv < C::HV && ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+        const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : (const void*)g_zero_page_h;
+        dma16h(src, lds0 + i * 1024);
+    }
+    // ---- weight chunk DMA: vector q = (tap_in_chunk*CP + col)*NVV + pv ----
+    constexpr int NI_W = C::WCH / 1024;
+    auto stage_w = [&](int ch, int buf) {
+        for (int i = wave; i < NI_W; i += 4) {
+            const int q = i * 64 + lane;
+            const int pv = q % NVV, col = (q / NVV) % CP, tj = q / (NVV * CP);
+            const int tap = ch * TPC + tj;
+            const int lv = pv ^ ((col / VPR) % NVV);
+            const bool ok = tj < TPC && tap < C::NTAPS;
+            const void* src = ok ? (const void*)(w + (size_t)col * a.k_pad + tap * CIN + lv * C::VEC) : (const void*)g_zero_page_h;
+            dma16h(src, lds0 + C::HALO_BYTES + buf * C::WCH + i * 1024);
+        }
+    };
+    stage_w(0, 0);
+
+    // ---- per-lane fragment bookkeeping ----
+    // rows of this wave: r = 64*wave + i*MF + (lane & (MF-1)); voxel (td,th,tw) with tw fastest
+    int hv0[SM];
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+        const int r = 64 * wave + i * MF + (lane & (MF - 1));
+        const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
+        hv0[i] = (td * C::HH + th) * C::HW + tw;
+    }
+    const int lvb = (MF == 32) ? (lane >> 5) : (lane >> 4);   // logical vector of group 0; group g adds (MF==32 ? 2g : 4g)
+    int boff[SN];                                             // weight fragment offset inside a tap slab, group 0
+    int bsw[SN];
+#pragma unroll
+    for (int j = 0; j < SN; ++j) {
+        const int col = j * MF + (lane & (MF - 1));
+        bsw[j] = (col / VPR) % NVV;
+        boff[j] = col * CINB;
+    }
+
+    acc_t acc[SM][SN];
+    double dacc[ACC64 ? SM : 1][ACC64 ? SN : 1][ACC64 ? NACC : 1];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int e = 0; e < NACC; ++e) {
+                acc[i][j][e] = 0.f;
+                if (ACC64) dacc[i][j][e] = 0.0;
+            }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    for (int ch = 0; ch < C::NCH; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < C::NCH) stage_w(ch + 1, buf ^ 1);
+        const unsigned char* wb = s_w + buf * C::WCH;
+#pragma unroll
+        for (int tj = 0; tj < TPC; ++tj) {
+            const int tap = ch * TPC + tj;            // wave-uniform
+            if (tap < C::NTAPS) {
+                const int kw = tap % KS, kh = (tap / KS) % KS, kd = tap / (KS * KS);
+                const int toff = (kd * C::HH + kh) * C::HW + kw;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int lv = lvb + ((MF == 32) ? 2 * g : 4 * g);
+                    V16 fa[SM], fb[SN];
+#pragma unroll
+                    for (int i = 0; i < SM; ++i) {
+                        const int hv = hv0[i] + toff;
+                        fa[i].u = *(const uint4*)(s_halo + hv * CINB + ((lv ^ ((hv / VPR) % NVV)) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < SN; ++j) fb[j].u = *(const uint4*)(wb + tj * C::SLAB + boff[j] + ((lv ^ bsw[j]) << 4));
+#pragma unroll
+                    for (int i = 0; i < SM; ++i)
+#pragma unroll
+                        for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[i], fb[j]);
+                }
+                if (ACC64 && ((tap & 1) == 1 || tap + 1 == C::NTAPS)) {
+#pragma unroll
+                    for (int i = 0; i < SM; ++i)
+#pragma unroll
+                        for (int j = 0; j < SN; ++j)
+#pragma unroll
+                            for (int e = 0; e < NACC; ++e) {
+                                dacc[i][j][e] += (double)acc[i][j][e];
+                                acc[i][j][e] = 0.f;
+                            }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- epilogue (same scheme as conv_igemm2: per-wave fp32 LDS tile -> 16-byte vectors) ----
+    float* ep = (float*)(smem + wave * (64 * C::EP_LD * 4));
+#pragma unroll
+    for (int j = 0; j < SN; ++j) {
+        const int colj = j * MF + (lane & (MF - 1));
+        const float bi = a.bias ? a.bias[colj] : 0.f;
+        const float sc = a.scale ? a.scale[colj] : 1.f;
+        const float sf = a.shift ? a.shift[colj] : 0.f;
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+            for (int e = 0; e < NACC; ++e) {
+                const int r = i * MF + ((MF == 32) ? ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) : ((lane >> 4) * 4 + e));
+                float val;
+                if (ACC64) val = (float)((dacc[i][j][e] + (double)bi) * (double)sc + (double)sf);
+                else val = (acc[i][j][e] + bi) * sc + sf;
+                ep[r * C::EP_LD + colj] = val;
+            }
+    }
+    __syncthreads();
+
+    const bool relu_pre = a.flags & LT_EPI_RELU_PRE, relu_post = a.flags & LT_EPI_RELU_POST;
+    const bool has_res = a.res != nullptr;
+    auto row_pix = [&](int r) -> size_t {   // r = row inside the workgroup tile
+        const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
+        return (((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw;
+    };
+    constexpr int VECO = C::VEC;              // fp32: 4 channels, bf16: 8 channels per 16 bytes
+    if ((a.Cout % VECO == 0) && (a.ldc % VECO == 0)) {
+        constexpr int LPR = CP / VECO, RPP = 64 / LPR;
+        const int cq = (lane % LPR) * VECO;
+        if (cq < a.Cout) {
+            for (int r = lane / LPR; r < 64; r += RPP) {
+                const size_t off = row_pix(64 * wave + r) * a.ldc + cq;
+                const float* src = ep + r * C::EP_LD + cq;
+                float vv[VECO], rr[VECO];
+#pragma unroll
+                for (int e = 0; e < VECO; e += 4) {
+                    const float4 q = *(const float4*)(src + e);
+                    vv[e] = q.x; vv[e + 1] = q.y; vv[e + 2] = q.z; vv[e + 3] = q.w;
+                }
+#pragma unroll
+                for (int e = 0; e < VECO; ++e) rr[e] = 0.f;
+                if (has_res) {
+                    const uint4 rv = *(const uint4*)((const T*)a.res + off);
+                    const T* r8 = (const T*)&rv;
+                    union { uint4 u; float f[4]; unsigned short h[8]; } cv;
+                    cv.u = rv;
+                    (void)r8;
+#pragma unroll
+                    for (int e = 0; e < VECO; ++e) rr[e] = sizeof(T) == 4 ? cv.f[e % 4] : bf16_to_f32(cv.h[e % 8]);
+                }
+                union { uint4 u; float f[4]; unsigned short h[8]; } ov;
+#pragma unroll
+                for (int e = 0; e < VECO; ++e) {
+                    const float val = epi_act_h(vv[e], relu_pre, has_res, rr[e], relu_post);
+                    if (sizeof(T) == 4) ov.f[e % 4] = val;
+                    else ov.h[e % 8] = f32_to_bf16(val);
+                }
+                *(uint4*)((T*)a.y + off) = ov.u;
+            }
+        }
+    } else {
+        for (int idx = lane; idx < 64 * CP; idx += 64) {
+            const int r = idx / CP, cc = idx - r * CP;
+            if (cc >= a.Cout) continue;
+            const size_t off = row_pix(64 * wave + r) * a.ldc + cc;
+            const float rr = has_res ? elt<T>::ld((const T*)a.res + off) : 0.f;
+            elt<T>::st((T*)a.y + off, epi_act_h(ep[r * C::EP_LD + cc], relu_pre, has_res, rr, relu_post));
+        }
+    }
+}
+
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC>
+int launch_halo(const HaloArgs& a, hipStream_t s) {
+    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC> C;
+    static_assert(C::LDS_BYTES <= 160 * 1024, "halo tile does not fit LDS");
+    auto kern = conv3d_halo_kernel<T, KS, CIN, CP, TD, TH, TW, TPC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const long long nblk = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, s, a);
+    LT_CHECK_LAUNCH("lt_conv_fwd(halo)");
+    return LT_OK;
+}
+
+}  // namespace
+
+namespace lt {
+
+// Returns 1 and launches when the problem matches one of the instantiated halo configurations, 0 when the caller should
+// fall back to the implicit-GEMM path, negative on error.
+int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool forced, hipStream_t s) {
+    const PhaseArg& p0 = c.phase[0];
+    if (nphase != 1 || c.sd != 1 || c.sh != 1 || c.sw != 1 || c.osd != 1 || c.osh != 1 || c.osw != 1) return 0;
+    if (p0.ood || p0.ooh || p0.oow || c.D != c.Do || c.H != c.Ho || c.W != c.Wo || c.OD != c.Do || c.OH != c.Ho || c.OW != c.Wo) return 0;
+    if (c.flags & (LT_EPI_STORE_F32 | LT_EPI_SIGMOID)) return 0;
+    int ks = 0;
+    if (p0.ntaps == 27 && c.pd == 1 && c.ph == 1 && c.pw == 1) ks = 3;
+    else if (p0.ntaps == 343 && c.pd == 3 && c.ph == 3 && c.pw == 3) ks = 7;
+    else return 0;
+    if (c.D % 4 || c.H % 8 || c.W % 8) return 0;
+    const long long nblk = (long long)c.N * (c.D / 4) * (c.H / 8) * (c.W / 8);
+    if (nblk < 256 && !forced) return 0;   // too few workgroups: the 64x64 implicit-GEMM tile fills the chip better
+    HaloArgs a;
+    a.x = c.x; a.w = p0.w; a.y = c.y; a.res = c.res; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
+    a.N = c.N; a.D = c.D; a.H = c.H; a.W = c.W; a.Cout = c.Cout; a.ldc = c.ldc; a.k_pad = c.k_pad; a.flags = c.flags;
+    a.tiles_d = c.D / 4; a.tiles_h = c.H / 8; a.tiles_w = c.W / 8;
+    a.xcd_pin = (c.N % 8 == 0) ? 1 : 0;
+    const bool bf = dtype == LT_BF16;
+#define HALO_CASE(T_, KS_, CIN_, CP_, TPC_)                                                      \
+    if (ks == KS_ && c.Cin == CIN_ && cout_pad == CP_) {                                        \
+        int rc = launch_halo<T_, KS_, CIN_, CP_, 4, 8, 8, TPC_>(a, s);                          \
+        return rc == LT_OK ? 1 : rc;                                                            \
+    }
+    if (bf) {
+        HALO_CASE(bf16_t, 3, 32, 32, 9)
+        HALO_CASE(bf16_t, 3, 16, 32, 9)
+        HALO_CASE(bf16_t, 3, 64, 64, 3)
+        HALO_CASE(bf16_t, 3, 32, 64, 9)
+        HALO_CASE(bf16_t, 7, 32, 16, 7)
+    } else {
+        HALO_CASE(float, 3, 32, 32, 3)
+        HALO_CASE(float, 3, 16, 32, 9)
+    }
+#undef HALO_CASE
+    return 0;
+}
+
+}  // namespace lt

@@ -84,5 +84,7 @@ constexpr int ROW_BYTES = 128;  // K bytes per tile row per step
 
 // launchers implemented in conv_igemm2.hip, used by the dispatcher in conv_igemm.hip
 int conv2_dispatch(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile, hipStream_t s);
+// conv3d_halo.hip: 1 = launched, 0 = not applicable (fall back), < 0 = error
+int conv3d_halo_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, bool forced, hipStream_t s);
 
 }  // namespace lt

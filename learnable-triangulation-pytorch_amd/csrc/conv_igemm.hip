@@ -263,7 +263,17 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
         LT_CHECK_LAUNCH("lt_conv_fwd(direct)");
         return LT_OK;
     }
-    static const bool force_v1 = getenv("LT_CONV_V1") != nullptr;   // A/B switch for profiling sessions
+    static const bool force_v1 = getenv("LT_CONV_V1") != nullptr;   // A/B switches for profiling sessions
+    static const bool no_halo = getenv("LT_CONV_NO_HALO") != nullptr;
+    if ((tile == LT_TILE_AUTO && !force_v1 && !no_halo) || tile == LT_TILE_HALO) {
+        const int rc = conv3d_halo_try(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, tile == LT_TILE_HALO, s);
+        if (rc == 1) return LT_OK;
+        if (rc < 0) return rc;
+        if (tile == LT_TILE_HALO) {
+            set_error("lt_conv_fwd: LT_TILE_HALO requested but the problem is not a supported stride-1 3^3/7^3 conv3d");
+            return LT_ERR_UNSUPPORTED;
+        }
+    }
     if ((tile == LT_TILE_AUTO && !force_v1) || (tile >= LT_TILE2_128x128 && tile <= LT_TILE2_64x64))
         return conv2_dispatch(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, max_taps, tile, s);
     if (tile == LT_TILE_AUTO) {

@@ -267,3 +267,33 @@ def test_conv_epilogue_variants(dtype):
         assert y.t.dtype == torch.float32
         check("conv1x1x1->17 fp32 store/%s/tile%d" % (dtype, tile), from_cl(y.t, 3), F.conv3d(rd(x), rd(w), bias), tol)
         check("linear+sigmoid/%s/tile%d" % (dtype, tile), yl.t.reshape(6, 40).cpu(), torch.sigmoid(F.linear(rd(xl), rd(wl), bl)), tol)
+
+
+HALO_CASES = {  # name: (N, cin, cout, k, (D,H,W), dtypes)
+    "halo_3x3_32_32": (2, 32, 32, 3, (8, 16, 16), ("f32", "bf16")),
+    "halo_3x3_16_32": (1, 16, 32, 3, (4, 16, 8), ("f32", "bf16")),
+    "halo_3x3_64_64": (1, 64, 64, 3, (8, 8, 16), ("bf16",)),
+    "halo_3x3_32_64": (3, 32, 64, 3, (4, 8, 16), ("bf16",)),
+    "halo_7x7_32_16": (1, 32, 16, 7, (8, 16, 8), ("bf16",)),
+    "halo_3x3_32_32_xcdpin": (8, 32, 32, 3, (4, 8, 8), ("bf16",)),
+}
+
+
+@pytest.mark.parametrize("case", list(HALO_CASES))
+def test_conv3d_halo_kernel(case):
+    """LDS-resident halo conv3d (LT_TILE_HALO) vs torch conv3d, incl. zero padding at every face, residual + ReLU."""
+    N, cin, cout, k, sp, dts = HALO_CASES[case]
+    g = torch.Generator().manual_seed(len(case))
+    x = torch.randn(N, cin, *sp, generator=g)
+    w = torch.randn(cout, cin, k, k, k, generator=g) * (1.0 / (cin * k ** 3) ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    bn = _bn(cout, g)
+    res = torch.randn(N, cout, *sp, generator=g)
+    for dname in dts:
+        dtype = torch.float32 if dname == "f32" else torch.bfloat16
+        rd = (lambda t: bf16_round(t)) if dtype == torch.bfloat16 else (lambda t: t)
+        ref = torch.relu(_bn_ref(F.conv3d(rd(x), rd(w), bias, 1, k // 2), bn) + rd(res))
+        out = run_conv(x, w, bias, bn, 1, k // 2, dtype, H.TILE_HALO, relu=True, residual=res)
+        check("conv3d_halo/%s/%s" % (case, dname), out, ref, 2e-5 if dtype == torch.float32 else 1.5e-2)
+        out2 = run_conv(x, w, bias, bn, 1, k // 2, dtype, 0, relu=True, residual=res)   # AUTO (generic or halo) agrees
+        check("conv3d_auto/%s/%s" % (case, dname), out2, ref, 2e-5 if dtype == torch.float32 else 1.5e-2)

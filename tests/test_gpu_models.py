@@ -152,7 +152,9 @@ def test_eager_equals_graph_and_batch_independence():
     record("B=8 XCD-pinned path vs oracle: features rel", rel_err(outs["graph8"][1][:2].cpu(), o["features"]))
     record("B=8 XCD-pinned path vs oracle: volumes rel", rel_err(outs["graph8"][2][:2].cpu(), o["volumes"]))
     record("B=8 XCD-pinned path vs oracle: coord rel", rel_err(outs["graph8"][5][:2].cpu(), o["coord_volumes"]))
-    assert float(rel) <= 1e-4
+    # near-uniform soft-argmax: joints sit within a few mm of the world origin, where a RELATIVE gate is meaningless
+    # (fp32 sum of 32768 terms of magnitude ~1e3 mm): gate the absolute deviation at 0.01 mm = 4e-6 of the cuboid side
+    assert float((outs["graph8"][0][:2].cpu() - o["keypoints_3d"]).abs().max()) <= 1e-2
     p = outs["graph8"][2]
     assert float((p.sum(dim=(2, 3, 4)) - 1).abs().max()) < 1e-4                      # probabilities sum to one
     lo = outs["graph8"][5].amin(dim=(1, 2, 3)); hi = outs["graph8"][5].amax(dim=(1, 2, 3))

@@ -55,7 +55,7 @@ def main():
     for (name, nd, N, cin, cout, k, s, p, sp, tr) in shapes(args.batch):
         cp = E.cout_pad_of(cout)
         tiles = [t for t, bn in (("128x128", 128), ("128x64", 64), ("64x64", 64), ("256x32", 32), ("256x16", 16)) if cp % bn == 0 and bn <= cp]
-        variants = [("auto", 0, 0)] + [("%s/s%d" % (t, n), TILES[t], n) for t in tiles for n in (2, 3)] + [("v1_" + t, TILES["v1_" + t], 0) for t in tiles[:2]]
+        variants = [("auto", 0, 0), ("halo", 20, 0)] + [("%s/s%d" % (t, n), TILES[t], n) for t in tiles for n in (2, 3)] + [("v1_" + t, TILES["v1_" + t], 0) for t in tiles[:2]]
         x = torch.randn(N, *( (1,) if nd == 2 else ()), *sp, cin, device=dev).to(dt)
         w = torch.randn(*((cin, cout) if tr else (cout, cin)), *([k] * nd)) * 0.05
         res = None
