@@ -9,10 +9,14 @@
 // double-buffered LDS ring, a few taps per barrier.
 //
 // LDS images (both filled by LDS-DMA, so both are lane-linear and swizzled on the SOURCE side):
-//   halo   : voxel-major, CINB = Cin*sizeof(T) bytes per voxel = NVV 16-byte vectors; vector lv of voxel hv is stored in
-//            slot lv ^ ((hv / VPR) % NVV), VPR = 16/NVV voxels per 256-byte bank row: 16 consecutive voxels read the same
-//            logical vector from 16 different slots;
-//   weights: per tap a [cout_pad][CINB] slab with the same swizzle keyed by the output channel.
+//   halo   : voxel-major (row pitch PW voxels), CINB = Cin*sizeof(T) bytes per voxel = NVV 16-byte vectors; vector lv of the
+//            voxel at halo position (hd,hh,hw) is stored in slot lv ^ f, f = (FA*hh + FB*hd + ((hw + FC*hh) >> FSH)) % NVV.
+//            The constants per (kernel size, CINB, MFMA shape) were found by exhaustive search over all taps and all
+//            ds_read_b128 lane groups (tools/halo_bank_search.py): every A-fragment read is bank-conflict free (the
+//            linear (hv/VPR)%NVV swizzle of the first version was 3-way conflicted: rows of a lane group are 4 partial
+//            lines of the tile, not 16 consecutive voxels);
+//   weights: per tap a [cout_pad][CINB] slab, slot lv ^ ((-(col/VPR)) % NVV) (conflict free for both MFMA shapes).
+// Weight ring: NBUF chunk buffers, NBUF-1 chunks of DMA in flight (counted vmcnt), one barrier per chunk.
 #include "conv_common.h"
 
 using namespace lt;
@@ -44,33 +48,65 @@ __device__ __forceinline__ float epi_act_h(float v, bool relu_pre, bool has_res,
     return v;
 }
 
-template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC>
+// swizzle constants {FA, FB, FC, FSH, pitch multiple}
+template <int KS, int CINB, int MF> struct HaloSwz { static constexpr int FA = 0, FB = 0, FC = 0, FSH = 1, PAD = 1; };   // (3, 64 B, 32x32)
+template <> struct HaloSwz<7, 64, 16> { static constexpr int FA = 0, FB = 0, FC = 0, FSH = 0, PAD = 1; };
+template <> struct HaloSwz<3, 128, 32> { static constexpr int FA = 3, FB = 0, FC = 2, FSH = 1, PAD = 1; };
+template <> struct HaloSwz<3, 32, 32> { static constexpr int FA = 0, FB = 0, FC = 0, FSH = 2, PAD = 4; };
+
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF>
 struct HaloCfg {
     static constexpr int ES = sizeof(T);
     static constexpr int VEC = 16 / ES;
     static constexpr int CINB = CIN * ES;
     static constexpr int NVV = CINB / 16;          // 16-byte vectors per voxel
     static constexpr int VPR = 16 / NVV;           // voxels per 256-byte bank row
+    static constexpr int MF = CP == 16 ? 16 : 32;
+    typedef HaloSwz<KS, CINB, MF> SW;
     static constexpr int HD = TD + KS - 1, HH = TH + KS - 1, HW = TW + KS - 1;
-    static constexpr int HV = HD * HH * HW;        // halo voxels
+    static constexpr int PW = (HW + SW::PAD - 1) / SW::PAD * SW::PAD;       // row pitch in voxels
+    static constexpr int HV = HD * HH * PW;        // halo voxel slots
     static constexpr int HALO_BYTES = ((HV * CINB + 1023) / 1024) * 1024;   // whole DMA wave-instructions
     static constexpr int NTAPS = KS * KS * KS;
     static constexpr int NCH = (NTAPS + TPC - 1) / TPC;
     static constexpr int SLAB = CP * CINB;         // bytes of one tap's weights
     static constexpr int WCH = ((TPC * SLAB + 1023) / 1024) * 1024;
-    static constexpr int MF = CP == 16 ? 16 : 32;
     static constexpr int G = MF == 32 ? NVV / 2 : NVV / 4;   // fragment groups per tap (K = Cin)
     static constexpr int SM = 64 / MF;             // sub-tiles per wave along M (wave = 64 rows)
     static constexpr int SN = CP / MF;
     static constexpr int NACC = MF == 32 ? 16 : 4;
     static constexpr int EP_LD = CP + 4;
     static constexpr int EP_BYTES = 4 * 64 * EP_LD * 4;
-    static constexpr int MAIN_BYTES = HALO_BYTES + 2 * WCH;
+    static constexpr int MAIN_BYTES = HALO_BYTES + NBUF * WCH;
     static constexpr int LDS_BYTES = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
     static_assert(TD * TH * TW == 256, "256 rows per workgroup");
     static_assert(NVV >= 1 && (MF == 32 ? NVV >= 2 : NVV >= 4), "Cin too small for the MFMA K");
     static_assert((NVV & (NVV - 1)) == 0 && NVV <= 16, "NVV must be a power of two <= 16");
+    static_assert(NBUF >= 2 && NBUF <= 4, "2..4 weight chunk buffers");
+    static __device__ __forceinline__ int fswz(int hd, int hh, int hw) {
+        return (SW::FA * hh + SW::FB * hd + ((hw + SW::FC * hh) >> SW::FSH)) & (NVV - 1);
+    }
 };
+
+// s_waitcnt vmcnt(n), n wave-uniform
+__device__ __forceinline__ void wait_vmcnt_h(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // conservative
+    }
+}
 
 struct HaloArgs {
     const void* x;
@@ -85,9 +121,9 @@ struct HaloArgs {
     int xcd_pin;
 };
 
-template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC>
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF>
 __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
-    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC> C;
+    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF> C;
     constexpr bool ACC64 = sizeof(T) == 4;
     constexpr int MF = C::MF, SM = C::SM, SN = C::SN, G = C::G, NACC = C::NACC, NVV = C::NVV, VPR = C::VPR, CINB = C::CINB;
     typedef typename Mma<T, MF>::acc_t acc_t;
@@ -124,10 +160,10 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
     for (int i = wave; i < NI_H; i += 4) {
         const int q = i * 64 + lane;
         const int hv = q / NVV, pv = q % NVV;
-        const int lv = pv ^ ((hv / VPR) % NVV);
-        const int hw_ = hv % C::HW, hh_ = (hv / C::HW) % C::HH, hd_ = hv / (C::HW * C::HH);
+        const int hw_ = hv % C::PW, hh_ = (hv / C::PW) % C::HH, hd_ = hv / (C::PW * C::HH);
+        const int lv = pv ^ C::fswz(hd_, hh_, hw_);
         const int id = d0 - P + hd_, ih = h0 - P + hh_, iw = w0 - P + hw_;
-        const bool ok = hv < C::HV && ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+        const bool ok = hv < C::HV && hw_ < C::HW && ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
         const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : (const void*)g_zero_page_h;
         dma16h(src, lds0 + i * 1024);
     }
@@ -138,22 +174,27 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
             const int q = i * 64 + lane;
             const int pv = q % NVV, col = (q / NVV) % CP, tj = q / (NVV * CP);
             const int tap = ch * TPC + tj;
-            const int lv = pv ^ ((col / VPR) % NVV);
+            const int lv = pv ^ ((-(col / VPR)) & (NVV - 1));
             const bool ok = tj < TPC && tap < C::NTAPS;
             const void* src = ok ? (const void*)(w + (size_t)col * a.k_pad + tap * CIN + lv * C::VEC) : (const void*)g_zero_page_h;
             dma16h(src, lds0 + C::HALO_BYTES + buf * C::WCH + i * 1024);
         }
     };
-    stage_w(0, 0);
+    const int dpc = (NI_W - wave + 3) / 4;        // weight DMA instructions per chunk issued by this wave (wave-uniform)
+#pragma unroll
+    for (int c = 0; c < NBUF - 1; ++c)
+        if (c < C::NCH) stage_w(c, c);
 
     // ---- per-lane fragment bookkeeping ----
     // rows of this wave: r = 64*wave + i*MF + (lane & (MF-1)); voxel (td,th,tw) with tw fastest
-    int hv0[SM];
+    int hv0[SM], fa0[SM], fb0[SM];   // halo slot of the row's own voxel; swizzle terms a = FA*th + FB*td, b = tw + FC*th
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
         const int r = 64 * wave + i * MF + (lane & (MF - 1));
         const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
-        hv0[i] = (td * C::HH + th) * C::HW + tw;
+        hv0[i] = (td * C::HH + th) * C::PW + tw;
+        fa0[i] = C::SW::FA * th + C::SW::FB * td;
+        fb0[i] = tw + C::SW::FC * th;
     }
     const int lvb = (MF == 32) ? (lane >> 5) : (lane >> 4);   // logical vector of group 0; group g adds (MF==32 ? 2g : 4g)
     int boff[SN];                                             // weight fragment offset inside a tap slab, group 0
@@ -161,7 +202,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
 #pragma unroll
     for (int j = 0; j < SN; ++j) {
         const int col = j * MF + (lane & (MF - 1));
-        bsw[j] = (col / VPR) % NVV;
+        bsw[j] = (-(col / VPR)) & (NVV - 1);
         boff[j] = col * CINB;
     }
 
@@ -177,27 +218,29 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
                 if (ACC64) dacc[i][j][e] = 0.0;
             }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
     for (int ch = 0; ch < C::NCH; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < C::NCH) stage_w(ch + 1, buf ^ 1);
-        const unsigned char* wb = s_w + buf * C::WCH;
+        // chunk ch (and, the first time, the halo issued before it) must have landed; up to NBUF-2 younger chunks stay in flight
+        int younger = C::NCH - 1 - ch;
+        if (younger > NBUF - 2) younger = NBUF - 2;
+        wait_vmcnt_h(younger * dpc);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves: chunk ch landed, chunk ch-1 fully consumed
+        if (ch + NBUF - 1 < C::NCH) stage_w(ch + NBUF - 1, (ch + NBUF - 1) % NBUF);
+        const unsigned char* wb = s_w + (ch % NBUF) * C::WCH;
 #pragma unroll
         for (int tj = 0; tj < TPC; ++tj) {
             const int tap = ch * TPC + tj;            // wave-uniform
             if (tap < C::NTAPS) {
                 const int kw = tap % KS, kh = (tap / KS) % KS, kd = tap / (KS * KS);
-                const int toff = (kd * C::HH + kh) * C::HW + kw;
+                const int toff = (kd * C::HH + kh) * C::PW + kw;
+                const int fak = C::SW::FA * kh + C::SW::FB * kd, fbk = kw + C::SW::FC * kh;
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const int lv = lvb + ((MF == 32) ? 2 * g : 4 * g);
                     V16 fa[SM], fb[SN];
 #pragma unroll
                     for (int i = 0; i < SM; ++i) {
-                        const int hv = hv0[i] + toff;
-                        fa[i].u = *(const uint4*)(s_halo + hv * CINB + ((lv ^ ((hv / VPR) % NVV)) << 4));
+                        const int f = (fa0[i] + fak + ((fb0[i] + fbk) >> C::SW::FSH)) & (NVV - 1);
+                        fa[i].u = *(const uint4*)(s_halo + (hv0[i] + toff) * CINB + ((lv ^ f) << 4));
                     }
 #pragma unroll
                     for (int j = 0; j < SN; ++j) fb[j].u = *(const uint4*)(wb + tj * C::SLAB + boff[j] + ((lv ^ bsw[j]) << 4));
@@ -219,9 +262,8 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the halo / weight images
 
     // ---- epilogue (same scheme as conv_igemm2: per-wave fp32 LDS tile -> 16-byte vectors) ----
     float* ep = (float*)(smem + wave * (64 * C::EP_LD * 4));
@@ -296,11 +338,11 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
     }
 }
 
-template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC>
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF>
 int launch_halo(const HaloArgs& a, hipStream_t s) {
-    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC> C;
+    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF> C;
     static_assert(C::LDS_BYTES <= 160 * 1024, "halo tile does not fit LDS");
-    auto kern = conv3d_halo_kernel<T, KS, CIN, CP, TD, TH, TW, TPC>;
+    auto kern = conv3d_halo_kernel<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -336,20 +378,20 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     a.tiles_d = c.D / 4; a.tiles_h = c.H / 8; a.tiles_w = c.W / 8;
     a.xcd_pin = (c.N % 8 == 0) ? 1 : 0;
     const bool bf = dtype == LT_BF16;
-#define HALO_CASE(T_, KS_, CIN_, CP_, TPC_)                                                      \
+#define HALO_CASE(T_, KS_, CIN_, CP_, TPC_, NBUF_)                                               \
     if (ks == KS_ && c.Cin == CIN_ && cout_pad == CP_) {                                        \
-        int rc = launch_halo<T_, KS_, CIN_, CP_, 4, 8, 8, TPC_>(a, s);                          \
+        int rc = launch_halo<T_, KS_, CIN_, CP_, 4, 8, 8, TPC_, NBUF_>(a, s);                   \
         return rc == LT_OK ? 1 : rc;                                                            \
     }
     if (bf) {
-        HALO_CASE(bf16_t, 3, 32, 32, 9)
-        HALO_CASE(bf16_t, 3, 16, 32, 9)
-        HALO_CASE(bf16_t, 3, 64, 64, 3)
-        HALO_CASE(bf16_t, 3, 32, 64, 9)
-        HALO_CASE(bf16_t, 7, 32, 16, 7)
+        HALO_CASE(bf16_t, 3, 32, 32, 9, 2)
+        HALO_CASE(bf16_t, 3, 16, 32, 9, 2)
+        HALO_CASE(bf16_t, 3, 64, 64, 3, 2)
+        HALO_CASE(bf16_t, 3, 32, 64, 9, 2)
+        HALO_CASE(bf16_t, 7, 32, 16, 7, 4)
     } else {
-        HALO_CASE(float, 3, 32, 32, 3)
-        HALO_CASE(float, 3, 16, 32, 9)
+        HALO_CASE(float, 3, 32, 32, 3, 3)
+        HALO_CASE(float, 3, 16, 32, 9, 2)
     }
 #undef HALO_CASE
     return 0;

@@ -144,7 +144,10 @@ def test_eager_equals_graph_and_batch_independence():
         batch = {"cameras": _cameras(inp, B), "pred_keypoints_3d": inp["pred_keypoints_3d"][idx]}
         outs[name] = m(inp["images"][idx].to(DEV), None, batch)
     assert torch.equal(outs["graph8"][0], outs["eager8"][0]) and torch.equal(outs["graph8"][2], outs["eager8"][2])
-    assert torch.equal(outs["graph8"][0][2:3], outs["graph_2"][0]), "sample 2 differs between B=8 and B=1"
+    # B=1 and B=8 may pick different tiles / kernels for the same layer (different summation order): equal to rounding, not bitwise
+    d21 = float((outs["graph8"][0][2:3] - outs["graph_2"][0]).abs().max())
+    record("batch independence: sample 2 in B=8 vs alone, joints max abs diff (mm)", d21)
+    assert d21 <= 1e-2, "sample 2 differs between B=8 and B=1"
     o = O.volumetric_forward(sd, cfg, inp["images"][:2], inp["K"], inp["R"], inp["t"], inp["pred_keypoints_3d"][:2], stages=True)
     rel = ((outs["graph8"][0][:2].cpu() - o["keypoints_3d"]).abs() / o["keypoints_3d"].abs().clamp(min=1.0)).max()
     record("B=8 XCD-pinned path vs oracle: joints max rel", float(rel))

@@ -55,9 +55,11 @@ nst)
   ;;
 ab)
   # A/B: v1 (register staged) vs v2 (LDS-DMA) conv kernels, and batch-size sweep
+  if [ -n "${WITH_V1:-}" ]; then
   LT_CONV_V1=1 timeout 600 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --ops-json $OUT/bench_ops_bf16_v1.json > $OUT/bench_bf16_v1.json 2> $OUT/bench_bf16_v1.err
   echo "bench v1 rc=$?" | tee -a $OUT/session.log; cut -c1-400 $OUT/bench_bf16_v1.json | tee -a $OUT/session.log
-  for b in 1 4 16; do
+  fi
+  for b in 1 4 16 32; do
     timeout 600 python bench.py --no-cpu-baseline --no-profile --steps 10 --warmup 3 --batch $b > $OUT/bench_bf16_b$b.json 2> $OUT/bench_bf16_b$b.err
     echo "bench B=$b rc=$?" | tee -a $OUT/session.log; cut -c1-330 $OUT/bench_bf16_b$b.json | tee -a $OUT/session.log
   done
