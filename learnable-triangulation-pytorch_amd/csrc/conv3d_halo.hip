@@ -226,29 +226,41 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves: chunk ch landed, chunk ch-1 fully consumed
         if (ch + NBUF - 1 < C::NCH) stage_w(ch + NBUF - 1, (ch + NBUF - 1) % NBUF);
         const unsigned char* wb = s_w + (ch % NBUF) * C::WCH;
+        // Fragments of tap tj+1 are requested before the MFMAs of tap tj are issued (register double buffer, order pinned
+        // with sched_barrier): with one wave per SIMD nothing else hides the ~100-cycle ds_read latency -- the first
+        // version waited for every read right in front of its MFMA (lgkmcnt(1) before each) and ran at 1/4 of the LDS rate.
+        V16 fa[2][G][SM], fb[2][G][SN];
+        auto load_tap = [&](int tj, int slot) {
+            const int tap = ch * TPC + tj;            // wave-uniform
+            const int kw = tap % KS, kh = (tap / KS) % KS, kd = tap / (KS * KS);
+            const int toff = (kd * C::HH + kh) * C::PW + kw;
+            const int fak = C::SW::FA * kh + C::SW::FB * kd, fbk = kw + C::SW::FC * kh;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int lv = lvb + ((MF == 32) ? 2 * g : 4 * g);
+#pragma unroll
+                for (int i = 0; i < SM; ++i) {
+                    const int f = (fa0[i] + fak + ((fb0[i] + fbk) >> C::SW::FSH)) & (NVV - 1);
+                    fa[slot][g][i].u = *(const uint4*)(s_halo + (hv0[i] + toff) * CINB + ((lv ^ f) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < SN; ++j) fb[slot][g][j].u = *(const uint4*)(wb + tj * C::SLAB + boff[j] + ((lv ^ bsw[j]) << 4));
+            }
+        };
+        load_tap(0, 0);
 #pragma unroll
         for (int tj = 0; tj < TPC; ++tj) {
-            const int tap = ch * TPC + tj;            // wave-uniform
+            const int tap = ch * TPC + tj;
             if (tap < C::NTAPS) {
-                const int kw = tap % KS, kh = (tap / KS) % KS, kd = tap / (KS * KS);
-                const int toff = (kd * C::HH + kh) * C::PW + kw;
-                const int fak = C::SW::FA * kh + C::SW::FB * kd, fbk = kw + C::SW::FC * kh;
+                if (tj + 1 < TPC && tap + 1 < C::NTAPS) load_tap(tj + 1, (tj + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const int lv = lvb + ((MF == 32) ? 2 * g : 4 * g);
-                    V16 fa[SM], fb[SN];
-#pragma unroll
-                    for (int i = 0; i < SM; ++i) {
-                        const int f = (fa0[i] + fak + ((fb0[i] + fbk) >> C::SW::FSH)) & (NVV - 1);
-                        fa[i].u = *(const uint4*)(s_halo + (hv0[i] + toff) * CINB + ((lv ^ f) << 4));
-                    }
-#pragma unroll
-                    for (int j = 0; j < SN; ++j) fb[j].u = *(const uint4*)(wb + tj * C::SLAB + boff[j] + ((lv ^ bsw[j]) << 4));
+                for (int g = 0; g < G; ++g)
 #pragma unroll
                     for (int i = 0; i < SM; ++i)
 #pragma unroll
-                        for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[i], fb[j]);
-                }
+                        for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[tj & 1][g][i], fb[tj & 1][g][j]);
+                __builtin_amdgcn_sched_barrier(0);
                 if (ACC64 && ((tap & 1) == 1 || tap + 1 == C::NTAPS)) {
 #pragma unroll
                     for (int i = 0; i < SM; ++i)
@@ -297,34 +309,33 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
         constexpr int LPR = CP / VECO, RPP = 64 / LPR;
         const int cq = (lane % LPR) * VECO;
         if (cq < a.Cout) {
-            for (int r = lane / LPR; r < 64; r += RPP) {
-                const size_t off = row_pix(64 * wave + r) * a.ldc + cq;
-                const float* src = ep + r * C::EP_LD + cq;
-                float vv[VECO], rr[VECO];
+            constexpr int NIT = 64 / RPP;
+            union Pack { uint4 u; float f[4]; unsigned short h[8]; };
+            Pack rv[NIT];
+            size_t offs[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {      // all residual loads first: independent HBM round trips
+                offs[it] = row_pix(64 * wave + lane / LPR + it * RPP) * a.ldc + cq;
+                rv[it].u = make_uint4(0, 0, 0, 0);
+                if (has_res) rv[it].u = *(const uint4*)((const T*)a.res + offs[it]);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const float* src = ep + (lane / LPR + it * RPP) * C::EP_LD + cq;
+                Pack ov;
 #pragma unroll
                 for (int e = 0; e < VECO; e += 4) {
                     const float4 q = *(const float4*)(src + e);
-                    vv[e] = q.x; vv[e + 1] = q.y; vv[e + 2] = q.z; vv[e + 3] = q.w;
-                }
+                    const float vq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                for (int e = 0; e < VECO; ++e) rr[e] = 0.f;
-                if (has_res) {
-                    const uint4 rv = *(const uint4*)((const T*)a.res + off);
-                    const T* r8 = (const T*)&rv;
-                    union { uint4 u; float f[4]; unsigned short h[8]; } cv;
-                    cv.u = rv;
-                    (void)r8;
-#pragma unroll
-                    for (int e = 0; e < VECO; ++e) rr[e] = sizeof(T) == 4 ? cv.f[e % 4] : bf16_to_f32(cv.h[e % 8]);
+                    for (int k = 0; k < 4; ++k) {
+                        const float rr = sizeof(T) == 4 ? rv[it].f[(e + k) % 4] : bf16_to_f32(rv[it].h[(e + k) % 8]);
+                        const float val = epi_act_h(vq[k], relu_pre, has_res, has_res ? rr : 0.f, relu_post);
+                        if (sizeof(T) == 4) ov.f[(e + k) % 4] = val;
+                        else ov.h[(e + k) % 8] = f32_to_bf16(val);
+                    }
                 }
-                union { uint4 u; float f[4]; unsigned short h[8]; } ov;
-#pragma unroll
-                for (int e = 0; e < VECO; ++e) {
-                    const float val = epi_act_h(vv[e], relu_pre, has_res, rr[e], relu_post);
-                    if (sizeof(T) == 4) ov.f[e % 4] = val;
-                    else ov.h[e % 8] = f32_to_bf16(val);
-                }
-                *(uint4*)((T*)a.y + off) = ov.u;
+                *(uint4*)((T*)a.y + offs[it]) = ov.u;
             }
         }
     } else {
@@ -388,7 +399,7 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
         HALO_CASE(bf16_t, 3, 16, 32, 9, 2)
         HALO_CASE(bf16_t, 3, 64, 64, 3, 2)
         HALO_CASE(bf16_t, 3, 32, 64, 9, 2)
-        HALO_CASE(bf16_t, 7, 32, 16, 7, 4)
+        HALO_CASE(bf16_t, 7, 32, 16, 14, 2)
     } else {
         HALO_CASE(float, 3, 32, 32, 3, 3)
         HALO_CASE(float, 3, 16, 32, 9, 2)

@@ -18,6 +18,8 @@
 //   * PW = pointwise fast path (1x1, stride 1, dense output): rows are contiguous, no tap/bounds logic.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_common.h"
 
 using namespace lt;
@@ -248,17 +250,24 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
         const int buf = ks % NST;
         const unsigned char* pa = smem + buf * STAGE + a_base;
         const unsigned char* pb = smem + buf * STAGE + b_base;
+        // fragment group g+1 is requested before the MFMAs of group g issue (register double buffer, order pinned)
+        V16 fa[2][SM], fb[2][SN];
+        auto load_group = [&](int g, int slot) {
+#pragma unroll
+            for (int i = 0; i < SM; ++i) fa[slot][i].u = *(const uint4*)(pa + i * MF * ROW_BYTES + foff[g]);
+#pragma unroll
+            for (int j = 0; j < SN; ++j) fb[slot][j].u = *(const uint4*)(pb + j * MF * ROW_BYTES + foff[g]);
+        };
+        load_group(0, 0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            V16 fa[SM], fb[SN];
-#pragma unroll
-            for (int i = 0; i < SM; ++i) fa[i].u = *(const uint4*)(pa + i * MF * ROW_BYTES + foff[g]);
-#pragma unroll
-            for (int j = 0; j < SN; ++j) fb[j].u = *(const uint4*)(pb + j * MF * ROW_BYTES + foff[g]);
+            if (g + 1 < G) load_group(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < SM; ++i)
 #pragma unroll
-                for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[i], fb[j]);
+                for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[g & 1][i], fb[g & 1][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (ACC64 && ((ks & 1) == 1 || ks + 1 == nk)) {
 #pragma unroll
@@ -307,41 +316,52 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
         return s_rowpix[r];
     };
     if (vec_ok) {
-        const int lpr = WN / veco;                 // lanes per row
-        const int rpp = 64 / lpr;                  // rows per pass
-        const int cq = (lane % lpr) * veco;        // channel offset inside the sub-tile
-        const int col = col0 + cq;
-        if (col < a.Cout) {
-            for (int r = lane / lpr; r < WM; r += rpp) {
-                const int pix = row_pix(wm * WM + r);
-                if (pix < 0) continue;
-                const size_t off = (size_t)pix * a.ldc + col;
-                const float* src = ep + r * EP_LD + cq;
-                if (store_f32) {
-                    float vv[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
-                    const float4 q = *(const float4*)src;
-                    vv[0] = q.x; vv[1] = q.y; vv[2] = q.z; vv[3] = q.w;
-                    if (has_res) {
-                        if (sizeof(T) == 4) OutVec<4>::ld_res((const float*)a.res + off, rr);
-                        else {
+        // All residual loads of the lane are issued first (they are independent), then consumed: the first version
+        // loaded, waited and stored row by row, i.e. WM/rows-per-pass serialized HBM round trips per workgroup.
+        auto rows = [&](auto veco_tag, auto f32_tag) {
+            constexpr int VECO = decltype(veco_tag)::value;
+            constexpr bool OUT_F32 = decltype(f32_tag)::value;
+            constexpr int LPR = WN / VECO, RPP = 64 / LPR, NIT = WM / RPP;
+            const int cq = (lane % LPR) * VECO;        // channel offset inside the sub-tile
+            const int col = col0 + cq;
+            if (col >= a.Cout) return;
+            int pix[NIT];
+            float rr[NIT][VECO];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) rr[e] = bf16_to_f32(((const bf16_t*)a.res)[off + e]);
-                        }
+            for (int it = 0; it < NIT; ++it) {
+                pix[it] = row_pix(wm * WM + lane / LPR + it * RPP);
+#pragma unroll
+                for (int e = 0; e < VECO; ++e) rr[it][e] = 0.f;
+                if (has_res && pix[it] >= 0) {
+                    const size_t off = (size_t)pix[it] * a.ldc + col;
+                    if (sizeof(T) == 4) OutVec<4>::ld_res((const float*)a.res + off, *(float(*)[4])rr[it]);
+                    else if (!OUT_F32) OutVec<8>::ld_res((const bf16_t*)a.res + off, *(float(*)[8])rr[it]);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < VECO; ++e) rr[it][e] = bf16_to_f32(((const bf16_t*)a.res)[off + e]);
                     }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) vv[e] = epi_act(vv[e], relu_pre, has_res, rr[e], relu_post, sigm);
-                    OutVec<4>::st((float*)a.y + off, vv);
-                } else {
-                    float vv[8], rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
-                    vv[0] = q0.x; vv[1] = q0.y; vv[2] = q0.z; vv[3] = q0.w; vv[4] = q1.x; vv[5] = q1.y; vv[6] = q1.z; vv[7] = q1.w;
-                    if (has_res) OutVec<8>::ld_res((const bf16_t*)a.res + off, rr);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) vv[e] = epi_act(vv[e], relu_pre, has_res, rr[e], relu_post, sigm);
-                    OutVec<8>::st((bf16_t*)a.y + off, vv);
                 }
             }
-        }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (pix[it] < 0) continue;
+                const int r = lane / LPR + it * RPP;
+                const size_t off = (size_t)pix[it] * a.ldc + col;
+                const float* src = ep + r * EP_LD + cq;
+                float vv[VECO];
+#pragma unroll
+                for (int e = 0; e < VECO; e += 4) {
+                    const float4 q = *(const float4*)(src + e);
+                    vv[e] = q.x; vv[e + 1] = q.y; vv[e + 2] = q.z; vv[e + 3] = q.w;
+                }
+#pragma unroll
+                for (int e = 0; e < VECO; ++e) vv[e] = epi_act(vv[e], relu_pre, has_res, rr[it][e], relu_post, sigm);
+                if (OUT_F32) OutVec<4>::st((float*)a.y + off, *(float(*)[4])vv);
+                else OutVec<8>::st((bf16_t*)a.y + off, *(float(*)[8])vv);
+            }
+        };
+        if (store_f32) rows(std::integral_constant<int, 4>{}, std::true_type{});
+        else rows(std::integral_constant<int, (sizeof(T) == 4 ? 4 : 8)>{}, std::false_type{});
     } else {
         // ragged channel counts (Cout = 17, ...): one element per lane, lanes along channels
         for (int idx = lane; idx < WM * WN; idx += 64) {

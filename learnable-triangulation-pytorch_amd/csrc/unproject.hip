@@ -93,6 +93,11 @@ struct UnprojArgs {
     int xcd_pin;        // B % 8 == 0
 };
 
+// fp32 (parity) mode keeps IEEE divisions / expf; bf16 (throughput) mode uses v_rcp_f32 / v_exp_f32: the kernel was
+// issue-bound (PMC: SQ_WAIT_INST_ANY 40 %, ~50 IEEE divisions + 32 expf per lane-item), not memory-bound.
+template <bool FAST> __device__ __forceinline__ float div_(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : __fdiv_rn(a, b); }
+template <bool FAST> __device__ __forceinline__ float exp_(float x) { return FAST ? __expf(x) : expf(x); }
+
 // Bilinear sample of CH channels for one voxel in one view; mirrors ATen's CPU grid_sampler_2d
 // (bilinear, zeros padding, align_corners=True) and op.py:116-141.
 template <typename T, int CH>
@@ -104,10 +109,11 @@ __device__ __forceinline__ void sample_view(const T* __restrict__ fmap, const fl
     float pz = __fadd_rn(fmaf(X2, P[10], fmaf(X1, P[9], __fmul_rn(X0, P[8]))), P[11]);
     const bool invalid = pz <= 0.0f;  // op.py:123
     if (pz == 0.0f) pz = 1.0f;        // op.py:125
-    const float u = __fdiv_rn(px, pz), v = __fdiv_rn(py, pz);
+    constexpr bool FAST = sizeof(T) == 2;
+    const float u = div_<FAST>(px, pz), v = div_<FAST>(py, pz);
     // op.py:128-129: x normalised by heatmap_shape[0] (= h), y by heatmap_shape[1] (= w)
-    const float gx = __fmul_rn(2.0f, __fsub_rn(__fdiv_rn(u, (float)h), 0.5f));
-    const float gy = __fmul_rn(2.0f, __fsub_rn(__fdiv_rn(v, (float)w), 0.5f));
+    const float gx = __fmul_rn(2.0f, __fsub_rn(div_<FAST>(u, (float)h), 0.5f));
+    const float gy = __fmul_rn(2.0f, __fsub_rn(div_<FAST>(v, (float)w), 0.5f));
     // grid_sample, align_corners=True: pixel = (g + 1) * (size - 1) / 2
     const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), 0.5f * (float)(w - 1));
     const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), 0.5f * (float)(h - 1));
@@ -137,6 +143,7 @@ __device__ __forceinline__ void sample_view(const T* __restrict__ fmap, const fl
 
 template <typename T, int CH, bool SMALL_NV>
 __global__ __launch_bounds__(256) void unproject_kernel(const UnprojArgs a) {
+    constexpr bool FAST = sizeof(T) == 2;
     const int tpv = a.C / CH;  // lanes per voxel
     // workgroup -> (sample, chunk); XCD-pinned when B % 8 == 0 (block b runs on XCD b % 8)
     int b, chunk;
@@ -182,12 +189,11 @@ __global__ __launch_bounds__(256) void unproject_kernel(const UnprojArgs a) {
                     float m = vals[0][e];
 #pragma unroll
                     for (int v = 1; v < 8; ++v) if (v < a.NV) m = fmaxf(m, vals[v][e]);
-                    float s = 0.f, ex[8];
+                    // sum_v x_v softmax_v(x) = (sum_v x_v e_v) / (sum_v e_v): one division per channel
+                    float s = 0.f, tt = 0.f;
 #pragma unroll
-                    for (int v = 0; v < 8; ++v) if (v < a.NV) { ex[v] = expf(vals[v][e] - m); s += ex[v]; }
-                    r = 0.f;
-#pragma unroll
-                    for (int v = 0; v < 8; ++v) if (v < a.NV) r += vals[v][e] * __fdiv_rn(ex[v], s);
+                    for (int v = 0; v < 8; ++v) if (v < a.NV) { const float ex = exp_<FAST>(vals[v][e] - m); s += ex; tt += vals[v][e] * ex; }
+                    r = div_<FAST>(tt, s);
                 } else if (a.agg == LT_AGG_MAX) {
                     r = vals[0][e];
 #pragma unroll
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256) void unproject_kernel(const UnprojArgs a) {
                     sample_view<T, CH>(feats + (long long)v * a.h * a.w * a.C, P + v * 12, X0, X1, X2, a.h, a.w, a.C, c0, val);
 #pragma unroll
                     for (int e = 0; e < CH; ++e) {
-                        if (a.agg == LT_AGG_SOFTMAX) { const float ex = expf(val[e] - m[e]); s[e] += ex; acc[e] += val[e] * ex; }
+                        if (a.agg == LT_AGG_SOFTMAX) { const float ex = exp_<FAST>(val[e] - m[e]); s[e] += ex; acc[e] += val[e] * ex; }
                         else if (a.agg == LT_AGG_CONF || a.agg == LT_AGG_CONF_NORM)
                             acc[e] += val[e] * __fdiv_rn(a.conf[((long long)b * a.NV + v) * a.C + c0 + e], cs[e]);
                         else acc[e] += val[e];
