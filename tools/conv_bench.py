@@ -47,15 +47,22 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--json", default="")
+    ap.add_argument("--only", default="", help="substring filter on the layer name")
+    ap.add_argument("--variants", default="", help="comma list of variant names to keep (default all)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dev = "cuda:0"
     st = torch.cuda.current_stream().cuda_stream
     results = []
     for (name, nd, N, cin, cout, k, s, p, sp, tr) in shapes(args.batch):
+        if args.only and args.only not in name:
+            continue
         cp = E.cout_pad_of(cout)
         tiles = [t for t, bn in (("128x128", 128), ("128x64", 64), ("64x64", 64), ("256x32", 32), ("256x16", 16)) if cp % bn == 0 and bn <= cp]
         variants = [("auto", 0, 0), ("halo", 20, 0)] + [("%s/s%d" % (t, n), TILES[t], n) for t in tiles for n in (2, 3)] + [("v1_" + t, TILES["v1_" + t], 0) for t in tiles[:2]]
+        if args.variants:
+            keep = set(args.variants.split(","))
+            variants = [v for v in variants if v[0] in keep]
         x = torch.randn(N, *( (1,) if nd == 2 else ()), *sp, cin, device=dev).to(dt)
         w = torch.randn(*((cin, cout) if tr else (cout, cin)), *([k] * nd)) * 0.05
         res = None

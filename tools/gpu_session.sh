@@ -46,6 +46,14 @@ pmcsq)
   echo "pmc sq rc=$?" | tee -a $OUT/session.log; ls $OUT/pmc_sq | head
   cd $R
   ;;
+pmcconv)
+  cd /tmp; export TMPDIR=/tmp
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_conv -o cb -- python $R/tools/conv_bench.py --only v2v --variants halo,256x32/s2,256x16/s2,128x64/s2 --rounds 1 > $OUT/pmc_conv.log 2>&1
+  echo "pmcconv rc=$?" | tee -a $OUT/session.log
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_INSTS_VMEM --output-format csv -d $OUT/pmc_conv2 -o cb -- python $R/tools/conv_bench.py --only v2v --variants halo,256x32/s2,256x16/s2,128x64/s2 --rounds 1 > $OUT/pmc_conv2.log 2>&1
+  echo "pmcconv2 rc=$?" | tee -a $OUT/session.log
+  cd $R
+  ;;
 nst)
   # A/B: 2-stage vs 3-stage LDS-DMA ring in the v2 conv kernels
   for n in 2 3; do
