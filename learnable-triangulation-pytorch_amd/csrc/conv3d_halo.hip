@@ -185,25 +185,39 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
     for (int c = 0; c < NBUF - 1; ++c)
         if (c < C::NCH) stage_w(c, c);
 
-    // ---- per-lane fragment bookkeeping ----
-    // rows of this wave: r = 64*wave + i*MF + (lane & (MF-1)); voxel (td,th,tw) with tw fastest
-    int hv0[SM], fa0[SM], fb0[SM];   // halo slot of the row's own voxel; swizzle terms a = FA*th + FB*td, b = tw + FC*th
+    // ---- per-lane fragment addresses, hoisted out of the tap loop ----
+    // PMC on the first version: 8.4 VALU + 6 SALU per MFMA (the 7^3 kernel was issue-bound on address arithmetic, not on
+    // LDS or MFMA).  Now: A address = abase[kwv][g][i] (per lane: own voxel + swizzle term, which depends on the tap only
+    // through kw -- or (kh,kw) for the 128-byte-voxel swizzle) + per-chunk scalar (kd / (kd,kh) plane or row offset)
+    // + compile-time immediate (the rest of the tap offset).  The tap loop itself is ds_reads and MFMAs only.
+    constexpr bool ROWCH = TPC == KS;                       // a chunk is one (kd,kh) row of taps; else one kd plane (TPC == KS*KS)
+    static_assert(TPC == KS || TPC == KS * KS, "chunk = one tap row or one tap plane");
+    constexpr bool KW_ONLY = C::SW::FA == 0 && C::SW::FC == 0;   // swizzle term independent of kh
+    static_assert(C::SW::FB == 0, "swizzle must not depend on kd");
+    static_assert(KW_ONLY || KS == 3, "kh-dependent swizzle only instantiated for 3^3");
+    constexpr int NXV = KW_ONLY ? KS : KS * KS;             // swizzle variants
+    const int lvb = (MF == 32) ? (lane >> 5) : (lane >> 4);   // logical vector of group 0; group g adds (MF==32 ? 2g : 4g)
+    int abase[NXV][G][SM];                                  // bytes: own voxel * CINB + ((lv_g ^ f) << 4)
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
         const int r = 64 * wave + i * MF + (lane & (MF - 1));
         const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
-        hv0[i] = (td * C::HH + th) * C::PW + tw;
-        fa0[i] = C::SW::FA * th + C::SW::FB * td;
-        fb0[i] = tw + C::SW::FC * th;
+        const int own = ((td * C::HH + th) * C::PW + tw) * CINB;
+#pragma unroll
+        for (int v = 0; v < NXV; ++v) {
+            const int kw = KW_ONLY ? v : v % KS, kh = KW_ONLY ? 0 : v / KS;
+            const int f = C::fswz(0, th + kh, tw + kw);
+#pragma unroll
+            for (int g = 0; g < G; ++g) abase[v][g][i] = own + (((lvb + ((MF == 32) ? 2 * g : 4 * g)) ^ f) << 4);
+        }
     }
-    const int lvb = (MF == 32) ? (lane >> 5) : (lane >> 4);   // logical vector of group 0; group g adds (MF==32 ? 2g : 4g)
-    int boff[SN];                                             // weight fragment offset inside a tap slab, group 0
-    int bsw[SN];
+    int bbase[G][SN];                                       // bytes inside a tap slab
 #pragma unroll
     for (int j = 0; j < SN; ++j) {
         const int col = j * MF + (lane & (MF - 1));
-        bsw[j] = (-(col / VPR)) & (NVV - 1);
-        boff[j] = col * CINB;
+        const int bsw = (-(col / VPR)) & (NVV - 1);
+#pragma unroll
+        for (int g = 0; g < G; ++g) bbase[g][j] = col * CINB + (((lvb + ((MF == 32) ? 2 * g : 4 * g)) ^ bsw) << 4);
     }
 
     acc_t acc[SM][SN];
@@ -225,26 +239,59 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
         wait_vmcnt_h(younger * dpc);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves: chunk ch landed, chunk ch-1 fully consumed
         if (ch + NBUF - 1 < C::NCH) stage_w(ch + NBUF - 1, (ch + NBUF - 1) % NBUF);
+        // per-chunk scalar parts
+        const int kd = ROWCH ? ch / KS : ch, kh_row = ROWCH ? ch % KS : 0;
+        const int coff = ((kd * C::HH + kh_row) * C::PW) * CINB;           // bytes, wave-uniform
         const unsigned char* wb = s_w + (ch % NBUF) * C::WCH;
         // Fragments of tap tj+1 are requested before the MFMAs of tap tj are issued (register double buffer, order pinned
-        // with sched_barrier): with one wave per SIMD nothing else hides the ~100-cycle ds_read latency -- the first
-        // version waited for every read right in front of its MFMA (lgkmcnt(1) before each) and ran at 1/4 of the LDS rate.
+        // with sched_barrier): with one wave per SIMD nothing else hides the ~100-cycle ds_read latency.
+        // kh-dependent swizzle with row chunks: pick this row's variants with a wave-uniform switch (keeps every register
+        // index static: a select chain here was turned into a dynamically indexed array = scratch memory)
+        int arow[(ROWCH && !KW_ONLY) ? KS : 1][G][SM];
+        if (ROWCH && !KW_ONLY) {
+            switch (kh_row) {
+                case 0:
+#pragma unroll
+                    for (int k = 0; k < KS; ++k)
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int i = 0; i < SM; ++i) arow[k][g][i] = abase[(0 * KS + k) % NXV][g][i];
+                    break;
+                case 1:
+#pragma unroll
+                    for (int k = 0; k < KS; ++k)
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int i = 0; i < SM; ++i) arow[k][g][i] = abase[(1 * KS + k) % NXV][g][i];
+                    break;
+                default:
+#pragma unroll
+                    for (int k = 0; k < KS; ++k)
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int i = 0; i < SM; ++i) arow[k][g][i] = abase[(2 * KS + k) % NXV][g][i];
+                    break;
+            }
+        }
         V16 fa[2][G][SM], fb[2][G][SN];
-        auto load_tap = [&](int tj, int slot) {
-            const int tap = ch * TPC + tj;            // wave-uniform
-            const int kw = tap % KS, kh = (tap / KS) % KS, kd = tap / (KS * KS);
-            const int toff = (kd * C::HH + kh) * C::PW + kw;
-            const int fak = C::SW::FA * kh + C::SW::FB * kd, fbk = kw + C::SW::FC * kh;
+        auto load_tap = [&](int tj, int slot) {     // tj is a compile-time constant after unrolling
+            const int kw = ROWCH ? tj : tj % KS, kh = ROWCH ? 0 : tj / KS;
+            const int imm = (kh * C::PW + kw) * CINB;                       // compile-time immediate
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const int lv = lvb + ((MF == 32) ? 2 * g : 4 * g);
 #pragma unroll
                 for (int i = 0; i < SM; ++i) {
-                    const int f = (fa0[i] + fak + ((fb0[i] + fbk) >> C::SW::FSH)) & (NVV - 1);
-                    fa[slot][g][i].u = *(const uint4*)(s_halo + (hv0[i] + toff) * CINB + ((lv ^ f) << 4));
+                    int ab;
+                    if (KW_ONLY) ab = abase[kw][g][i];
+                    else if (!ROWCH) ab = abase[kh * KS + kw][g][i];
+                    else ab = arow[kw][g][i];
+                    fa[slot][g][i].u = *(const uint4*)(s_halo + (ab + coff) + imm);
                 }
 #pragma unroll
-                for (int j = 0; j < SN; ++j) fb[slot][g][j].u = *(const uint4*)(wb + tj * C::SLAB + boff[j] + ((lv ^ bsw[j]) << 4));
+                for (int j = 0; j < SN; ++j) fb[slot][g][j].u = *(const uint4*)(wb + bbase[g][j] + tj * C::SLAB);
             }
         };
         load_tap(0, 0);
@@ -399,7 +446,7 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
         HALO_CASE(bf16_t, 3, 16, 32, 9, 2)
         HALO_CASE(bf16_t, 3, 64, 64, 3, 2)
         HALO_CASE(bf16_t, 3, 32, 64, 9, 2)
-        HALO_CASE(bf16_t, 7, 32, 16, 14, 2)
+        HALO_CASE(bf16_t, 7, 32, 16, 7, 4)
     } else {
         HALO_CASE(float, 3, 32, 32, 3, 3)
         HALO_CASE(float, 3, 16, 32, 9, 2)

@@ -99,8 +99,10 @@ __device__ __forceinline__ float epi_act(float v, bool relu_pre, bool has_res, f
     return v;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int MF, int NST, bool PW>
+template <typename T, int BM, int BN, int WM, int WN, int MF, int NST, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
+    constexpr bool PW = MODE == 1;   // pointwise: rows contiguous, no taps
+    constexpr bool UT = MODE == 2;   // uniform tap: a 128-byte K step never straddles two taps (Cin*sizeof(T) % 128 == 0)
     constexpr bool ACC64 = sizeof(T) == 4;  // fp32 = parity mode
     constexpr int VEC = elt<T>::vec;
     constexpr int BK = 8 * VEC;
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
             }
         }
     }
+    int cur[UT ? A_IT : 1];   // UT: element offset of (row, current tap, this lane's vector) or -1 when the tap is out of the image
     const T* wrow[B_IT];
     int nb_wave = 0;  // B-tile DMA instructions this wave issues per stage
 #pragma unroll
@@ -189,6 +192,27 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const void* src = baseC[i] >= 0 ? (const void*)(x + (baseC[i] + ks * BK)) : (const void*)g_zero_page;
+                dma16(src, sA + (8 * wave + 32 * i) * ROW_BYTES);
+            }
+        } else if (UT) {
+            // the tap (and with it the bounds test) changes only every Cin/BK steps: PMC on the generic path showed 15-40 VALU
+            // instructions of address arithmetic per MFMA on narrow tiles
+            const int k0 = ks * BK;                      // wave-uniform
+            const int c0 = k0 & (a.Cin - 1);
+            if (c0 == 0) {
+                const int tap = k0 >> a.log2Cin;
+                int4 tp = make_int4(-(1 << 24), 0, 0, 0);
+                if (tap < ph.ntaps) tp = s_taps[tap];
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) {
+                    const int id = id0[i] + tp.x, ih = ih0[i] + tp.y, iw = iw0[i] + tp.z;
+                    const bool ok = ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+                    cur[i] = ok ? baseC[i] + tp.w + v * VEC : -1;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const void* src = cur[i] >= 0 ? (const void*)(x + (cur[i] + c0)) : (const void*)g_zero_page;
                 dma16(src, sA + (8 * wave + 32 * i) * ROW_BYTES);
             }
         } else {
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int MF, int NST, bool PW>
+template <typename T, int BM, int BN, int WM, int WN, int MF, int NST, int MODE>
 int launch2(ConvArgs a, int cout_pad, int nphase, int max_taps, hipStream_t s) {
     a.tiles_n = cout_pad / BN;
     const long long nblk = cdiv(a.M, BM) * a.tiles_n;
@@ -388,7 +412,7 @@ int launch2(ConvArgs a, int cout_pad, int nphase, int max_taps, hipStream_t s) {
     constexpr int REGION = (NST * STAGE > 4 * EP_WAVE) ? NST * STAGE : 4 * EP_WAVE;
     const size_t lds = REGION + BM * sizeof(int) + (size_t)max_taps * sizeof(int4);
     LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: tile needs %zu B of LDS", lds);
-    auto kern = conv_igemm2_kernel<T, BM, BN, WM, WN, MF, NST, PW>;
+    auto kern = conv_igemm2_kernel<T, BM, BN, WM, WN, MF, NST, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -400,14 +424,17 @@ int launch2(ConvArgs a, int cout_pad, int nphase, int max_taps, hipStream_t s) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int MF>
-int launch2_pick(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int nst, bool pw, hipStream_t s) {
+int launch2_pick(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int nst, int mode, hipStream_t s) {
     LT_REQUIRE(cout_pad % BN == 0, LT_ERR_INVALID, "lt_conv_fwd: cout_pad %d not a multiple of tile N %d", cout_pad, BN);
-    if (nst == 3) {
-        if (pw) return launch2<T, BM, BN, WM, WN, MF, 3, true>(a, cout_pad, nphase, max_taps, s);
-        return launch2<T, BM, BN, WM, WN, MF, 3, false>(a, cout_pad, nphase, max_taps, s);
+#define LT_PICK(NST_)                                                                                       \
+    switch (mode) {                                                                                         \
+        case 1: return launch2<T, BM, BN, WM, WN, MF, NST_, 1>(a, cout_pad, nphase, max_taps, s);           \
+        case 2: return launch2<T, BM, BN, WM, WN, MF, NST_, 2>(a, cout_pad, nphase, max_taps, s);           \
+        default: return launch2<T, BM, BN, WM, WN, MF, NST_, 0>(a, cout_pad, nphase, max_taps, s);          \
     }
-    if (pw) return launch2<T, BM, BN, WM, WN, MF, 2, true>(a, cout_pad, nphase, max_taps, s);
-    return launch2<T, BM, BN, WM, WN, MF, 2, false>(a, cout_pad, nphase, max_taps, s);
+    if (nst == 3) { LT_PICK(3) }
+    LT_PICK(2)
+#undef LT_PICK
 }
 
 template <typename T>
@@ -427,6 +454,8 @@ int dispatch2(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int til
     const bool pw = nphase == 1 && p0.ntaps == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.pd == 0 && a.ph == 0 && a.pw == 0 &&
                     a.osd == 1 && a.osh == 1 && a.osw == 1 && p0.ood == 0 && p0.ooh == 0 && p0.oow == 0 && a.OD == a.Do && a.OH == a.Ho &&
                     a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
+    // uniform-tap path: every 128-byte K step lies inside one tap
+    const int mode = pw ? 1 : ((a.Cin * (int)sizeof(T)) % ROW_BYTES == 0 ? 2 : 0);
     // ring depth: 3 stages cost a resident workgroup per CU on the big tiles, so they only pay when the grid leaves at most
     // one workgroup per CU anyway (tiny layers: pure latency chains)
     int nst = a.stages;
@@ -441,11 +470,11 @@ int dispatch2(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int til
         nst = nblk <= 256 ? 3 : 2;
     }
     switch (tile) {
-        case LT_TILE2_128x128: return launch2_pick<T, 128, 128, 64, 64, 32>(a, cout_pad, nphase, max_taps, nst, pw, s);
-        case LT_TILE2_128x64: return launch2_pick<T, 128, 64, 64, 32, 32>(a, cout_pad, nphase, max_taps, nst, pw, s);
-        case LT_TILE2_256x32: return launch2_pick<T, 256, 32, 64, 32, 32>(a, cout_pad, nphase, max_taps, nst, pw, s);
-        case LT_TILE2_256x16: return launch2_pick<T, 256, 16, 64, 16, 16>(a, cout_pad, nphase, max_taps, nst, pw, s);
-        case LT_TILE2_64x64: return launch2_pick<T, 64, 64, 32, 32, 32>(a, cout_pad, nphase, max_taps, nst, pw, s);
+        case LT_TILE2_128x128: return launch2_pick<T, 128, 128, 64, 64, 32>(a, cout_pad, nphase, max_taps, nst, mode, s);
+        case LT_TILE2_128x64: return launch2_pick<T, 128, 64, 64, 32, 32>(a, cout_pad, nphase, max_taps, nst, mode, s);
+        case LT_TILE2_256x32: return launch2_pick<T, 256, 32, 64, 32, 32>(a, cout_pad, nphase, max_taps, nst, mode, s);
+        case LT_TILE2_256x16: return launch2_pick<T, 256, 16, 64, 16, 16>(a, cout_pad, nphase, max_taps, nst, mode, s);
+        case LT_TILE2_64x64: return launch2_pick<T, 64, 64, 32, 32, 32>(a, cout_pad, nphase, max_taps, nst, mode, s);
         default: break;
     }
     set_error("lt_conv_fwd: unknown tile id %d", tile);
