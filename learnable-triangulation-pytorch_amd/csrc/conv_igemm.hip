@@ -265,6 +265,8 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
     }
     static const bool force_v1 = getenv("LT_CONV_V1") != nullptr;   // A/B switches for profiling sessions
     static const bool no_halo = getenv("LT_CONV_NO_HALO") != nullptr;
+    static const bool no_respf = getenv("LT_CONV_NO_RESPF") != nullptr;
+    if (no_respf) const_cast<ConvArgs&>(a).flags |= LT_EPI_NO_RES_PREFETCH;
     if ((tile == LT_TILE_AUTO && !force_v1 && !no_halo) || tile == LT_TILE_HALO) {
         const int rc = conv3d_halo_try(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, tile == LT_TILE_HALO, s);
         if (rc == 1) return LT_OK;

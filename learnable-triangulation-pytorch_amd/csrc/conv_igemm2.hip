@@ -185,6 +185,41 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     __syncthreads();
 
     const int nk = a.k_pad / BK;
+
+    // ---- residual prefetch (bf16 vector epilogue only): the lane's 16-byte residual vectors are requested BEFORE the K loop.
+    // The whole forward is HBM-traffic-bound in bf16 (35.6 GB of activation traffic per B=16 step vs 9.6 TFLOP); this adds
+    // WM*WN*2 bytes per wave of loads in flight under the main loop and takes the residual round trip out of the epilogue.
+    constexpr int PF_LPR = WN / 8, PF_RPP = 64 / PF_LPR, PF_NIT = WM / PF_RPP;
+    static_assert(PF_NIT <= 8, "at most 8 residual vectors per lane");
+    // eight NAMED registers (an array -- even fully unrolled -- was kept in scratch memory by hipcc across the asm K loop)
+    uint4 rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7;
+    rp0 = rp1 = rp2 = rp3 = rp4 = rp5 = rp6 = rp7 = make_uint4(0, 0, 0, 0);
+    const bool pre_res = sizeof(T) == 2 && a.res != nullptr && !(a.flags & (LT_EPI_STORE_F32 | LT_EPI_NO_RES_PREFETCH)) &&
+                         (a.Cout % 8 == 0) && (a.ldc % 8 == 0);
+    if constexpr (sizeof(T) == 2) {
+        if (pre_res) {
+            const int colp = n0 + wn * WN + (lane % PF_LPR) * 8;
+            auto pf = [&](int it) -> uint4 {
+                const int r = wm * WM + lane / PF_LPR + it * PF_RPP;
+                int pix;
+                if (PW) { const int m = m0 + r; pix = m < a.M ? m : -1; }
+                else pix = s_rowpix[r];
+                // rows beyond M / channels beyond Cout read the zero page; their values are never used
+                const void* src = (pix >= 0 && colp < a.Cout) ? (const void*)((const bf16_t*)a.res + (size_t)pix * a.ldc + colp)
+                                                             : (const void*)g_zero_page;
+                return *(const uint4*)src;
+            };
+            if (PF_NIT > 0) rp0 = pf(0);
+            if (PF_NIT > 1) rp1 = pf(1);
+            if (PF_NIT > 2) rp2 = pf(2);
+            if (PF_NIT > 3) rp3 = pf(3);
+            if (PF_NIT > 4) rp4 = pf(4);
+            if (PF_NIT > 5) rp5 = pf(5);
+            if (PF_NIT > 6) rp6 = pf(6);
+            if (PF_NIT > 7) rp7 = pf(7);
+        }
+    }
+
     auto stage = [&](int ks, int buf) {
         const unsigned sA = lds0 + buf * STAGE;
         const unsigned sB = sA + BM * ROW_BYTES;
@@ -342,50 +377,91 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     if (vec_ok) {
         // All residual loads of the lane are issued first (they are independent), then consumed: the first version
         // loaded, waited and stored row by row, i.e. WM/rows-per-pass serialized HBM round trips per workgroup.
-        auto rows = [&](auto veco_tag, auto f32_tag) {
-            constexpr int VECO = decltype(veco_tag)::value;
-            constexpr bool OUT_F32 = decltype(f32_tag)::value;
-            constexpr int LPR = WN / VECO, RPP = 64 / LPR, NIT = WM / RPP;
-            const int cq = (lane % LPR) * VECO;        // channel offset inside the sub-tile
-            const int col = col0 + cq;
-            if (col >= a.Cout) return;
-            int pix[NIT];
-            float rr[NIT][VECO];
+        // (a macro, not a lambda: capturing the prefetched-residual array by reference kept it in scratch memory)
+#define LT_EPILOGUE_ROWS(VECO_, OUT_F32_, PRE_)                                                                           \
+        {                                                                                                              \
+            constexpr int VECO = VECO_;                                                                                \
+            constexpr bool OUT_F32 = OUT_F32_;                                                                         \
+            constexpr int LPR = WN / VECO, RPP = 64 / LPR, NIT = WM / RPP;                                             \
+            const int cq = (lane % LPR) * VECO;                                                                        \
+            const int col = col0 + cq;                                                                                 \
+            if (col < a.Cout) {                                                                                        \
+                int pix[NIT];                                                                                          \
+                float rr[NIT][VECO];                                                                                   \
+                _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                   \
+                    pix[it] = row_pix(wm * WM + lane / LPR + it * RPP);                                                \
+                    _Pragma("unroll") for (int e = 0; e < VECO; ++e) rr[it][e] = 0.f;                                  \
+                    if (has_res && pix[it] >= 0) {                                                                     \
+                        const size_t off = (size_t)pix[it] * a.ldc + col;                                              \
+                        if constexpr (sizeof(T) == 4) OutVec<VECO>::ld_res((const float*)a.res + off, rr[it]);         \
+                        else if constexpr (!OUT_F32) {                                                                 \
+                            uint4 pv;                                                                                  \
+                            if (pre_res) pv = PRE_;                                                                    \
+                            else pv = *(const uint4*)((const bf16_t*)a.res + off);                                     \
+                            const unsigned u[4] = {pv.x, pv.y, pv.z, pv.w};                                            \
+                            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+                                rr[it][2 * e] = __uint_as_float(u[e] << 16);                                           \
+                                rr[it][2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);                               \
+                            }                                                                                          \
+                        } else {                                                                                       \
+                            _Pragma("unroll") for (int e = 0; e < VECO; ++e) rr[it][e] = bf16_to_f32(((const bf16_t*)a.res)[off + e]); \
+                        }                                                                                              \
+                    }                                                                                                  \
+                }                                                                                                      \
+                _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                   \
+                    if (pix[it] < 0) continue;                                                                         \
+                    const int r = lane / LPR + it * RPP;                                                               \
+                    const size_t off = (size_t)pix[it] * a.ldc + col;                                                  \
+                    const float* src = ep + r * EP_LD + cq;                                                            \
+                    float vv[VECO];                                                                                    \
+                    _Pragma("unroll") for (int e = 0; e < VECO; e += 4) {                                              \
+                        const float4 q = *(const float4*)(src + e);                                                    \
+                        vv[e] = q.x; vv[e + 1] = q.y; vv[e + 2] = q.z; vv[e + 3] = q.w;                                \
+                    }                                                                                                  \
+                    _Pragma("unroll") for (int e = 0; e < VECO; ++e) vv[e] = epi_act(vv[e], relu_pre, has_res, rr[it][e], relu_post, sigm); \
+                    typedef typename std::conditional<VECO == 4, float, bf16_t>::type out_t;                          \
+                    OutVec<VECO>::st((out_t*)a.y + off, vv);                                                           \
+                }                                                                                                      \
+            }                                                                                                          \
+        }
+        if constexpr (sizeof(T) == 4) LT_EPILOGUE_ROWS(4, true, make_uint4(0, 0, 0, 0))
+        else {
+            if (store_f32) LT_EPILOGUE_ROWS(4, true, make_uint4(0, 0, 0, 0))
+            else if (!pre_res) LT_EPILOGUE_ROWS(8, false, make_uint4(0, 0, 0, 0))
+            else {
+                // prefetched residual: one explicitly numbered row per named register (no indexing by a loop variable)
+                constexpr int LPR = WN / 8, RPP = 64 / LPR, NIT = WM / RPP;
+                const int cq = (lane % LPR) * 8;
+                const int col = col0 + cq;
+                auto row = [&](int it, uint4 pv) {
+                    const int r = lane / LPR + it * RPP;
+                    const int pixv = row_pix(wm * WM + r);
+                    if (pixv < 0) return;
+                    const size_t off = (size_t)pixv * a.ldc + col;
+                    const float* src = ep + r * EP_LD + cq;
+                    const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
+                    float vv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                    const unsigned u[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                pix[it] = row_pix(wm * WM + lane / LPR + it * RPP);
-#pragma unroll
-                for (int e = 0; e < VECO; ++e) rr[it][e] = 0.f;
-                if (has_res && pix[it] >= 0) {
-                    const size_t off = (size_t)pix[it] * a.ldc + col;
-                    if (sizeof(T) == 4) OutVec<4>::ld_res((const float*)a.res + off, *(float(*)[4])rr[it]);
-                    else if (!OUT_F32) OutVec<8>::ld_res((const bf16_t*)a.res + off, *(float(*)[8])rr[it]);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < VECO; ++e) rr[it][e] = bf16_to_f32(((const bf16_t*)a.res)[off + e]);
+                    for (int e = 0; e < 4; ++e) {
+                        vv[2 * e] = epi_act(vv[2 * e], relu_pre, true, __uint_as_float(u[e] << 16), relu_post, sigm);
+                        vv[2 * e + 1] = epi_act(vv[2 * e + 1], relu_pre, true, __uint_as_float(u[e] & 0xffff0000u), relu_post, sigm);
                     }
+                    OutVec<8>::st((bf16_t*)a.y + off, vv);
+                };
+                if (col < a.Cout) {
+                    if (NIT > 0) row(0, rp0);
+                    if (NIT > 1) row(1, rp1);
+                    if (NIT > 2) row(2, rp2);
+                    if (NIT > 3) row(3, rp3);
+                    if (NIT > 4) row(4, rp4);
+                    if (NIT > 5) row(5, rp5);
+                    if (NIT > 6) row(6, rp6);
+                    if (NIT > 7) row(7, rp7);
                 }
             }
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                if (pix[it] < 0) continue;
-                const int r = lane / LPR + it * RPP;
-                const size_t off = (size_t)pix[it] * a.ldc + col;
-                const float* src = ep + r * EP_LD + cq;
-                float vv[VECO];
-#pragma unroll
-                for (int e = 0; e < VECO; e += 4) {
-                    const float4 q = *(const float4*)(src + e);
-                    vv[e] = q.x; vv[e + 1] = q.y; vv[e + 2] = q.z; vv[e + 3] = q.w;
-                }
-#pragma unroll
-                for (int e = 0; e < VECO; ++e) vv[e] = epi_act(vv[e], relu_pre, has_res, rr[it][e], relu_post, sigm);
-                if (OUT_F32) OutVec<4>::st((float*)a.y + off, *(float(*)[4])vv);
-                else OutVec<8>::st((bf16_t*)a.y + off, *(float(*)[8])vv);
-            }
-        };
-        if (store_f32) rows(std::integral_constant<int, 4>{}, std::true_type{});
-        else rows(std::integral_constant<int, (sizeof(T) == 4 ? 4 : 8)>{}, std::false_type{});
+        }
+#undef LT_EPILOGUE_ROWS
     } else {
         // ragged channel counts (Cout = 17, ...): one element per lane, lanes along channels
         for (int idx = lane; idx < WM * WN; idx += 64) {
@@ -455,7 +531,8 @@ int dispatch2(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int til
                     a.osd == 1 && a.osh == 1 && a.osw == 1 && p0.ood == 0 && p0.ooh == 0 && p0.oow == 0 && a.OD == a.Do && a.OH == a.Ho &&
                     a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
     // uniform-tap path: every 128-byte K step lies inside one tap
-    const int mode = pw ? 1 : ((a.Cin * (int)sizeof(T)) % ROW_BYTES == 0 ? 2 : 0);
+    static const bool no_ut = getenv("LT_CONV_NO_UT") != nullptr;   // A/B switch
+    const int mode = pw ? 1 : (((a.Cin * (int)sizeof(T)) % ROW_BYTES == 0 && !no_ut) ? 2 : 0);
     // ring depth: 3 stages cost a resident workgroup per CU on the big tiles, so they only pay when the grid leaves at most
     // one workgroup per CU anyway (tiny layers: pure latency chains)
     int nst = a.stages;

@@ -54,6 +54,16 @@ pmcconv)
   echo "pmcconv2 rc=$?" | tee -a $OUT/session.log
   cd $R
   ;;
+abenv)
+  # in-session A/B of env switches (two interleaved rounds each): baseline, no residual prefetch, no uniform-tap path, no halo kernel
+  for round in 1 2; do
+    for v in base LT_CONV_NO_RESPF LT_CONV_NO_UT LT_CONV_NO_HALO; do
+      if [ $v = base ]; then E=""; else E="$v=1"; fi
+      env $E timeout 600 python bench.py --no-cpu-baseline --no-profile --steps 10 --warmup 3 > $OUT/ab_${v}_$round.json 2> $OUT/ab_${v}_$round.err
+      echo "ab $v round $round: $(python -c "import json;d=json.load(open('$OUT/ab_${v}_$round.json'));print('%.1f samples/s %.2f ms/step'%(d['value'],d['ms_per_step']))")" | tee -a $OUT/session.log
+    done
+  done
+  ;;
 nst)
   # A/B: 2-stage vs 3-stage LDS-DMA ring in the v2 conv kernels
   for n in 2 3; do
