@@ -17,6 +17,8 @@
 //            lines of the tile, not 16 consecutive voxels);
 //   weights: per tap a [cout_pad][CINB] slab, slot lv ^ ((-(col/VPR)) % NVV) (conflict free for both MFMA shapes).
 // Weight ring: NBUF chunk buffers, NBUF-1 chunks of DMA in flight (counted vmcnt), one barrier per chunk.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 using namespace lt;
@@ -184,6 +186,34 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
 #pragma unroll
     for (int c = 0; c < NBUF - 1; ++c)
         if (c < C::NCH) stage_w(c, c);
+
+    // ---- residual prefetch: the lane's 16-byte residual vectors (up to 8) are requested before the tap loop, in named
+    // registers (see conv_igemm2.hip for why not an array); they are consumed in the epilogue ----
+    constexpr int E_VECO = C::VEC, E_LPR = CP / E_VECO, E_RPP = 64 / E_LPR, E_NIT = 64 / E_RPP;
+    static_assert(E_NIT <= 16, "epilogue rows per lane");
+    constexpr bool PRE_OK = E_NIT <= 8;
+    const bool vec_epi = (a.Cout % E_VECO == 0) && (a.ldc % E_VECO == 0);
+    const bool pre_res = PRE_OK && vec_epi && a.res != nullptr && !(a.flags & LT_EPI_NO_RES_PREFETCH);
+    uint4 rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7;
+    rp0 = rp1 = rp2 = rp3 = rp4 = rp5 = rp6 = rp7 = make_uint4(0, 0, 0, 0);
+    if (pre_res) {
+        const int cqp = (lane % E_LPR) * E_VECO;
+        auto pf = [&](int it) -> uint4 {
+            const int r = 64 * wave + lane / E_LPR + it * E_RPP;
+            const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
+            const size_t pixv = (((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw;
+            const void* src = cqp < a.Cout ? (const void*)((const T*)a.res + pixv * a.ldc + cqp) : (const void*)g_zero_page_h;
+            return *(const uint4*)src;
+        };
+        if (E_NIT > 0) rp0 = pf(0);
+        if (E_NIT > 1) rp1 = pf(1);
+        if (E_NIT > 2) rp2 = pf(2);
+        if (E_NIT > 3) rp3 = pf(3);
+        if (E_NIT > 4) rp4 = pf(4);
+        if (E_NIT > 5) rp5 = pf(5);
+        if (E_NIT > 6) rp6 = pf(6);
+        if (E_NIT > 7) rp7 = pf(7);
+    }
 
     // ---- per-lane fragment addresses, hoisted out of the tap loop ----
     // PMC on the first version: 8.4 VALU + 6 SALU per MFMA (the 7^3 kernel was issue-bound on address arithmetic, not on
@@ -358,31 +388,45 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
         if (cq < a.Cout) {
             constexpr int NIT = 64 / RPP;
             union Pack { uint4 u; float f[4]; unsigned short h[8]; };
-            Pack rv[NIT];
-            size_t offs[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {      // all residual loads first: independent HBM round trips
-                offs[it] = row_pix(64 * wave + lane / LPR + it * RPP) * a.ldc + cq;
-                rv[it].u = make_uint4(0, 0, 0, 0);
-                if (has_res) rv[it].u = *(const uint4*)((const T*)a.res + offs[it]);
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
+            auto row = [&](int it, uint4 resv) {      // resv: this row's residual vector (zeros when there is none)
+                const size_t off = row_pix(64 * wave + lane / LPR + it * RPP) * a.ldc + cq;
                 const float* src = ep + (lane / LPR + it * RPP) * C::EP_LD + cq;
-                Pack ov;
+                Pack rv, ov;
+                rv.u = resv;
 #pragma unroll
                 for (int e = 0; e < VECO; e += 4) {
                     const float4 q = *(const float4*)(src + e);
                     const float vq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float rr = sizeof(T) == 4 ? rv[it].f[(e + k) % 4] : bf16_to_f32(rv[it].h[(e + k) % 8]);
+                        const float rr = sizeof(T) == 4 ? rv.f[(e + k) % 4] : bf16_to_f32(rv.h[(e + k) % 8]);
                         const float val = epi_act_h(vq[k], relu_pre, has_res, has_res ? rr : 0.f, relu_post);
                         if (sizeof(T) == 4) ov.f[(e + k) % 4] = val;
                         else ov.h[(e + k) % 8] = f32_to_bf16(val);
                     }
                 }
-                *(uint4*)((T*)a.y + offs[it]) = ov.u;
+                *(uint4*)((T*)a.y + off) = ov.u;
+            };
+            if (pre_res || !has_res) {
+                if (NIT > 0) row(0, rp0);
+                if (NIT > 1) row(1, rp1);
+                if (NIT > 2) row(2, rp2);
+                if (NIT > 3) row(3, rp3);
+                if (NIT > 4) row(4, rp4);
+                if (NIT > 5) row(5, rp5);
+                if (NIT > 6) row(6, rp6);
+                if (NIT > 7) row(7, rp7);
+                if (NIT > 8) {   // fp32 with a narrow tile: no prefetch (PRE_OK false), rows 8.. have no residual here
+#pragma unroll
+                    for (int it = 8; it < NIT; ++it) row(it, make_uint4(0, 0, 0, 0));
+                }
+            } else {
+                Pack rv[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)      // all residual loads first: independent HBM round trips
+                    rv[it].u = *(const uint4*)((const T*)a.res + row_pix(64 * wave + lane / LPR + it * RPP) * a.ldc + cq);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) row(it, rv[it].u);
             }
         }
     } else {
@@ -441,7 +485,9 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
         int rc = launch_halo<T_, KS_, CIN_, CP_, 4, 8, 8, TPC_, NBUF_>(a, s);                   \
         return rc == LT_OK ? 1 : rc;                                                            \
     }
+    static const bool row_chunks = getenv("LT_HALO_ROW") != nullptr;   // A/B: 3-tap weight chunks -> 51 KB of LDS -> 3 workgroups per CU
     if (bf) {
+        if (row_chunks) { HALO_CASE(bf16_t, 3, 32, 32, 3, 2) }
         HALO_CASE(bf16_t, 3, 32, 32, 9, 2)
         HALO_CASE(bf16_t, 3, 16, 32, 9, 2)
         HALO_CASE(bf16_t, 3, 64, 64, 3, 2)

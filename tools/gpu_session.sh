@@ -57,7 +57,7 @@ pmcconv)
 abenv)
   # in-session A/B of env switches (two interleaved rounds each): baseline, no residual prefetch, no uniform-tap path, no halo kernel
   for round in 1 2; do
-    for v in base LT_CONV_NO_RESPF LT_CONV_NO_UT LT_CONV_NO_HALO; do
+    for v in ${ABVARS:-base LT_CONV_NO_RESPF LT_HALO_ROW}; do
       if [ $v = base ]; then E=""; else E="$v=1"; fi
       env $E timeout 600 python bench.py --no-cpu-baseline --no-profile --steps 10 --warmup 3 > $OUT/ab_${v}_$round.json 2> $OUT/ab_${v}_$round.err
       echo "ab $v round $round: $(python -c "import json;d=json.load(open('$OUT/ab_${v}_$round.json'));print('%.1f samples/s %.2f ms/step'%(d['value'],d['ms_per_step']))")" | tee -a $OUT/session.log
