@@ -19,6 +19,8 @@
 // Weight ring: NBUF chunk buffers, NBUF-1 chunks of DMA in flight (counted vmcnt), one barrier per chunk.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_common.h"
 
 using namespace lt;
@@ -41,6 +43,36 @@ __device__ __forceinline__ void dma16h(const void* src, unsigned lds_base) {
         : "=&s"(keep)
         : "v"(src), "s"(lds_base)
         : "memory");
+}
+
+// ---- hand-scheduled LDS fragment reads -------------------------------------------------------------------------------------
+// hipcc's own s_waitcnt insertion degrades to lgkmcnt(0) as soon as more than one tap of fragment reads is in flight (seen
+// in the ISA: every third tap drained the whole queue).  The deep-lookahead paths therefore issue ds_read_b128 themselves
+// and wait with an explicit count; frag_ready() ties the wait to the registers so that no MFMA can be scheduled above it.
+template <int IMM>
+__device__ __forceinline__ void lds_read16(V16& d, unsigned addr) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds_read offset field");
+    f32x4 t;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(addr), "n"(IMM));
+    d.f = t;
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+}
+__device__ __forceinline__ void frag_ready(V16& f) {
+    f32x4 t = f.f;   // a native vector: HIP's uint4 is a struct, which inline asm can only take indirectly
+    asm volatile("" : "+v"(t));
+    f.f = t;
+}
+
+template <int I0, int I1, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
 }
 
 __device__ __forceinline__ float epi_act_h(float v, bool relu_pre, bool has_res, float r, bool relu_post) {
@@ -123,7 +155,103 @@ struct HaloArgs {
     int xcd_pin;
 };
 
-template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF>
+// Epilogue shared by the halo kernels (same scheme as conv_igemm2): (acc + bias)*scale + shift into this wave's fp32 LDS tile
+// (64 rows, padded), then 16-byte vectors: optional pre-activation ReLU, residual, ReLU, store.  rp0..rp7: the lane's residual
+// vectors when they were prefetched (pre_res), in named registers (an array was kept in scratch memory by hipcc).
+template <typename T, int CP, int MF, int SM, int SN, int NACC, int TH, int TW, bool ACC64, typename ACC, typename DACC>
+__device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArgs& a, int wave, int lane, int n, int d0, int h0, int w0,
+                                              ACC& acc, DACC& dacc, bool pre_res, uint4 rp0, uint4 rp1, uint4 rp2, uint4 rp3, uint4 rp4,
+                                              uint4 rp5, uint4 rp6, uint4 rp7, const void* zero_page) {
+    constexpr int EP_LD = CP + 4;
+    constexpr int VEC_ = 16 / (int)sizeof(T);
+    (void)zero_page;
+    // ---- epilogue (same scheme as conv_igemm2: per-wave fp32 LDS tile -> 16-byte vectors) ----
+    float* ep = (float*)(smem + wave * (64 * EP_LD * 4));
+#pragma unroll
+    for (int j = 0; j < SN; ++j) {
+        const int colj = j * MF + (lane & (MF - 1));
+        const float bi = a.bias ? a.bias[colj] : 0.f;
+        const float sc = a.scale ? a.scale[colj] : 1.f;
+        const float sf = a.shift ? a.shift[colj] : 0.f;
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+            for (int e = 0; e < NACC; ++e) {
+                const int r = i * MF + ((MF == 32) ? ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) : ((lane >> 4) * 4 + e));
+                float val;
+                if (ACC64) val = (float)((dacc[i][j][e] + (double)bi) * (double)sc + (double)sf);
+                else val = (acc[i][j][e] + bi) * sc + sf;
+                ep[r * EP_LD + colj] = val;
+            }
+    }
+    __syncthreads();
+
+    const bool relu_pre = a.flags & LT_EPI_RELU_PRE, relu_post = a.flags & LT_EPI_RELU_POST;
+    const bool has_res = a.res != nullptr;
+    auto row_pix = [&](int r) -> size_t {   // r = row inside the workgroup tile
+        const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
+        return (((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw;
+    };
+    constexpr int VECO = VEC_;              // fp32: 4 channels, bf16: 8 channels per 16 bytes
+    if ((a.Cout % VECO == 0) && (a.ldc % VECO == 0)) {
+        constexpr int LPR = CP / VECO, RPP = 64 / LPR;
+        const int cq = (lane % LPR) * VECO;
+        if (cq < a.Cout) {
+            constexpr int NIT = 64 / RPP;
+            union Pack { uint4 u; float f[4]; unsigned short h[8]; };
+            auto row = [&](int it, uint4 resv) {      // resv: this row's residual vector (zeros when there is none)
+                const size_t off = row_pix(64 * wave + lane / LPR + it * RPP) * a.ldc + cq;
+                const float* src = ep + (lane / LPR + it * RPP) * EP_LD + cq;
+                Pack rv, ov;
+                rv.u = resv;
+#pragma unroll
+                for (int e = 0; e < VECO; e += 4) {
+                    const float4 q = *(const float4*)(src + e);
+                    const float vq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float rr = sizeof(T) == 4 ? rv.f[(e + k) % 4] : bf16_to_f32(rv.h[(e + k) % 8]);
+                        const float val = epi_act_h(vq[k], relu_pre, has_res, has_res ? rr : 0.f, relu_post);
+                        if (sizeof(T) == 4) ov.f[(e + k) % 4] = val;
+                        else ov.h[(e + k) % 8] = f32_to_bf16(val);
+                    }
+                }
+                *(uint4*)((T*)a.y + off) = ov.u;
+            };
+            if (pre_res || !has_res) {
+                if (NIT > 0) row(0, rp0);
+                if (NIT > 1) row(1, rp1);
+                if (NIT > 2) row(2, rp2);
+                if (NIT > 3) row(3, rp3);
+                if (NIT > 4) row(4, rp4);
+                if (NIT > 5) row(5, rp5);
+                if (NIT > 6) row(6, rp6);
+                if (NIT > 7) row(7, rp7);
+                if (NIT > 8) {   // fp32 with a narrow tile: no prefetch (PRE_OK false), rows 8.. have no residual here
+#pragma unroll
+                    for (int it = 8; it < NIT; ++it) row(it, make_uint4(0, 0, 0, 0));
+                }
+            } else {
+                Pack rv[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)      // all residual loads first: independent HBM round trips
+                    rv[it].u = *(const uint4*)((const T*)a.res + row_pix(64 * wave + lane / LPR + it * RPP) * a.ldc + cq);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) row(it, rv[it].u);
+            }
+        }
+    } else {
+        for (int idx = lane; idx < 64 * CP; idx += 64) {
+            const int r = idx / CP, cc = idx - r * CP;
+            if (cc >= a.Cout) continue;
+            const size_t off = row_pix(64 * wave + r) * a.ldc + cc;
+            const float rr = has_res ? elt<T>::ld((const T*)a.res + off) : 0.f;
+            elt<T>::st((T*)a.y + off, epi_act_h(ep[r * EP_LD + cc], relu_pre, has_res, rr, relu_post));
+        }
+    }
+}
+
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF, int PD>
 __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF> C;
     constexpr bool ACC64 = sizeof(T) == 4;
@@ -134,6 +262,11 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     unsigned char* s_halo = smem;
     unsigned char* s_w = smem + C::HALO_BYTES;
+
+    // zero-page address made opaque once (else each use is an s_load from the GOT + s_waitcnt lgkmcnt(0) in the tap loop)
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page_h;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -146,8 +279,11 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
         n = xcd + 8 * (j / tps);
         tix = j % tps;
     } else {
-        n = blockIdx.x / tps;
-        tix = blockIdx.x % tps;
+        // other batch sizes: every XCD takes one contiguous run of the (sample, tile) raster
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        n = lin / tps;
+        tix = lin % tps;
     }
     const int w0 = (tix % a.tiles_w) * TW;
     const int h0 = ((tix / a.tiles_w) % a.tiles_h) * TH;
@@ -166,7 +302,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
         const int lv = pv ^ C::fswz(hd_, hh_, hw_);
         const int id = d0 - P + hd_, ih = h0 - P + hh_, iw = w0 - P + hw_;
         const bool ok = hv < C::HV && hw_ < C::HW && ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-        const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : (const void*)g_zero_page_h;
+        const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : zero_page;
         dma16h(src, lds0 + i * 1024);
     }
     // ---- weight chunk DMA: vector q = (tap_in_chunk*CP + col)*NVV + pv ----
@@ -178,7 +314,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
             const int tap = ch * TPC + tj;
             const int lv = pv ^ ((-(col / VPR)) & (NVV - 1));
             const bool ok = tj < TPC && tap < C::NTAPS;
-            const void* src = ok ? (const void*)(w + (size_t)col * a.k_pad + tap * CIN + lv * C::VEC) : (const void*)g_zero_page_h;
+            const void* src = ok ? (const void*)(w + (size_t)col * a.k_pad + tap * CIN + lv * C::VEC) : zero_page;
             dma16h(src, lds0 + C::HALO_BYTES + buf * C::WCH + i * 1024);
         }
     };
@@ -202,7 +338,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
             const int r = 64 * wave + lane / E_LPR + it * E_RPP;
             const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
             const size_t pixv = (((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw;
-            const void* src = cqp < a.Cout ? (const void*)((const T*)a.res + pixv * a.ldc + cqp) : (const void*)g_zero_page_h;
+            const void* src = cqp < a.Cout ? (const void*)((const T*)a.res + pixv * a.ldc + cqp) : zero_page;
             return *(const uint4*)src;
         };
         if (E_NIT > 0) rp0 = pf(0);
@@ -262,189 +398,431 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
                 if (ACC64) dacc[i][j][e] = 0.0;
             }
 
-    for (int ch = 0; ch < C::NCH; ++ch) {
-        // chunk ch (and, the first time, the halo issued before it) must have landed; up to NBUF-2 younger chunks stay in flight
-        int younger = C::NCH - 1 - ch;
-        if (younger > NBUF - 2) younger = NBUF - 2;
-        wait_vmcnt_h(younger * dpc);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves: chunk ch landed, chunk ch-1 fully consumed
-        if (ch + NBUF - 1 < C::NCH) stage_w(ch + NBUF - 1, (ch + NBUF - 1) % NBUF);
-        // per-chunk scalar parts
-        const int kd = ROWCH ? ch / KS : ch, kh_row = ROWCH ? ch % KS : 0;
-        const int coff = ((kd * C::HH + kh_row) * C::PW) * CINB;           // bytes, wave-uniform
-        const unsigned char* wb = s_w + (ch % NBUF) * C::WCH;
-        // Fragments of tap tj+1 are requested before the MFMAs of tap tj are issued (register double buffer, order pinned
-        // with sched_barrier): with one wave per SIMD nothing else hides the ~100-cycle ds_read latency.
-        // kh-dependent swizzle with row chunks: pick this row's variants with a wave-uniform switch (keeps every register
-        // index static: a select chain here was turned into a dynamically indexed array = scratch memory)
-        int arow[(ROWCH && !KW_ONLY) ? KS : 1][G][SM];
-        if (ROWCH && !KW_ONLY) {
-            switch (kh_row) {
-                case 0:
-#pragma unroll
-                    for (int k = 0; k < KS; ++k)
-#pragma unroll
-                        for (int g = 0; g < G; ++g)
-#pragma unroll
-                            for (int i = 0; i < SM; ++i) arow[k][g][i] = abase[(0 * KS + k) % NXV][g][i];
-                    break;
-                case 1:
-#pragma unroll
-                    for (int k = 0; k < KS; ++k)
-#pragma unroll
-                        for (int g = 0; g < G; ++g)
-#pragma unroll
-                            for (int i = 0; i < SM; ++i) arow[k][g][i] = abase[(1 * KS + k) % NXV][g][i];
-                    break;
-                default:
-#pragma unroll
-                    for (int k = 0; k < KS; ++k)
-#pragma unroll
-                        for (int g = 0; g < G; ++g)
-#pragma unroll
-                            for (int i = 0; i < SM; ++i) arow[k][g][i] = abase[(2 * KS + k) % NXV][g][i];
-                    break;
-            }
-        }
-        V16 fa[2][G][SM], fb[2][G][SN];
-        auto load_tap = [&](int tj, int slot) {     // tj is a compile-time constant after unrolling
-            const int kw = ROWCH ? tj : tj % KS, kh = ROWCH ? 0 : tj / KS;
-            const int imm = (kh * C::PW + kw) * CINB;                       // compile-time immediate
+    if constexpr (PD > 1) {
+        // ---- fragment RING (7^3): one workgroup per CU (the halo takes 123 KB) = one wave per SIMD, so nothing but the wave's
+        // own lookahead hides the LDS latency; with the one-tap lookahead below the kernel ran at ~290 cycles per tap against
+        // 64 cycles of MFMA.  Here the fragments of tap t+PD are requested before the MFMAs of tap t, across chunk boundaries:
+        // ring slot = tap index inside the chunk (TPC slots), the halo image is static, and the weight ring runs one chunk
+        // further ahead (chunk ch+1 has landed at the barrier of chunk ch) so that its fragments may be read early.
+        static_assert(ROWCH && KW_ONLY && PD < TPC && NBUF >= 4, "ring path: row chunks, kw-only swizzle, >= 4 weight buffers");
+        V16 fa[TPC][G][SM], fb[TPC][G][SN];
+        constexpr int RPT = G * (SM + SN);                  // ds_reads per tap
+        static_assert((PD + 1) * RPT <= 15, "lookahead exceeds the lgkmcnt counter");
+        const unsigned lds_w = lds0 + C::HALO_BYTES;
+        // tap TJ of the chunk whose halo row offset is coff_x and whose weight buffer starts at LDS byte wb_x
+        auto load_ring = [&](int coff_x, unsigned wb_x, auto tjc) {
+            constexpr int TJ = decltype(tjc)::value;
+            static_for<0, G>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                static_for<0, SM>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    lds_read16<TJ * CINB>(fa[TJ][g][i], lds0 + abase[TJ][g][i] + coff_x);
+                });
+                static_for<0, SN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    lds_read16<TJ * C::SLAB>(fb[TJ][g][j], wb_x + bbase[g][j]);
+                });
+            });
+        };
+        auto mma_tap = [&](auto tjc) {
+            constexpr int TJ = decltype(tjc)::value;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
 #pragma unroll
-                for (int i = 0; i < SM; ++i) {
-                    int ab;
-                    if (KW_ONLY) ab = abase[kw][g][i];
-                    else if (!ROWCH) ab = abase[kh * KS + kw][g][i];
-                    else ab = arow[kw][g][i];
-                    fa[slot][g][i].u = *(const uint4*)(s_halo + (ab + coff) + imm);
-                }
+                for (int i = 0; i < SM; ++i) frag_ready(fa[TJ][g][i]);
 #pragma unroll
-                for (int j = 0; j < SN; ++j) fb[slot][g][j].u = *(const uint4*)(wb + bbase[g][j] + tj * C::SLAB);
+                for (int j = 0; j < SN; ++j) frag_ready(fb[TJ][g][j]);
             }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int i = 0; i < SM; ++i)
+#pragma unroll
+                    for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[TJ][g][i], fb[TJ][g][j]);
         };
-        load_tap(0, 0);
-#pragma unroll
-        for (int tj = 0; tj < TPC; ++tj) {
-            const int tap = ch * TPC + tj;
-            if (tap < C::NTAPS) {
-                if (tj + 1 < TPC && tap + 1 < C::NTAPS) load_tap(tj + 1, (tj + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < G; ++g)
-#pragma unroll
-                    for (int i = 0; i < SM; ++i)
-#pragma unroll
-                        for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[tj & 1][g][i], fb[tj & 1][g][j]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ACC64 && ((tap & 1) == 1 || tap + 1 == C::NTAPS)) {
-#pragma unroll
-                    for (int i = 0; i < SM; ++i)
-#pragma unroll
-                        for (int j = 0; j < SN; ++j)
-#pragma unroll
-                            for (int e = 0; e < NACC; ++e) {
-                                dacc[i][j][e] += (double)acc[i][j][e];
-                                acc[i][j][e] = 0.f;
-                            }
+        // LAST_ (compile time): no chunk follows.  Two copies of the chunk body instead of a uniform branch around the
+        // cross-chunk loads, so that the number of reads in flight at every wait is a compile-time constant.
+#define LT_HALO_RING_CHUNK(LAST_)                                                                                       \
+    {                                                                                                                   \
+        /* chunks <= ch+1 must have landed; at most NBUF-3 younger chunks stay in flight */                             \
+        int younger = C::NCH - 2 - ch;                                                                                  \
+        if (younger > NBUF - 3) younger = NBUF - 3;                                                                     \
+        if (younger < 0) younger = 0;                                                                                   \
+        wait_vmcnt_h(younger * dpc);                                                                                    \
+        asm volatile("s_barrier" ::: "memory"); /* all waves: chunks <= ch+1 landed, chunk ch-1 fully consumed */       \
+        if (ch + NBUF - 1 < C::NCH) stage_w(ch + NBUF - 1, (ch + NBUF - 1) % NBUF);                                     \
+        const int coff = (((ch / KS) * C::HH + (ch % KS)) * C::PW) * CINB; /* bytes, wave-uniform */                    \
+        const int coff_n = ((((ch + 1) / KS) * C::HH + ((ch + 1) % KS)) * C::PW) * CINB;                                \
+        const unsigned wb = lds_w + (ch % NBUF) * C::WCH;                                                               \
+        const unsigned wb_n = lds_w + ((ch + 1) % NBUF) * C::WCH;                                                       \
+        static_for<0, TPC>([&](auto tjc) {                                                                              \
+            constexpr int tj = decltype(tjc)::value;                                                                    \
+            constexpr int ahead = (tj + PD < TPC) ? PD : (LAST_ ? TPC - 1 - tj : PD); /* taps in flight behind tj */    \
+            if constexpr (tj + PD < TPC) load_ring(coff, wb, std::integral_constant<int, tj + PD>{});                   \
+            else if constexpr (!LAST_) load_ring(coff_n, wb_n, std::integral_constant<int, (tj + PD) % TPC>{});         \
+            lgkm_wait<ahead * RPT>();                                                                                   \
+            mma_tap(tjc);                                                                                               \
+            if (ACC64 && (((ch * TPC + tj) & 1) == 1 || ch * TPC + tj + 1 == C::NTAPS)) {                               \
+                _Pragma("unroll") for (int i = 0; i < SM; ++i)                                                          \
+                    _Pragma("unroll") for (int j = 0; j < SN; ++j)                                                      \
+                        _Pragma("unroll") for (int e = 0; e < NACC; ++e) {                                              \
+                            dacc[i][j][e] += (double)acc[i][j][e];                                                      \
+                            acc[i][j][e] = 0.f;                                                                         \
+                        }                                                                                               \
+            }                                                                                                           \
+        });                                                                                                             \
+    }
+        // prologue: the first PD taps of chunk 0 (needs the halo and chunk 0: same wait as the loop's first barrier)
+        {
+            int younger = C::NCH - 2;
+            if (younger > NBUF - 3) younger = NBUF - 3;
+            if (younger < 0) younger = 0;
+            wait_vmcnt_h(younger * dpc);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            static_for<0, PD>([&](auto tjc) { load_ring(0, lds_w, tjc); });
+        }
+        int ch = 0;
+        for (; ch < C::NCH - 1; ++ch) LT_HALO_RING_CHUNK(false)
+        LT_HALO_RING_CHUNK(true)
+#undef LT_HALO_RING_CHUNK
+    } else {
+        for (int ch = 0; ch < C::NCH; ++ch) {
+            // chunk ch (and, the first time, the halo issued before it) must have landed; up to NBUF-2 younger chunks stay in flight
+            int younger = C::NCH - 1 - ch;
+            if (younger > NBUF - 2) younger = NBUF - 2;
+            wait_vmcnt_h(younger * dpc);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves: chunk ch landed, chunk ch-1 fully consumed
+            if (ch + NBUF - 1 < C::NCH) stage_w(ch + NBUF - 1, (ch + NBUF - 1) % NBUF);
+            // per-chunk scalar parts
+            const int kd = ROWCH ? ch / KS : ch, kh_row = ROWCH ? ch % KS : 0;
+            const int coff = ((kd * C::HH + kh_row) * C::PW) * CINB;           // bytes, wave-uniform
+            const unsigned char* wb = s_w + (ch % NBUF) * C::WCH;
+            // Fragments of tap tj+1 are requested before the MFMAs of tap tj are issued (register double buffer, order pinned
+            // with sched_barrier): with one wave per SIMD nothing else hides the ~100-cycle ds_read latency.
+            // kh-dependent swizzle with row chunks: pick this row's variants with a wave-uniform switch (keeps every register
+            // index static: a select chain here was turned into a dynamically indexed array = scratch memory)
+            int arow[(ROWCH && !KW_ONLY) ? KS : 1][G][SM];
+            if (ROWCH && !KW_ONLY) {
+                switch (kh_row) {
+                    case 0:
+    #pragma unroll
+                        for (int k = 0; k < KS; ++k)
+    #pragma unroll
+                            for (int g = 0; g < G; ++g)
+    #pragma unroll
+                                for (int i = 0; i < SM; ++i) arow[k][g][i] = abase[(0 * KS + k) % NXV][g][i];
+                        break;
+                    case 1:
+    #pragma unroll
+                        for (int k = 0; k < KS; ++k)
+    #pragma unroll
+                            for (int g = 0; g < G; ++g)
+    #pragma unroll
+                                for (int i = 0; i < SM; ++i) arow[k][g][i] = abase[(1 * KS + k) % NXV][g][i];
+                        break;
+                    default:
+    #pragma unroll
+                        for (int k = 0; k < KS; ++k)
+    #pragma unroll
+                            for (int g = 0; g < G; ++g)
+    #pragma unroll
+                                for (int i = 0; i < SM; ++i) arow[k][g][i] = abase[(2 * KS + k) % NXV][g][i];
+                        break;
+                }
+            }
+            V16 fa[2][G][SM], fb[2][G][SN];
+            auto load_tap = [&](int tj, int slot) {     // tj is a compile-time constant after unrolling
+                const int kw = ROWCH ? tj : tj % KS, kh = ROWCH ? 0 : tj / KS;
+                const int imm = (kh * C::PW + kw) * CINB;                       // compile-time immediate
+    #pragma unroll
+                for (int g = 0; g < G; ++g) {
+    #pragma unroll
+                    for (int i = 0; i < SM; ++i) {
+                        int ab;
+                        if (KW_ONLY) ab = abase[kw][g][i];
+                        else if (!ROWCH) ab = abase[kh * KS + kw][g][i];
+                        else ab = arow[kw][g][i];
+                        fa[slot][g][i].u = *(const uint4*)(s_halo + (ab + coff) + imm);
+                    }
+    #pragma unroll
+                    for (int j = 0; j < SN; ++j) fb[slot][g][j].u = *(const uint4*)(wb + bbase[g][j] + tj * C::SLAB);
+                }
+            };
+            load_tap(0, 0);
+    #pragma unroll
+            for (int tj = 0; tj < TPC; ++tj) {
+                const int tap = ch * TPC + tj;
+                if (tap < C::NTAPS) {
+                    if (tj + 1 < TPC && tap + 1 < C::NTAPS) load_tap(tj + 1, (tj + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                    for (int g = 0; g < G; ++g)
+    #pragma unroll
+                        for (int i = 0; i < SM; ++i)
+    #pragma unroll
+                            for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[tj & 1][g][i], fb[tj & 1][g][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ACC64 && ((tap & 1) == 1 || tap + 1 == C::NTAPS)) {
+    #pragma unroll
+                        for (int i = 0; i < SM; ++i)
+    #pragma unroll
+                            for (int j = 0; j < SN; ++j)
+    #pragma unroll
+                                for (int e = 0; e < NACC; ++e) {
+                                    dacc[i][j][e] += (double)acc[i][j][e];
+                                    acc[i][j][e] = 0.f;
+                                }
+                    }
                 }
             }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the halo / weight images
 
-    // ---- epilogue (same scheme as conv_igemm2: per-wave fp32 LDS tile -> 16-byte vectors) ----
-    float* ep = (float*)(smem + wave * (64 * C::EP_LD * 4));
+    halo_epilogue<T, CP, MF, SM, SN, NACC, TH, TW, ACC64>(smem, a, wave, lane, n, d0, h0, w0, acc, dacc, pre_res, rp0, rp1, rp2, rp3, rp4, rp5,
+                                                         rp6, rp7, zero_page);
+}
+
+// ---- persistent 3^3 kernel: weights resident in LDS, halo double-buffered --------------------------------------------------
+// The one-tile-per-workgroup kernel above spends most of a tile's life NOT in MFMAs at the 32-channel levels: a tile is only
+// 27 taps x 4 MFMAs per wave (~3.5k matrix cycles), but its halo DMA round trip (~2 us), the 27 x 2 KB weight stream with a
+// barrier per chunk, and the epilogue are all serial inside the workgroup, with just two workgroups per CU to overlap them
+// (measured 680 TF/s = 27 % of the MFMA peak, 9 layers per forward).  Here a workgroup stays on its CU and walks tiles:
+//   * all 27 tap slabs (54 KB at 32->32 bf16) are DMA'd once;
+//   * the halo of tile i+1 lands in the other halo buffer while tile i computes;
+//   * the tap loop has no barrier, and runs a fragment pipeline PDU (k-group) units deep with hand-counted lgkmcnt;
+//   * the epilogue tile of a wave is staged in the halo buffer it just finished with.
+// Tiles are dealt so that workgroup b (XCD b % 8) keeps to the samples / raster run of that XCD, as above.
+template <typename T, int CIN, int CP>
+__global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs a, const int total_tiles) {
+    constexpr int KS = 3, TD = 4, TH = 8, TW = 8;
+    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, 9, 2> C;
+    static_assert(sizeof(T) == 2, "bf16 only: fp32 slabs do not fit beside two halo buffers");
+    constexpr int MF = C::MF, SM = C::SM, SN = C::SN, G = C::G, NACC = C::NACC, NVV = C::NVV, VPR = C::VPR, CINB = C::CINB;
+    constexpr int W_BYTES = ((C::NTAPS * C::SLAB + 1023) / 1024) * 1024;
+    static_assert(C::SW::FA == 0 && C::SW::FC == 0 && C::SW::FB == 0, "kw-only swizzle");
+    static_assert(C::EP_BYTES <= C::HALO_BYTES, "epilogue staging must fit a halo buffer");
+    typedef typename Mma<T, MF>::acc_t acc_t;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned lds_halo = lds0 + W_BYTES;            // two halo buffers follow the weights
+
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page_h;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int P = 1;
+    const int tps = a.tiles_d * a.tiles_h * a.tiles_w;
+    const T* __restrict__ w = (const T*)a.w;
+
+    auto tile_of = [&](int v, int& n, int& d0, int& h0, int& w0) {   // v: virtual workgroup index (v % 8 = XCD of this workgroup)
+        int tix;
+        if (a.xcd_pin) {
+            const int xcd = v & 7, j = v >> 3;
+            n = xcd + 8 * (j / tps);
+            tix = j % tps;
+        } else {
+            const int nb = total_tiles, q = nb >> 3, r = nb & 7, xcd = v & 7, j = v >> 3;
+            const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+            n = lin / tps;
+            tix = lin % tps;
+        }
+        w0 = (tix % a.tiles_w) * TW;
+        h0 = ((tix / a.tiles_w) % a.tiles_h) * TH;
+        d0 = (tix / (a.tiles_w * a.tiles_h)) * TD;
+    };
+    constexpr int NI_H = C::HALO_BYTES / 1024;
+    auto issue_halo = [&](int n, int d0, int h0, int w0, int buf) {
+        const T* __restrict__ x = (const T*)a.x + (size_t)n * a.D * a.H * a.W * CIN;
+        for (int i = wave; i < NI_H; i += 4) {
+            const int q = i * 64 + lane;
+            const int hv = q / NVV, pv = q % NVV;
+            const int hw_ = hv % C::PW, hh_ = (hv / C::PW) % C::HH, hd_ = hv / (C::PW * C::HH);
+            const int lv = pv ^ C::fswz(hd_, hh_, hw_);
+            const int id = d0 - P + hd_, ih = h0 - P + hh_, iw = w0 - P + hw_;
+            const bool ok = hv < C::HV && hw_ < C::HW && ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : zero_page;
+            dma16h(src, lds_halo + buf * C::HALO_BYTES + i * 1024);
+        }
+    };
+
+    // ---- weights: every tap slab, once ----
+    constexpr int NI_W = W_BYTES / 1024;
+    for (int i = wave; i < NI_W; i += 4) {
+        const int q = i * 64 + lane;
+        const int pv = q % NVV, col = (q / NVV) % CP, tap = q / (NVV * CP);
+        const int lv = pv ^ ((-(col / VPR)) & (NVV - 1));
+        const void* src = tap < C::NTAPS ? (const void*)(w + (size_t)col * a.k_pad + tap * CIN + lv * C::VEC) : zero_page;
+        dma16h(src, lds0 + i * 1024);
+    }
+
+    int v = blockIdx.x;
+    int n, d0, h0, w0;
+    tile_of(v, n, d0, h0, w0);
+    issue_halo(n, d0, h0, w0, 0);
+
+    // ---- per-lane fragment bases (halo part is rebased per tile: the buffer alternates) ----
+    const int lvb = (MF == 32) ? (lane >> 5) : (lane >> 4);
+    int abase[KS][G][SM];
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+        const int r = 64 * wave + i * MF + (lane & (MF - 1));
+        const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
+        const int own = ((td * C::HH + th) * C::PW + tw) * CINB;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+            const int f = C::fswz(0, th, tw + kw);
+#pragma unroll
+            for (int g = 0; g < G; ++g) abase[kw][g][i] = own + (((lvb + ((MF == 32) ? 2 * g : 4 * g)) ^ f) << 4);
+        }
+    }
+    unsigned bbase[G][SN];
 #pragma unroll
     for (int j = 0; j < SN; ++j) {
-        const int colj = j * MF + (lane & (MF - 1));
-        const float bi = a.bias ? a.bias[colj] : 0.f;
-        const float sc = a.scale ? a.scale[colj] : 1.f;
-        const float sf = a.shift ? a.shift[colj] : 0.f;
+        const int col = j * MF + (lane & (MF - 1));
+        const int bsw = (-(col / VPR)) & (NVV - 1);
+#pragma unroll
+        for (int g = 0; g < G; ++g) bbase[g][j] = lds0 + col * CINB + (((lvb + ((MF == 32) ? 2 * g : 4 * g)) ^ bsw) << 4);
+    }
+
+    constexpr int E_VECO = C::VEC, E_LPR = CP / E_VECO, E_RPP = 64 / E_LPR, E_NIT = 64 / E_RPP;
+    static_assert(E_NIT <= 8, "epilogue rows per lane");
+    const bool vec_epi = (a.Cout % E_VECO == 0) && (a.ldc % E_VECO == 0);
+    const bool pre_res = vec_epi && a.res != nullptr && !(a.flags & LT_EPI_NO_RES_PREFETCH);
+
+    // fragment pipeline: unit u = tap * G + g (SM A reads + SN B reads, SM*SN MFMAs); PDU units of lookahead
+    constexpr int RPU = SM + SN;
+    constexpr int PDU = 15 / RPU - 1 >= 4 ? 4 : 15 / RPU - 1;
+    constexpr int RING = PDU + 1;
+    constexpr int NU = C::NTAPS * G;
+    static_assert(PDU >= 1 && (PDU + 1) * RPU <= 15, "lookahead exceeds the lgkmcnt counter");
+
+    for (int it = 0;; ++it) {
+        const int buf = it & 1;
+        const int vn = v + gridDim.x;
+        const bool have_next = vn < total_tiles;
+        // halo(it) (issued one tile ago), the weights, and the stores of tile it-1 are complete; every wave is done with tile it-1
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        int nn = 0, nd0 = 0, nh0 = 0, nw0 = 0;
+        if (have_next) {
+            tile_of(vn, nn, nd0, nh0, nw0);
+            issue_halo(nn, nd0, nh0, nw0, buf ^ 1);      // lands while this tile computes
+        }
+        // residual vectors of this tile: requested AFTER the DMAs (they must be the youngest VMEM operations for the compiler's
+        // own vmcnt bookkeeping to be right), consumed in the epilogue
+        uint4 rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7;
+        rp0 = rp1 = rp2 = rp3 = rp4 = rp5 = rp6 = rp7 = make_uint4(0, 0, 0, 0);
+        if (pre_res) {
+            const int cqp = (lane % E_LPR) * E_VECO;
+            auto pf = [&](int k) -> uint4 {
+                const int r = 64 * wave + lane / E_LPR + k * E_RPP;
+                const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
+                const size_t pixv = (((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw;
+                const void* src = cqp < a.Cout ? (const void*)((const T*)a.res + pixv * a.ldc + cqp) : zero_page;
+                return *(const uint4*)src;
+            };
+            if (E_NIT > 0) rp0 = pf(0);
+            if (E_NIT > 1) rp1 = pf(1);
+            if (E_NIT > 2) rp2 = pf(2);
+            if (E_NIT > 3) rp3 = pf(3);
+            if (E_NIT > 4) rp4 = pf(4);
+            if (E_NIT > 5) rp5 = pf(5);
+            if (E_NIT > 6) rp6 = pf(6);
+            if (E_NIT > 7) rp7 = pf(7);
+        }
+
+        acc_t acc[SM][SN];
+        double dacc[1][1][1];
 #pragma unroll
         for (int i = 0; i < SM; ++i)
 #pragma unroll
-            for (int e = 0; e < NACC; ++e) {
-                const int r = i * MF + ((MF == 32) ? ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) : ((lane >> 4) * 4 + e));
-                float val;
-                if (ACC64) val = (float)((dacc[i][j][e] + (double)bi) * (double)sc + (double)sf);
-                else val = (acc[i][j][e] + bi) * sc + sf;
-                ep[r * C::EP_LD + colj] = val;
-            }
-    }
-    __syncthreads();
+            for (int j = 0; j < SN; ++j)
+#pragma unroll
+                for (int e = 0; e < NACC; ++e) acc[i][j][e] = 0.f;
 
-    const bool relu_pre = a.flags & LT_EPI_RELU_PRE, relu_post = a.flags & LT_EPI_RELU_POST;
-    const bool has_res = a.res != nullptr;
-    auto row_pix = [&](int r) -> size_t {   // r = row inside the workgroup tile
-        const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
-        return (((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw;
-    };
-    constexpr int VECO = C::VEC;              // fp32: 4 channels, bf16: 8 channels per 16 bytes
-    if ((a.Cout % VECO == 0) && (a.ldc % VECO == 0)) {
-        constexpr int LPR = CP / VECO, RPP = 64 / LPR;
-        const int cq = (lane % LPR) * VECO;
-        if (cq < a.Cout) {
-            constexpr int NIT = 64 / RPP;
-            union Pack { uint4 u; float f[4]; unsigned short h[8]; };
-            auto row = [&](int it, uint4 resv) {      // resv: this row's residual vector (zeros when there is none)
-                const size_t off = row_pix(64 * wave + lane / LPR + it * RPP) * a.ldc + cq;
-                const float* src = ep + (lane / LPR + it * RPP) * C::EP_LD + cq;
-                Pack rv, ov;
-                rv.u = resv;
+        unsigned ha[KS][G][SM];
+        const unsigned hbase = lds_halo + buf * C::HALO_BYTES;
 #pragma unroll
-                for (int e = 0; e < VECO; e += 4) {
-                    const float4 q = *(const float4*)(src + e);
-                    const float vq[4] = {q.x, q.y, q.z, q.w};
+        for (int kw = 0; kw < KS; ++kw)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float rr = sizeof(T) == 4 ? rv.f[(e + k) % 4] : bf16_to_f32(rv.h[(e + k) % 8]);
-                        const float val = epi_act_h(vq[k], relu_pre, has_res, has_res ? rr : 0.f, relu_post);
-                        if (sizeof(T) == 4) ov.f[(e + k) % 4] = val;
-                        else ov.h[(e + k) % 8] = f32_to_bf16(val);
-                    }
-                }
-                *(uint4*)((T*)a.y + off) = ov.u;
-            };
-            if (pre_res || !has_res) {
-                if (NIT > 0) row(0, rp0);
-                if (NIT > 1) row(1, rp1);
-                if (NIT > 2) row(2, rp2);
-                if (NIT > 3) row(3, rp3);
-                if (NIT > 4) row(4, rp4);
-                if (NIT > 5) row(5, rp5);
-                if (NIT > 6) row(6, rp6);
-                if (NIT > 7) row(7, rp7);
-                if (NIT > 8) {   // fp32 with a narrow tile: no prefetch (PRE_OK false), rows 8.. have no residual here
+            for (int g = 0; g < G; ++g)
 #pragma unroll
-                    for (int it = 8; it < NIT; ++it) row(it, make_uint4(0, 0, 0, 0));
-                }
-            } else {
-                Pack rv[NIT];
+                for (int i = 0; i < SM; ++i) ha[kw][g][i] = hbase + abase[kw][g][i];
+
+        V16 fa[RING][SM], fb[RING][SN];
+        auto load_unit = [&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int tap = u / G, g = u % G, slot = u % RING;
+            constexpr int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            constexpr int imm = ((kd * C::HH + kh) * C::PW + kw) * CINB;
+            static_for<0, SM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                lds_read16<imm>(fa[slot][i], ha[kw][g][i]);
+            });
+            static_for<0, SN>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                lds_read16<tap * C::SLAB>(fb[slot][j], bbase[g][j]);
+            });
+        };
+        static_for<0, PDU>([&](auto uc) { load_unit(uc); });
+        static_for<0, NU>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int slot = u % RING;
+            constexpr int ahead = (u + PDU < NU) ? PDU : NU - 1 - u;     // units in flight behind u at the wait
+            if constexpr (u + PDU < NU) load_unit(std::integral_constant<int, u + PDU>{});
+            lgkm_wait<ahead * RPU>();
 #pragma unroll
-                for (int it = 0; it < NIT; ++it)      // all residual loads first: independent HBM round trips
-                    rv[it].u = *(const uint4*)((const T*)a.res + row_pix(64 * wave + lane / LPR + it * RPP) * a.ldc + cq);
+            for (int i = 0; i < SM; ++i) frag_ready(fa[slot][i]);
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) row(it, rv[it].u);
-            }
-        }
-    } else {
-        for (int idx = lane; idx < 64 * CP; idx += 64) {
-            const int r = idx / CP, cc = idx - r * CP;
-            if (cc >= a.Cout) continue;
-            const size_t off = row_pix(64 * wave + r) * a.ldc + cc;
-            const float rr = has_res ? elt<T>::ld((const T*)a.res + off) : 0.f;
-            elt<T>::st((T*)a.y + off, epi_act_h(ep[r * C::EP_LD + cc], relu_pre, has_res, rr, relu_post));
-        }
+            for (int j = 0; j < SN; ++j) frag_ready(fb[slot][j]);
+#pragma unroll
+            for (int i = 0; i < SM; ++i)
+#pragma unroll
+                for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[slot][i], fb[slot][j]);
+        });
+        // every wave is done reading this halo buffer (it becomes the epilogue staging area); halo(it+1) has long landed and
+        // nothing else is in flight, so the compiler's vmcnt counts for the residual vectors hold
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        halo_epilogue<T, CP, MF, SM, SN, NACC, TH, TW, false>(smem + W_BYTES + buf * C::HALO_BYTES, a, wave, lane, n, d0, h0, w0, acc, dacc,
+                                                             pre_res, rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7, zero_page);
+        if (!have_next) break;
+        v = vn; n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
     }
 }
 
-template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF>
+template <typename T, int CIN, int CP>
+int launch_halo_persist(const HaloArgs& a, hipStream_t s) {
+    typedef HaloCfg<T, 3, CIN, CP, 4, 8, 8, 9, 2> C;
+    constexpr int W_BYTES = ((C::NTAPS * C::SLAB + 1023) / 1024) * 1024;
+    constexpr int LDS = W_BYTES + 2 * C::HALO_BYTES;
+    static_assert(LDS <= 160 * 1024, "weights + two halo buffers do not fit LDS");
+    auto kern = conv3d_halo_persist_kernel<T, CIN, CP>;
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+        n_cu -= n_cu % 8;   // the tile dealing assumes workgroup b runs on XCD b % 8
+        attr_set = true;
+    }
+    const long long total = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
+    const int grid = (int)(total < n_cu ? total - total % 8 : n_cu);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, s, a, (int)total);
+    LT_CHECK_LAUNCH("lt_conv_fwd(halo, persistent)");
+    return LT_OK;
+}
+
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF, int PD>
 int launch_halo(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF> C;
     static_assert(C::LDS_BYTES <= 160 * 1024, "halo tile does not fit LDS");
-    auto kern = conv3d_halo_kernel<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF>;
+    auto kern = conv3d_halo_kernel<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF, PD>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -480,22 +858,30 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     a.tiles_d = c.D / 4; a.tiles_h = c.H / 8; a.tiles_w = c.W / 8;
     a.xcd_pin = (c.N % 8 == 0) ? 1 : 0;
     const bool bf = dtype == LT_BF16;
-#define HALO_CASE(T_, KS_, CIN_, CP_, TPC_, NBUF_)                                               \
+#define HALO_CASE(T_, KS_, CIN_, CP_, TPC_, NBUF_, PD_)                                          \
     if (ks == KS_ && c.Cin == CIN_ && cout_pad == CP_) {                                        \
-        int rc = launch_halo<T_, KS_, CIN_, CP_, 4, 8, 8, TPC_, NBUF_>(a, s);                   \
+        int rc = launch_halo<T_, KS_, CIN_, CP_, 4, 8, 8, TPC_, NBUF_, PD_>(a, s);              \
         return rc == LT_OK ? 1 : rc;                                                            \
+    }
+    // persistent variant: needs a few tiles per workgroup to amortise the weight load, and total % 8 == 0 for the XCD dealing
+    static const bool no_persist = getenv("LT_HALO_NO_PERSIST") != nullptr;   // A/B
+    if (bf && ks == 3 && cout_pad == 32 && c.Cin == 32 && nblk >= 1024 && nblk % 8 == 0 && !no_persist) {
+        int rc = launch_halo_persist<bf16_t, 32, 32>(a, s);
+        return rc == LT_OK ? 1 : rc;
     }
     static const bool row_chunks = getenv("LT_HALO_ROW") != nullptr;   // A/B: 3-tap weight chunks -> 51 KB of LDS -> 3 workgroups per CU
     if (bf) {
-        if (row_chunks) { HALO_CASE(bf16_t, 3, 32, 32, 3, 2) }
-        HALO_CASE(bf16_t, 3, 32, 32, 9, 2)
-        HALO_CASE(bf16_t, 3, 16, 32, 9, 2)
-        HALO_CASE(bf16_t, 3, 64, 64, 3, 2)
-        HALO_CASE(bf16_t, 3, 32, 64, 9, 2)
-        HALO_CASE(bf16_t, 7, 32, 16, 7, 4)
+        if (row_chunks) { HALO_CASE(bf16_t, 3, 32, 32, 3, 2, 1) }
+        HALO_CASE(bf16_t, 3, 32, 32, 9, 2, 1)
+        HALO_CASE(bf16_t, 3, 16, 32, 9, 2, 1)
+        HALO_CASE(bf16_t, 3, 64, 64, 3, 2, 1)
+        HALO_CASE(bf16_t, 3, 32, 64, 9, 2, 1)
+        static const bool no_ring = getenv("LT_HALO_NO_RING") != nullptr;   // A/B: 1-tap fragment lookahead for 7^3
+        if (no_ring) { HALO_CASE(bf16_t, 7, 32, 16, 7, 4, 1) }
+        HALO_CASE(bf16_t, 7, 32, 16, 7, 4, 2)
     } else {
-        HALO_CASE(float, 3, 32, 32, 3, 3)
-        HALO_CASE(float, 3, 16, 32, 9, 2)
+        HALO_CASE(float, 3, 32, 32, 3, 3, 1)
+        HALO_CASE(float, 3, 16, 32, 9, 2, 1)
     }
 #undef HALO_CASE
     return 0;

@@ -82,6 +82,7 @@ __device__ __forceinline__ void decode_row(const ConvArgs& a, int m, int& n, int
 
 constexpr int ROW_BYTES = 128;  // K bytes per tile row per step
 constexpr int LT_EPI_NO_RES_PREFETCH = 1 << 16;   // internal A/B switch (env LT_CONV_NO_RESPF), not part of the ABI
+constexpr int LT_EPI_NO_XCD_REMAP = 1 << 17;      // internal A/B switch (env LT_CONV_NO_XCD)
 
 // launchers implemented in conv_igemm2.hip, used by the dispatcher in conv_igemm.hip
 int conv2_dispatch(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile, hipStream_t s);

@@ -267,6 +267,8 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
     static const bool no_halo = getenv("LT_CONV_NO_HALO") != nullptr;
     static const bool no_respf = getenv("LT_CONV_NO_RESPF") != nullptr;
     if (no_respf) const_cast<ConvArgs&>(a).flags |= LT_EPI_NO_RES_PREFETCH;
+    static const bool no_xcd = getenv("LT_CONV_NO_XCD") != nullptr;
+    if (no_xcd) const_cast<ConvArgs&>(a).flags |= LT_EPI_NO_XCD_REMAP;
     if ((tile == LT_TILE_AUTO && !force_v1 && !no_halo) || tile == LT_TILE_HALO) {
         const int rc = conv3d_halo_try(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, tile == LT_TILE_HALO, s);
         if (rc == 1) return LT_OK;

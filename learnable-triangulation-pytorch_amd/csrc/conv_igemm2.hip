@@ -125,12 +125,27 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     int4* s_taps = (int4*)(s_rowpix + BM);         // [ntaps]
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic region
 
+    // Address of the zero page, made opaque once: otherwise every use re-loads it from the GOT (s_load + s_waitcnt lgkmcnt(0)),
+    // which inside the K loop also drains the fragment ds_reads in flight
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int tile_n = blockIdx.x % a.tiles_n;
-    const int tile_m = blockIdx.x / a.tiles_n;
+    // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs (each with its own L2),
+    // so workgroup b runs on XCD b%8. Give every XCD one contiguous run of the (tile_m, tile_n) raster instead of every
+    // 8th tile: the tiles_n workgroups that re-read one A row panel, and the neighbouring row panels whose 3x3 taps
+    // overlap, then meet in the same L2 rather than each pulling the panel from HBM / Infinity Cache.
+    int lin = blockIdx.x;
+    if (!(a.flags & LT_EPI_NO_XCD_REMAP)) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = lin & 7, j = lin >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tile_n = lin % a.tiles_n;
+    const int tile_m = lin / a.tiles_n;
     const PhaseArg ph = a.phase[blockIdx.y];
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const T* __restrict__ x = (const T*)a.x;
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                 else pix = s_rowpix[r];
                 // rows beyond M / channels beyond Cout read the zero page; their values are never used
                 const void* src = (pix >= 0 && colp < a.Cout) ? (const void*)((const bf16_t*)a.res + (size_t)pix * a.ldc + colp)
-                                                             : (const void*)g_zero_page;
+                                                             : zero_page;
                 return *(const uint4*)src;
             };
             if (PF_NIT > 0) rp0 = pf(0);
@@ -220,13 +235,17 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
         }
     }
 
-    auto stage = [&](int ks, int buf) {
+    // DMA pieces of one stage: A pieces 0..A_IT-1, then B pieces A_IT..A_IT+B_IT-1; [p0, p1) selects a slice (compile-time
+    // after unrolling) so that the K loop can issue them between MFMA groups
+    constexpr int NPIECE = A_IT + B_IT;
+    auto stage = [&](int ks, int buf, int p0, int p1) {
         const unsigned sA = lds0 + buf * STAGE;
         const unsigned sB = sA + BM * ROW_BYTES;
         if (PW) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                const void* src = baseC[i] >= 0 ? (const void*)(x + (baseC[i] + ks * BK)) : (const void*)g_zero_page;
+                if (i < p0 || i >= p1) continue;
+                const void* src = baseC[i] >= 0 ? (const void*)(x + (baseC[i] + ks * BK)) : zero_page;
                 dma16(src, sA + (8 * wave + 32 * i) * ROW_BYTES);
             }
         } else if (UT) {
@@ -234,7 +253,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
             // instructions of address arithmetic per MFMA on narrow tiles
             const int k0 = ks * BK;                      // wave-uniform
             const int c0 = k0 & (a.Cin - 1);
-            if (c0 == 0) {
+            if (c0 == 0 && p0 == 0) {
                 const int tap = k0 >> a.log2Cin;
                 int4 tp = make_int4(-(1 << 24), 0, 0, 0);
                 if (tap < ph.ntaps) tp = s_taps[tap];
@@ -247,7 +266,8 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                const void* src = cur[i] >= 0 ? (const void*)(x + (cur[i] + c0)) : (const void*)g_zero_page;
+                if (i < p0 || i >= p1) continue;
+                const void* src = cur[i] >= 0 ? (const void*)(x + (cur[i] + c0)) : zero_page;
                 dma16(src, sA + (8 * wave + 32 * i) * ROW_BYTES);
             }
         } else {
@@ -258,14 +278,16 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
             if (tap < ph.ntaps) tp = s_taps[tap];
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
+                if (i < p0 || i >= p1) continue;
                 const int id = id0[i] + tp.x, ih = ih0[i] + tp.y, iw = iw0[i] + tp.z;
                 const bool ok = ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-                const void* src = ok ? (const void*)(x + (baseC[i] + tp.w + c)) : (const void*)g_zero_page;
+                const void* src = ok ? (const void*)(x + (baseC[i] + tp.w + c)) : zero_page;
                 dma16(src, sA + (8 * wave + 32 * i) * ROW_BYTES);
             }
         }
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
+            if (A_IT + j < p0 || A_IT + j >= p1) continue;
             if (B_VECS >= 256 * (j + 1) || 8 * wave + 32 * j < BN)   // wave-uniform: whole 8-row groups
                 dma16(wrow[j] + ks * BK, sB + (8 * wave + 32 * j) * ROW_BYTES);
         }
@@ -297,49 +319,57 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     // prologue: NST-1 stages in flight
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
-        if (s < nk) stage(s, s);
+        if (s < nk) stage(s, s, 0, NPIECE);
 
-    for (int ks = 0; ks < nk; ++ks) {
-        // stage ks must have landed; the (up to NST-2) younger stages may stay in flight
-        int younger = nk - 1 - ks;
-        if (younger > NST - 2) younger = NST - 2;
-        wait_vmcnt(younger * dps);
-        block_barrier();   // everybody's stage-ks DMAs landed, everybody is done reading stage ks-1
-        if (ks + NST - 1 < nk) stage(ks + NST - 1, (ks + NST - 1) % NST);
-        const int buf = ks % NST;
-        const unsigned char* pa = smem + buf * STAGE + a_base;
-        const unsigned char* pb = smem + buf * STAGE + b_base;
-        // fragment group g+1 is requested before the MFMAs of group g issue (register double buffer, order pinned)
-        V16 fa[2][SM], fb[2][SN];
-        auto load_group = [&](int g, int slot) {
-#pragma unroll
-            for (int i = 0; i < SM; ++i) fa[slot][i].u = *(const uint4*)(pa + i * MF * ROW_BYTES + foff[g]);
-#pragma unroll
-            for (int j = 0; j < SN; ++j) fb[slot][j].u = *(const uint4*)(pb + j * MF * ROW_BYTES + foff[g]);
-        };
-        load_group(0, 0);
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (g + 1 < G) load_group(g + 1, (g + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < SM; ++i)
-#pragma unroll
-                for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[g & 1][i], fb[g & 1][j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (ACC64 && ((ks & 1) == 1 || ks + 1 == nk)) {
-#pragma unroll
-            for (int i = 0; i < SM; ++i)
-#pragma unroll
-                for (int j = 0; j < SN; ++j)
-#pragma unroll
-                    for (int e = 0; e < NACC; ++e) {
-                        dacc[i][j][e] += (double)acc[i][j][e];
-                        acc[i][j][e] = 0.f;
-                    }
-        }
+    // One K step. MORE_ (compile time): stage ks+NST-1 is still to be requested. Its DMA pieces are issued in slices BEHIND
+    // the MFMAs of each fragment group: a piece costs the wave ~60-180 issue cycles (MI355X_MICROARCH.md), and eight of them
+    // in front of the first MFMA left the matrix pipe idle for about as long as the K step's MFMAs take. The main loop and the
+    // NST-1 drain steps are separate loops so that the K step has no control flow (a uniform branch around the inline-asm
+    // DMAs made the compiler fall back to s_waitcnt lgkmcnt(0) for the fragment reads).  -DLT_DMA_UPFRONT: old order (A/B).
+#ifdef LT_DMA_UPFRONT
+    constexpr bool UPFRONT = true;
+#else
+    constexpr bool UPFRONT = false;
+#endif
+#define LT_KSTEP(MORE_)                                                                                              \
+    {                                                                                                                \
+        wait_vmcnt((MORE_ ? NST - 2 : (nk - 1 - ks < NST - 2 ? nk - 1 - ks : NST - 2)) * dps);                       \
+        block_barrier(); /* everybody's stage-ks DMAs landed, everybody is done reading stage ks-1 */                \
+        if (MORE_ && UPFRONT) stage(ks + NST - 1, (ks + NST - 1) % NST, 0, NPIECE);                                  \
+        const int buf = ks % NST;                                                                                    \
+        const unsigned char* pa = smem + buf * STAGE + a_base;                                                       \
+        const unsigned char* pb = smem + buf * STAGE + b_base;                                                       \
+        /* fragment group g+1 is requested before the MFMAs of group g issue (register double buffer, order pinned) */ \
+        V16 fa[2][SM], fb[2][SN];                                                                                    \
+        auto load_group = [&](int g, int slot) {                                                                     \
+            _Pragma("unroll") for (int i = 0; i < SM; ++i) fa[slot][i].u = *(const uint4*)(pa + i * MF * ROW_BYTES + foff[g]); \
+            _Pragma("unroll") for (int j = 0; j < SN; ++j) fb[slot][j].u = *(const uint4*)(pb + j * MF * ROW_BYTES + foff[g]); \
+        };                                                                                                           \
+        load_group(0, 0);                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                              \
+            if (g + 1 < G) load_group(g + 1, (g + 1) & 1);                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            _Pragma("unroll") for (int i = 0; i < SM; ++i)                                                           \
+                _Pragma("unroll") for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[g & 1][i], fb[g & 1][j]); \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            if (MORE_ && !UPFRONT) {                                                                                 \
+                stage(ks + NST - 1, (ks + NST - 1) % NST, g * NPIECE / G, (g + 1) * NPIECE / G);                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                   \
+            }                                                                                                        \
+        }                                                                                                            \
+        if (ACC64 && ((ks & 1) == 1 || ks + 1 == nk)) {                                                              \
+            _Pragma("unroll") for (int i = 0; i < SM; ++i)                                                           \
+                _Pragma("unroll") for (int j = 0; j < SN; ++j)                                                       \
+                    _Pragma("unroll") for (int e = 0; e < NACC; ++e) {                                               \
+                        dacc[i][j][e] += (double)acc[i][j][e];                                                       \
+                        acc[i][j][e] = 0.f;                                                                          \
+                    }                                                                                                \
+        }                                                                                                            \
     }
+    int ks = 0;
+    for (; ks + NST - 1 < nk; ++ks) LT_KSTEP(true)
+    for (; ks < nk; ++ks) LT_KSTEP(false)
+#undef LT_KSTEP
     block_barrier();   // all waves done with the last stage: the region is reused by the epilogue tiles
 
     // ---- epilogue: (acc + bias)*scale + shift, then this wave's LDS sub-tile (fp32, padded rows) -> 16-byte vectors ---

@@ -39,8 +39,20 @@ def build(force=False, verbose=True):
     """Compile every csrc/*.hip for gfx950 and link lib/liblt_hip.so.  Returns the library path."""
     if not force and not is_stale():
         return LIB
+    return _build(LIB, "build", [], verbose)
+
+
+def build_variant(name, defines, verbose=True):
+    """A/B build: lib/liblt_hip_<name>.so compiled with extra -D switches (kernel-scheduling experiments that must be
+    compile-time).  Selected at run time with LT_HIP_LIB=<path> (see lt_hip.py); never built or loaded by default."""
+    lib = os.path.join(LIBDIR, "liblt_hip_%s.so" % name)
+    return _build(lib, "build_" + name, ["-D" + d for d in defines], verbose)
+
+
+def _build(LIB, objsub, extra, verbose):
+    FLAGS = globals()["FLAGS"] + list(extra)
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, objsub)
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
 
@@ -64,4 +76,8 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:   # python lt_build.py --variant upfront LT_DMA_UPFRONT
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+    else:
+        build(force="--force" in sys.argv)

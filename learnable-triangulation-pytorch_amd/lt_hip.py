@@ -9,7 +9,8 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "liblt_hip.so")
+# LT_HIP_LIB: load an A/B variant build of the same ABI instead (lt_build.build_variant); never a different backend
+LIB_PATH = os.environ.get("LT_HIP_LIB") or os.path.join(HERE, "lib", "liblt_hip.so")
 
 LT_F32, LT_BF16 = 0, 1
 AGG = {"sum": 0, "max": 1, "softmax": 2, "conf": 3, "conf_norm": 4}

@@ -276,6 +276,11 @@ HALO_CASES = {  # name: (N, cin, cout, k, (D,H,W), dtypes)
     "halo_3x3_32_64": (3, 32, 64, 3, (4, 8, 16), ("bf16",)),
     "halo_7x7_32_16": (1, 32, 16, 7, (8, 16, 8), ("bf16",)),
     "halo_3x3_32_32_xcdpin": (8, 32, 32, 3, (4, 8, 8), ("bf16",)),
+    # >= 1024 tiles: the persistent kernel (weights resident, double-buffered halo), raster dealing and XCD-pinned dealing
+    "halo_3x3_32_32_persist": (2, 32, 32, 3, (32, 64, 64), ("bf16",)),
+    "halo_3x3_32_32_persist_xcdpin": (8, 32, 32, 3, (16, 32, 64), ("bf16",)),
+    # 7^3 at a size with several tiles per CU (fragment ring across weight chunks)
+    "halo_7x7_32_16_big": (1, 32, 16, 7, (32, 32, 32), ("bf16",)),
 }
 
 
@@ -297,3 +302,7 @@ def test_conv3d_halo_kernel(case):
         check("conv3d_halo/%s/%s" % (case, dname), out, ref, 2e-5 if dtype == torch.float32 else 1.5e-2)
         out2 = run_conv(x, w, bias, bn, 1, k // 2, dtype, 0, relu=True, residual=res)   # AUTO (generic or halo) agrees
         check("conv3d_auto/%s/%s" % (case, dname), out2, ref, 2e-5 if dtype == torch.float32 else 1.5e-2)
+        if "persist" in case:   # no residual, no ReLU: the epilogue without prefetched vectors
+            ref3 = _bn_ref(F.conv3d(rd(x), rd(w), bias, 1, k // 2), bn)
+            out3 = run_conv(x, w, bias, bn, 1, k // 2, dtype, H.TILE_HALO, relu=False, residual=None)
+            check("conv3d_halo_nores/%s/%s" % (case, dname), out3, ref3, 1.5e-2)

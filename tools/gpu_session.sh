@@ -57,8 +57,13 @@ pmcconv)
 abenv)
   # in-session A/B of env switches (two interleaved rounds each): baseline, no residual prefetch, no uniform-tap path, no halo kernel
   for round in 1 2; do
-    for v in ${ABVARS:-base LT_CONV_NO_RESPF LT_HALO_ROW}; do
-      if [ $v = base ]; then E=""; else E="$v=1"; fi
+    for v in ${ABVARS:-base LT_CONV_NO_XCD LT_HALO_NO_PERSIST LT_HALO_NO_RING LIB_upfront}; do
+      # LIB_<name>: an A/B build of the library (lt_build.build_variant), else an env switch read by the kernels' dispatchers
+      case $v in
+        base) E="LT_AB=base" ;;
+        LIB_*) E="LT_HIP_LIB=$PWD/learnable-triangulation-pytorch_amd/lib/liblt_hip_${v#LIB_}.so" ;;
+        *) E="$v=1" ;;
+      esac
       env $E timeout 600 python bench.py --no-cpu-baseline --no-profile --steps 10 --warmup 3 > $OUT/ab_${v}_$round.json 2> $OUT/ab_${v}_$round.err
       echo "ab $v round $round: $(python -c "import json;d=json.load(open('$OUT/ab_${v}_$round.json'));print('%.1f samples/s %.2f ms/step'%(d['value'],d['ms_per_step']))")" | tee -a $OUT/session.log
     done
