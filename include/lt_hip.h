@@ -104,6 +104,8 @@ enum { LT_TILE_AUTO = 0,
        LT_TILE2_128x128 = 11, LT_TILE2_128x64 = 12, LT_TILE2_256x32 = 13, LT_TILE2_256x16 = 14, LT_TILE2_64x64 = 15,
        /* stride-1 3^3 / 7^3 conv3d with the input halo tile resident in LDS (auto-selected where it applies) */
        LT_TILE_HALO = 20,
+       /* 288-row tile, eight waves, three-stage ring (bf16, auto-selected for the wide ResNet levels) */
+       LT_TILE3_288 = 30,
        LT_TILE_DIRECT = 99 /* scalar fp32 VALU kernel, debug cross-check only */ };
 
 int lt_conv_fwd(const lt_conv_desc* desc, const void* x, const float* bias, const float* scale, const float* shift,

@@ -29,6 +29,13 @@ namespace {
 
 __device__ uint4 g_zero_page_h[2];
 
+#ifdef LT_TRACE
+// profiling build: shader-clock accounting of the persistent kernel's per-tile phases, written by wave 0 of every 8th workgroup:
+// [total, top wait+barrier, halo issue, residual issue, tap loop, barrier, epilogue, tiles]
+__device__ long long g_trace_h[8 * 64];
+#define LT_CLKH() ((long long)__builtin_amdgcn_s_memtime())
+#endif
+
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ void dma16h(const void* src, unsigned lds_base) {
@@ -141,6 +148,12 @@ __device__ __forceinline__ void wait_vmcnt_h(int n) {
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // conservative
     }
 }
+
+#ifdef LT_ABL_NO_MMA
+#define LT_HMMA(c_, a_, b_) (void)0
+#else
+#define LT_HMMA(c_, a_, b_) Mma<T, MF>::run(c_, a_, b_)
+#endif
 
 struct HaloArgs {
     const void* x;
@@ -295,6 +308,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
 
     // ---- halo DMA: vector q = hv*NVV + pv, wave-instruction i covers q in [64 i, 64 i + 64) ----
     constexpr int NI_H = C::HALO_BYTES / 1024;
+#ifndef LT_ABL_NO_A   // -DLT_ABL_*: timing ablations for profiling builds (results are WRONG with any of them)
     for (int i = wave; i < NI_H; i += 4) {
         const int q = i * 64 + lane;
         const int hv = q / NVV, pv = q % NVV;
@@ -305,9 +319,13 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
         const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : zero_page;
         dma16h(src, lds0 + i * 1024);
     }
+#endif
     // ---- weight chunk DMA: vector q = (tap_in_chunk*CP + col)*NVV + pv ----
     constexpr int NI_W = C::WCH / 1024;
     auto stage_w = [&](int ch, int buf) {
+#ifdef LT_ABL_NO_B
+        return;
+#endif
         for (int i = wave; i < NI_W; i += 4) {
             const int q = i * 64 + lane;
             const int pv = q % NVV, col = (q / NVV) % CP, tj = q / (NVV * CP);
@@ -318,7 +336,11 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
             dma16h(src, lds0 + C::HALO_BYTES + buf * C::WCH + i * 1024);
         }
     };
+#ifdef LT_ABL_NO_B
+    const int dpc = 0;
+#else
     const int dpc = (NI_W - wave + 3) / 4;        // weight DMA instructions per chunk issued by this wave (wave-uniform)
+#endif
 #pragma unroll
     for (int c = 0; c < NBUF - 1; ++c)
         if (c < C::NCH) stage_w(c, c);
@@ -438,7 +460,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
 #pragma unroll
                 for (int i = 0; i < SM; ++i)
 #pragma unroll
-                    for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[TJ][g][i], fb[TJ][g][j]);
+                    for (int j = 0; j < SN; ++j) LT_HMMA(acc[i][j], fa[TJ][g][i], fb[TJ][g][j]);
         };
         // LAST_ (compile time): no chunk follows.  Two copies of the chunk body instead of a uniform branch around the
         // cross-chunk loads, so that the number of reads in flight at every wait is a compile-time constant.
@@ -560,7 +582,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
     #pragma unroll
                         for (int i = 0; i < SM; ++i)
     #pragma unroll
-                            for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[tj & 1][g][i], fb[tj & 1][g][j]);
+                            for (int j = 0; j < SN; ++j) LT_HMMA(acc[i][j], fa[tj & 1][g][i], fb[tj & 1][g][j]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (ACC64 && ((tap & 1) == 1 || tap + 1 == C::NTAPS)) {
     #pragma unroll
@@ -579,6 +601,9 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the halo / weight images
 
+#ifdef LT_ABL_NO_EPI
+    if (a.N < 0)
+#endif
     halo_epilogue<T, CP, MF, SM, SN, NACC, TH, TW, ACC64>(smem, a, wave, lane, n, d0, h0, w0, acc, dacc, pre_res, rp0, rp1, rp2, rp3, rp4, rp5,
                                                          rp6, rp7, zero_page);
 }
@@ -700,17 +725,29 @@ __global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs
     constexpr int NU = C::NTAPS * G;
     static_assert(PDU >= 1 && (PDU + 1) * RPU <= 15, "lookahead exceeds the lgkmcnt counter");
 
+#ifdef LT_TRACE
+    long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
+    const long long tr_begin = LT_CLKH();
+#define LT_TRH(k_) { const long long c_ = LT_CLKH(); tr[k_] += c_ - tr_last; tr_last = c_; }
+    long long tr_last = tr_begin;
+#else
+#define LT_TRH(k_)
+#endif
     for (int it = 0;; ++it) {
         const int buf = it & 1;
         const int vn = v + gridDim.x;
         const bool have_next = vn < total_tiles;
         // halo(it) (issued one tile ago), the weights, and the stores of tile it-1 are complete; every wave is done with tile it-1
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        LT_TRH(1)
         int nn = 0, nd0 = 0, nh0 = 0, nw0 = 0;
         if (have_next) {
             tile_of(vn, nn, nd0, nh0, nw0);
+#ifndef LT_ABL_NO_A
             issue_halo(nn, nd0, nh0, nw0, buf ^ 1);      // lands while this tile computes
+#endif
         }
+        LT_TRH(2)
         // residual vectors of this tile: requested AFTER the DMAs (they must be the youngest VMEM operations for the compiler's
         // own vmcnt bookkeeping to be right), consumed in the epilogue
         uint4 rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7;
@@ -734,6 +771,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs
             if (E_NIT > 7) rp7 = pf(7);
         }
 
+        LT_TRH(3)
         acc_t acc[SM][SN];
         double dacc[1][1][1];
 #pragma unroll
@@ -767,6 +805,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs
                 lds_read16<tap * C::SLAB>(fb[slot][j], bbase[g][j]);
             });
         };
+#ifndef LT_ABL_NO_MMA
         static_for<0, PDU>([&](auto uc) { load_unit(uc); });
         static_for<0, NU>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
@@ -783,14 +822,33 @@ __global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs
 #pragma unroll
                 for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[slot][i], fb[slot][j]);
         });
+#endif
+        LT_TRH(4)
         // every wave is done reading this halo buffer (it becomes the epilogue staging area); halo(it+1) has long landed and
         // nothing else is in flight, so the compiler's vmcnt counts for the residual vectors hold
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        LT_TRH(5)
+#ifdef LT_ABL_NO_EPI
+        if (a.N < 0)
+#endif
         halo_epilogue<T, CP, MF, SM, SN, NACC, TH, TW, false>(smem + W_BYTES + buf * C::HALO_BYTES, a, wave, lane, n, d0, h0, w0, acc, dacc,
                                                              pre_res, rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7, zero_page);
+        LT_TRH(6)
+#ifdef LT_TRACE
+        tr[0] += 1;
+#endif
         if (!have_next) break;
         v = vn; n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
     }
+#ifdef LT_TRACE
+    if (wave == 0 && lane == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64) {
+        long long* o = g_trace_h + (blockIdx.x >> 3) * 8;
+        o[0] = LT_CLKH() - tr_begin;
+        for (int k = 1; k < 7; ++k) o[k] = tr[k];
+        o[7] = tr[0];
+    }
+#endif
+#undef LT_TRH
 }
 
 template <typename T, int CIN, int CP>
@@ -888,3 +946,12 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
 }
 
 }  // namespace lt
+
+#ifdef LT_TRACE
+extern "C" int lt_trace_read_halo(long long* dst, int n) {
+    if (n > 8 * 64) n = 8 * 64;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace_h), (size_t)n * sizeof(long long)) != hipSuccess) return -2;
+    return n;
+}
+#endif

@@ -86,6 +86,8 @@ constexpr int LT_EPI_NO_XCD_REMAP = 1 << 17;      // internal A/B switch (env LT
 
 // launchers implemented in conv_igemm2.hip, used by the dispatcher in conv_igemm.hip
 int conv2_dispatch(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile, hipStream_t s);
+// conv_igemm3.hip (288-row tile, 8 waves): 1 = launched, 0 = not applicable (fall back), < 0 = error
+int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, bool forced, hipStream_t s);
 // conv3d_halo.hip: 1 = launched, 0 = not applicable (fall back), < 0 = error
 int conv3d_halo_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, bool forced, hipStream_t s);
 

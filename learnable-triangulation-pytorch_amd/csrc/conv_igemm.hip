@@ -278,6 +278,16 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
             return LT_ERR_UNSUPPORTED;
         }
     }
+    static const bool no_v3 = getenv("LT_CONV_NO_V3") != nullptr;   // A/B switch
+    if ((tile == LT_TILE_AUTO && !force_v1 && !no_v3) || tile == LT_TILE3_288) {
+        const int rc = conv3_try(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, max_taps, tile == LT_TILE3_288, s);
+        if (rc < 0) return rc;
+        if (rc == 1) return LT_OK;
+        if (tile == LT_TILE3_288) {
+            set_error("lt_conv_fwd: LT_TILE3_288 requested but the problem is not supported by the 288-row kernel");
+            return LT_ERR_UNSUPPORTED;
+        }
+    }
     if ((tile == LT_TILE_AUTO && !force_v1) || (tile >= LT_TILE2_128x128 && tile <= LT_TILE2_64x64))
         return conv2_dispatch(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, max_taps, tile, s);
     if (tile == LT_TILE_AUTO) {

@@ -28,6 +28,13 @@ namespace {
 
 __device__ uint4 g_zero_page[2];  // source of out-of-image taps
 
+#ifdef LT_TRACE
+// -DLT_TRACE (profiling build, lt_build.build_variant): shader-clock accounting of the K loop phases, summed per wave and
+// written by wave 0 of every 32nd workgroup: [total, wait_vmcnt, barrier, dma_issue, compute, nk, realtime_100MHz, blockIdx]
+__device__ long long g_trace[8 * 1024];
+#define LT_CLK() ((long long)__builtin_amdgcn_s_memtime())
+#endif
+
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // one LDS-DMA wave-instruction: 64 lanes x 16 B -> lds_base .. lds_base + 1 KiB (wave-uniform base)
@@ -196,7 +203,18 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
         wrow[j] = w + (size_t)(n0 + ((t + 256 * j) >> 3)) * a.k_pad + v * VEC;
         if (B_VECS >= 256 * (j + 1) || 8 * wave + 32 * j < BN) ++nb_wave;
     }
-    const int dps = A_IT + nb_wave;  // DMA instructions per stage per wave (wave-uniform)
+    // -DLT_ABL_*: timing ablations for profiling builds (lt_build.build_variant); results are WRONG with any of them
+#ifdef LT_ABL_NO_A
+    constexpr bool ABL_A = true;
+#else
+    constexpr bool ABL_A = false;
+#endif
+#ifdef LT_ABL_NO_B
+    constexpr bool ABL_B = true;
+#else
+    constexpr bool ABL_B = false;
+#endif
+    const int dps = (ABL_A ? 0 : A_IT) + (ABL_B ? 0 : nb_wave);  // DMA instructions per stage per wave (wave-uniform)
     __syncthreads();
 
     const int nk = a.k_pad / BK;
@@ -241,6 +259,8 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     auto stage = [&](int ks, int buf, int p0, int p1) {
         const unsigned sA = lds0 + buf * STAGE;
         const unsigned sB = sA + BM * ROW_BYTES;
+        if (ABL_A) p0 = p0 < A_IT ? A_IT : p0;
+        if (ABL_B) p1 = p1 > A_IT ? A_IT : p1;
         if (PW) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
@@ -321,21 +341,40 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     for (int s = 0; s < NST - 1; ++s)
         if (s < nk) stage(s, s, 0, NPIECE);
 
-    // One K step. MORE_ (compile time): stage ks+NST-1 is still to be requested. Its DMA pieces are issued in slices BEHIND
-    // the MFMAs of each fragment group: a piece costs the wave ~60-180 issue cycles (MI355X_MICROARCH.md), and eight of them
-    // in front of the first MFMA left the matrix pipe idle for about as long as the K step's MFMAs take. The main loop and the
-    // NST-1 drain steps are separate loops so that the K step has no control flow (a uniform branch around the inline-asm
-    // DMAs made the compiler fall back to s_waitcnt lgkmcnt(0) for the fragment reads).  -DLT_DMA_UPFRONT: old order (A/B).
-#ifdef LT_DMA_UPFRONT
-    constexpr bool UPFRONT = true;
-#else
+    // One K step. MORE_ (compile time): stage ks+NST-1 is still to be requested, right after the barrier, so that it has the
+    // whole K step to land.  (-DLT_DMA_SLICED issues the pieces in slices behind the MFMAs of each fragment group instead:
+    // measured 5 % SLOWER end to end with the 2-stage ring -- the last slice then has only a quarter of a K step to land.)
+    // The main loop and the NST-1 drain steps are separate loops so that the K step has no control flow.
+#ifdef LT_DMA_SLICED
     constexpr bool UPFRONT = false;
+#else
+    constexpr bool UPFRONT = true;
+#endif
+#ifdef LT_TRACE
+#define LT_TR0 const long long tr0 = LT_CLK(); if (ks > 0) tr_cmp += tr0 - tr_prev;
+#define LT_TR1 const long long tr1 = LT_CLK(); tr_vm += tr1 - tr0;
+#define LT_TR2 const long long tr2 = LT_CLK(); tr_bar += tr2 - tr1;
+#define LT_TR3 const long long tr3 = LT_CLK(); tr_iss += tr3 - tr2; tr_prev = tr3;
+#else
+#define LT_TR0
+#define LT_TR1
+#define LT_TR2
+#define LT_TR3
+#endif
+#ifdef LT_ABL_NO_MMA
+#define LT_MMA_RUN(c_, a_, b_) (void)0
+#else
+#define LT_MMA_RUN(c_, a_, b_) Mma<T, MF>::run(c_, a_, b_)
 #endif
 #define LT_KSTEP(MORE_)                                                                                              \
     {                                                                                                                \
+        LT_TR0                                                                                                       \
         wait_vmcnt((MORE_ ? NST - 2 : (nk - 1 - ks < NST - 2 ? nk - 1 - ks : NST - 2)) * dps);                       \
+        LT_TR1                                                                                                       \
         block_barrier(); /* everybody's stage-ks DMAs landed, everybody is done reading stage ks-1 */                \
+        LT_TR2                                                                                                       \
         if (MORE_ && UPFRONT) stage(ks + NST - 1, (ks + NST - 1) % NST, 0, NPIECE);                                  \
+        LT_TR3                                                                                                       \
         const int buf = ks % NST;                                                                                    \
         const unsigned char* pa = smem + buf * STAGE + a_base;                                                       \
         const unsigned char* pb = smem + buf * STAGE + b_base;                                                       \
@@ -350,7 +389,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
             if (g + 1 < G) load_group(g + 1, (g + 1) & 1);                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
             _Pragma("unroll") for (int i = 0; i < SM; ++i)                                                           \
-                _Pragma("unroll") for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[g & 1][i], fb[g & 1][j]); \
+                _Pragma("unroll") for (int j = 0; j < SN; ++j) LT_MMA_RUN(acc[i][j], fa[g & 1][i], fb[g & 1][j]);      \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
             if (MORE_ && !UPFRONT) {                                                                                 \
                 stage(ks + NST - 1, (ks + NST - 1) % NST, g * NPIECE / G, (g + 1) * NPIECE / G);                     \
@@ -366,10 +405,30 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                     }                                                                                                \
         }                                                                                                            \
     }
+#ifdef LT_TRACE
+    long long tr_vm = 0, tr_bar = 0, tr_iss = 0, tr_cmp = 0, tr_prev = 0;
+    const long long tr_begin = LT_CLK();
+    const long long tr_rt0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     int ks = 0;
     for (; ks + NST - 1 < nk; ++ks) LT_KSTEP(true)
     for (; ks < nk; ++ks) LT_KSTEP(false)
 #undef LT_KSTEP
+#undef LT_MMA_RUN
+#ifdef LT_TRACE
+    {
+        const long long tr_end = LT_CLK();
+        tr_cmp += tr_end - tr_prev;
+        const long long tr_rt1 = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wave == 0 && (blockIdx.x & 31) == 0 && blockIdx.y == 0 && (blockIdx.x >> 5) < 1024 && lane == 0) {
+            long long* o = g_trace + (blockIdx.x >> 5) * 8;
+            o[0] = tr_end - tr_begin; o[1] = tr_vm; o[2] = tr_bar; o[3] = tr_iss; o[4] = tr_cmp; o[5] = nk; o[6] = tr_rt1 - tr_rt0; o[7] = blockIdx.x;
+        }
+    }
+#endif
+#ifdef LT_ABL_NO_EPI
+    if (a.M >= 0) return;
+#endif
     block_barrier();   // all waves done with the last stage: the region is reused by the epilogue tiles
 
     // ---- epilogue: (acc + bias)*scale + shift, then this wave's LDS sub-tile (fp32, padded rows) -> 16-byte vectors ---
@@ -549,17 +608,19 @@ int dispatch2(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int til
     // 2-stage ring, so the largest tile that still gives >= 480 workgroups wins (measured: 288 workgroups of 128x128 on a
     // M=18432, N=256 layer ran 1.6x slower than 576 of 128x64)
     auto blocks = [&](int bm, int bn) { return cdiv(a.M, bm) * (long long)(cout_pad / bn) * nphase; };
-    if (tile == LT_TILE_AUTO) {
-        if (cout_pad <= 16) tile = LT_TILE2_256x16;
-        else if (cout_pad <= 32) tile = LT_TILE2_256x32;
-        else if (cout_pad <= 64) tile = blocks(128, 64) >= 480 ? LT_TILE2_128x64 : LT_TILE2_64x64;
-        else tile = blocks(128, 128) >= 480 ? LT_TILE2_128x128 : (blocks(128, 64) >= 480 ? LT_TILE2_128x64 : LT_TILE2_64x64);
-    }
     // pointwise fast path: one tap at offset 0, unit strides, dense output rows
     const PhaseArg& p0 = a.phase[0];
     const bool pw = nphase == 1 && p0.ntaps == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.pd == 0 && a.ph == 0 && a.pw == 0 &&
                     a.osd == 1 && a.osh == 1 && a.osw == 1 && p0.ood == 0 && p0.ooh == 0 && p0.oow == 0 && a.OD == a.Do && a.OH == a.Ho &&
                     a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
+    if (tile == LT_TILE_AUTO) {
+        if (cout_pad <= 16) tile = LT_TILE2_256x16;
+        else if (cout_pad <= 32) tile = LT_TILE2_256x32;
+        else if (cout_pad <= 64) tile = blocks(128, 64) >= 480 ? LT_TILE2_128x64 : LT_TILE2_64x64;
+        else if (pw && a.k_pad <= 256 && blocks(128, 64) >= 480) tile = LT_TILE2_128x64;   // short-K expand convs: epilogue-bound,
+        // more and smaller workgroups overlap stores with loads (measured 171 vs 204 us on 64->256 at 96^2, 111 vs 120 on 128->512)
+        else tile = blocks(128, 128) >= 480 ? LT_TILE2_128x128 : (blocks(128, 64) >= 480 ? LT_TILE2_128x64 : LT_TILE2_64x64);
+    }
     // uniform-tap path: every 128-byte K step lies inside one tap
     static const bool no_ut = getenv("LT_CONV_NO_UT") != nullptr;   // A/B switch
     const int mode = pw ? 1 : (((a.Cin * (int)sizeof(T)) % ROW_BYTES == 0 && !no_ut) ? 2 : 0);
@@ -596,3 +657,16 @@ int conv2_dispatch(int dtype, const ConvArgs& a, int cout_pad, int nphase, int m
     return dispatch2<bf16_t>(a, cout_pad, nphase, max_taps, tile, s);
 }
 }  // namespace lt
+
+#ifdef LT_TRACE
+extern "C" int lt_trace_read(long long* dst, int n, int clear) {
+    if (n > 8 * 1024) n = 8 * 1024;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), (size_t)n * sizeof(long long)) != hipSuccess) return -2;
+    if (clear) {
+        static long long zeros[8 * 1024];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace), zeros, sizeof(zeros)) != hipSuccess) return -3;
+    }
+    return n;
+}
+#endif

@@ -1,0 +1,492 @@
+// Implicit-GEMM convolution, third generation: 288 x BN tile, eight waves, three-stage LDS-DMA ring, skewed DMA issue.
+//
+// Why (measured on MI355X with the shader-clock build of conv_igemm2, tools/trace_kstep.py, ResNet-152 layer3 at 64 images):
+//   * a 128x128 tile needs 64 bytes of A/B per CU clock at the MFMA peak = exactly what the vector-memory path can deliver;
+//     its K step cost 2130 cycles = 1080 (DMA issue: eight waves of two co-resident workgroups queue on the same TA, the
+//     wave is stuck in the issue for that long) + 860 (fragment reads + MFMAs), the two phases in lock step, not overlapped;
+//   * M = 36864 rows give 576 tiles of 128x128 for 512 workgroup slots: a second round at 12 % occupancy.
+// Here:
+//   * BM = 288 = 2 x 144 rows: every ResNet level of the 384x384 input is a multiple of 144 pixels per image (24^2 = 4 x 144,
+//     48^2, 96^2, 12^2 = 144), so layer3 at 64 images is 128 x (Cout/128) tiles = one workgroup per CU, rounds are exact;
+//   * one workgroup per CU, eight waves = 2 (M) x 4 (N), wave tile 144 x BN/4 on the 16x16x32 MFMA (9 x 2 accumulator tiles);
+//     288x128 needs 46 B/clk at the MFMA peak (below the 64 B/clk of the load path);
+//   * three stages: a stage is requested two K steps before it is needed, so WHEN inside the step it is requested is free:
+//     every wave issues one DMA piece behind every second A fragment (a piece holds the wave in the issue stage for ~100
+//     cycles; the other wave of its SIMD feeds the matrix pipe meanwhile);
+//   * fragments: hand-issued ds_read_b128 with counted lgkmcnt (hipcc falls back to lgkmcnt(0) beyond one group in flight).
+// bf16 only (the fp32 parity mode stays on conv_igemm2), one phase, pointwise or uniform-tap addressing, vector epilogue.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_common.h"
+
+using namespace lt;
+
+namespace {
+
+__device__ uint4 g_zero_page3[2];
+
+#ifdef LT_TRACE
+__device__ long long g_trace3[8 * 1024];
+#define LT_CLK3() ((long long)__builtin_amdgcn_s_memtime())
+#endif
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void dma16(const void* src, unsigned lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_base)
+        : "memory");
+}
+
+__device__ __forceinline__ void wait_vmcnt3(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // conservative
+    }
+}
+
+template <int IMM>
+__device__ __forceinline__ void lds_read16(V16& d, unsigned addr) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds_read offset field");
+    f32x4 t;   // a native vector (HIP's uint4 is a struct, which inline asm can only take indirectly)
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(addr), "n"(IMM));
+    d.f = t;
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+}
+__device__ __forceinline__ void frag_ready(V16& f) {
+    f32x4 t = f.f;
+    asm volatile("" : "+v"(t));
+    f.f = t;
+}
+template <int I0, int I1, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+
+__device__ __forceinline__ float act3(float v, bool relu_pre, float r, bool relu_post) {
+    if (relu_pre) v = fmaxf(v, 0.f);
+    v += r;
+    if (relu_post) v = fmaxf(v, 0.f);
+    return v;
+}
+
+constexpr int BM3 = 288;
+
+// read stream of one K step (see the kernel): position of A fragment u, and how far the stream must have been issued before
+// fragment u is waited for (LOOK entries of lookahead)
+constexpr int s3_pos(int u, int SM, int SN) { return (u / SM) * (SM + SN) + SN + u % SM; }
+constexpr int s3_target(int u, int SM, int SN, int LOOK, int TOTAL) {
+    return u < 0 ? 0 : (s3_pos(u, SM, SN) + 1 + LOOK < TOTAL ? s3_pos(u, SM, SN) + 1 + LOOK : TOTAL);
+}
+
+template <int BN, int MODE, int NWM>
+__global__ __launch_bounds__(256 * NWM) void conv_igemm3_kernel(const ConvArgs a) {
+    typedef bf16_t T;
+    constexpr bool PW = MODE == 1;   // pointwise: rows contiguous, no taps; else uniform tap (Cin*2 % 128 == 0)
+    // NWM waves along M x 4 along N: 2 -> eight waves of 144 x BN/4, 3 -> twelve waves of 96 x BN/4 (three per SIMD)
+    constexpr int BM = BM3, NW = 4 * NWM, WM = BM / NWM, WN = BN / 4, MF = 16, SM = WM / MF, SN = WN / MF, G = 2, NST = 3, VEC = 8, BK = 64;
+    constexpr int NPA = BM / 8, NPB = BN / 8;            // 1 KiB DMA pieces per stage (8 rows of 128 B each)
+    constexpr int A_IT = (NPA + NW - 1) / NW;            // piece wave + NW i, valid while < NPA (wave-uniform)
+    constexpr int B_IT = (NPB + NW - 1) / NW;
+    constexpr int NPASS = WM / 48;                       // epilogue passes of 48 rows
+    constexpr int STAGE = (BM + BN) * ROW_BYTES;
+    constexpr int REGION = NST * STAGE;
+    constexpr int EP_ROWS = 48, EP_LD = WN + 4, EP_WAVE = EP_ROWS * EP_LD * 4;   // per-wave fp32 staging, three passes of 48 rows
+    static_assert(SN >= 1 && NW * EP_WAVE <= REGION && WM == NPASS * EP_ROWS && (NPASS == 2 || NPASS == 3), "tile shape");
+    typedef typename Mma<T, MF>::acc_t acc_t;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int4* s_taps = (int4*)(smem + REGION);               // [ntaps] (unused when PW)
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page3;
+    asm volatile("" : "+s"(zp_bits));                    // opaque: keeps the address in SGPRs instead of a GOT load per use
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    // XCD-aware tile order (see conv_igemm2.hip): every XCD walks one contiguous run of the (tile_m, tile_n) raster
+    int lin = blockIdx.x;
+    if (!(a.flags & LT_EPI_NO_XCD_REMAP)) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = lin & 7, j = lin >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tile_n = lin % a.tiles_n;
+    const int tile_m = lin / a.tiles_n;
+    const PhaseArg ph = a.phase[0];
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const T* __restrict__ x = (const T*)a.x;
+    const T* __restrict__ w = (const T*)ph.w;
+
+    // DMA ownership: thread t fills physical slot t&7 of rows (t>>3) + 8 NW i; the logical K vector it must fetch is
+    // v = (t&7) ^ ((row>>1)&7), the same for all its rows (8 NW i = 64 i or 96 i does not change (row>>1)&7)
+    const int v = (t & 7) ^ ((t >> 4) & 7);
+    // the last round of A / B pieces may be partial: only waves < NP % NW own a piece in it (wave-uniform)
+    const bool a_tail = (NPA % NW == 0) || wave < NPA % NW;
+    const bool b_tail = (NPB % NW == 0) || wave < NPB % NW;
+    const int na = A_IT - (a_tail ? 0 : 1), nbp = B_IT - (b_tail ? 0 : 1);
+    const int dps = na + nbp;                            // DMA pieces of this wave per stage
+    int id0[PW ? 1 : A_IT], ih0[PW ? 1 : A_IT], iw0[PW ? 1 : A_IT], baseC[A_IT];
+    if (PW) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int m = m0 + (t >> 3) + 8 * NW * i;
+            baseC[i] = (m < a.M && i < na) ? m * a.Cin + v * VEC : -1;
+        }
+    } else {
+        for (int i = t; i < ph.ntaps; i += 64 * NW) s_taps[i] = ph.taps[i];
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int m = m0 + (t >> 3) + 8 * NW * i;
+            if (m < a.M && i < na) {
+                int n, od, oh, ow;
+                decode_row(a, m, n, od, oh, ow);
+                id0[i] = od * a.sd - a.pd;
+                ih0[i] = oh * a.sh - a.ph;
+                iw0[i] = ow * a.sw - a.pw;
+                baseC[i] = (((n * a.D + id0[i]) * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
+            } else {
+                id0[i] = -(1 << 24);
+                ih0[i] = iw0[i] = baseC[i] = 0;
+            }
+        }
+    }
+    int cur[PW ? 1 : A_IT];   // element offset of (row, current tap, this lane's vector) or -1 when the tap is out of the image
+    const T* wrow[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) wrow[j] = w + (size_t)(n0 + (t >> 3) + 8 * NW * j) * a.k_pad + v * VEC;
+    __syncthreads();
+
+    const int nk = a.k_pad / BK;
+
+    // ---- output rows of this lane in the epilogue: pass p (48 rows of the wave tile), iteration k ----
+    constexpr int LPR = WN / 8, RPP = 64 / LPR, ITP = (EP_ROWS + RPP - 1) / RPP, NRES = NPASS * ITP;   // <= 9
+    static_assert(NRES <= 9, "named residual registers");
+    const int colv = n0 + wn * WN + (lane % LPR) * 8;
+    auto out_off = [&](int p, int k) -> long long {   // element offset of the lane's 8-channel vector, or -1
+        const int rr = k * RPP + lane / LPR;
+        const int m = m0 + wm * WM + p * EP_ROWS + rr;
+        if (rr >= EP_ROWS || m >= a.M || colv >= a.Cout) return -1;
+        long long pix = m;
+        if (!PW) {
+            int n, od, oh, ow;
+            decode_row(a, m, n, od, oh, ow);
+            pix = ((long long)(n * a.OD + od * a.osd + ph.ood) * a.OH + oh * a.osh + ph.ooh) * a.OW + ow * a.osw + ph.oow;
+        }
+        return pix * a.ldc + colv;
+    };
+    // residual vectors requested before the K loop, in named registers (an array stayed in scratch memory, see conv_igemm2.hip)
+    uint4 rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7, rp8;
+    rp0 = rp1 = rp2 = rp3 = rp4 = rp5 = rp6 = rp7 = rp8 = make_uint4(0, 0, 0, 0);
+    const bool has_res = a.res != nullptr;
+    if (has_res) {
+        auto pf = [&](int idx) -> uint4 {
+            const long long o = out_off(idx / ITP, idx % ITP);
+            const void* src = o >= 0 ? (const void*)((const T*)a.res + o) : zero_page;
+            return *(const uint4*)src;
+        };
+        if (NRES > 0) rp0 = pf(0);
+        if (NRES > 1) rp1 = pf(1);
+        if (NRES > 2) rp2 = pf(2);
+        if (NRES > 3) rp3 = pf(3);
+        if (NRES > 4) rp4 = pf(4);
+        if (NRES > 5) rp5 = pf(5);
+        if (NRES > 6) rp6 = pf(6);
+        if (NRES > 7) rp7 = pf(7);
+        if (NRES > 8) rp8 = pf(8);
+    }
+
+    // ---- DMA of this wave's pieces of one stage: stage_prep (tap bookkeeping), then pieces 0..NPIECE-1 (A rounds, then B) ----
+    constexpr int NPIECE = A_IT + B_IT;
+    int c0s = 0;                                         // channel offset of the stage being requested (uniform-tap mode)
+    auto stage_prep = [&](int ks) {
+        if (!PW) {
+            const int k0 = ks * BK;                      // wave-uniform
+            c0s = k0 & (a.Cin - 1);
+            if (c0s == 0) {                              // the tap (and with it the bounds test) changes every Cin/BK steps
+                const int tap = k0 >> a.log2Cin;
+                int4 tp = make_int4(-(1 << 24), 0, 0, 0);
+                if (tap < ph.ntaps) tp = s_taps[tap];
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) {
+                    const int id = id0[i] + tp.x, ih = ih0[i] + tp.y, iw = iw0[i] + tp.z;
+                    const bool ok = ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+                    cur[i] = ok ? baseC[i] + tp.w + v * VEC : -1;
+                }
+            }
+        }
+    };
+    auto stage_piece = [&](int ks, int buf, auto pc) {
+        constexpr int P = decltype(pc)::value;
+        const unsigned sA = lds0 + buf * STAGE;
+        if constexpr (P < A_IT) {
+            if (P == A_IT - 1 && !a_tail) return;
+            const void* src;
+            if (PW) src = baseC[P] >= 0 ? (const void*)(x + (baseC[P] + ks * BK)) : zero_page;
+            else src = cur[P] >= 0 ? (const void*)(x + (cur[P] + c0s)) : zero_page;
+            dma16(src, sA + (wave + NW * P) * 1024);
+        } else {
+            constexpr int j = P - A_IT;
+            if (j == B_IT - 1 && !b_tail) return;
+            dma16(wrow[j] + ks * BK, sA + BM * ROW_BYTES + (wave + NW * j) * 1024);
+        }
+    };
+    auto stage = [&](int ks, int buf) {
+        stage_prep(ks);
+        static_for<0, NPIECE>([&](auto pc) { stage_piece(ks, buf, pc); });
+    };
+
+    // ---- fragment addresses: row r15 = lane & 15 of a 16-row MFMA tile, K vector (lane >> 4) + 4 g, slot = vector ^ ((row>>1)&7)
+    // ((row>>1)&7 depends on r15 only: 144 wm, 16 i, WN wn and 16 j are all multiples of 16) ----
+    const int r15 = lane & 15;
+    const int fsw = (r15 >> 1) & 7;
+    unsigned aoff[G], boff[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const unsigned fo = r15 * ROW_BYTES + ((((lane >> 4) + 4 * g) ^ fsw) << 4);
+        aoff[g] = lds0 + wm * WM * ROW_BYTES + fo;
+        boff[g] = lds0 + BM * ROW_BYTES + wn * WN * ROW_BYTES + fo;
+    }
+
+    acc_t acc[SM][SN];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    // prologue: two stages in flight
+    if (0 < nk) stage(0, 0);
+    if (1 < nk) stage(1, 1);
+
+    // read stream of one K step: per group g the SN B fragments, then the SM A fragments; LOOK entries of lookahead
+    constexpr int RPG = SN + SM, TOTAL = G * RPG, LOOK = 6, RA = LOOK + 1;
+    static_assert(LOOK + 1 <= 15, "lgkmcnt range");
+
+#ifdef LT_TRACE
+    long long tr_vm = 0, tr_bar = 0, tr_iss = 0, tr_cmp = 0, tr_prev = 0;
+    const long long tr_begin = LT_CLK3();
+    const long long tr_rt0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    for (int ks = 0; ks < nk; ++ks) {
+#ifdef LT_TRACE
+        const long long tr0 = LT_CLK3();
+        if (ks > 0) tr_cmp += tr0 - tr_prev;
+#endif
+        // stage ks must have landed; stage ks+1 (this wave's dps pieces, if it exists) may stay in flight
+        wait_vmcnt3(ks + 1 < nk ? dps : 0);
+#ifdef LT_TRACE
+        const long long tr1 = LT_CLK3();
+        tr_vm += tr1 - tr0;
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all DMAs of stage ks landed; stage ks-1 fully consumed
+#ifdef LT_TRACE
+        const long long tr2 = LT_CLK3();
+        tr_bar += tr2 - tr1;
+#endif
+        const bool more = ks + 2 < nk;
+        const int nbuf = (ks + 2) % NST;
+        if (more) stage_prep(ks + 2);                    // tap table read here, while no fragment read is in flight
+#ifdef LT_TRACE
+        const long long tr3 = LT_CLK3();
+        tr_iss += tr3 - tr2;
+        tr_prev = tr3;
+#endif
+        const unsigned sbase = (ks % NST) * STAGE;
+        const unsigned abase[G] = {aoff[0] + sbase, aoff[1] + sbase};
+        const unsigned bbase[G] = {boff[0] + sbase, boff[1] + sbase};
+        V16 fa[RA], fb[G][SN];
+        auto issue = [&](auto kc) {                      // stream entry K
+            constexpr int K = decltype(kc)::value;
+            constexpr int g = K / RPG, r = K % RPG;
+            if constexpr (r < SN) lds_read16<r * 16 * ROW_BYTES>(fb[g][r], bbase[g]);
+            else lds_read16<(r - SN) * 16 * ROW_BYTES>(fa[(g * SM + r - SN) % RA], abase[g]);
+        };
+        auto step_u = [&](auto uc) {                     // A fragment u = g * SM + i: bring the stream up to date, wait, 2 MFMAs
+            constexpr int u = decltype(uc)::value;
+            constexpr int g = u / SM, i = u % SM;
+            constexpr int pos = s3_pos(u, SM, SN);
+            constexpr int prev_target = s3_target(u - 1, SM, SN, LOOK, TOTAL);
+            constexpr int target = s3_target(u, SM, SN, LOOK, TOTAL);
+            static_for<prev_target, target>([&](auto kc) { issue(kc); });
+            lgkm_wait<target - pos - 1>();
+            if constexpr (i == 0) {
+#pragma unroll
+                for (int j = 0; j < SN; ++j) frag_ready(fb[g][j]);
+            }
+            frag_ready(fa[u % RA]);
+#pragma unroll
+            for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[u % RA], fb[g][j]);
+            __builtin_amdgcn_sched_barrier(0);           // keep the MFMAs with their wait (they are not volatile and would sink)
+            // one DMA piece of stage ks+2 behind every second fragment: the ~100 cycles a wave spends in a DMA issue are then
+            // filled by the MFMAs of the other wave on its SIMD (three stages: the piece has two K steps to land)
+            static_assert(2 * NPIECE <= G * SM, "one DMA piece behind every second fragment");
+            if constexpr (u % 2 == 1 && u / 2 < NPIECE) {
+                if (more) stage_piece(ks + 2, nbuf, std::integral_constant<int, u / 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        static_for<0, G * SM>([&](auto uc) { step_u(uc); });
+    }
+#ifdef LT_TRACE
+    {
+        const long long tr_end = LT_CLK3();
+        tr_cmp += tr_end - tr_prev;
+        const long long tr_rt1 = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wave == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 1024 && lane == 0) {
+            long long* o = g_trace3 + (blockIdx.x >> 3) * 8;
+            o[0] = tr_end - tr_begin; o[1] = tr_vm; o[2] = tr_bar; o[3] = tr_iss; o[4] = tr_cmp; o[5] = nk; o[6] = tr_rt1 - tr_rt0; o[7] = blockIdx.x;
+        }
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring becomes the epilogue staging area
+
+    // ---- epilogue: three passes of 48 rows through this wave's private fp32 LDS tile -> 16-byte vectors ----
+    const bool relu_pre = a.flags & LT_EPI_RELU_PRE, relu_post = a.flags & LT_EPI_RELU_POST;
+    float* ep = (float*)(smem + wave * EP_WAVE);
+    float bi[SN], sc[SN], sf[SN];
+#pragma unroll
+    for (int j = 0; j < SN; ++j) {
+        const int colj = n0 + wn * WN + j * MF + r15;   // < cout_pad: the constant arrays are padded
+        bi[j] = a.bias ? a.bias[colj] : 0.f;
+        sc[j] = a.scale ? a.scale[colj] : 1.f;
+        sf[j] = a.shift ? a.shift[colj] : 0.f;
+    }
+    auto row_out = [&](int p, int k, uint4 resv) {
+        const long long o = out_off(p, k);
+        if (o < 0) return;
+        const float* src = ep + (k * RPP + lane / LPR) * EP_LD + (lane % LPR) * 8;
+        const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
+        const float vv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const unsigned ru[4] = {resv.x, resv.y, resv.z, resv.w};
+        unsigned ou[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = act3(vv[2 * e], relu_pre, __uint_as_float(ru[e] << 16), relu_post);
+            const float hi = act3(vv[2 * e + 1], relu_pre, __uint_as_float(ru[e] & 0xffff0000u), relu_post);
+            ou[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+        }
+        *(uint4*)((T*)a.y + o) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+    };
+#define LT3_PASS(P_, RA_, RB_, RC_)                                                                      \
+    {                                                                                                    \
+        _Pragma("unroll") for (int ii = 0; ii < 3; ++ii)                                                 \
+            _Pragma("unroll") for (int j = 0; j < SN; ++j)                                               \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                            \
+                    ep[(ii * MF + (lane >> 4) * 4 + e) * EP_LD + j * MF + r15] =                        \
+                        (acc[(3 * P_ + ii) % SM][j][e] + bi[j]) * sc[j] + sf[j];                         \
+        if (ITP > 0) row_out(P_, 0, RA_);                                                                \
+        if (ITP > 1) row_out(P_, 1, RB_);                                                                \
+        if (ITP > 2) row_out(P_, 2, RC_);                                                                \
+    }
+    if (ITP == 3) {
+        LT3_PASS(0, rp0, rp1, rp2)
+        LT3_PASS(1, rp3, rp4, rp5)
+        if (NPASS > 2) LT3_PASS(2, rp6, rp7, rp8)
+    } else {
+        LT3_PASS(0, rp0, rp1, rp1)
+        LT3_PASS(1, rp2, rp3, rp3)
+        if (NPASS > 2) LT3_PASS(2, rp4, rp5, rp5)
+    }
+#undef LT3_PASS
+}
+
+template <int BN, int MODE, int NWM>
+int launch3(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
+    a.tiles_n = cout_pad / BN;
+    const long long nblk = cdiv(a.M, BM3) * a.tiles_n;
+    LT_REQUIRE(nblk < (1ll << 31), LT_ERR_INVALID, "lt_conv_fwd: grid too large");
+    const size_t lds = 3 * (size_t)(BM3 + BN) * ROW_BYTES + (size_t)max_taps * sizeof(int4);
+    LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: 288-row tile needs %zu B of LDS", lds);
+    auto kern = conv_igemm3_kernel<BN, MODE, NWM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256 * NWM), lds, s, a);
+    LT_CHECK_LAUNCH("lt_conv_fwd(v3)");
+    return LT_OK;
+}
+
+}  // namespace
+
+namespace lt {
+
+// 1 = launched, 0 = not applicable (caller falls back to conv_igemm2), < 0 = error
+int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, bool forced, hipStream_t s) {
+    if (dtype != LT_BF16 || nphase != 1) return 0;
+    if (a.flags & (LT_EPI_STORE_F32 | LT_EPI_SIGMOID)) return 0;
+    if ((a.Cout % 8) || (a.ldc % 8) || (a.k_pad % 64)) return 0;
+    if ((a.Cin * 2) % ROW_BYTES || (a.Cin & (a.Cin - 1))) return 0;   // a 128-byte K step must lie inside one tap; Cin = 2^k
+    if (max_taps > 64) return 0;                         // tap table beside the 156 KB ring
+    // BN = 64 is only reachable when forced (tests): its 96x16 wave tiles re-read A four times from LDS and measured
+    // 1.5x slower than the 128x64 tile of conv_igemm2 on the 64-channel level
+    const int BN = cout_pad % 128 == 0 ? 128 : ((cout_pad == 64 && forced) ? 64 : 0);
+    if (!BN) return 0;
+    const PhaseArg& p0 = a.phase[0];
+    const bool pw = p0.ntaps == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.pd == 0 && a.ph == 0 && a.pw == 0 && a.osd == 1 &&
+                    a.osh == 1 && a.osw == 1 && p0.ood == 0 && p0.ooh == 0 && p0.oow == 0 && a.OD == a.Do && a.OH == a.Ho && a.OW == a.Wo &&
+                    a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
+    if (!forced) {
+        // one workgroup per CU: worth it from about one round of the chip (below that the 64x64 / 128x64 tiles spread better),
+        // and only when the 288-row tiles leave little of the last one empty
+        const long long tiles_m = cdiv(a.M, BM3), nblk = tiles_m * (cout_pad / BN);
+        if (nblk < 200) return 0;
+        if (tiles_m * BM3 - a.M > a.M / 16) return 0;
+        // short-K layers (the 1x1 expand convs) are bound by their epilogue traffic: many small tiles overlap one workgroup's
+        // stores with the next one's loads better than one big tile per CU (measured: 128x64 beats this kernel below K = 512)
+        if (a.k_pad < 512) return 0;
+    }
+    static const bool w8 = getenv("LT_CONV_V3_W8") != nullptr;   // A/B: eight waves (2 per SIMD) instead of twelve
+    int rc;
+    if (w8) {
+        if (BN == 128) rc = pw ? launch3<128, 1, 2>(a, cout_pad, max_taps, s) : launch3<128, 2, 2>(a, cout_pad, max_taps, s);
+        else rc = pw ? launch3<64, 1, 2>(a, cout_pad, max_taps, s) : launch3<64, 2, 2>(a, cout_pad, max_taps, s);
+    } else {
+        if (BN == 128) rc = pw ? launch3<128, 1, 3>(a, cout_pad, max_taps, s) : launch3<128, 2, 3>(a, cout_pad, max_taps, s);
+        else rc = pw ? launch3<64, 1, 3>(a, cout_pad, max_taps, s) : launch3<64, 2, 3>(a, cout_pad, max_taps, s);
+    }
+    return rc == LT_OK ? 1 : rc;
+}
+
+}  // namespace lt
+
+#ifdef LT_TRACE
+extern "C" int lt_trace_read3(long long* dst, int n, int clear) {
+    if (n > 8 * 1024) n = 8 * 1024;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace3), (size_t)n * sizeof(long long)) != hipSuccess) return -2;
+    if (clear) {
+        static long long zeros[8 * 1024];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace3), zeros, sizeof(zeros)) != hipSuccess) return -3;
+    }
+    return n;
+}
+#endif

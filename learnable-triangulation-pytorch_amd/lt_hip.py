@@ -18,6 +18,7 @@ EPI_RELU_PRE, EPI_RELU_POST, EPI_STORE_F32, EPI_SIGMOID = 1, 2, 4, 8
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_256x32, TILE_256x16, TILE_64x64, TILE_DIRECT = 0, 1, 2, 3, 4, 5, 99
 TILE2_128x128, TILE2_128x64, TILE2_256x32, TILE2_256x16, TILE2_64x64 = 11, 12, 13, 14, 15
 TILE_HALO = 20
+TILE3_288 = 30
 MAX_PHASES = 8
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float

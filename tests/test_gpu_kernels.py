@@ -91,6 +91,41 @@ def test_conv_all_tiles(case, dtype):
         check("conv/%s/%s/%s" % (case, "f32" if dtype == torch.float32 else "bf16", tname), out, ref, tol)
 
 
+V3_CASES = {  # name: (nd, N, cin, cout, k, stride, pad, spatial, residual)
+    # 288-row tile kernel (LT_TILE3_288): pointwise and uniform-tap addressing, BN = 128 and 64, ragged last M tile, strides
+    "v3_1x1_256_128": (2, 3, 256, 128, 1, 1, 0, (24, 24), True),      # M = 1728 = 6 x 288
+    "v3_1x1_64_256_ragged": (2, 1, 64, 256, 1, 1, 0, (25, 23), True),  # M = 575: last tile 287 rows short of... ragged
+    "v3_3x3_128_128": (2, 2, 128, 128, 3, 1, 1, (24, 24), True),
+    "v3_3x3_64_64": (2, 2, 64, 64, 3, 1, 1, (20, 19), True),           # BN = 64
+    "v3_3x3s2_128_256": (2, 2, 128, 256, 3, 2, 1, (24, 24), False),
+    "v3_1x1s2_256_512": (2, 2, 256, 512, 1, 2, 0, (24, 24), False),    # strided 1x1 (downsample): uniform-tap path
+    "v3_3x3x3_64_128": (3, 1, 64, 128, 3, 1, 1, (6, 8, 10), True),
+    "v3_1x1_1024_256": (2, 1, 1024, 256, 1, 1, 0, (24, 12), True),     # 16 K steps
+}
+
+
+@pytest.mark.parametrize("case", list(V3_CASES))
+def test_conv_v3_288(case):
+    """288-row / 8-wave / 3-stage kernel vs torch (bf16), forced with LT_TILE3_288, and AUTO agrees."""
+    nd, N, cin, cout, k, s, p, sp, with_res = V3_CASES[case]
+    g = torch.Generator().manual_seed(len(case) * 7 + cin)
+    x = torch.randn(N, cin, *sp, generator=g)
+    w = torch.randn(cout, cin, *([k] * nd), generator=g) * (1.0 / (cin * k ** nd) ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    bn = _bn(cout, g)
+    conv = F.conv2d if nd == 2 else F.conv3d
+    pre = _bn_ref(conv(bf16_round(x), bf16_round(w), bias, s, p), bn)
+    res = torch.randn(pre.shape, generator=g) if with_res else None
+    ref = torch.relu(pre + bf16_round(res)) if with_res else torch.relu(pre)
+    out = run_conv(x, w, bias, bn, s, p, torch.bfloat16, H.TILE3_288, relu=True, residual=res)
+    check("conv_v3/%s/forced" % case, out, ref, 1.5e-2)
+    out2 = run_conv(x, w, bias, bn, s, p, torch.bfloat16, 0, relu=True, residual=res)
+    check("conv_v3/%s/auto" % case, out2, ref, 1.5e-2)
+    out3 = run_conv(x, w, bias, bn, s, p, torch.bfloat16, H.TILE3_288, relu=False, relu_pre=True, residual=res)   # V2V-style epilogue
+    ref3 = torch.relu(pre) + bf16_round(res) if with_res else torch.relu(pre)
+    check("conv_v3/%s/relu_pre" % case, out3, ref3, 1.5e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_stem_conv_padded_channels(dtype):
     g = torch.Generator().manual_seed(7)

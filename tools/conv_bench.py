@@ -47,7 +47,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--json", default="")
-    ap.add_argument("--only", default="", help="substring filter on the layer name")
+    ap.add_argument("--only", default="", help="comma list of substrings: keep layers whose name contains one of them")
+    ap.add_argument("--residual", action="store_true", help="add a residual input (the epilogue of the res-block layers)")
     ap.add_argument("--variants", default="", help="comma list of variant names to keep (default all)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -55,23 +56,26 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     results = []
     for (name, nd, N, cin, cout, k, s, p, sp, tr) in shapes(args.batch):
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(",")):
             continue
         cp = E.cout_pad_of(cout)
         tiles = [t for t, bn in (("128x128", 128), ("128x64", 64), ("64x64", 64), ("256x32", 32), ("256x16", 16)) if cp % bn == 0 and bn <= cp]
-        variants = [("auto", 0, 0), ("halo", 20, 0)] + [("%s/s%d" % (t, n), TILES[t], n) for t in tiles for n in (2, 3)] + [("v1_" + t, TILES["v1_" + t], 0) for t in tiles[:2]]
+        variants = [("auto", 0, 0), ("halo", 20, 0), ("v3", 30, 0)] + [("%s/s%d" % (t, n), TILES[t], n) for t in tiles for n in (2, 3)] + [("v1_" + t, TILES["v1_" + t], 0) for t in tiles[:2]]
         if args.variants:
             keep = set(args.variants.split(","))
             variants = [v for v in variants if v[0] in keep]
         x = torch.randn(N, *( (1,) if nd == 2 else ()), *sp, cin, device=dev).to(dt)
         w = torch.randn(*((cin, cout) if tr else (cout, cin)), *([k] * nd)) * 0.05
         res = None
+        if args.residual and not tr:
+            osp = [(d + 2 * p - k) // s + 1 for d in sp]
+            res = E.Act(torch.randn(N, *((1,) if nd == 2 else ()), *osp, cout, device=dev).to(dt))
         plans = []
         for vname, tile, nst in variants:
             b = E.PlanBuilder(dev, dt, tile_override=tile, stages=nst)
             xa = E.Act(x)
             try:
-                y = b.conv(xa, w, None, None, stride=s, pad=p, transposed=tr, relu=True)
+                y = b.conv(xa, w, None, None, stride=s, pad=p, transposed=tr, relu=True, residual=res)
                 plans.append((vname, b.finish(), b.flops))
             except Exception as e:  # LDS too large etc.
                 plans.append((vname, None, str(e)))

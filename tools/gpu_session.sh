@@ -57,7 +57,7 @@ pmcconv)
 abenv)
   # in-session A/B of env switches (two interleaved rounds each): baseline, no residual prefetch, no uniform-tap path, no halo kernel
   for round in 1 2; do
-    for v in ${ABVARS:-base LT_CONV_NO_XCD LT_HALO_NO_PERSIST LT_HALO_NO_RING LIB_upfront}; do
+    for v in ${ABVARS:-base LT_CONV_NO_XCD LT_HALO_NO_PERSIST LT_HALO_NO_RING LIB_sliced}; do
       # LIB_<name>: an A/B build of the library (lt_build.build_variant), else an env switch read by the kernels' dispatchers
       case $v in
         base) E="LT_AB=base" ;;
@@ -68,6 +68,26 @@ abenv)
       echo "ab $v round $round: $(python -c "import json;d=json.load(open('$OUT/ab_${v}_$round.json'));print('%.1f samples/s %.2f ms/step'%(d['value'],d['ms_per_step']))")" | tee -a $OUT/session.log
     done
   done
+  ;;
+ablate)
+  # where does the time of the big conv layers go?  ablation builds of the library (results wrong by design, timing only):
+  # no MFMAs / no epilogue / no A-side DMA (halo) / no B-side DMA (weights), for the persistent and the one-tile halo kernels
+  L=$R/learnable-triangulation-pytorch_amd/lib
+  for lib in base nomma noepi noa nob; do
+    for pers in persist onetile; do
+      E="LT_AB=1"; [ $lib != base ] && E="LT_HIP_LIB=$L/liblt_hip_abl_$lib.so"
+      P="LT_AB2=1"; [ $pers = onetile ] && P="LT_HALO_NO_PERSIST=1 LT_HALO_NO_RING=1"
+      [ $pers = onetile ] && ONLY="v2v 3^3 32->32,v2v 7^3" || ONLY="${ABL_LAYERS:-v2v 3^3 32->32,v2v 7^3,rn l3,rn l2 1x1 128,rn l1 1x1}"
+      echo "== ablate lib=$lib halo=$pers" | tee -a $OUT/ablate.log
+      env $E $P timeout 300 python tools/conv_bench.py --batch 16 --only "$ONLY" --variants auto --residual --rounds 3 2>&1 | grep -v amdgpu.ids | tee -a $OUT/ablate.log
+    done
+  done
+  ;;
+trace)
+  timeout 600 python tools/trace_kstep.py ${TRACE_ARGS:-} 2>&1 | grep -v amdgpu.ids | tee $OUT/trace_kstep.log
+  ;;
+tracehalo)
+  timeout 300 python tools/trace_halo.py 2>&1 | grep -v amdgpu.ids | tee $OUT/trace_halo.log
   ;;
 nst)
   # A/B: 2-stage vs 3-stage LDS-DMA ring in the v2 conv kernels
