@@ -183,6 +183,34 @@ int lt_triangulate_dlt(const float* proj, const float* points, const float* conf
                        int32_t J, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Chain of up to LT_PWCHAIN_MAX pointwise (1x1x1) convolutions evaluated per voxel without the
+ * intermediate activations leaving the registers:  y = L_n(...L_1(x)),
+ * L_i(v) = act_i((W_i v + bias_i) * scale_i + shift_i)  (same epilogue constants as lt_conv_fwd).
+ * Replaces the tail of V2VModel.forward (mvn/models/v2v.py:157-169: back_layers[1:] =
+ * Basic3DBlock(32,32,1) x 2, then output_layer = Conv3d(32, J, 1)): one pass over the volume
+ * instead of three.  bf16 activations, 32 input channels, inner widths 32, last width <= 32;
+ * intermediate activations are rounded to bf16 exactly where separate launches would store them;
+ * the last layer stores fp32 rows of ldy == cout[last] floats.  x: rows x 32 bf16 (channels-last
+ * volume), rows % 64 == 0.  weight[i]: the lt_conv_fwd packing [32][k_pad[i]] (k = input channel).
+ * -------------------------------------------------------------------------------------------*/
+#define LT_PWCHAIN_MAX 3
+typedef struct {
+    int32_t dtype;                       /* LT_BF16 */
+    int32_t nlayers;                     /* 1..LT_PWCHAIN_MAX */
+    int64_t rows;                        /* voxels */
+    int32_t cin;                         /* 32 */
+    int32_t ldy;                         /* == cout[nlayers-1] */
+    int32_t cout[LT_PWCHAIN_MAX];
+    int32_t k_pad[LT_PWCHAIN_MAX];
+    int32_t flags[LT_PWCHAIN_MAX];       /* LT_EPI_RELU_POST; LT_EPI_STORE_F32 on the last layer (required) */
+    const void* weight[LT_PWCHAIN_MAX];
+    const float* bias[LT_PWCHAIN_MAX];   /* 32 entries each (padded), or NULL */
+    const float* scale[LT_PWCHAIN_MAX];
+    const float* shift[LT_PWCHAIN_MAX];
+} lt_pwchain_desc;
+int lt_pwchain_fwd(const lt_pwchain_desc* desc, const void* x, void* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * hipGraph + event helpers (the forward is ~230 launches: replay it as one graph)
  * -------------------------------------------------------------------------------------------*/
 int lt_graph_begin(void* stream);

@@ -82,13 +82,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ float epi_act_h(float v, bool relu_pre, bool has_res, float r, bool relu_post) {
-    if (relu_pre) v = fmaxf(v, 0.f);
-    if (has_res) v += r;
-    if (relu_post) v = fmaxf(v, 0.f);
-    return v;
-}
-
 // swizzle constants {FA, FB, FC, FSH, pitch multiple}
 template <int KS, int CINB, int MF> struct HaloSwz { static constexpr int FA = 0, FB = 0, FC = 0, FSH = 1, PAD = 1; };   // (3, 64 B, 32x32)
 template <> struct HaloSwz<7, 64, 16> { static constexpr int FA = 0, FB = 0, FC = 0, FSH = 0, PAD = 1; };
@@ -168,24 +161,36 @@ struct HaloArgs {
     int xcd_pin;
 };
 
+// per-column epilogue constants of the lane (column j*MF + lane % MF), loaded once per kernel, well before they are needed
+template <int SN>
+struct HaloCst {
+    float bi[SN], sc[SN], sf[SN];
+    __device__ __forceinline__ void load(const HaloArgs& a, int lane, int MF) {
+#pragma unroll
+        for (int j = 0; j < SN; ++j) {
+            const int colj = j * MF + (lane & (MF - 1));   // < cout_pad: the constant arrays are padded
+            bi[j] = a.bias ? a.bias[colj] : 0.f;
+            sc[j] = a.scale ? a.scale[colj] : 1.f;
+            sf[j] = a.shift ? a.shift[colj] : 0.f;
+        }
+    }
+};
+
 // Epilogue shared by the halo kernels (same scheme as conv_igemm2): (acc + bias)*scale + shift into this wave's fp32 LDS tile
 // (64 rows, padded), then 16-byte vectors: optional pre-activation ReLU, residual, ReLU, store.  rp0..rp7: the lane's residual
 // vectors when they were prefetched (pre_res), in named registers (an array was kept in scratch memory by hipcc).
 template <typename T, int CP, int MF, int SM, int SN, int NACC, int TH, int TW, bool ACC64, typename ACC, typename DACC>
 __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArgs& a, int wave, int lane, int n, int d0, int h0, int w0,
                                               ACC& acc, DACC& dacc, bool pre_res, uint4 rp0, uint4 rp1, uint4 rp2, uint4 rp3, uint4 rp4,
-                                              uint4 rp5, uint4 rp6, uint4 rp7, const void* zero_page) {
+                                              uint4 rp5, uint4 rp6, uint4 rp7, const HaloCst<SN>& cst) {
     constexpr int EP_LD = CP + 4;
     constexpr int VEC_ = 16 / (int)sizeof(T);
-    (void)zero_page;
     // ---- epilogue (same scheme as conv_igemm2: per-wave fp32 LDS tile -> 16-byte vectors) ----
     float* ep = (float*)(smem + wave * (64 * EP_LD * 4));
 #pragma unroll
     for (int j = 0; j < SN; ++j) {
         const int colj = j * MF + (lane & (MF - 1));
-        const float bi = a.bias ? a.bias[colj] : 0.f;
-        const float sc = a.scale ? a.scale[colj] : 1.f;
-        const float sf = a.shift ? a.shift[colj] : 0.f;
+        const float bi = cst.bi[j], sc = cst.sc[j], sf = cst.sf[j];
 #pragma unroll
         for (int i = 0; i < SM; ++i)
 #pragma unroll
@@ -197,9 +202,9 @@ __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArg
                 ep[r * EP_LD + colj] = val;
             }
     }
-    __syncthreads();
+    // (the tile is wave-private and LDS operations of one wave execute in order: no barrier)
 
-    const bool relu_pre = a.flags & LT_EPI_RELU_PRE, relu_post = a.flags & LT_EPI_RELU_POST;
+    const EpiFloors fl = epi_floors(a.flags);
     const bool has_res = a.res != nullptr;
     auto row_pix = [&](int r) -> size_t {   // r = row inside the workgroup tile
         const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
@@ -208,28 +213,44 @@ __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArg
     constexpr int VECO = VEC_;              // fp32: 4 channels, bf16: 8 channels per 16 bytes
     if ((a.Cout % VECO == 0) && (a.ldc % VECO == 0)) {
         constexpr int LPR = CP / VECO, RPP = 64 / LPR;
+        static_assert(RPP % TW == 0 && TW * TH == 64, "a wave owns one d-plane of the tile; an iteration advances whole rows of it");
         const int cq = (lane % LPR) * VECO;
         if (cq < a.Cout) {
             constexpr int NIT = 64 / RPP;
-            union Pack { uint4 u; float f[4]; unsigned short h[8]; };
+            // the wave's 64 rows are the d-plane td = wave of the tile: row lr + it*RPP -> (th, tw) = (lr / TW + it*RPP/TW, lr % TW),
+            // so the element offset of iteration `it` is off0 + it * step (one 64-bit multiply per tile, not per row)
+            const int lr = lane / LPR;
+            const size_t off0 = ((((size_t)n * a.D + d0 + wave) * a.H + h0 + lr / TW) * a.W + w0 + lr % TW) * a.ldc + cq;
+            const size_t step = (size_t)(RPP / TW) * a.W * a.ldc;
+            const unsigned no_res = has_res ? 0u : 0x80008000u;   // zeros -> -0.0 pairs: v + -0.0 == v
             auto row = [&](int it, uint4 resv) {      // resv: this row's residual vector (zeros when there is none)
-                const size_t off = row_pix(64 * wave + lane / LPR + it * RPP) * a.ldc + cq;
-                const float* src = ep + (lane / LPR + it * RPP) * EP_LD + cq;
-                Pack rv, ov;
-                rv.u = resv;
+                const size_t off = off0 + it * step;
+                const float* src = ep + (lr + it * RPP) * EP_LD + cq;
+                uint4 ov;
+                if constexpr (sizeof(T) == 4) {
+                    const float4 q = *(const float4*)src;
+                    const float nr = has_res ? 0.f : -0.0f;
+                    float4 o;
+                    o.x = epi_apply(q.x, fl, has_res ? __uint_as_float(resv.x) : nr);
+                    o.y = epi_apply(q.y, fl, has_res ? __uint_as_float(resv.y) : nr);
+                    o.z = epi_apply(q.z, fl, has_res ? __uint_as_float(resv.z) : nr);
+                    o.w = epi_apply(q.w, fl, has_res ? __uint_as_float(resv.w) : nr);
+                    ov = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w));
+                } else {
+                    const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
+                    const float vv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                    const unsigned ru[4] = {resv.x | no_res, resv.y | no_res, resv.z | no_res, resv.w | no_res};
+                    unsigned ou[4];
 #pragma unroll
-                for (int e = 0; e < VECO; e += 4) {
-                    const float4 q = *(const float4*)(src + e);
-                    const float vq[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float rr = sizeof(T) == 4 ? rv.f[(e + k) % 4] : bf16_to_f32(rv.h[(e + k) % 8]);
-                        const float val = epi_act_h(vq[k], relu_pre, has_res, has_res ? rr : 0.f, relu_post);
-                        if (sizeof(T) == 4) ov.f[(e + k) % 4] = val;
-                        else ov.h[(e + k) % 8] = f32_to_bf16(val);
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        ou[e] = pack_bf16x2(epi_apply(vv[2 * e], fl, __uint_as_float(ru[e] << 16)),
+                                            epi_apply(vv[2 * e + 1], fl, __uint_as_float(ru[e] & 0xffff0000u)));
+                    ov = make_uint4(ou[0], ou[1], ou[2], ou[3]);
                 }
-                *(uint4*)((T*)a.y + off) = ov.u;
+#ifdef LT_ABL_NO_STORE
+                if (a.N < 0)
+#endif
+                *(uint4*)((T*)a.y + off) = ov;
             };
             if (pre_res || !has_res) {
                 if (NIT > 0) row(0, rp0);
@@ -245,12 +266,12 @@ __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArg
                     for (int it = 8; it < NIT; ++it) row(it, make_uint4(0, 0, 0, 0));
                 }
             } else {
-                Pack rv[NIT];
+                uint4 rv[NIT];
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)      // all residual loads first: independent HBM round trips
-                    rv[it].u = *(const uint4*)((const T*)a.res + row_pix(64 * wave + lane / LPR + it * RPP) * a.ldc + cq);
+                    rv[it] = *(const uint4*)((const T*)a.res + off0 + it * step);
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) row(it, rv[it].u);
+                for (int it = 0; it < NIT; ++it) row(it, rv[it]);
             }
         }
     } else {
@@ -258,8 +279,8 @@ __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArg
             const int r = idx / CP, cc = idx - r * CP;
             if (cc >= a.Cout) continue;
             const size_t off = row_pix(64 * wave + r) * a.ldc + cc;
-            const float rr = has_res ? elt<T>::ld((const T*)a.res + off) : 0.f;
-            elt<T>::st((T*)a.y + off, epi_act_h(ep[r * EP_LD + cc], relu_pre, has_res, rr, relu_post));
+            const float rr = has_res ? elt<T>::ld((const T*)a.res + off) : -0.0f;
+            elt<T>::st((T*)a.y + off, epi_apply(ep[r * EP_LD + cc], fl, rr));
         }
     }
 }
@@ -345,6 +366,8 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
     for (int c = 0; c < NBUF - 1; ++c)
         if (c < C::NCH) stage_w(c, c);
 
+    HaloCst<SN> cst;
+    cst.load(a, lane, MF);
     // ---- residual prefetch: the lane's 16-byte residual vectors (up to 8) are requested before the tap loop, in named
     // registers (see conv_igemm2.hip for why not an array); they are consumed in the epilogue ----
     constexpr int E_VECO = C::VEC, E_LPR = CP / E_VECO, E_RPP = 64 / E_LPR, E_NIT = 64 / E_RPP;
@@ -605,21 +628,26 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
     if (a.N < 0)
 #endif
     halo_epilogue<T, CP, MF, SM, SN, NACC, TH, TW, ACC64>(smem, a, wave, lane, n, d0, h0, w0, acc, dacc, pre_res, rp0, rp1, rp2, rp3, rp4, rp5,
-                                                         rp6, rp7, zero_page);
+                                                         rp6, rp7, cst);
 }
 
-// ---- persistent 3^3 kernel: weights resident in LDS, halo double-buffered --------------------------------------------------
+// ---- persistent 3^3 kernel: weights resident in LDS, halo double-buffered, loader waves -----------------------------------
 // The one-tile-per-workgroup kernel above spends most of a tile's life NOT in MFMAs at the 32-channel levels: a tile is only
-// 27 taps x 4 MFMAs per wave (~3.5k matrix cycles), but its halo DMA round trip (~2 us), the 27 x 2 KB weight stream with a
-// barrier per chunk, and the epilogue are all serial inside the workgroup, with just two workgroups per CU to overlap them
-// (measured 680 TF/s = 27 % of the MFMA peak, 9 layers per forward).  Here a workgroup stays on its CU and walks tiles:
+// 27 taps x 4 MFMAs per wave (~3.4k matrix cycles), but its halo DMA round trip, the 27 x 2 KB weight stream with a barrier
+// (and an L2 round trip) per chunk, and the epilogue are all serial inside the workgroup (measured 17 us per tile and
+// workgroup).  Here a workgroup stays on its CU and walks tiles:
 //   * all 27 tap slabs (54 KB at 32->32 bf16) are DMA'd once;
-//   * the halo of tile i+1 lands in the other halo buffer while tile i computes;
+//   * waves 4-7 are LOADERS: they do nothing but request the halo of tile i+1 into the other halo buffer while waves 0-3
+//     (CONSUMERS) compute tile i.  Shader-clock accounting of the first version, where the four compute waves also issued the
+//     DMAs: 4.4k cycles per tile in the halo issue (the wave sits in the issue stage while the load path queues the requests),
+//     3.4k in the tap loop, 5.9k in the epilogue (most of it the wait for that same DMA) -- all serial;
 //   * the tap loop has no barrier, and runs a fragment pipeline PDU (k-group) units deep with hand-counted lgkmcnt;
-//   * the epilogue tile of a wave is staged in the halo buffer it just finished with.
-// Tiles are dealt so that workgroup b (XCD b % 8) keeps to the samples / raster run of that XCD, as above.
+//   * the epilogue tile of a consumer wave is staged in the halo buffer it just finished with (wave-private, no barrier).
+// Two workgroup barriers per tile: A (halo i landed, everybody done with tile i-1) and B (tap loop i done: the buffer may
+// become staging space; the loaders' DMA for tile i+1 has landed).  Tiles are dealt so that workgroup b (XCD b % 8) keeps to
+// the samples / raster run of that XCD, as above.
 template <typename T, int CIN, int CP>
-__global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs a, const int total_tiles) {
+__global__ __launch_bounds__(512) void conv3d_halo_persist_kernel(const HaloArgs a, const int total_tiles) {
     constexpr int KS = 3, TD = 4, TH = 8, TW = 8;
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, 9, 2> C;
     static_assert(sizeof(T) == 2, "bf16 only: fp32 slabs do not fit beside two halo buffers");
@@ -639,6 +667,8 @@ __global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool loader = wave >= 4;
+    const int wl = wave & 3;                             // index inside the role
     constexpr int P = 1;
     const int tps = a.tiles_d * a.tiles_h * a.tiles_w;
     const T* __restrict__ w = (const T*)a.w;
@@ -660,9 +690,9 @@ __global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs
         d0 = (tix / (a.tiles_w * a.tiles_h)) * TD;
     };
     constexpr int NI_H = C::HALO_BYTES / 1024;
-    auto issue_halo = [&](int n, int d0, int h0, int w0, int buf) {
+    auto issue_halo = [&](int n, int d0, int h0, int w0, int buf) {   // loaders only: piece wl, wl + 4, ...
         const T* __restrict__ x = (const T*)a.x + (size_t)n * a.D * a.H * a.W * CIN;
-        for (int i = wave; i < NI_H; i += 4) {
+        for (int i = wl; i < NI_H; i += 4) {
             const int q = i * 64 + lane;
             const int hv = q / NVV, pv = q % NVV;
             const int hw_ = hv % C::PW, hh_ = (hv / C::PW) % C::HH, hd_ = hv / (C::PW * C::HH);
@@ -674,9 +704,9 @@ __global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs
         }
     };
 
-    // ---- weights: every tap slab, once ----
+    // ---- weights: every tap slab, once (all eight waves) ----
     constexpr int NI_W = W_BYTES / 1024;
-    for (int i = wave; i < NI_W; i += 4) {
+    for (int i = wave; i < NI_W; i += 8) {
         const int q = i * 64 + lane;
         const int pv = q % NVV, col = (q / NVV) % CP, tap = q / (NVV * CP);
         const int lv = pv ^ ((-(col / VPR)) & (NVV - 1));
@@ -687,8 +717,38 @@ __global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs
     int v = blockIdx.x;
     int n, d0, h0, w0;
     tile_of(v, n, d0, h0, w0);
-    issue_halo(n, d0, h0, w0, 0);
 
+#ifdef LT_TRACE
+    long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
+    const long long tr_begin = LT_CLKH();
+#define LT_TRH(k_) { const long long c_ = LT_CLKH(); tr[k_] += c_ - tr_last; tr_last = c_; }
+    long long tr_last = tr_begin;
+#else
+#define LT_TRH(k_)
+#endif
+
+    if (loader) {
+        // ================================= loader waves =================================
+        issue_halo(n, d0, h0, w0, 0);
+        for (int it = 0;; ++it) {
+            const int vn = v + gridDim.x;
+            const bool have_next = vn < total_tiles;
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // A: halo(it) (and the weights) landed
+#ifndef LT_ABL_NO_A
+            if (have_next) {
+                int nn, nd0, nh0, nw0;
+                tile_of(vn, nn, nd0, nh0, nw0);
+                issue_halo(nn, nd0, nh0, nw0, (it & 1) ^ 1);               // lands while the consumers compute tile it
+            }
+#endif
+            asm volatile("s_barrier" ::: "memory");                         // B: consumers are done with the tap loop
+            if (!have_next) break;
+            v = vn;
+        }
+        return;
+    }
+
+    // ================================= consumer waves =================================
     // ---- per-lane fragment bases (halo part is rebased per tile: the buffer alternates) ----
     const int lvb = (MF == 32) ? (lane >> 5) : (lane >> 4);
     int abase[KS][G][SM];
@@ -725,31 +785,21 @@ __global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs
     constexpr int NU = C::NTAPS * G;
     static_assert(PDU >= 1 && (PDU + 1) * RPU <= 15, "lookahead exceeds the lgkmcnt counter");
 
-#ifdef LT_TRACE
-    long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
-    const long long tr_begin = LT_CLKH();
-#define LT_TRH(k_) { const long long c_ = LT_CLKH(); tr[k_] += c_ - tr_last; tr_last = c_; }
-    long long tr_last = tr_begin;
-#else
-#define LT_TRH(k_)
-#endif
+    HaloCst<SN> cst;
+    cst.load(a, lane, MF);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the weight slabs (and the constants)
     for (int it = 0;; ++it) {
         const int buf = it & 1;
         const int vn = v + gridDim.x;
         const bool have_next = vn < total_tiles;
-        // halo(it) (issued one tile ago), the weights, and the stores of tile it-1 are complete; every wave is done with tile it-1
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // A: halo(it) has landed (the loaders waited for it); every consumer is done with tile it-1, its stores may still fly
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         LT_TRH(1)
         int nn = 0, nd0 = 0, nh0 = 0, nw0 = 0;
-        if (have_next) {
-            tile_of(vn, nn, nd0, nh0, nw0);
-#ifndef LT_ABL_NO_A
-            issue_halo(nn, nd0, nh0, nw0, buf ^ 1);      // lands while this tile computes
-#endif
-        }
+        if (have_next) tile_of(vn, nn, nd0, nh0, nw0);
         LT_TRH(2)
-        // residual vectors of this tile: requested AFTER the DMAs (they must be the youngest VMEM operations for the compiler's
-        // own vmcnt bookkeeping to be right), consumed in the epilogue
+        // residual vectors of this tile, consumed in the epilogue (no inline-asm memory operation in a consumer wave: the
+        // compiler's own vmcnt bookkeeping is exact)
         uint4 rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7;
         rp0 = rp1 = rp2 = rp3 = rp4 = rp5 = rp6 = rp7 = make_uint4(0, 0, 0, 0);
         if (pre_res) {
@@ -824,15 +874,14 @@ __global__ __launch_bounds__(256) void conv3d_halo_persist_kernel(const HaloArgs
         });
 #endif
         LT_TRH(4)
-        // every wave is done reading this halo buffer (it becomes the epilogue staging area); halo(it+1) has long landed and
-        // nothing else is in flight, so the compiler's vmcnt counts for the residual vectors hold
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // B: every consumer is done reading this halo buffer: it becomes the (wave-private) epilogue staging area
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         LT_TRH(5)
 #ifdef LT_ABL_NO_EPI
         if (a.N < 0)
 #endif
         halo_epilogue<T, CP, MF, SM, SN, NACC, TH, TW, false>(smem + W_BYTES + buf * C::HALO_BYTES, a, wave, lane, n, d0, h0, w0, acc, dacc,
-                                                             pre_res, rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7, zero_page);
+                                                             pre_res, rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7, cst);
         LT_TRH(6)
 #ifdef LT_TRACE
         tr[0] += 1;
@@ -871,7 +920,7 @@ int launch_halo_persist(const HaloArgs& a, hipStream_t s) {
     }
     const long long total = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
     const int grid = (int)(total < n_cu ? total - total % 8 : n_cu);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, s, a, (int)total);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, (int)total);
     LT_CHECK_LAUNCH("lt_conv_fwd(halo, persistent)");
     return LT_OK;
 }

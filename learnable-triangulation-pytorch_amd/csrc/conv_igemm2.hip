@@ -91,18 +91,13 @@ template <> struct OutVec<8> {      // bf16 out
         for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(u[i] << 16); f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
     }
     static __device__ __forceinline__ void st(bf16_t* p, const float (&f)[8]) {
-        unsigned u[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = (unsigned)f32_to_bf16(f[2 * i]) | ((unsigned)f32_to_bf16(f[2 * i + 1]) << 16);
-        *(uint4*)p = make_uint4(u[0], u[1], u[2], u[3]);
+        *(uint4*)p = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
     }
 };
 
-__device__ __forceinline__ float epi_act(float v, bool relu_pre, bool has_res, float r, bool relu_post, bool sigm) {
-    if (relu_pre) v = fmaxf(v, 0.f);
-    if (has_res) v += r;
-    if (relu_post) v = fmaxf(v, 0.f);
-    if (sigm) v = 1.f / (1.f + expf(-v));
+__device__ __forceinline__ float epi_act(float v, const EpiFloors& fl, float r, bool sigm) {
+    v = epi_apply(v, fl, r);
+    if (sigm) v = 1.f / (1.f + expf(-v));   // wave-uniform, only the confidence heads
     return v;
 }
 
@@ -453,7 +448,8 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     }
     __syncthreads();
 
-    const bool relu_pre = a.flags & LT_EPI_RELU_PRE, relu_post = a.flags & LT_EPI_RELU_POST, sigm = a.flags & LT_EPI_SIGMOID;
+    const EpiFloors fl = epi_floors(a.flags);
+    const bool sigm = a.flags & LT_EPI_SIGMOID;
     const bool store_f32 = (a.flags & LT_EPI_STORE_F32) != 0 || sizeof(T) == 4;
     const bool has_res = a.res != nullptr;
     const int col0 = n0 + wn * WN;                 // first output channel of this wave's sub-tile
@@ -479,7 +475,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                 float rr[NIT][VECO];                                                                                   \
                 _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                   \
                     pix[it] = row_pix(wm * WM + lane / LPR + it * RPP);                                                \
-                    _Pragma("unroll") for (int e = 0; e < VECO; ++e) rr[it][e] = 0.f;                                  \
+                    _Pragma("unroll") for (int e = 0; e < VECO; ++e) rr[it][e] = -0.0f; /* v + -0.0 == v */              \
                     if (has_res && pix[it] >= 0) {                                                                     \
                         const size_t off = (size_t)pix[it] * a.ldc + col;                                              \
                         if constexpr (sizeof(T) == 4) OutVec<VECO>::ld_res((const float*)a.res + off, rr[it]);         \
@@ -507,7 +503,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                         const float4 q = *(const float4*)(src + e);                                                    \
                         vv[e] = q.x; vv[e + 1] = q.y; vv[e + 2] = q.z; vv[e + 3] = q.w;                                \
                     }                                                                                                  \
-                    _Pragma("unroll") for (int e = 0; e < VECO; ++e) vv[e] = epi_act(vv[e], relu_pre, has_res, rr[it][e], relu_post, sigm); \
+                    _Pragma("unroll") for (int e = 0; e < VECO; ++e) vv[e] = epi_act(vv[e], fl, rr[it][e], sigm); \
                     typedef typename std::conditional<VECO == 4, float, bf16_t>::type out_t;                          \
                     OutVec<VECO>::st((out_t*)a.y + off, vv);                                                           \
                 }                                                                                                      \
@@ -533,8 +529,8 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                     const unsigned u[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        vv[2 * e] = epi_act(vv[2 * e], relu_pre, true, __uint_as_float(u[e] << 16), relu_post, sigm);
-                        vv[2 * e + 1] = epi_act(vv[2 * e + 1], relu_pre, true, __uint_as_float(u[e] & 0xffff0000u), relu_post, sigm);
+                        vv[2 * e] = epi_act(vv[2 * e], fl, __uint_as_float(u[e] << 16), sigm);
+                        vv[2 * e + 1] = epi_act(vv[2 * e + 1], fl, __uint_as_float(u[e] & 0xffff0000u), sigm);
                     }
                     OutVec<8>::st((bf16_t*)a.y + off, vv);
                 };
@@ -559,8 +555,8 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
             const int pix = row_pix(wm * WM + r);
             if (pix < 0 || col >= a.Cout) continue;
             const size_t off = (size_t)pix * a.ldc + col;
-            const float rr = has_res ? elt<T>::ld((const T*)a.res + off) : 0.f;
-            const float val = epi_act(ep[r * EP_LD + cc], relu_pre, has_res, rr, relu_post, sigm);
+            const float rr = has_res ? elt<T>::ld((const T*)a.res + off) : -0.0f;
+            const float val = epi_act(ep[r * EP_LD + cc], fl, rr, sigm);
             if (store_f32) ((float*)a.y)[off] = val;
             else elt<T>::st((T*)a.y + off, val);
         }

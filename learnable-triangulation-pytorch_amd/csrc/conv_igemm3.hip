@@ -86,14 +86,13 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ float act3(float v, bool relu_pre, float r, bool relu_post) {
-    if (relu_pre) v = fmaxf(v, 0.f);
-    v += r;
-    if (relu_post) v = fmaxf(v, 0.f);
-    return v;
-}
-
 constexpr int BM3 = 288;
+
+#ifdef LT_ABL_NO_MMA
+#define LT3_MMA(c_, a_, b_) (void)0
+#else
+#define LT3_MMA(c_, a_, b_) Mma<T, MF>::run(c_, a_, b_)
+#endif
 
 // read stream of one K step (see the kernel): position of A fragment u, and how far the stream must have been issued before
 // fragment u is waited for (LOOK entries of lookahead)
@@ -150,7 +149,18 @@ __global__ __launch_bounds__(256 * NWM) void conv_igemm3_kernel(const ConvArgs a
     const bool a_tail = (NPA % NW == 0) || wave < NPA % NW;
     const bool b_tail = (NPB % NW == 0) || wave < NPB % NW;
     const int na = A_IT - (a_tail ? 0 : 1), nbp = B_IT - (b_tail ? 0 : 1);
-    const int dps = na + nbp;                            // DMA pieces of this wave per stage
+    // -DLT_ABL_*: timing ablations for profiling builds (lt_build.build_variant); results are WRONG with any of them
+#ifdef LT_ABL_NO_A
+    constexpr bool ABL_A = true;
+#else
+    constexpr bool ABL_A = false;
+#endif
+#ifdef LT_ABL_NO_B
+    constexpr bool ABL_B = true;
+#else
+    constexpr bool ABL_B = false;
+#endif
+    const int dps = (ABL_A ? 0 : na) + (ABL_B ? 0 : nbp);   // DMA pieces of this wave per stage
     int id0[PW ? 1 : A_IT], ih0[PW ? 1 : A_IT], iw0[PW ? 1 : A_IT], baseC[A_IT];
     if (PW) {
 #pragma unroll
@@ -245,14 +255,14 @@ __global__ __launch_bounds__(256 * NWM) void conv_igemm3_kernel(const ConvArgs a
         constexpr int P = decltype(pc)::value;
         const unsigned sA = lds0 + buf * STAGE;
         if constexpr (P < A_IT) {
-            if (P == A_IT - 1 && !a_tail) return;
+            if (ABL_A || (P == A_IT - 1 && !a_tail)) return;
             const void* src;
             if (PW) src = baseC[P] >= 0 ? (const void*)(x + (baseC[P] + ks * BK)) : zero_page;
             else src = cur[P] >= 0 ? (const void*)(x + (cur[P] + c0s)) : zero_page;
             dma16(src, sA + (wave + NW * P) * 1024);
         } else {
             constexpr int j = P - A_IT;
-            if (j == B_IT - 1 && !b_tail) return;
+            if (ABL_B || (j == B_IT - 1 && !b_tail)) return;
             dma16(wrow[j] + ks * BK, sA + BM * ROW_BYTES + (wave + NW * j) * 1024);
         }
     };
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256 * NWM) void conv_igemm3_kernel(const ConvArgs a
             }
             frag_ready(fa[u % RA]);
 #pragma unroll
-            for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[u % RA], fb[g][j]);
+            for (int j = 0; j < SN; ++j) LT3_MMA(acc[i][j], fa[u % RA], fb[g][j]);
             __builtin_amdgcn_sched_barrier(0);           // keep the MFMAs with their wait (they are not volatile and would sink)
             // one DMA piece of stage ks+2 behind every second fragment: the ~100 cycles a wave spends in a DMA issue are then
             // filled by the MFMAs of the other wave on its SIMD (three stages: the piece has two K steps to land)
@@ -366,9 +376,13 @@ __global__ __launch_bounds__(256 * NWM) void conv_igemm3_kernel(const ConvArgs a
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring becomes the epilogue staging area
+#ifdef LT_ABL_NO_EPI
+    if (a.M >= 0) return;
+#endif
 
     // ---- epilogue: three passes of 48 rows through this wave's private fp32 LDS tile -> 16-byte vectors ----
-    const bool relu_pre = a.flags & LT_EPI_RELU_PRE, relu_post = a.flags & LT_EPI_RELU_POST;
+    const EpiFloors fl = epi_floors(a.flags);
+    const unsigned no_res = has_res ? 0u : 0x80008000u;   // residual registers are zero without a residual: make them -0.0 (v + -0.0 == v)
     float* ep = (float*)(smem + wave * EP_WAVE);
     float bi[SN], sc[SN], sf[SN];
 #pragma unroll
@@ -384,14 +398,11 @@ __global__ __launch_bounds__(256 * NWM) void conv_igemm3_kernel(const ConvArgs a
         const float* src = ep + (k * RPP + lane / LPR) * EP_LD + (lane % LPR) * 8;
         const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
         const float vv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-        const unsigned ru[4] = {resv.x, resv.y, resv.z, resv.w};
+        const unsigned ru[4] = {resv.x | no_res, resv.y | no_res, resv.z | no_res, resv.w | no_res};
         unsigned ou[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float lo = act3(vv[2 * e], relu_pre, __uint_as_float(ru[e] << 16), relu_post);
-            const float hi = act3(vv[2 * e + 1], relu_pre, __uint_as_float(ru[e] & 0xffff0000u), relu_post);
-            ou[e] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
-        }
+        for (int e = 0; e < 4; ++e)
+            ou[e] = pack_bf16x2(epi_apply(vv[2 * e], fl, __uint_as_float(ru[e] << 16)), epi_apply(vv[2 * e + 1], fl, __uint_as_float(ru[e] & 0xffff0000u)));
         *(uint4*)((T*)a.y + o) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
     };
 #define LT3_PASS(P_, RA_, RB_, RC_)                                                                      \

@@ -41,6 +41,32 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// two fp32 -> packed bf16 pair (lo in bits 0-15) with one v_cvt_pk_bf16_f32: round-to-nearest-even like torch; a NaN comes
+// out as a quiet NaN (payload not preserved).  The software f32_to_bf16 above costs ~12 VALU instructions per value: in the
+// vector epilogues that was most of ~2400 instructions per tile (shader-clock accounting of the persistent 3^3 kernel).
+typedef __bf16 lt_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float lt_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    lt_f32x2 f = {lo, hi};
+    lt_bf16x2 b = __builtin_convertvector(f, lt_bf16x2);
+    return __builtin_bit_cast(unsigned, b);
+}
+
+// The activation part of the conv epilogues with the ReLU flags turned into floors: v = max(max(v, pre) + r, post) with
+// floor = 0 when that ReLU is on and -inf when it is off (max(v, -inf) == v; one v_max instead of v_max + v_cndmask), and
+// r = -0.0f when there is no residual (v + -0.0 == v for every v, signed zeros included).  A NaN v does not survive a
+// floor (maxNum semantics), exactly as it did not survive an active ReLU before.
+struct EpiFloors {
+    float pre, post;
+};
+__device__ __forceinline__ EpiFloors epi_floors(int flags) {
+    EpiFloors f;
+    f.pre = (flags & LT_EPI_RELU_PRE) ? 0.f : -__builtin_inff();
+    f.post = (flags & LT_EPI_RELU_POST) ? 0.f : -__builtin_inff();
+    return f;
+}
+__device__ __forceinline__ float epi_apply(float v, const EpiFloors& f, float r) { return fmaxf(fmaxf(v, f.pre) + r, f.post); }
+
 template <typename T> struct elt;
 template <> struct elt<float> {
     static constexpr int bytes = 4;

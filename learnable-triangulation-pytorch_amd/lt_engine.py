@@ -283,6 +283,55 @@ class PlanBuilder:
                   "conv", label, 2 * macs, nbytes, {"spec": spec, "x": x, "y": y, "res": residual})
         return y
 
+    def can_chain_pointwise(self, x, layers):
+        """True when lt_pwchain_fwd covers this chain: bf16 plan, 32 input channels, 1x1x1 kernels, inner widths 32, last
+        width <= 32 stored as fp32, voxel count a multiple of 64.  layers: [(weight, bias, bn, relu), ...]."""
+        if self.dtype != torch.bfloat16 or not (1 <= len(layers) <= H.PWCHAIN_MAX) or x.shape[-1] != 32:
+            return False
+        if int(np.prod(x.shape[:-1])) % 64:
+            return False
+        cin = 32
+        for i, (w, _, _, _) in enumerate(layers):
+            if tuple(w.shape[2:]) != (1,) * (w.dim() - 2) or w.shape[1] != cin or w.shape[0] > 32:
+                return False
+            if i + 1 < len(layers) and w.shape[0] != 32:
+                return False
+            cin = w.shape[0]
+        return True
+
+    def pwchain(self, x, layers):
+        """Chain of pointwise convolutions in one pass over the volume (lt_pwchain_fwd); the last layer's output is fp32.
+        layers: [(weight [Cout,Cin,1,1,1], bias, bn-tuple-or-None, relu), ...].  Returns the output Act [N,D,H,W,Cout_last]."""
+        assert self.can_chain_pointwise(x, layers)
+        N, D, Hh, W, _ = x.shape
+        d = H.PwChainDesc()
+        d.dtype, d.nlayers, d.rows, d.cin = self.code, len(layers), N * D * Hh * W, 32
+        specs = []
+        shape = x.shape
+        flops = 0
+        for i, (w, bias, bn, relu) in enumerate(layers):
+            last = i + 1 == len(layers)
+            flags = (H.EPI_RELU_POST if relu else 0) | (H.EPI_STORE_F32 if last else 0)
+            spec = make_conv_spec(w, bias, bn, shape, 1, 0, self.dtype, False, flags)
+            specs.append(spec)
+            wdev = self.const(spec.phases[0].weight, self.dtype)
+            bi, sc, sh = self.const(spec.bias), self.const(spec.scale), self.const(spec.shift)
+            d.cout[i], d.k_pad[i], d.flags[i] = spec.Cout, spec.k_pad, flags
+            d.weight[i], d.bias[i], d.scale[i], d.shift[i] = wdev.data_ptr(), bi.data_ptr(), sc.data_ptr(), sh.data_ptr()
+            flops += 2 * d.rows * spec.Cout * w.shape[1]
+            shape = (N, D, Hh, W, spec.Cout)
+        d.ldy = specs[-1].Cout
+        y = self.alloc(shape, torch.float32)
+        self.keep.append(x.t)
+        self.keep.append(d)
+        self.flops += flops
+        lib = None if self.dry_run else H.lib()
+        label = "pwchain " + "->".join(str(c) for c in [32] + [sp.Cout for sp in specs]) + " @" + "x".join(str(v) for v in (N, D, Hh, W))
+        nbytes = x.t.numel() * x.t.element_size() + y.t.numel() * 4
+        self._add(lambda s, d=d, xp=x.t.data_ptr(), yp=y.t.data_ptr(): H.check(lib.lt_pwchain_fwd(C.byref(d), xp, yp, s), "lt_pwchain_fwd"),
+                  "pwchain", label, flops, nbytes, {"specs": specs, "x": x, "y": y})
+        return y
+
     def maxpool(self, x, k, s, p, nd):
         N, D, Hh, W, Cc = x.shape
         kk = (1, k, k) if nd == 2 else (k, k, k)

@@ -37,6 +37,15 @@ class ConvDesc(C.Structure):
                 ("phase", ConvPhase * MAX_PHASES)]
 
 
+PWCHAIN_MAX = 3
+
+
+class PwChainDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("nlayers", i32), ("rows", i64), ("cin", i32), ("ldy", i32),
+                ("cout", i32 * PWCHAIN_MAX), ("k_pad", i32 * PWCHAIN_MAX), ("flags", i32 * PWCHAIN_MAX),
+                ("weight", vp * PWCHAIN_MAX), ("bias", vp * PWCHAIN_MAX), ("scale", vp * PWCHAIN_MAX), ("shift", vp * PWCHAIN_MAX)]
+
+
 # symbol -> (restype, argtypes); must list every symbol include/lt_hip.h declares
 SIGNATURES = {
     "lt_last_error": (C.c_char_p, []),
@@ -44,6 +53,7 @@ SIGNATURES = {
     "lt_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "lt_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
     "lt_conv_cout_pad": (C.c_int, [i32]),
+    "lt_pwchain_fwd": (C.c_int, [C.POINTER(PwChainDesc), vp, vp, vp]),
     "lt_maxpool_fwd": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32 * 3, vp]),
     "lt_global_avgpool": (C.c_int, [i32, vp, vp, i32, i32, i32, vp]),
     "lt_nchw_to_nhwc": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, vp]),

@@ -122,9 +122,17 @@ class V2VModel(nn.Module):
         for m in self.front_layers:
             y = m.record(b, x); b.release(x); x = y
         x = self.encoder_decoder.record(b, x)
-        for m in self.back_layers:
-            y = m.record(b, x); b.release(x); x = y
         o = self.output_layer
+        # the pointwise tail (back_layers[1:] + output_layer) runs as ONE pass over the volume when the plan is bf16
+        tail = [m for m in list(self.back_layers)[1:]]
+        chain = [(m.block[0].weight, m.block[0].bias, bn_tuple(m.block[1]), True) for m in tail] + [(o.weight, o.bias, None, False)]
+        y = self.back_layers[0].record(b, x); b.release(x); x = y
+        if all(isinstance(m, Basic3DBlock) and m.block[0].kernel_size == (1, 1, 1) for m in tail) and b.can_chain_pointwise(x, chain):
+            y = b.pwchain(x, chain)
+            b.release(x)
+            return y
+        for m in tail:
+            y = m.record(b, x); b.release(x); x = y
         y = b.conv(x, o.weight, o.bias, None, out_f32=True)
         b.release(x)
         return y

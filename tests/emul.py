@@ -65,6 +65,13 @@ def run_plan_on_cpu(plan):
             res = None if info["res"] is None else info["res"].t.float().clone()
             out = emulate_conv(info["spec"], info["x"].t.float().clone(), res)
             info["y"].t.copy_(out)
+        elif kind == "pwchain":   # lt_pwchain_fwd: the layers one after the other, intermediates rounded to the plan dtype
+            cur = info["x"].t.float().clone()
+            for i, spec in enumerate(info["specs"]):
+                cur = emulate_conv(spec, cur)
+                if i + 1 < len(info["specs"]):
+                    cur = cur.to(info["x"].t.dtype).float()
+            info["y"].t.copy_(cur)
         elif kind == "maxpool":
             x = info["x"].t.float().permute(0, 4, 1, 2, 3)
             y = F.max_pool3d(x, tuple(info["k"]), tuple(info["s"]), tuple(info["p"]))

@@ -341,3 +341,37 @@ def test_conv3d_halo_kernel(case):
             ref3 = _bn_ref(F.conv3d(rd(x), rd(w), bias, 1, k // 2), bn)
             out3 = run_conv(x, w, bias, bn, 1, k // 2, dtype, H.TILE_HALO, relu=False, residual=None)
             check("conv3d_halo_nores/%s/%s" % (case, dname), out3, ref3, 1.5e-2)
+
+
+@pytest.mark.parametrize("nlayers,J", [(3, 17), (2, 32), (1, 17), (3, 5)])
+def test_pwchain(nlayers, J):
+    """lt_pwchain_fwd (pointwise chain in registers) vs torch: every layer's output rounded to bf16 except the fp32 last one."""
+    g = torch.Generator().manual_seed(40 + nlayers + J)
+    x = torch.randn(2, 8, 8, 16, 32, generator=g)                      # 2048 voxels, channels last
+    widths = [32] * (nlayers - 1) + [J]
+    layers, cin = [], 32
+    for i, co in enumerate(widths):
+        w = torch.randn(co, cin, 1, 1, 1, generator=g) * (1.0 / cin ** 0.5)
+        bias = torch.randn(co, generator=g) * 0.1
+        last = i + 1 == nlayers
+        bn = None if last else _bn(co, g)
+        layers.append((w, bias, bn, not last))
+        cin = co
+    b = E.PlanBuilder(DEV, torch.bfloat16)
+    xa = E.Act(x.to(DEV).to(torch.bfloat16))
+    assert b.can_chain_pointwise(xa, layers)
+    y = b.pwchain(xa, layers)
+    b.finish().run_eager(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    cur = bf16_round(x).permute(0, 4, 1, 2, 3)
+    for i, (w, bias, bn, relu) in enumerate(layers):
+        cur = F.conv3d(cur, bf16_round(w), bias)
+        if bn is not None:
+            cur = _bn_ref(cur, bn)
+        if relu:
+            cur = torch.relu(cur)
+        if i + 1 < nlayers:
+            cur = bf16_round(cur)
+    ref = cur.permute(0, 2, 3, 4, 1)
+    assert y.t.dtype == torch.float32 and tuple(y.t.shape) == tuple(ref.shape)
+    check("pwchain/L%d_J%d" % (nlayers, J), y.t.cpu(), ref, 1e-2)

@@ -51,3 +51,51 @@ def test_recorded_plan_matches_oracle(nl, method, kind, Himg):
     assert float(d.max()) < 1e-4, float(d.max())
     assert np.allclose(base, O.base_points_from_batch(inp["pred_keypoints_3d"], kind))
     assert P["plan"].flops > 0 and len(P["plan"].ops) > 50
+
+
+def test_pointwise_chain_is_recorded_for_bf16_and_matches_the_layers():
+    """bf16 plans run V2V's pointwise tail (back_layers[1:] + output_layer) as ONE lt_pwchain_fwd; the recorded chain must
+    be the same function as the three lt_conv_fwd launches an fp32 plan records (interpreted on the CPU)."""
+    import lt_engine as E
+    from mvn.models.v2v import V2VModel
+    torch.manual_seed(3)
+    m = V2VModel(32, 17).eval()
+    for bn in [mm for mm in m.modules() if isinstance(mm, torch.nn.BatchNorm3d)]:
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.1)
+    x = torch.randn(1, 4, 4, 4, 32)
+    outs = {}
+    for dt in (torch.bfloat16, torch.float32):
+        b = E.PlanBuilder("cpu", dt, dry_run=True)
+        inp = b.alloc(tuple(x.shape)); inp.pooled = False
+        tail = list(m.back_layers)[1:]
+        chain = [(t.block[0].weight, t.block[0].bias, (t.block[1].weight, t.block[1].bias, t.block[1].running_mean, t.block[1].running_var), True)
+                 for t in tail] + [(m.output_layer.weight, m.output_layer.bias, None, False)]
+        assert b.can_chain_pointwise(inp, chain) == (dt == torch.bfloat16)
+        if dt == torch.bfloat16:
+            y = b.pwchain(inp, chain)
+        else:
+            cur = inp
+            for (w, bias, bn, relu) in chain[:-1]:
+                cur = b.conv(cur, w, bias, bn, relu=relu)
+            y = b.conv(cur, chain[-1][0], chain[-1][1], None, out_f32=True)
+        plan = b.finish()
+        kinds = [meta["kind"] for _, meta in plan.ops]
+        assert kinds == (["pwchain"] if dt == torch.bfloat16 else ["conv"] * 3)
+        inp.t.copy_(x)
+        run_plan_on_cpu(plan)
+        outs[dt] = y.t.float().clone()
+        assert y.t.dtype == torch.float32 and tuple(y.t.shape) == (1, 4, 4, 4, 17)
+    ref = outs[torch.float32]
+    assert float((outs[torch.bfloat16] - ref).abs().max() / ref.abs().max()) < 3e-2   # bf16 inputs / intermediates vs fp32
+
+
+def test_v2v_bf16_plan_uses_the_chain():
+    import lt_engine as E
+    from mvn.models.v2v import V2VModel
+    m = V2VModel(32, 17).eval()
+    b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
+    inp = b.alloc((1, 32, 32, 32, 32)); inp.pooled = False
+    out = m.record(b, inp)
+    kinds = [meta["kind"] for _, meta in b.finish().ops]
+    assert kinds[-1] == "pwchain" and kinds.count("pwchain") == 1
+    assert tuple(out.t.shape) == (1, 32, 32, 32, 17) and out.t.dtype == torch.float32

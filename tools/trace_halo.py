@@ -17,6 +17,7 @@ import lt_hip as H
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    with_res = "--no-residual" not in sys.argv
     lib = H.lib()
     lib.lt_trace_read_halo.restype = C.c_int
     lib.lt_trace_read_halo.argtypes = [C.c_void_p, C.c_int]
@@ -26,7 +27,7 @@ def main():
     w = torch.randn(32, 32, 3, 3, 3) * 0.05
     res = E.Act(torch.randn(B, 64, 64, 64, 32, device=dev).to(dt))
     b = E.PlanBuilder(dev, dt)
-    b.conv(E.Act(x), w, None, None, stride=1, pad=1, relu=True, residual=res)
+    b.conv(E.Act(x), w, None, None, stride=1, pad=1, relu=True, residual=res if with_res else None)
     plan = b.finish()
     for _ in range(3):
         plan.run_eager(st)
