@@ -900,6 +900,237 @@ __global__ __launch_bounds__(512) void conv3d_halo_persist_kernel(const HaloArgs
 #undef LT_TRH
 }
 
+// ---- 7^3 kernel with loader waves -------------------------------------------------------------------------------------------
+// PMC on the ring version above (7^3 32->16 at 64^3): 3.3 VALU + 3.4 SALU + 1.3 LDS instructions per MFMA and no LDS bank
+// conflicts -- with one workgroup per CU (the halo takes 123 KB) and so one compute wave per SIMD, the kernel was bound by
+// the INSTRUCTIONS a wave issues between MFMAs (address arithmetic per chunk, the weight DMA and its ~100-cycle issue
+// stalls, waitcnt bookkeeping): ~210 cycles per tap against 64 cycles of MFMA.  Here:
+//   * waves 4-7 are loaders: halo + the whole weight stream (343 KB per tile, NBUF-deep chunk ring); waves 0-3 never issue
+//     a memory instruction inside the tap loop;
+//   * a chunk is one (kd, kh) row of 7 taps; kd is the only runtime loop: (kh, kw) offsets are ds_read immediates, the
+//     fragment base registers are rebased once per kd (16 v_add per 49 taps), the weight buffer base once per chunk;
+//   * fragments: hand-issued reads two taps ahead across chunk boundaries (15 reads in flight = the lgkmcnt counter).
+// Measured (B = 16, 64^3): 2261 -> 1550 us (~105 cycles per tap; the LDS fragment reads alone need ~81: 20 ds_read_b128 per
+// tap and CU).  Tried and dropped: a 5-deep instead of 4-deep weight ring (no change, kept), walking several tiles per
+// workgroup with the next tile's first halo planes prefetched into the planes the tap loop has passed, and separate halo /
+// weight loader waves (both ~10 % slower: the plane bursts delay the weight pieces queued behind them).  The next lever is
+// LDS traffic: keeping the 7 kd-taps of one (kh, kw) in registers and sweeping the 10 input planes (17 reads per 28 MFMAs).
+template <typename T>
+__global__ __launch_bounds__(512) void conv3d_halo7_kernel(const HaloArgs a) {
+    constexpr int KS = 7, CIN = 32, CP = 16, TD = 4, TH = 8, TW = 8, TPC = 7, NBUF = 5, PD = 2;
+    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, 4> C;
+    static_assert(sizeof(T) == 2, "bf16 only");
+    constexpr int MF = C::MF, SM = C::SM, SN = C::SN, G = C::G, NACC = C::NACC, NVV = C::NVV, VPR = C::VPR, CINB = C::CINB;
+    static_assert(MF == 16 && SM == 4 && SN == 1 && G == 1 && NVV == 4 && C::SW::FSH == 0 && C::SW::FA == 0 && C::SW::FC == 0, "7^3 32->16 layout");
+    static_assert(C::SLAB == 1024 && C::WCH == TPC * 1024, "one DMA piece per tap of a chunk");
+    static_assert(C::HALO_BYTES + NBUF * C::WCH <= 160 * 1024, "halo + weight ring must fit LDS");
+    typedef typename Mma<T, MF>::acc_t acc_t;
+    constexpr int NCH = KS * KS;                         // 49 chunks: c = kd*7 + kh
+    constexpr int KDSTEP = C::HH * C::PW * CINB;         // bytes per d-plane of the halo image
+    constexpr int NI_H = C::HALO_BYTES / 1024;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned lds_w = lds0 + C::HALO_BYTES;
+
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page_h;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool loader = wave >= 4;
+    const int wl = wave & 3;
+    constexpr int P = KS / 2;
+
+    const int tps = a.tiles_d * a.tiles_h * a.tiles_w;
+    int n, tix;
+    if (a.xcd_pin) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        n = xcd + 8 * (j / tps);
+        tix = j % tps;
+    } else {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        n = lin / tps;
+        tix = lin % tps;
+    }
+    const int w0 = (tix % a.tiles_w) * TW;
+    const int h0 = ((tix / a.tiles_w) % a.tiles_h) * TH;
+    const int d0 = (tix / (a.tiles_w * a.tiles_h)) * TD;
+
+    if (loader) {
+        // ================================= loader waves =================================
+        const T* __restrict__ x = (const T*)a.x + (size_t)n * a.D * a.H * a.W * CIN;
+        const T* __restrict__ w = (const T*)a.w;
+#ifndef LT_ABL_NO_A
+        for (int i = wl; i < NI_H; i += 4) {
+            const int q = i * 64 + lane;
+            const int hv = q / NVV, pv = q % NVV;
+            const int hw_ = hv % C::PW, hh_ = (hv / C::PW) % C::HH, hd_ = hv / (C::PW * C::HH);
+            const int lv = pv ^ C::fswz(hd_, hh_, hw_);
+            const int id = d0 - P + hd_, ih = h0 - P + hh_, iw = w0 - P + hw_;
+            const bool ok = hv < C::HV && hw_ < C::HW && ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : zero_page;
+            dma16h(src, lds0 + i * 1024);
+        }
+#endif
+        // weight pieces of this loader: tap wl (and wl + 4 when < 7) of every chunk; chunk c, tap tj -> weight column block
+        // (c*7 + tj)*CIN: the source advances by 7*CIN elements per chunk
+        const int pv = lane % NVV, col = lane / NVV;     // 64 lanes = 16 columns x 4 vectors = one tap slab
+        const int lv = pv ^ ((-(col / VPR)) & (NVV - 1));
+        const T* wsrc0 = w + (size_t)col * a.k_pad + (size_t)wl * CIN + lv * C::VEC;
+        const T* wsrc1 = wsrc0 + 4 * CIN;
+        const bool two = wl + 4 < TPC;
+#ifdef LT_ABL_NO_B
+        const int dpc = 0;
+#else
+        const int dpc = two ? 2 : 1;
+#endif
+        auto stage_w = [&](int c) {
+#ifdef LT_ABL_NO_B
+            return;
+#endif
+            const unsigned dst = lds_w + (c % NBUF) * C::WCH;
+            dma16h(wsrc0 + (size_t)c * TPC * CIN, dst + wl * 1024);
+            if (two) dma16h(wsrc1 + (size_t)c * TPC * CIN, dst + (wl + 4) * 1024);
+        };
+#pragma unroll
+        for (int c = 0; c < NBUF - 1; ++c) stage_w(c);
+        for (int c = 0; c < NCH; ++c) {
+            // chunks <= c+1 (and, before them, the halo) must have landed; at most NBUF-3 younger chunks stay in flight
+            int younger = NCH - 2 - c;
+            if (younger > NBUF - 3) younger = NBUF - 3;
+            if (younger < 0) younger = 0;
+            wait_vmcnt_h(younger * dpc);
+            asm volatile("s_barrier" ::: "memory");
+            if (c + NBUF - 1 < NCH) stage_w(c + NBUF - 1);
+        }
+        asm volatile("s_barrier" ::: "memory");          // the consumers' "done with the LDS images" barrier
+        return;
+    }
+
+    // ================================= consumer waves =================================
+    HaloCst<SN> cst;
+    cst.load(a, lane, MF);
+    constexpr int E_VECO = C::VEC, E_LPR = CP / E_VECO, E_RPP = 64 / E_LPR, E_NIT = 64 / E_RPP;
+    static_assert(E_NIT <= 4, "epilogue rows per lane");
+    const bool vec_epi = (a.Cout % E_VECO == 0) && (a.ldc % E_VECO == 0);
+    const bool pre_res = vec_epi && a.res != nullptr && !(a.flags & LT_EPI_NO_RES_PREFETCH);
+    uint4 rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7;
+    rp0 = rp1 = rp2 = rp3 = rp4 = rp5 = rp6 = rp7 = make_uint4(0, 0, 0, 0);
+    if (pre_res) {
+        const int cqp = (lane % E_LPR) * E_VECO;
+        auto pf = [&](int k) -> uint4 {
+            const int r = 64 * wave + lane / E_LPR + k * E_RPP;
+            const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
+            const size_t pixv = (((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw;
+            const void* src = cqp < a.Cout ? (const void*)((const T*)a.res + pixv * a.ldc + cqp) : zero_page;
+            return *(const uint4*)src;
+        };
+        if (E_NIT > 0) rp0 = pf(0);
+        if (E_NIT > 1) rp1 = pf(1);
+        if (E_NIT > 2) rp2 = pf(2);
+        if (E_NIT > 3) rp3 = pf(3);
+    }
+
+    // fragment bases: row r = 64 wave + 16 i + (lane & 15) = voxel (td = wave, th = 2 i + (r15 >> 3), tw = r15 & 7); the lane's K
+    // vector lane >> 4; swizzle f = (tw + kw) & 3 -> four variants by kw & 3
+    const int r15 = lane & 15, lvb = lane >> 4;
+    int abase[4][SM];
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+        const int tw = r15 & 7, th = 2 * i + (r15 >> 3);
+        const int own = ((wave * C::HH + th) * C::PW + tw) * CINB;
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) abase[vv][i] = (int)lds0 + own + ((lvb ^ ((tw + vv) & 3)) << 4);
+    }
+    const int bsw = (-(r15 / VPR)) & (NVV - 1);
+    const unsigned bbase = lds_w + r15 * CINB + ((lvb ^ bsw) << 4);
+
+    acc_t acc[SM][SN];
+    double dacc[1][1][1];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int e = 0; e < NACC; ++e) acc[i][0][e] = 0.f;
+
+    constexpr int RPT = SM + SN;                         // 5 reads per tap
+    static_assert((PD + 1) * RPT <= 15, "lookahead exceeds the lgkmcnt counter");
+    V16 fa[TPC][SM], fb[TPC];
+    unsigned cur[4][SM];                                 // abase + kd * KDSTEP
+    // tap (KH, KW) of the chunk whose weight buffer starts at wb, relative to the kd plane in `cur` (+ DKD planes)
+    auto load_tap = [&](unsigned wb, auto khc, auto kwc, auto dkdc) {
+        constexpr int KH = decltype(khc)::value, KW = decltype(kwc)::value, DKD = decltype(dkdc)::value;
+        constexpr int imm = DKD * KDSTEP + (KH * C::PW + KW) * CINB;
+        static_for<0, SM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            lds_read16<imm>(fa[KW][i], cur[KW & 3][i]);
+        });
+        lds_read16<KW * C::SLAB>(fb[KW], wb);
+    };
+    auto do_kd = [&](int kd, auto lastc) {
+        constexpr bool LAST_KD = decltype(lastc)::value;
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv)
+#pragma unroll
+            for (int i = 0; i < SM; ++i) cur[vv][i] = (unsigned)abase[vv][i] + kd * KDSTEP;
+        const int rb = (kd * KS) % NBUF;                  // ring slot of this kd's first chunk
+        static_for<0, KS>([&](auto khc) {
+            constexpr int KH = decltype(khc)::value;
+            constexpr bool LAST = LAST_KD && KH == KS - 1;
+            asm volatile("s_barrier" ::: "memory");      // the loaders have chunks <= c+1 (and, the first time, the halo) in LDS
+            const unsigned wb = bbase + ((rb + KH) % NBUF) * C::WCH, wb_n = bbase + ((rb + KH + 1) % NBUF) * C::WCH;
+            if constexpr (KH == 0) {
+                if (kd == 0) {                           // pipeline prologue: the first PD taps
+                    static_for<0, PD>([&](auto kwc) { load_tap(wb, std::integral_constant<int, 0>{}, kwc, std::integral_constant<int, 0>{}); });
+                }
+            }
+            static_for<0, TPC>([&](auto kwc) {
+                constexpr int KW = decltype(kwc)::value;
+                constexpr int ahead = (KW + PD < TPC) ? PD : (LAST ? TPC - 1 - KW : PD);   // taps in flight behind this one
+                if constexpr (KW + PD < TPC) load_tap(wb, khc, std::integral_constant<int, KW + PD>{}, std::integral_constant<int, 0>{});
+                else if constexpr (!LAST) {
+                    if constexpr (KH + 1 < KS) load_tap(wb_n, std::integral_constant<int, KH + 1>{}, std::integral_constant<int, KW + PD - TPC>{},
+                                                        std::integral_constant<int, 0>{});
+                    else load_tap(wb_n, std::integral_constant<int, 0>{}, std::integral_constant<int, KW + PD - TPC>{}, std::integral_constant<int, 1>{});
+                }
+                lgkm_wait<ahead * RPT>();
+#pragma unroll
+                for (int i = 0; i < SM; ++i) frag_ready(fa[KW][i]);
+                frag_ready(fb[KW]);
+#pragma unroll
+                for (int i = 0; i < SM; ++i) LT_HMMA(acc[i][0], fa[KW][i], fb[KW]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
+    for (int kd = 0; kd < KS - 1; ++kd) do_kd(kd, std::false_type{});
+    do_kd(KS - 1, std::true_type{});
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the halo / weight images
+
+#ifdef LT_ABL_NO_EPI
+    if (a.N < 0)
+#endif
+    halo_epilogue<T, CP, MF, SM, SN, NACC, TH, TW, false>(smem, a, wave, lane, n, d0, h0, w0, acc, dacc, pre_res, rp0, rp1, rp2, rp3, rp4, rp5,
+                                                         rp6, rp7, cst);
+}
+
+int launch_halo7(const HaloArgs& a, hipStream_t s) {
+    typedef HaloCfg<bf16_t, 7, 32, 16, 4, 8, 8, 7, 4> C;
+    constexpr int LDS = C::HALO_BYTES + 5 * C::WCH;
+    auto kern = conv3d_halo7_kernel<bf16_t>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const long long nblk = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), LDS, s, a);
+    LT_CHECK_LAUNCH("lt_conv_fwd(halo 7^3)");
+    return LT_OK;
+}
+
 template <typename T, int CIN, int CP>
 int launch_halo_persist(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<T, 3, CIN, CP, 4, 8, 8, 9, 2> C;
@@ -984,7 +1215,12 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
         HALO_CASE(bf16_t, 3, 64, 64, 3, 2, 1)
         HALO_CASE(bf16_t, 3, 32, 64, 9, 2, 1)
         static const bool no_ring = getenv("LT_HALO_NO_RING") != nullptr;   // A/B: 1-tap fragment lookahead for 7^3
+        static const bool no_h7 = getenv("LT_HALO_NO_H7") != nullptr;       // A/B: no loader-wave 7^3 kernel
         if (no_ring) { HALO_CASE(bf16_t, 7, 32, 16, 7, 4, 1) }
+        if (ks == 7 && c.Cin == 32 && cout_pad == 16 && !no_h7) {
+            int rc = launch_halo7(a, s);
+            return rc == LT_OK ? 1 : rc;
+        }
         HALO_CASE(bf16_t, 7, 32, 16, 7, 4, 2)
     } else {
         HALO_CASE(float, 3, 32, 32, 3, 3, 1)
