@@ -642,10 +642,10 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
 //     DMAs: 4.4k cycles per tile in the halo issue (the wave sits in the issue stage while the load path queues the requests),
 //     3.4k in the tap loop, 5.9k in the epilogue (most of it the wait for that same DMA) -- all serial;
 //   * the tap loop has no barrier, and runs a fragment pipeline PDU (k-group) units deep with hand-counted lgkmcnt;
-//   * the epilogue tile of a consumer wave is staged in the halo buffer it just finished with (wave-private, no barrier).
-// Two workgroup barriers per tile: A (halo i landed, everybody done with tile i-1) and B (tap loop i done: the buffer may
-// become staging space; the loaders' DMA for tile i+1 has landed).  Tiles are dealt so that workgroup b (XCD b % 8) keeps to
-// the samples / raster run of that XCD, as above.
+//   * the MFMAs compute the transposed product (weights first): a lane ends up with 16 channels of its own voxel and stores
+//     them as 8-byte bf16 groups straight from the accumulators -- no LDS staging tile.
+// One workgroup barrier per tile (halo i landed / everybody done with the tap loop of tile i-1).  Tiles are dealt so that
+// workgroup b (XCD b % 8) keeps to the samples / raster run of that XCD, as above.
 template <typename T, int CIN, int CP>
 __global__ __launch_bounds__(512) void conv3d_halo_persist_kernel(const HaloArgs a, const int total_tiles) {
     constexpr int KS = 3, TD = 4, TH = 8, TW = 8;
@@ -741,7 +741,6 @@ __global__ __launch_bounds__(512) void conv3d_halo_persist_kernel(const HaloArgs
                 issue_halo(nn, nd0, nh0, nw0, (it & 1) ^ 1);               // lands while the consumers compute tile it
             }
 #endif
-            asm volatile("s_barrier" ::: "memory");                         // B: consumers are done with the tap loop
             if (!have_next) break;
             v = vn;
         }
@@ -773,63 +772,62 @@ __global__ __launch_bounds__(512) void conv3d_halo_persist_kernel(const HaloArgs
         for (int g = 0; g < G; ++g) bbase[g][j] = lds0 + col * CINB + (((lvb + ((MF == 32) ? 2 * g : 4 * g)) ^ bsw) << 4);
     }
 
-    constexpr int E_VECO = C::VEC, E_LPR = CP / E_VECO, E_RPP = 64 / E_LPR, E_NIT = 64 / E_RPP;
-    static_assert(E_NIT <= 8, "epilogue rows per lane");
-    const bool vec_epi = (a.Cout % E_VECO == 0) && (a.ldc % E_VECO == 0);
-    const bool pre_res = vec_epi && a.res != nullptr && !(a.flags & LT_EPI_NO_RES_PREFETCH);
-
-    // fragment pipeline: unit u = tap * G + g (SM A reads + SN B reads, SM*SN MFMAs); PDU units of lookahead
+    // fragment pipeline: unit u = tap * G + g (SM voxel-fragment reads + SN weight-fragment reads, SM*SN MFMAs); PDU units of lookahead
     constexpr int RPU = SM + SN;
     constexpr int PDU = 15 / RPU - 1 >= 4 ? 4 : 15 / RPU - 1;
     constexpr int RING = PDU + 1;
     constexpr int NU = C::NTAPS * G;
     static_assert(PDU >= 1 && (PDU + 1) * RPU <= 15, "lookahead exceeds the lgkmcnt counter");
 
-    HaloCst<SN> cst;
-    cst.load(a, lane, MF);
+    // ---- epilogue without LDS: the MFMAs compute the TRANSPOSED product D[co][voxel] (weights as the first operand), so lane
+    // (voxel v = lane & 31 of fragment i, half h = lane >> 5) ends up with the channels c(e) = (e & 3) + 8 (e >> 2) + 4 h of ITS
+    // voxel: four runs of four consecutive channels = four 8-byte bf16 stores (and four 8-byte residual loads) per fragment.
+    // No staging tile, no second workgroup barrier per tile.
+    static_assert(MF == 32 && SN == 1 && NACC == 16 && CP == 32, "transposed epilogue: one 32-channel column block");
+    const int vl = lane & 31, hh = lane >> 5;
+    float ebi[16], esc[16], esf[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = (e & 3) + 8 * (e >> 2) + 4 * hh;   // < 32 = cout_pad: the constant arrays are padded
+        ebi[e] = a.bias ? a.bias[c] : 0.f;
+        esc[e] = a.scale ? a.scale[c] : 1.f;
+        esf[e] = a.shift ? a.shift[c] : 0.f;
+    }
+    const EpiFloors fl = epi_floors(a.flags);
+    const bool has_res = a.res != nullptr;
+    const unsigned no_res = has_res ? 0u : 0x80008000u;  // zeros -> -0.0 pairs: v + -0.0 == v
+    // element offset of the lane's voxel of fragment i inside the tile, relative to the tile origin (td = wave, th = 4 i + v/8, tw = v%8)
+    const size_t ldc = (size_t)a.ldc;
+    const size_t voff0 = (((size_t)wave * a.H + (vl >> 3)) * a.W + (vl & 7)) * ldc + 4 * hh;
+    const size_t vstep = (size_t)4 * a.W * ldc;          // fragment i -> th + 4
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the weight slabs (and the constants)
     for (int it = 0;; ++it) {
         const int buf = it & 1;
         const int vn = v + gridDim.x;
         const bool have_next = vn < total_tiles;
-        // A: halo(it) has landed (the loaders waited for it); every consumer is done with tile it-1, its stores may still fly
+        // A: halo(it) has landed (the loaders waited for it); every consumer is done with the tap loop of tile it-1 (its stores may still fly)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         LT_TRH(1)
         int nn = 0, nd0 = 0, nh0 = 0, nw0 = 0;
         if (have_next) tile_of(vn, nn, nd0, nh0, nw0);
         LT_TRH(2)
-        // residual vectors of this tile, consumed in the epilogue (no inline-asm memory operation in a consumer wave: the
-        // compiler's own vmcnt bookkeeping is exact)
-        uint4 rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7;
-        rp0 = rp1 = rp2 = rp3 = rp4 = rp5 = rp6 = rp7 = make_uint4(0, 0, 0, 0);
-        if (pre_res) {
-            const int cqp = (lane % E_LPR) * E_VECO;
-            auto pf = [&](int k) -> uint4 {
-                const int r = 64 * wave + lane / E_LPR + k * E_RPP;
-                const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
-                const size_t pixv = (((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw;
-                const void* src = cqp < a.Cout ? (const void*)((const T*)a.res + pixv * a.ldc + cqp) : zero_page;
-                return *(const uint4*)src;
-            };
-            if (E_NIT > 0) rp0 = pf(0);
-            if (E_NIT > 1) rp1 = pf(1);
-            if (E_NIT > 2) rp2 = pf(2);
-            if (E_NIT > 3) rp3 = pf(3);
-            if (E_NIT > 4) rp4 = pf(4);
-            if (E_NIT > 5) rp5 = pf(5);
-            if (E_NIT > 6) rp6 = pf(6);
-            if (E_NIT > 7) rp7 = pf(7);
+        const size_t tbase = ((((size_t)n * a.D + d0) * a.H + h0) * a.W + w0) * ldc + voff0;
+        // residual of this tile: 8-byte pieces in named registers (an array stayed in scratch memory), consumed after the tap loop
+        uint2 rq00, rq01, rq02, rq03, rq10, rq11, rq12, rq13;
+        rq00 = rq01 = rq02 = rq03 = rq10 = rq11 = rq12 = rq13 = make_uint2(0, 0);
+        if (has_res) {
+            const T* rb = (const T*)a.res + tbase;
+            rq00 = *(const uint2*)(rb + 0); rq01 = *(const uint2*)(rb + 8); rq02 = *(const uint2*)(rb + 16); rq03 = *(const uint2*)(rb + 24);
+            rb += vstep;
+            rq10 = *(const uint2*)(rb + 0); rq11 = *(const uint2*)(rb + 8); rq12 = *(const uint2*)(rb + 16); rq13 = *(const uint2*)(rb + 24);
         }
-
         LT_TRH(3)
-        acc_t acc[SM][SN];
-        double dacc[1][1][1];
+        acc_t acc[SM];
 #pragma unroll
         for (int i = 0; i < SM; ++i)
 #pragma unroll
-            for (int j = 0; j < SN; ++j)
-#pragma unroll
-                for (int e = 0; e < NACC; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < NACC; ++e) acc[i][e] = 0.f;
 
         unsigned ha[KS][G][SM];
         const unsigned hbase = lds_halo + buf * C::HALO_BYTES;
@@ -865,23 +863,36 @@ __global__ __launch_bounds__(512) void conv3d_halo_persist_kernel(const HaloArgs
             lgkm_wait<ahead * RPU>();
 #pragma unroll
             for (int i = 0; i < SM; ++i) frag_ready(fa[slot][i]);
+            frag_ready(fb[slot][0]);
 #pragma unroll
-            for (int j = 0; j < SN; ++j) frag_ready(fb[slot][j]);
-#pragma unroll
-            for (int i = 0; i < SM; ++i)
-#pragma unroll
-                for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[slot][i], fb[slot][j]);
+            for (int i = 0; i < SM; ++i) Mma<T, MF>::run(acc[i], fb[slot][0], fa[slot][i]);   // D[co][voxel]: weights first
         });
 #endif
         LT_TRH(4)
-        // B: every consumer is done reading this halo buffer: it becomes the (wave-private) epilogue staging area
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         LT_TRH(5)
+        // ---- epilogue straight from the accumulators ----
 #ifdef LT_ABL_NO_EPI
         if (a.N < 0)
 #endif
-        halo_epilogue<T, CP, MF, SM, SN, NACC, TH, TW, false>(smem + W_BYTES + buf * C::HALO_BYTES, a, wave, lane, n, d0, h0, w0, acc, dacc,
-                                                             pre_res, rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7, cst);
+        {
+            T* yb = (T*)a.y + tbase;
+#define LT_HALO_T_ROW(I_, G_, RQ_)                                                                                  \
+            {                                                                                                       \
+                const unsigned r0 = RQ_.x | no_res, r1 = RQ_.y | no_res;                                            \
+                float v0 = (acc[I_][4 * G_ + 0] + ebi[4 * G_ + 0]) * esc[4 * G_ + 0] + esf[4 * G_ + 0];             \
+                float v1 = (acc[I_][4 * G_ + 1] + ebi[4 * G_ + 1]) * esc[4 * G_ + 1] + esf[4 * G_ + 1];             \
+                float v2 = (acc[I_][4 * G_ + 2] + ebi[4 * G_ + 2]) * esc[4 * G_ + 2] + esf[4 * G_ + 2];             \
+                float v3 = (acc[I_][4 * G_ + 3] + ebi[4 * G_ + 3]) * esc[4 * G_ + 3] + esf[4 * G_ + 3];             \
+                v0 = epi_apply(v0, fl, __uint_as_float(r0 << 16));                                                  \
+                v1 = epi_apply(v1, fl, __uint_as_float(r0 & 0xffff0000u));                                          \
+                v2 = epi_apply(v2, fl, __uint_as_float(r1 << 16));                                                  \
+                v3 = epi_apply(v3, fl, __uint_as_float(r1 & 0xffff0000u));                                          \
+                *(uint2*)(yb + I_ * vstep + 8 * G_) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));         \
+            }
+            LT_HALO_T_ROW(0, 0, rq00) LT_HALO_T_ROW(0, 1, rq01) LT_HALO_T_ROW(0, 2, rq02) LT_HALO_T_ROW(0, 3, rq03)
+            LT_HALO_T_ROW(1, 0, rq10) LT_HALO_T_ROW(1, 1, rq11) LT_HALO_T_ROW(1, 2, rq12) LT_HALO_T_ROW(1, 3, rq13)
+#undef LT_HALO_T_ROW
+        }
         LT_TRH(6)
 #ifdef LT_TRACE
         tr[0] += 1;
@@ -1203,7 +1214,7 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     }
     // persistent variant: needs a few tiles per workgroup to amortise the weight load, and total % 8 == 0 for the XCD dealing
     static const bool no_persist = getenv("LT_HALO_NO_PERSIST") != nullptr;   // A/B
-    if (bf && ks == 3 && cout_pad == 32 && c.Cin == 32 && nblk >= 1024 && nblk % 8 == 0 && !no_persist) {
+    if (bf && ks == 3 && cout_pad == 32 && c.Cout == 32 && c.ldc % 4 == 0 && c.Cin == 32 && nblk >= 1024 && nblk % 8 == 0 && !no_persist) {
         int rc = launch_halo_persist<bf16_t, 32, 32>(a, s);
         return rc == LT_OK ? 1 : rc;
     }

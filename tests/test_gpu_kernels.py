@@ -283,6 +283,12 @@ def test_softargmax3d_large_sharp():
         assert float(rel) < 2e-5
         check("integrate3d/64^3 sharp/%s volumes" % layout, p.cpu(), rv, 1e-5)
         assert float((p.sum(dim=(2, 3, 4)) - 1).abs().max()) < 1e-4
+    # the ReLU variant (op.py:90-94, not normalised) on the channels-last fast path
+    rc0, rv0 = O.integrate_tensor_3d_with_coordinates((lg * 0.01).double(), cv.double(), softmax=False)
+    v = (lg * 0.01).to(DEV).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+    c0, p0 = op.integrate_tensor_3d_with_coordinates(v, cv.to(DEV), softmax=False)
+    check("integrate3d/64^3 relu/channels_last coords", c0.cpu(), rc0.float(), 2e-4)
+    check("integrate3d/64^3 relu/channels_last volumes", p0.cpu(), rv0.float(), 1e-6)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
