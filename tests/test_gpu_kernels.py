@@ -381,3 +381,25 @@ def test_pwchain(nlayers, J):
     ref = cur.permute(0, 2, 3, 4, 1)
     assert y.t.dtype == torch.float32 and tuple(y.t.shape) == tuple(ref.shape)
     check("pwchain/L%d_J%d" % (nlayers, J), y.t.cpu(), ref, 1e-2)
+
+
+@pytest.mark.parametrize("staged", ["0", "1"])
+def test_unproject_bf16_lds_staged(staged, monkeypatch):
+    """bf16 / C = 32 / bricked volumes: the default gather kernel and the opt-in LDS-staged kernel (LT_UNPROJ_LDS=1): patches that
+    fit (V = 32, 24x24 maps) and the per-view fallback to global gathers (V = 16 bricks spanning the whole cube side on 96x96
+    maps), every aggregation, vs the oracle."""
+    from mvn.utils import op
+    monkeypatch.setenv("LT_UNPROJ_LDS", staged)
+    synth = __import__("oracle.synth", fromlist=["x"])
+    g = torch.Generator().manual_seed(21)
+    for B, NV, V, hw in ((8, 4, 32, 24), (2, 3, 16, 96), (1, 8, 16, 24)):
+        K, R, t = synth.ring_cameras(NV, 96, inside=(NV == 3))
+        P = torch.from_numpy(O.resized_projection(K, R, t, (96, 96), (hw, hw))).float()[None].repeat(B, 1, 1, 1).contiguous()
+        hm = torch.randn(B, NV, 32, hw, hw, generator=g)
+        conf = torch.rand(B, NV, 32, generator=g) + 0.1
+        base = torch.randn(B, 3, generator=g).numpy() * 100
+        cv = torch.stack([O.coord_volume(base[b], 2500.0, V, 0.3 * b) for b in range(B)])
+        for method in ("softmax", "sum", "max", "conf", "conf_norm"):
+            out = op.unproject_heatmaps(hm.to(DEV).bfloat16(), P.to(DEV), cv.to(DEV), method, conf.to(DEV))
+            ref = O.unproject_heatmaps(bf16_round(hm), P, cv, method, conf)
+            check("unproject_bf16/staged=%s/B%d_NV%d_V%d_hw%d/%s" % (staged, B, NV, V, hw, method), out.float().cpu(), ref, 1e-2)
