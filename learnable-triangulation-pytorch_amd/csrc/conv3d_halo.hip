@@ -285,9 +285,12 @@ __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArg
     }
 }
 
-template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF, int PD>
-__global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
+// LDR: eight waves, waves 4-7 are loaders (halo + weight chunk ring, nothing else); waves 0-3 then issue no DMA and wait on
+// no vmcnt inside the tap loop (same idea as the 7^3 and the persistent kernels; non-ring path only)
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF, int PD, bool LDR>
+__global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const HaloArgs a) {
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF> C;
+    static_assert(!LDR || PD == 1, "loader waves: non-ring path");
     constexpr bool ACC64 = sizeof(T) == 4;
     constexpr int MF = C::MF, SM = C::SM, SN = C::SN, G = C::G, NACC = C::NACC, NVV = C::NVV, VPR = C::VPR, CINB = C::CINB;
     typedef typename Mma<T, MF>::acc_t acc_t;
@@ -304,6 +307,9 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool is_loader = LDR && wave >= 4;
+    const bool do_dma = !LDR || is_loader;
+    const int dw = wave & 3;                             // index of this wave among the four that issue DMAs
 
     // ---- workgroup -> (sample, tile); with N % 8 == 0 sample n is pinned to XCD n % 8 (its d-slabs stay in that L2) ----
     const int tps = a.tiles_d * a.tiles_h * a.tiles_w;
@@ -330,7 +336,8 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
     // ---- halo DMA: vector q = hv*NVV + pv, wave-instruction i covers q in [64 i, 64 i + 64) ----
     constexpr int NI_H = C::HALO_BYTES / 1024;
 #ifndef LT_ABL_NO_A   // -DLT_ABL_*: timing ablations for profiling builds (results are WRONG with any of them)
-    for (int i = wave; i < NI_H; i += 4) {
+    if (do_dma)
+    for (int i = dw; i < NI_H; i += 4) {
         const int q = i * 64 + lane;
         const int hv = q / NVV, pv = q % NVV;
         const int hw_ = hv % C::PW, hh_ = (hv / C::PW) % C::HH, hd_ = hv / (C::PW * C::HH);
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
 #ifdef LT_ABL_NO_B
         return;
 #endif
-        for (int i = wave; i < NI_W; i += 4) {
+        for (int i = dw; i < NI_W; i += 4) {
             const int q = i * 64 + lane;
             const int pv = q % NVV, col = (q / NVV) % CP, tj = q / (NVV * CP);
             const int tap = ch * TPC + tj;
@@ -360,11 +367,25 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
 #ifdef LT_ABL_NO_B
     const int dpc = 0;
 #else
-    const int dpc = (NI_W - wave + 3) / 4;        // weight DMA instructions per chunk issued by this wave (wave-uniform)
+    const int dpc = (NI_W - dw + 3) / 4;          // weight DMA instructions per chunk issued by this wave (wave-uniform)
 #endif
+    if (do_dma) {
 #pragma unroll
-    for (int c = 0; c < NBUF - 1; ++c)
-        if (c < C::NCH) stage_w(c, c);
+        for (int c = 0; c < NBUF - 1; ++c)
+            if (c < C::NCH) stage_w(c, c);
+    }
+    if (is_loader) {
+        // ================================= loader waves: the chunk ring, then out =================================
+        for (int ch = 0; ch < C::NCH; ++ch) {
+            int younger = C::NCH - 1 - ch;
+            if (younger > NBUF - 2) younger = NBUF - 2;
+            wait_vmcnt_h(younger * dpc);
+            asm volatile("s_barrier" ::: "memory");
+            if (ch + NBUF - 1 < C::NCH) stage_w(ch + NBUF - 1, (ch + NBUF - 1) % NBUF);
+        }
+        asm volatile("s_barrier" ::: "memory");          // the compute waves' "done with the LDS images" barrier
+        return;
+    }
 
     HaloCst<SN> cst;
     cst.load(a, lane, MF);
@@ -372,7 +393,8 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
     // registers (see conv_igemm2.hip for why not an array); they are consumed in the epilogue ----
     constexpr int E_VECO = C::VEC, E_LPR = CP / E_VECO, E_RPP = 64 / E_LPR, E_NIT = 64 / E_RPP;
     static_assert(E_NIT <= 16, "epilogue rows per lane");
-    constexpr bool PRE_OK = E_NIT <= 8;
+    // (the 64-channel loader-wave configuration is at its 256-VGPR budget: it loads the residual in the epilogue instead)
+    constexpr bool PRE_OK = E_NIT <= 8 && !(LDR && CINB == 128);
     const bool vec_epi = (a.Cout % E_VECO == 0) && (a.ldc % E_VECO == 0);
     const bool pre_res = PRE_OK && vec_epi && a.res != nullptr && !(a.flags & LT_EPI_NO_RES_PREFETCH);
     uint4 rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7;
@@ -535,9 +557,9 @@ __global__ __launch_bounds__(256) void conv3d_halo_kernel(const HaloArgs a) {
             // chunk ch (and, the first time, the halo issued before it) must have landed; up to NBUF-2 younger chunks stay in flight
             int younger = C::NCH - 1 - ch;
             if (younger > NBUF - 2) younger = NBUF - 2;
-            wait_vmcnt_h(younger * dpc);
+            if (!LDR) wait_vmcnt_h(younger * dpc);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves: chunk ch landed, chunk ch-1 fully consumed
-            if (ch + NBUF - 1 < C::NCH) stage_w(ch + NBUF - 1, (ch + NBUF - 1) % NBUF);
+            if (!LDR && ch + NBUF - 1 < C::NCH) stage_w(ch + NBUF - 1, (ch + NBUF - 1) % NBUF);
             // per-chunk scalar parts
             const int kd = ROWCH ? ch / KS : ch, kh_row = ROWCH ? ch % KS : 0;
             const int coff = ((kd * C::HH + kh_row) * C::PW) * CINB;           // bytes, wave-uniform
@@ -1167,18 +1189,18 @@ int launch_halo_persist(const HaloArgs& a, hipStream_t s) {
     return LT_OK;
 }
 
-template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF, int PD>
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF, int PD, bool LDR>
 int launch_halo(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF> C;
     static_assert(C::LDS_BYTES <= 160 * 1024, "halo tile does not fit LDS");
-    auto kern = conv3d_halo_kernel<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF, PD>;
+    auto kern = conv3d_halo_kernel<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF, PD, LDR>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const long long nblk = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), C::LDS_BYTES, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(LDR ? 512 : 256), C::LDS_BYTES, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(halo)");
     return LT_OK;
 }
@@ -1207,9 +1229,14 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     a.tiles_d = c.D / 4; a.tiles_h = c.H / 8; a.tiles_w = c.W / 8;
     a.xcd_pin = (c.N % 8 == 0) ? 1 : 0;
     const bool bf = dtype == LT_BF16;
+#define HALO_CASE_L(T_, KS_, CIN_, CP_, TPC_, NBUF_, PD_, LDR_)                                  \
+    if (ks == KS_ && c.Cin == CIN_ && cout_pad == CP_) {                                        \
+        int rc = launch_halo<T_, KS_, CIN_, CP_, 4, 8, 8, TPC_, NBUF_, PD_, LDR_>(a, s);        \
+        return rc == LT_OK ? 1 : rc;                                                            \
+    }
 #define HALO_CASE(T_, KS_, CIN_, CP_, TPC_, NBUF_, PD_)                                          \
     if (ks == KS_ && c.Cin == CIN_ && cout_pad == CP_) {                                        \
-        int rc = launch_halo<T_, KS_, CIN_, CP_, 4, 8, 8, TPC_, NBUF_, PD_>(a, s);              \
+        int rc = launch_halo<T_, KS_, CIN_, CP_, 4, 8, 8, TPC_, NBUF_, PD_, false>(a, s);       \
         return rc == LT_OK ? 1 : rc;                                                            \
     }
     // persistent variant: needs a few tiles per workgroup to amortise the weight load, and total % 8 == 0 for the XCD dealing
@@ -1220,6 +1247,13 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     }
     static const bool row_chunks = getenv("LT_HALO_ROW") != nullptr;   // A/B: 3-tap weight chunks -> 51 KB of LDS -> 3 workgroups per CU
     if (bf) {
+        static const bool no_ldr = getenv("LT_HALO_NO_LDR") != nullptr;   // A/B: no loader waves in the one-tile kernel
+        if (!no_ldr) {
+            HALO_CASE_L(bf16_t, 3, 64, 64, 3, 3, 1, true)
+            HALO_CASE_L(bf16_t, 3, 32, 32, 9, 2, 1, true)
+            HALO_CASE_L(bf16_t, 3, 16, 32, 9, 2, 1, true)
+            HALO_CASE_L(bf16_t, 3, 32, 64, 9, 2, 1, true)
+        }
         if (row_chunks) { HALO_CASE(bf16_t, 3, 32, 32, 3, 2, 1) }
         HALO_CASE(bf16_t, 3, 32, 32, 9, 2, 1)
         HALO_CASE(bf16_t, 3, 16, 32, 9, 2, 1)
@@ -1238,6 +1272,7 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
         HALO_CASE(float, 3, 16, 32, 9, 2, 1)
     }
 #undef HALO_CASE
+#undef HALO_CASE_L
     return 0;
 }
 
