@@ -180,8 +180,19 @@ def main():
             conv = fam["conv"]
             peak = PEAK_TFLOPS[args.dtype]
             ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-            result["roofline"] = {"kernel": "conv_igemm_kernel (all %d conv launches of one step)" % conv["launches"], "bound": "mfma",
-                                  "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            # HBM traffic of the conv family per step from the committed PMC passes (tools/pmc_summary.py; same batch only)
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.json")))
+                if pm.get("per_gpu_batch") == B and args.dtype == "bf16":
+                    traffic = pm["conv_family_bytes_per_step"]
+            except (OSError, ValueError, KeyError):
+                pass
+            if "pwchain" in fam:   # the fused pointwise tail is convolution work too
+                conv = {k: conv[k] + fam["pwchain"][k] for k in conv}
+            ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+            result["roofline"] = {"kernel": "conv family: conv_igemm2/3, conv3d_halo*, pwchain (all %d launches of one step)" % conv["launches"], "bound": "mfma",
+                                  "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                   "flop_per_step": conv["flops"], "ms_per_step_in_kernel": conv["ms"]}
             hb = {}
             for k in ("unproject", "softargmax3d"):
