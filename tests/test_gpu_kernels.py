@@ -104,9 +104,12 @@ V3_CASES = {  # name: (nd, N, cin, cout, k, stride, pad, spatial, residual)
 }
 
 
+@pytest.mark.parametrize("v4", ["0", "1"])
 @pytest.mark.parametrize("case", list(V3_CASES))
-def test_conv_v3_288(case):
-    """288-row / 8-wave / 3-stage kernel vs torch (bf16), forced with LT_TILE3_288, and AUTO agrees."""
+def test_conv_v3_288(case, v4, monkeypatch):
+    """288-row / 3-stage kernels vs torch (bf16), forced with LT_TILE3_288, and AUTO agrees: the 12-wave kernel and (LT_CONV_V4=1,
+    Cout % 128 == 0) the role-specialised one with four compute and four loader waves."""
+    monkeypatch.setenv("LT_CONV_V4", v4)
     nd, N, cin, cout, k, s, p, sp, with_res = V3_CASES[case]
     g = torch.Generator().manual_seed(len(case) * 7 + cin)
     x = torch.randn(N, cin, *sp, generator=g)
@@ -118,12 +121,12 @@ def test_conv_v3_288(case):
     res = torch.randn(pre.shape, generator=g) if with_res else None
     ref = torch.relu(pre + bf16_round(res)) if with_res else torch.relu(pre)
     out = run_conv(x, w, bias, bn, s, p, torch.bfloat16, H.TILE3_288, relu=True, residual=res)
-    check("conv_v3/%s/forced" % case, out, ref, 1.5e-2)
+    check("conv_v3/%s/v4=%s/forced" % (case, v4), out, ref, 1.5e-2)
     out2 = run_conv(x, w, bias, bn, s, p, torch.bfloat16, 0, relu=True, residual=res)
-    check("conv_v3/%s/auto" % case, out2, ref, 1.5e-2)
+    check("conv_v3/%s/v4=%s/auto" % (case, v4), out2, ref, 1.5e-2)
     out3 = run_conv(x, w, bias, bn, s, p, torch.bfloat16, H.TILE3_288, relu=False, relu_pre=True, residual=res)   # V2V-style epilogue
     ref3 = torch.relu(pre) + bf16_round(res) if with_res else torch.relu(pre)
-    check("conv_v3/%s/relu_pre" % case, out3, ref3, 1.5e-2)
+    check("conv_v3/%s/v4=%s/relu_pre" % (case, v4), out3, ref3, 1.5e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
