@@ -27,7 +27,7 @@ def load(pattern, counter):
 
 def main():
     out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4       # bench.py --steps 3 --warmup 1
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6       # forwards in the run: bench.py --steps 3 --warmup 1 + its 2 setup calls
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
     fetch = load(os.path.join(out_dir, "pmc_fetch", "*counter_collection.csv"), "FETCH_SIZE")
     write = load(os.path.join(out_dir, "pmc_write", "*counter_collection.csv"), "WRITE_SIZE")
