@@ -57,7 +57,7 @@ pmcconv)
 abenv)
   # in-session A/B of env switches (two interleaved rounds each): baseline, no residual prefetch, no uniform-tap path, no halo kernel
   for round in 1 2; do
-    for v in ${ABVARS:-base LT_CONV_NO_XCD LT_HALO_NO_PERSIST LT_HALO_NO_RING LIB_sliced}; do
+    for v in ${ABVARS:-base LT_CONV_NO_V3 LT_CONV_NO_XCD LT_HALO_NO_PERSIST LT_HALO_NO_H7 LT_HALO_NO_LDR}; do
       # LIB_<name>: an A/B build of the library (lt_build.build_variant), else an env switch read by the kernels' dispatchers
       case $v in
         base) E="LT_AB=base" ;;
@@ -73,6 +73,12 @@ ablate)
   # where does the time of the big conv layers go?  ablation builds of the library (results wrong by design, timing only):
   # no MFMAs / no epilogue / no A-side DMA (halo) / no B-side DMA (weights), for the persistent and the one-tile halo kernels
   L=$R/learnable-triangulation-pytorch_amd/lib
+  python - <<'PYEOF'
+import sys; sys.path.insert(0, "learnable-triangulation-pytorch_amd")
+import lt_build
+for n, d in (("abl_nomma", ["LT_ABL_NO_MMA"]), ("abl_noepi", ["LT_ABL_NO_EPI"]), ("abl_noa", ["LT_ABL_NO_A"]), ("abl_nob", ["LT_ABL_NO_B"])):
+    lt_build.build_variant(n, d)
+PYEOF
   for lib in base nomma noepi noa nob; do
     for pers in persist onetile; do
       E="LT_AB=1"; [ $lib != base ] && E="LT_HIP_LIB=$L/liblt_hip_abl_$lib.so"
