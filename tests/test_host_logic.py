@@ -202,3 +202,16 @@ def test_c_abi_exports_every_declared_symbol():
     assert l.lt_unproject_fwd(0, 1, 1, 1, None, 1, 1, 1, 4, 8, 8, 2, 2, 2, 9, None) == -1 and b"aggregation" in l.lt_last_error()
     assert l.lt_softargmax3d_fwd(1, 1, 1.0, 1, 1, 40, 1, None, 1, 40, 8, 1, None) == -2 and b"J=40" in l.lt_last_error()
     assert l.lt_softargmax3d_workspace(2, 17, 64 ** 3) == (2 * 17 * 128 * 5 + 2 * 17 * 2) * 4
+    # lt_pwchain_fwd: bf16 only, 32 input channels, rows % 64 == 0, inner widths 32, exactly the last layer stores fp32
+    pd = H.PwChainDesc()
+    pd.dtype, pd.nlayers, pd.rows, pd.cin, pd.ldy = 0, 1, 64, 32, 17
+    assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -2 and b"bf16" in l.lt_last_error()
+    pd.dtype, pd.rows = 1, 100
+    assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -2 and b"multiple of 64" in l.lt_last_error()
+    pd.rows, pd.nlayers = 64, 4
+    assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -1 and b"nlayers" in l.lt_last_error()
+    pd.nlayers = 2
+    pd.cout[0], pd.cout[1], pd.k_pad[0], pd.k_pad[1], pd.weight[0], pd.weight[1] = 16, 17, 64, 64, 1, 1
+    assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -2 and b"inner layers" in l.lt_last_error()
+    pd.cout[0] = 32
+    assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -2 and b"last layer stores fp32" in l.lt_last_error()
