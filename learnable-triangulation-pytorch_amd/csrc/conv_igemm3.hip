@@ -57,6 +57,9 @@ __device__ __forceinline__ void wait_vmcnt3(int n) {
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
         case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // conservative
     }
 }
@@ -705,6 +708,261 @@ int launch4(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
     return LT_OK;
 }
 
+// ---- 288 x 256 tile, 32-element K steps, four stages (Cout % 256 == 0) ---------------------------------------------------------
+// The L2->LDS stream is what bounds the kernels above (one 52 KB stage per ~2200 cycles with two stages in flight):
+// what helps is fewer staged bytes per FLOP at the same bytes in flight.  A 288 x 256 tile stages (288+256) rows per K step for
+// twice the MFMA work of 288 x 128 (135 instead of 88 FLOP per byte); to keep three stages in flight in 160 KB the K step is 32
+// elements: 64-byte LDS rows, 34 KB per stage, four stages.  Eight waves = 2 (M) x 4 (N), wave tile 144 x 64 (9 x 4 accumulator
+// tiles), every wave issues its share of the DMA pieces sliced between its fragment steps (as in the 12-wave kernel).
+// 64-byte rows: a 16-byte slot holds K vector (slot ^ g(row)), g = [0,2,3,1][(row >> 2) & 3] -- with that the four 16-lane groups
+// of a ds_read_b128 fragment read (rows r, K vector lane >> 4) each touch all 64 banks once (checked by enumeration, comment in
+// DESIGN.md); the DMA writes lane-linearly, so the swizzle is applied to the source address as everywhere else.
+__device__ __forceinline__ int swz64(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+template <int MODE>
+__global__ __launch_bounds__(512) void conv_igemm5_kernel(const ConvArgs a) {
+    typedef bf16_t T;
+    constexpr bool PW = MODE == 1;
+    constexpr int BM = BM3, BN = 256, NW = 8, WM = 144, WN = 64, MF = 16, SM = WM / MF, SN = WN / MF, NST = 4, VEC = 8, BK = 32, ROWB = 64;
+    constexpr int NPA = BM / 16, NPB = BN / 16;          // 1 KiB DMA pieces per stage (16 rows of 64 B each): 18 + 16
+    constexpr int A_IT = (NPA + NW - 1) / NW, B_IT = NPB / NW;   // 3 (waves 0,1) / 2, and 2
+    static_assert(NPB % NW == 0, "B pieces divide evenly");
+    constexpr int STAGE = (BM + BN) * ROWB;              // 34816 B
+    constexpr int REGION = NST * STAGE;
+    constexpr int EP_ROWS = 48, EP_LD = WN + 4, EP_WAVE = EP_ROWS * EP_LD * 4, NPASS = WM / EP_ROWS;
+    static_assert(NW * EP_WAVE <= REGION && NPASS == 3, "epilogue staging");
+    typedef typename Mma<T, MF>::acc_t acc_t;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int4* s_taps = (int4*)(smem + REGION);               // [ntaps] (unused when PW)
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page3;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int lin = blockIdx.x;
+    if (!(a.flags & LT_EPI_NO_XCD_REMAP)) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = lin & 7, j = lin >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tile_n = lin % a.tiles_n;
+    const int tile_m = lin / a.tiles_n;
+    const PhaseArg ph = a.phase[0];
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const T* __restrict__ x = (const T*)a.x;
+    const T* __restrict__ w = (const T*)ph.w;
+
+    // DMA ownership: piece p = wave + 8 i covers rows 16 p .. 16 p + 15; lane -> row 16 p + (lane >> 2), physical slot lane & 3,
+    // logical K vector kv = slot ^ g(row), and g(row) = g(lane >> 2) because 16 p is a multiple of 16
+    const int prow = lane >> 2;
+    const int kv = (lane & 3) ^ swz64(prow);
+    const bool a_tail = wave < NPA % NW;                 // waves 0, 1 own a third A piece
+    const int dps = (A_IT - 1) + (a_tail ? 1 : 0) + B_IT;   // 5 or 4 DMA pieces per wave and stage
+    int id0[PW ? 1 : A_IT], ih0[PW ? 1 : A_IT], iw0[PW ? 1 : A_IT], baseC[A_IT], cur[PW ? 1 : A_IT];
+    if (!PW)
+        for (int i = t; i < ph.ntaps; i += 64 * NW) s_taps[i] = ph.taps[i];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + 16 * (wave + NW * i) + prow;
+        const bool own = i < A_IT - 1 || a_tail;
+        if (PW) baseC[i] = (own && m < a.M) ? m * a.Cin + kv * VEC : -1;
+        else if (own && m < a.M) {
+            int n, od, oh, ow;
+            decode_row(a, m, n, od, oh, ow);
+            id0[i] = od * a.sd - a.pd;
+            ih0[i] = oh * a.sh - a.ph;
+            iw0[i] = ow * a.sw - a.pw;
+            baseC[i] = (((n * a.D + id0[i]) * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
+        } else {
+            id0[i] = -(1 << 24);
+            ih0[i] = iw0[i] = baseC[i] = 0;
+        }
+    }
+    const T* wrow[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) wrow[j] = w + (size_t)(n0 + 16 * (wave + NW * j) + prow) * a.k_pad + kv * VEC;
+    __syncthreads();
+
+    const int nk = a.k_pad / BK;
+    constexpr int NPIECE = A_IT + B_IT;                   // piece slots per wave and stage (the last A slot may be empty)
+    int c0s = 0;
+    auto stage_prep = [&](int ks) {
+        if (!PW) {
+            const int k0 = ks * BK;
+            c0s = k0 & (a.Cin - 1);
+            if (c0s == 0) {                              // the tap changes every Cin / 32 steps
+                const int tap = k0 >> a.log2Cin;
+                int4 tp = make_int4(-(1 << 24), 0, 0, 0);
+                if (tap < ph.ntaps) tp = s_taps[tap];
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) {
+                    const int id = id0[i] + tp.x, ih = ih0[i] + tp.y, iw = iw0[i] + tp.z;
+                    const bool ok = ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+                    cur[i] = ok ? baseC[i] + tp.w + kv * VEC : -1;
+                }
+            }
+        }
+    };
+    auto stage_piece = [&](int ks, int buf, auto pc) {
+        constexpr int P = decltype(pc)::value;
+        const unsigned sA = lds0 + buf * STAGE;
+        if constexpr (P < A_IT) {
+            if (P == A_IT - 1 && !a_tail) return;
+            const void* src;
+            if (PW) src = baseC[P] >= 0 ? (const void*)(x + (baseC[P] + ks * BK)) : zero_page;
+            else src = cur[P] >= 0 ? (const void*)(x + (cur[P] + c0s)) : zero_page;
+            dma16(src, sA + (wave + NW * P) * 1024);
+        } else {
+            constexpr int j = P - A_IT;
+            dma16(wrow[j] + ks * BK, sA + BM * ROWB + (wave + NW * j) * 1024);
+        }
+    };
+    auto stage = [&](int ks, int buf) {
+        stage_prep(ks);
+        static_for<0, NPIECE>([&](auto pc) { stage_piece(ks, buf, pc); });
+    };
+
+    // fragment addresses: row r15 = lane & 15 of a 16-row tile, K vector lane >> 4 in slot (lane >> 4) ^ g(r15) (tile bases are multiples of 16)
+    const int r15 = lane & 15;
+    const unsigned fo = r15 * ROWB + (((lane >> 4) ^ swz64(r15)) << 4);
+    const unsigned aoff = lds0 + wm * WM * ROWB + fo;
+    const unsigned boff = lds0 + BM * ROWB + wn * WN * ROWB + fo;
+
+    acc_t acc[SM][SN];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+    for (int sgi = 0; sgi < NST - 1; ++sgi)
+        if (sgi < nk) stage(sgi, sgi);
+
+    constexpr int RPG = SN + SM, LOOK = 6, RA = LOOK + 1;   // read stream of a step: SN B fragments, then SM A fragments
+    for (int ks = 0; ks < nk; ++ks) {
+        // stage ks must have landed; up to NST-2 younger stages of this wave's pieces stay in flight
+        int younger = nk - 1 - ks;
+        if (younger > NST - 2) younger = NST - 2;
+        wait_vmcnt3(younger * dps);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all DMAs of stage ks landed; stage ks-1 fully consumed
+        const bool more = ks + NST - 1 < nk;
+        const int nbuf = (ks + NST - 1) % NST;
+        if (more) stage_prep(ks + NST - 1);
+        const unsigned sbase = (ks % NST) * STAGE;
+        const unsigned abase = aoff + sbase, bbase = boff + sbase;
+        V16 fa[RA], fb[SN];
+        auto issue = [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            if constexpr (K < SN) lds_read16<K * 16 * ROWB>(fb[K], bbase);
+            else lds_read16<(K - SN) * 16 * ROWB>(fa[(K - SN) % RA], abase);
+        };
+        static_for<0, SM>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int pos = SN + u;
+            constexpr int prev_target = u == 0 ? 0 : (pos + LOOK < RPG ? pos + LOOK : RPG);
+            constexpr int target = pos + 1 + LOOK < RPG ? pos + 1 + LOOK : RPG;
+            static_for<prev_target, target>([&](auto kc) { issue(kc); });
+            lgkm_wait<target - pos - 1>();
+            if constexpr (u == 0) {
+#pragma unroll
+                for (int j = 0; j < SN; ++j) frag_ready(fb[j]);
+            }
+            frag_ready(fa[u % RA]);
+#pragma unroll
+            for (int j = 0; j < SN; ++j) LT3_MMA(acc[u][j], fa[u % RA], fb[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (u % 2 == 0 && u / 2 < NPIECE) {   // one DMA piece of stage ks+3 behind every second fragment
+                if (more) stage_piece(ks + NST - 1, nbuf, std::integral_constant<int, u / 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring becomes the epilogue staging area
+#ifdef LT_ABL_NO_EPI
+    if (a.M >= 0) return;
+#endif
+    // ---- epilogue: three passes of 48 rows through this wave's private fp32 LDS tile -> 16-byte vectors ----
+    constexpr int LPR = WN / 8, RPP = 64 / LPR, ITP = EP_ROWS / RPP;   // 8 lanes per row, 8 rows per iteration, 6 iterations per pass
+    const int colv = n0 + wn * WN + (lane % LPR) * 8;
+    auto out_off = [&](int p, int k) -> long long {
+        const int m = m0 + wm * WM + p * EP_ROWS + k * RPP + lane / LPR;
+        if (m >= a.M || colv >= a.Cout) return -1;
+        long long pix = m;
+        if (!PW) {
+            int n, od, oh, ow;
+            decode_row(a, m, n, od, oh, ow);
+            pix = ((long long)(n * a.OD + od * a.osd + ph.ood) * a.OH + oh * a.osh + ph.ooh) * a.OW + ow * a.osw + ph.oow;
+        }
+        return pix * a.ldc + colv;
+    };
+    const EpiFloors fl = epi_floors(a.flags);
+    const bool has_res = a.res != nullptr;
+    float* ep = (float*)(smem + wave * EP_WAVE);
+    float bi[SN], sc[SN], sf[SN];
+#pragma unroll
+    for (int j = 0; j < SN; ++j) {
+        const int colj = n0 + wn * WN + j * MF + r15;    // < cout_pad: the constant arrays are padded
+        bi[j] = a.bias ? a.bias[colj] : 0.f;
+        sc[j] = a.scale ? a.scale[colj] : 1.f;
+        sf[j] = a.shift ? a.shift[colj] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        long long off[ITP];
+        uint4 rv[ITP];
+#pragma unroll
+        for (int k = 0; k < ITP; ++k) {                  // this pass's residual vectors first: independent round trips
+            off[k] = out_off(p, k);
+            rv[k] = (has_res && off[k] >= 0) ? *(const uint4*)((const T*)a.res + off[k]) : make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+            for (int j = 0; j < SN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    ep[(ii * MF + (lane >> 4) * 4 + e) * EP_LD + j * MF + r15] = (acc[3 * p + ii][j][e] + bi[j]) * sc[j] + sf[j];
+#pragma unroll
+        for (int k = 0; k < ITP; ++k) {
+            if (off[k] < 0) continue;
+            const float* src = ep + (k * RPP + lane / LPR) * EP_LD + (lane % LPR) * 8;
+            const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
+            const float vv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const unsigned ru[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+            unsigned ou[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                ou[e] = pack_bf16x2(epi_apply(vv[2 * e], fl, __uint_as_float(ru[e] << 16)), epi_apply(vv[2 * e + 1], fl, __uint_as_float(ru[e] & 0xffff0000u)));
+            *(uint4*)((T*)a.y + off[k]) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+        }
+    }
+}
+
+template <int MODE>
+int launch5(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
+    a.tiles_n = cout_pad / 256;
+    const long long nblk = cdiv(a.M, BM3) * a.tiles_n;
+    LT_REQUIRE(nblk < (1ll << 31), LT_ERR_INVALID, "lt_conv_fwd: grid too large");
+    const size_t lds = 4 * (size_t)(BM3 + 256) * 64 + (size_t)max_taps * sizeof(int4);
+    LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: 288x256 tile needs %zu B of LDS", lds);
+    auto kern = conv_igemm5_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, s, a);
+    LT_CHECK_LAUNCH("lt_conv_fwd(v5)");
+    return LT_OK;
+}
+
 template <int BN, int MODE, int NWM>
 int launch3(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
     a.tiles_n = cout_pad / BN;
@@ -738,6 +996,21 @@ int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_ta
     // 1.5x slower than the 128x64 tile of conv_igemm2 on the 64-channel level
     const int BN = cout_pad % 128 == 0 ? 128 : ((cout_pad == 64 && forced) ? 64 : 0);
     if (!BN) return 0;
+    // 288 x 256 tile (v5): Cout a multiple of 256 and enough 288-row tiles to give every CU one (LT_CONV_V5=0/1 forces it off/on)
+    {
+        const char* v5e = getenv("LT_CONV_V5");
+        const long long tiles_m5 = cdiv(a.M, BM3), nblk5 = tiles_m5 * (cout_pad / 256);
+        const bool fits5 = cout_pad % 256 == 0 && a.k_pad % 32 == 0 && max_taps <= 64;
+        const bool want5 = v5e ? v5e[0] == '1' : (nblk5 >= 200 && tiles_m5 * BM3 - a.M <= a.M / 16 && a.k_pad >= 256);
+        if (fits5 && want5) {
+            const PhaseArg& q0 = a.phase[0];
+            const bool pw5 = q0.ntaps == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.pd == 0 && a.ph == 0 && a.pw == 0 && a.osd == 1 &&
+                             a.osh == 1 && a.osw == 1 && q0.ood == 0 && q0.ooh == 0 && q0.oow == 0 && a.OD == a.Do && a.OH == a.Ho &&
+                             a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
+            const int rc5 = pw5 ? launch5<1>(a, cout_pad, max_taps, s) : launch5<2>(a, cout_pad, max_taps, s);
+            return rc5 == LT_OK ? 1 : rc5;
+        }
+    }
     const PhaseArg& p0 = a.phase[0];
     const bool pw = p0.ntaps == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.pd == 0 && a.ph == 0 && a.pw == 0 && a.osd == 1 &&
                     a.osh == 1 && a.osw == 1 && p0.ood == 0 && p0.ooh == 0 && p0.oow == 0 && a.OD == a.Do && a.OH == a.Ho && a.OW == a.Wo &&

@@ -406,3 +406,35 @@ def test_unproject_bf16_lds_staged(staged, monkeypatch):
             out = op.unproject_heatmaps(hm.to(DEV).bfloat16(), P.to(DEV), cv.to(DEV), method, conf.to(DEV))
             ref = O.unproject_heatmaps(bf16_round(hm), P, cv, method, conf)
             check("unproject_bf16/staged=%s/B%d_NV%d_V%d_hw%d/%s" % (staged, B, NV, V, hw, method), out.float().cpu(), ref, 1e-2)
+
+
+V5_CASES = {  # name: (nd, N, cin, cout, k, stride, pad, spatial, residual)
+    "v5_1x1_256_512": (2, 2, 256, 512, 1, 1, 0, (24, 24), True),
+    "v5_1x1_1024_256": (2, 1, 1024, 256, 1, 1, 0, (24, 24), True),       # 32 K steps, one N tile
+    "v5_3x3_128_256": (2, 2, 128, 256, 3, 1, 1, (24, 24), True),
+    "v5_1x1_64_256_ragged": (2, 1, 64, 256, 1, 1, 0, (25, 23), True),     # M = 575: ragged last tile
+    "v5_3x3s2_128_256": (2, 2, 128, 256, 3, 2, 1, (24, 24), False),
+    "v5_1x1s2_256_512": (2, 2, 256, 512, 1, 2, 0, (24, 24), False),
+    "v5_3x3x3_64_256": (3, 1, 64, 256, 3, 1, 1, (6, 8, 10), True),
+}
+
+
+@pytest.mark.parametrize("case", list(V5_CASES))
+def test_conv_v5_288x256(case, monkeypatch):
+    """288x256 tile / 32-element K steps / four stages (Cout % 256 == 0), forced with LT_CONV_V5=1, vs torch (bf16)."""
+    monkeypatch.setenv("LT_CONV_V5", "1")
+    nd, N, cin, cout, k, s, p, sp, with_res = V5_CASES[case]
+    g = torch.Generator().manual_seed(len(case) * 5 + cin)
+    x = torch.randn(N, cin, *sp, generator=g)
+    w = torch.randn(cout, cin, *([k] * nd), generator=g) * (1.0 / (cin * k ** nd) ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    bn = _bn(cout, g)
+    conv = F.conv2d if nd == 2 else F.conv3d
+    pre = _bn_ref(conv(bf16_round(x), bf16_round(w), bias, s, p), bn)
+    res = torch.randn(pre.shape, generator=g) if with_res else None
+    ref = torch.relu(pre + bf16_round(res)) if with_res else torch.relu(pre)
+    out = run_conv(x, w, bias, bn, s, p, torch.bfloat16, H.TILE3_288, relu=True, residual=res)
+    check("conv_v5/%s/forced" % case, out, ref, 1.5e-2)
+    out3 = run_conv(x, w, bias, bn, s, p, torch.bfloat16, H.TILE3_288, relu=False, relu_pre=True, residual=res)
+    ref3 = torch.relu(pre) + bf16_round(res) if with_res else torch.relu(pre)
+    check("conv_v5/%s/relu_pre" % case, out3, ref3, 1.5e-2)
