@@ -1001,7 +1001,7 @@ int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_ta
         const char* v5e = getenv("LT_CONV_V5");
         const long long tiles_m5 = cdiv(a.M, BM3), nblk5 = tiles_m5 * (cout_pad / 256);
         const bool fits5 = cout_pad % 256 == 0 && a.k_pad % 32 == 0 && max_taps <= 64;
-        const bool want5 = v5e ? v5e[0] == '1' : (nblk5 >= 200 && tiles_m5 * BM3 - a.M <= a.M / 16 && a.k_pad >= 256);
+        const bool want5 = v5e ? v5e[0] == '1' : (nblk5 >= 200 && tiles_m5 * BM3 - a.M <= a.M / 16 && a.k_pad >= 64);
         if (fits5 && want5) {
             const PhaseArg& q0 = a.phase[0];
             const bool pw5 = q0.ntaps == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.pd == 0 && a.ph == 0 && a.pw == 0 && a.osd == 1 &&
