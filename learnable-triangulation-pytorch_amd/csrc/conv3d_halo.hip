@@ -1149,6 +1149,228 @@ __global__ __launch_bounds__(512) void conv3d_halo7_kernel(const HaloArgs a) {
                                                          rp6, rp7, cst);
 }
 
+// ---- 7^3 kernel, kd-register-blocked variant ------------------------------------------------------------------------------------
+// conv3d_halo7_kernel reads five fragments from LDS per four MFMAs (one voxel fragment per output plane + the tap's weights) and
+// is bound by those reads (81 of 105 cycles per tap).  Output plane td and tap plane kd meet in halo plane hd = td + kd, so for a
+// fixed (kh, kw) ONE voxel fragment of plane hd serves every (td, kd) pair on that diagonal: a compute wave now owns two h rows
+// of all four output planes (four accumulator tiles, one per td), keeps the seven kd weight fragments of the current (kh, kw)
+// in registers and sweeps the ten halo planes -- 10 + 7 fragment reads per 28 MFMAs instead of 35.  A chunk of the weight ring
+// is the seven kd slabs of one (kh, kw); the next chunk's slabs are read into the other register set while this one computes;
+// the whole tap nest is unrolled (49 chunks), every LDS offset is an immediate.
+constexpr int h7_lpos(int hd) { return hd < 6 ? hd : 2 * hd - 5; }                  // position of A_hd in a chunk's read stream
+// global stream position of A_hd of chunk c (49 chunks, 17 entries each but the last, after the 7 entries of B(0)), and how far the
+// stream must have been issued before that fragment is waited for
+constexpr int h7_gpos(int c, int hd) { return 7 + 17 * c + (c == 48 ? hd : h7_lpos(hd)); }
+constexpr int h7_target(int c, int hd, int look, int gend) { return h7_gpos(c, hd) + 1 + look < gend ? h7_gpos(c, hd) + 1 + look : gend; }
+template <typename T>
+__global__ __launch_bounds__(512) void conv3d_halo7b_kernel(const HaloArgs a) {
+    constexpr int KS = 7, CIN = 32, CP = 16, TD = 4, TH = 8, TW = 8, TPC = 7, NBUF = 5;
+    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, 4> C;
+    static_assert(sizeof(T) == 2, "bf16 only");
+    constexpr int MF = C::MF, NVV = C::NVV, VPR = C::VPR, CINB = C::CINB;
+    static_assert(MF == 16 && NVV == 4 && C::SW::FSH == 0 && C::SW::FA == 0 && C::SW::FC == 0 && C::SLAB == 1024 && C::WCH == TPC * 1024, "7^3 32->16 layout");
+    static_assert(C::HALO_BYTES + NBUF * C::WCH <= 160 * 1024, "halo + weight ring must fit LDS");
+    typedef typename Mma<T, MF>::acc_t acc_t;
+    constexpr int NCH = KS * KS;                         // 49 chunks: c = kh*7 + kw, each the 7 kd slabs of that (kh, kw)
+    static_assert(NCH == 49, "h7_gpos assumes 49 chunks");
+    constexpr int KDSTEP = C::HH * C::PW * CINB;         // bytes per d-plane of the halo image
+    constexpr int NI_H = C::HALO_BYTES / 1024;
+    constexpr int HDN = TD + KS - 1;                     // 10 halo planes
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned lds_w = lds0 + C::HALO_BYTES;
+
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page_h;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool loader = wave >= 4;
+    const int wl = wave & 3;
+    constexpr int P = KS / 2;
+
+    const int tps = a.tiles_d * a.tiles_h * a.tiles_w;
+    int n, tix;
+    if (a.xcd_pin) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        n = xcd + 8 * (j / tps);
+        tix = j % tps;
+    } else {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        n = lin / tps;
+        tix = lin % tps;
+    }
+    const int w0 = (tix % a.tiles_w) * TW;
+    const int h0 = ((tix / a.tiles_w) % a.tiles_h) * TH;
+    const int d0 = (tix / (a.tiles_w * a.tiles_h)) * TD;
+
+    if (loader) {
+        // ================================= loader waves =================================
+        const T* __restrict__ x = (const T*)a.x + (size_t)n * a.D * a.H * a.W * CIN;
+        const T* __restrict__ w = (const T*)a.w;
+        for (int i = wl; i < NI_H; i += 4) {
+            const int q = i * 64 + lane;
+            const int hv = q / NVV, pv = q % NVV;
+            const int hw_ = hv % C::PW, hh_ = (hv / C::PW) % C::HH, hd_ = hv / (C::PW * C::HH);
+            const int lv = pv ^ C::fswz(hd_, hh_, hw_);
+            const int id = d0 - P + hd_, ih = h0 - P + hh_, iw = w0 - P + hw_;
+            const bool ok = hv < C::HV && hw_ < C::HW && ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : zero_page;
+            dma16h(src, lds0 + i * 1024);
+        }
+        // chunk c = (kh, kw): slab kd is tap kd*49 + c; this loader carries kd = wl (and wl + 4 when < 7)
+        const int pv = lane % NVV, col = lane / NVV;
+        const int lv = pv ^ ((-(col / VPR)) & (NVV - 1));
+        const T* wsrc0 = w + (size_t)col * a.k_pad + (size_t)wl * NCH * CIN + lv * C::VEC;
+        const T* wsrc1 = wsrc0 + (size_t)4 * NCH * CIN;
+        const bool two = wl + 4 < KS;
+        const int dpc = two ? 2 : 1;
+        auto stage_w = [&](int c) {
+            const unsigned dst = lds_w + (c % NBUF) * C::WCH;
+            dma16h(wsrc0 + (size_t)c * CIN, dst + wl * 1024);
+            if (two) dma16h(wsrc1 + (size_t)c * CIN, dst + (wl + 4) * 1024);
+        };
+#pragma unroll
+        for (int c = 0; c < NBUF - 1; ++c) stage_w(c);
+        for (int c = 0; c < NCH; ++c) {
+            // chunks <= c+1 (and, before them, the halo) must have landed; at most NBUF-3 younger chunks stay in flight
+            int younger = NCH - 2 - c;
+            if (younger > NBUF - 3) younger = NBUF - 3;
+            if (younger < 0) younger = 0;
+            wait_vmcnt_h(younger * dpc);
+            asm volatile("s_barrier" ::: "memory");
+            if (c + NBUF - 1 < NCH) stage_w(c + NBUF - 1);
+        }
+        asm volatile("s_barrier" ::: "memory");          // the compute waves' "done with the LDS images" barrier
+        return;
+    }
+
+    // ================================= compute waves =================================
+    // wave -> output rows th = 2 wave + (r15 >> 3), tw = r15 & 7 of ALL four planes td (accumulator tile td)
+    const int r15 = lane & 15, lvb = lane >> 4;
+    const int th = 2 * wave + (r15 >> 3), tw = r15 & 7;
+    float cbi, csc, csf;
+    cbi = a.bias ? a.bias[r15] : 0.f; csc = a.scale ? a.scale[r15] : 1.f; csf = a.shift ? a.shift[r15] : 0.f;
+    constexpr int E_LPR = CP / C::VEC, E_RPP = 64 / E_LPR;   // 2 lanes per output row, 32 rows per iteration, 2 iterations
+    const bool vec_epi = (a.Cout % C::VEC == 0) && (a.ldc % C::VEC == 0);
+    const int cq = (lane % E_LPR) * C::VEC;
+    auto row_off = [&](int row) -> size_t {               // staging row = td*16 + rr  ->  element offset of (voxel, channel cq)
+        const int td = row >> 4, rr = row & 15;
+        return ((((size_t)n * a.D + d0 + td) * a.H + h0 + 2 * wave + (rr >> 3)) * a.W + w0 + (rr & 7)) * a.ldc + cq;
+    };
+    const bool has_res = a.res != nullptr;
+    uint4 rp0 = make_uint4(0, 0, 0, 0), rp1 = rp0;
+    if (vec_epi && has_res && cq < a.Cout) {
+        rp0 = *(const uint4*)((const T*)a.res + row_off(lane / E_LPR));
+        rp1 = *(const uint4*)((const T*)a.res + row_off(lane / E_LPR + E_RPP));
+    }
+    unsigned base0[4], base1[4];                         // halo fragment bases per swizzle variant (kw & 3): planes 0-4 / 5-9
+#pragma unroll
+    for (int vv = 0; vv < 4; ++vv) {
+        base0[vv] = lds0 + (th * C::PW + tw) * CINB + ((lvb ^ ((tw + vv) & 3)) << 4);
+        base1[vv] = base0[vv] + 5 * KDSTEP;
+    }
+    const int bsw = (-(r15 / VPR)) & (NVV - 1);
+    const unsigned bbase = lds_w + r15 * CINB + ((lvb ^ bsw) << 4);
+
+    acc_t acc[TD];
+#pragma unroll
+    for (int i = 0; i < TD; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+
+    // global read stream: [B(0) x 7] + per chunk c < 48: [A0..A5, B'0, A6, B'1, A7, B'2, A8, B'3, A9, B'4, B'5, B'6] (B' = chunk c+1)
+    //                                + last chunk: [A0..A9];  LOOK entries of lookahead (the first B' of a chunk sits at position 6,
+    //                                so the lookahead out of the previous chunk never reaches weights that may not have landed)
+    constexpr int LOOK = 6, SLEN = 17, GEND = 7 + SLEN * (NCH - 1) + HDN;
+    V16 fa[HDN], fbk[2][KS];
+    auto issue = [&](auto gic) {
+        constexpr int gi = decltype(gic)::value;
+        if constexpr (gi < 7) {
+            lds_read16<gi * 1024>(fbk[0][gi], bbase);                              // chunk 0 lives in ring slot 0
+        } else {
+            constexpr int c = (gi - 7) / SLEN < NCH - 1 ? (gi - 7) / SLEN : NCH - 1;
+            constexpr int q = gi - 7 - c * SLEN;
+            constexpr int kh = c / KS, kw = c % KS;
+            constexpr bool isA = q < 6 || c == NCH - 1 || (q <= 13 && (q & 1));   // positions 7, 9, 11, 13 are A6..A9
+            if constexpr (isA) {
+                constexpr int hd = (q < 6 || c == NCH - 1) ? q : (q + 5) / 2;
+                constexpr int imm = (hd < 5 ? hd : hd - 5) * KDSTEP + (kh * C::PW + kw) * CINB;
+                if constexpr (hd < 5) lds_read16<imm>(fa[hd], base0[kw & 3]);
+                else lds_read16<imm>(fa[hd], base1[kw & 3]);
+            } else {
+                constexpr int kd = q <= 12 ? (q - 6) / 2 : q - 10;                 // 6,8,10,12 -> 0..3; 14,15,16 -> 4..6
+                lds_read16<((c + 1) % NBUF) * C::WCH + kd * 1024>(fbk[(c + 1) & 1][kd], bbase);
+            }
+        }
+    };
+    static_for<0, NCH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        asm volatile("s_barrier" ::: "memory");          // the loaders have chunks <= c+1 (and, the first time, the halo) in LDS
+        if constexpr (c == 0) {
+            static_for<0, 7 + LOOK>([&](auto gic) { issue(gic); });   // B(0) and the first LOOK entries of chunk 0
+        }
+        static_for<0, HDN>([&](auto hc) {
+            constexpr int hd = decltype(hc)::value;
+            constexpr int gp = h7_gpos(c, hd);
+            constexpr int prev_target = (c == 0 && hd == 0) ? 7 + LOOK : (hd == 0 ? h7_target(c - 1, HDN - 1, LOOK, GEND) : h7_target(c, hd - 1, LOOK, GEND));
+            constexpr int target = h7_target(c, hd, LOOK, GEND);
+            static_for<prev_target, target>([&](auto gic) { issue(gic); });
+            lgkm_wait<target - gp - 1>();
+            frag_ready(fa[hd]);
+            if constexpr (hd == 0) {
+#pragma unroll
+                for (int kd = 0; kd < KS; ++kd) frag_ready(fbk[c & 1][kd]);
+            }
+#pragma unroll
+            for (int td = 0; td < TD; ++td) {
+                if (hd - td >= 0 && hd - td < KS) LT_HMMA(acc[td], fa[hd], fbk[c & 1][hd - td]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the halo / weight images
+
+    // ---- epilogue: this wave's 64 rows (td*16 + rr) x 16 channels through a private fp32 LDS tile ----
+    constexpr int EP_LD = CP + 4;
+    float* ep = (float*)(smem + wave * (64 * EP_LD * 4));
+#pragma unroll
+    for (int td = 0; td < TD; ++td)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ep[(td * 16 + (lane >> 4) * 4 + e) * EP_LD + r15] = (acc[td][e] + cbi) * csc + csf;
+    const EpiFloors fl = epi_floors(a.flags);
+    if (vec_epi) {
+        if (cq < a.Cout) {
+            const unsigned no_res = has_res ? 0u : 0x80008000u;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = lane / E_LPR + it * E_RPP;
+                const uint4 resv = it == 0 ? rp0 : rp1;
+                const float* src = ep + row * EP_LD + cq;
+                const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
+                const float vv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                const unsigned ru[4] = {resv.x | no_res, resv.y | no_res, resv.z | no_res, resv.w | no_res};
+                unsigned ou[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    ou[e] = pack_bf16x2(epi_apply(vv[2 * e], fl, __uint_as_float(ru[e] << 16)), epi_apply(vv[2 * e + 1], fl, __uint_as_float(ru[e] & 0xffff0000u)));
+                *(uint4*)((T*)a.y + row_off(row)) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+            }
+        }
+    } else {
+        for (int idx = lane; idx < 64 * CP; idx += 64) {
+            const int row = idx / CP, cc = idx - row * CP;
+            if (cc >= a.Cout) continue;
+            const size_t off = row_off(row) - cq + cc;
+            const float rr = has_res ? elt<T>::ld((const T*)a.res + off) : -0.0f;
+            elt<T>::st((T*)a.y + off, epi_apply(ep[row * EP_LD + cc], fl, rr));
+        }
+    }
+}
+
 int launch_halo7(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<bf16_t, 7, 32, 16, 4, 8, 8, 7, 4> C;
     constexpr int LDS = C::HALO_BYTES + 5 * C::WCH;
@@ -1159,6 +1381,18 @@ int launch_halo7(const HaloArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const long long nblk = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
+    const char* kdb = getenv("LT_HALO_7B");              // kd-register-blocked variant: default; LT_HALO_7B=0 selects the tap-major kernel
+    if (!kdb || kdb[0] != '0') {                         // (read per call: the tests run both)
+        auto kern_b = conv3d_halo7b_kernel<bf16_t>;
+        static bool attr_b = false;
+        if (!attr_b) {
+            (void)hipFuncSetAttribute((const void*)kern_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_b = true;
+        }
+        hipLaunchKernelGGL(kern_b, dim3((unsigned)nblk), dim3(512), LDS, s, a);
+        LT_CHECK_LAUNCH("lt_conv_fwd(halo 7^3, kd-blocked)");
+        return LT_OK;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), LDS, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(halo 7^3)");
     return LT_OK;

@@ -438,3 +438,24 @@ def test_conv_v5_288x256(case, monkeypatch):
     out3 = run_conv(x, w, bias, bn, s, p, torch.bfloat16, H.TILE3_288, relu=False, relu_pre=True, residual=res)
     ref3 = torch.relu(pre) + bf16_round(res) if with_res else torch.relu(pre)
     check("conv_v5/%s/relu_pre" % case, out3, ref3, 1.5e-2)
+
+
+@pytest.mark.parametrize("kdb", ["1", "0"])
+@pytest.mark.parametrize("case", ["halo_7x7_32_16", "halo_7x7_32_16_big"])
+def test_conv3d_halo7_variants(case, kdb, monkeypatch):
+    """Both 7^3 loader-wave kernels: kd-register-blocked (default, LT_HALO_7B=1) and tap-major (LT_HALO_7B=0)."""
+    monkeypatch.setenv("LT_HALO_7B", kdb)
+    N, cin, cout, k, sp, dts = HALO_CASES[case]
+    g = torch.Generator().manual_seed(len(case) + 3)
+    x = torch.randn(N, cin, *sp, generator=g)
+    w = torch.randn(cout, cin, k, k, k, generator=g) * (1.0 / (cin * k ** 3) ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    bn = _bn(cout, g)
+    res = torch.randn(N, cout, *sp, generator=g)
+    rd = bf16_round
+    ref = torch.relu(_bn_ref(F.conv3d(rd(x), rd(w), bias, 1, k // 2), bn) + rd(res))
+    out = run_conv(x, w, bias, bn, 1, k // 2, torch.bfloat16, H.TILE_HALO, relu=True, residual=res)
+    check("conv3d_halo7/kdb=%s/%s/res" % (kdb, case), out, ref, 1.5e-2)
+    ref2 = _bn_ref(F.conv3d(rd(x), rd(w), bias, 1, k // 2), bn)
+    out2 = run_conv(x, w, bias, bn, 1, k // 2, torch.bfloat16, H.TILE_HALO, relu=False, residual=None)
+    check("conv3d_halo7/kdb=%s/%s/plain" % (kdb, case), out2, ref2, 1.5e-2)
