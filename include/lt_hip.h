@@ -190,7 +190,10 @@ int lt_triangulate_dlt(const float* proj, const float* points, const float* conf
  * Basic3DBlock(32,32,1) x 2, then output_layer = Conv3d(32, J, 1)): one pass over the volume
  * instead of three.  bf16 activations, 32 input channels, inner widths 32, last width <= 32;
  * intermediate activations are rounded to bf16 exactly where separate launches would store them;
- * the last layer stores fp32 rows of ldy == cout[last] floats.  x: rows x 32 bf16 (channels-last
+ * the last layer stores fp32: plane == 0 -> rows of ldy == cout[last] floats (channels-last);
+ * plane > 0 -> planar, y[((row / plane) * cout[last] + c) * plane + row % plane] with plane = voxels
+ * per sample (a multiple of 64 that divides rows) -- the (N, J, V, V, V) layout of the reference's
+ * volumes, which is what lt_softargmax3d_fwd streams fastest.  x: rows x 32 bf16 (channels-last
  * volume), rows % 64 == 0.  weight[i]: the lt_conv_fwd packing [32][k_pad[i]] (k = input channel).
  * -------------------------------------------------------------------------------------------*/
 #define LT_PWCHAIN_MAX 3
@@ -207,6 +210,7 @@ typedef struct {
     const float* bias[LT_PWCHAIN_MAX];   /* 32 entries each (padded), or NULL */
     const float* scale[LT_PWCHAIN_MAX];
     const float* shift[LT_PWCHAIN_MAX];
+    int64_t plane;                       /* 0: channels-last output; > 0: planar output, voxels per sample */
 } lt_pwchain_desc;
 int lt_pwchain_fwd(const lt_pwchain_desc* desc, const void* x, void* y, void* stream);
 

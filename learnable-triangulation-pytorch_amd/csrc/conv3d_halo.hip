@@ -27,7 +27,7 @@ using namespace lt;
 
 namespace {
 
-__device__ uint4 g_zero_page_h[2];
+__device__ uint4 g_zero_page_h[4];   // 64 zero bytes: DMA source of padding voxels, and the 'residual' of layers without one
 
 #ifdef LT_TRACE
 // profiling build: shader-clock accounting of the persistent kernel's per-tile phases, written by wave 0 of every 8th workgroup:
@@ -132,10 +132,12 @@ __device__ __forceinline__ void wait_vmcnt_h(int n) {
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
         case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
         case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
         case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // conservative
@@ -933,6 +935,347 @@ __global__ __launch_bounds__(512) void conv3d_halo_persist_kernel(const HaloArgs
 #undef LT_TRH
 }
 
+// ---- column-walking 3^3 kernel: sliding window of halo planes, epilogue of tile i under the MFMAs of tile i+1 ------------------
+// Shader-clock accounting of the persistent kernel above (32 samples, 64^3): 6.8k cycles per tile = 0.7k waiting for the halo
+// + 0.5k tile arithmetic + 0.5k residual issue + 3.6k tap loop (108 MFMAs = 3.5k) + 1.5k epilogue, all serial in the consumer
+// waves; and the halo of tile i+1, requested right after the barrier of tile i, lands ~5.8k cycles later: one 38 KB halo in
+// flight per CU is what the memory system is given (Little's law: 256 x 38 KB / 2.7 us = 3.6 TB/s, the measured rate).  Here:
+//   * a workgroup walks COLUMNS of tiles along d: consecutive tiles share two of their six halo planes, so the halo becomes a
+//     stream of 4-plane groups (25 KB per tile instead of 38: -33 % L2->LDS traffic) in a ring of four groups -- two being
+//     read, two in flight or landed (51 KB requested ahead per CU);
+//   * the epilogue of tile i-1 (affine, ReLU floors, residual, 8-byte stores) is issued in eight pieces between the MFMA
+//     units of tile i, out of a copy of the accumulators; the residual of tile i is requested in the middle of its own tap
+//     loop, after the pieces have consumed the previous one; tile coordinates advance by a stride (no divisions per tile).
+template <typename T>
+__global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, const int total_cols) {
+    constexpr int KS = 3, CIN = 32, CP = 32, TD = 4, TH = 8, TW = 8;
+    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, 9, 2> C;
+    static_assert(sizeof(T) == 2, "bf16 only");
+    constexpr int MF = C::MF, SM = C::SM, SN = C::SN, G = C::G, NACC = C::NACC, NVV = C::NVV, VPR = C::VPR, CINB = C::CINB;
+    static_assert(MF == 32 && SM == 2 && SN == 1 && G == 2 && NACC == 16 && NVV == 4, "3^3 32->32 bf16 layout");
+    static_assert(C::SW::FA == 0 && C::SW::FC == 0 && C::SW::FB == 0, "the swizzle must not depend on the plane");
+    constexpr int W_BYTES = ((C::NTAPS * C::SLAB + 1023) / 1024) * 1024;
+    constexpr int PLANE_V = C::HH * C::PW;               // voxel slots of one halo plane
+    constexpr int PLANE_B = PLANE_V * CINB;
+    constexpr int GROUP_B = TD * PLANE_B;                // one tile step = TD new planes
+    constexpr int NI_G = GROUP_B / 1024;
+    static_assert(GROUP_B % 1024 == 0, "a plane group must be whole DMA wave-instructions");
+    static_assert(W_BYTES + 4 * GROUP_B <= 160 * 1024, "weights + four plane groups must fit LDS");
+    typedef typename Mma<T, MF>::acc_t acc_t;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned lds_halo = lds0 + W_BYTES;            // ring of four plane groups
+
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page_h;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool loader = wave >= 4;
+    const int wl = wave & 3;
+    const T* __restrict__ w = (const T*)a.w;
+    const int tpc = a.tiles_d, ngc = a.tiles_d + 1;      // tiles / plane groups per column
+    const int cps = a.tiles_h * a.tiles_w;               // columns per sample
+    const int ncol = (total_cols - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+
+    auto col_of = [&](int v, int& n, int& h0, int& w0) {  // v % 8 = XCD of this workgroup (gridDim.x % 8 == 0)
+        const int xcd = v & 7, j = v >> 3;
+        int cix;
+        if (a.xcd_pin) {
+            n = xcd + 8 * (j / cps);
+            cix = j % cps;
+        } else {
+            const int lin = xcd * (total_cols >> 3) + j;     // total_cols % 8 == 0
+            n = lin / cps;
+            cix = lin % cps;
+        }
+        w0 = (cix % a.tiles_w) * TW;
+        h0 = (cix / a.tiles_w) * TH;
+    };
+
+    // ---- weights: every tap slab, once (all eight waves) ----
+    constexpr int NI_W = W_BYTES / 1024;
+    for (int i = wave; i < NI_W; i += 8) {
+        const int q = i * 64 + lane;
+        const int pv = q % NVV, col = (q / NVV) % CP, tap = q / (NVV * CP);
+        const int lv = pv ^ ((-(col / VPR)) & (NVV - 1));
+        const void* src = tap < C::NTAPS ? (const void*)(w + (size_t)col * a.k_pad + tap * CIN + lv * C::VEC) : zero_page;
+        dma16h(src, lds0 + i * 1024);
+    }
+
+    if (loader) {
+        // ================================= loader waves =================================
+        // stream of plane groups: column c of this workgroup contributes groups 0..tpc (group g = planes 4g-1 .. 4g+2 of the
+        // column), stream index S = c * ngc + g lives in ring slot S & 3; tile (c, k) reads S and S + 1.
+        // The (plane, row, column, k-vector) a lane fetches for DMA piece i is the same for every group: decode it ONCE (the
+        // divisions below cost ~60 VALU instructions per piece, and the loaders share their SIMDs' issue slots with the
+        // consumers' MFMA stream); per group only the plane validity and one base pointer change.
+        const int total_groups = ncol * ngc;
+        constexpr int MAXP = (NI_G + 3) / 4;              // pieces per wave and group
+        int poff[MAXP], pmeta[MAXP];                      // element offset from (plane 4g-1, row h0, column w0); pj << 16 | hh << 8 | hw
+#pragma unroll
+        for (int m = 0; m < MAXP; ++m) {
+            const int q = (wl + 4 * m) * 64 + lane;
+            const int pj = q / (PLANE_V * NVV), r = q - pj * (PLANE_V * NVV);
+            const int hv = r / NVV, pv = r % NVV;
+            const int hh_ = hv / C::PW, hw_ = hv - hh_ * C::PW;
+            const int lv = pv ^ C::fswz(0, hh_, hw_);
+            poff[m] = ((pj * a.H + hh_ - 1) * a.W + hw_ - 1) * CIN + lv * C::VEC;
+            pmeta[m] = (pj << 16) | (hh_ << 8) | hw_;
+        }
+        int issued = 0, icol = 0, ig = 0, in, ih0, iw0;
+        unsigned okhw = 0;                                // bit m: piece m's (row, column) lies inside the sample for this column
+        auto enter_col = [&](int v) {
+            col_of(v, in, ih0, iw0);
+            okhw = 0;
+#pragma unroll
+            for (int m = 0; m < MAXP; ++m) {
+                const int hh_ = (pmeta[m] >> 8) & 255, hw_ = pmeta[m] & 255;
+                const bool ok = hw_ < C::HW && ((unsigned)(ih0 - 1 + hh_) < (unsigned)a.H) & ((unsigned)(iw0 - 1 + hw_) < (unsigned)a.W);
+                okhw |= ok ? (1u << m) : 0u;
+            }
+        };
+        enter_col(blockIdx.x);
+        auto issue_next = [&]() {
+            const int d_first = 4 * ig - 1;
+            // plane d_first, row h0, column w0 of sample n (outside the tensor for the padding planes: only formed, never read)
+            const T* __restrict__ gb = (const T*)a.x + (((ptrdiff_t)in * a.D + d_first) * a.H + ih0) * (ptrdiff_t)a.W * CIN + (ptrdiff_t)iw0 * CIN;
+            const unsigned dst = lds_halo + (issued & 3) * GROUP_B;
+#pragma unroll
+            for (int m = 0; m < MAXP; ++m) {
+                if (wl + 4 * m < NI_G) {
+                    const bool ok = ((okhw >> m) & 1u) && (unsigned)(d_first + (pmeta[m] >> 16)) < (unsigned)a.D;
+                    const void* src = ok ? (const void*)(gb + poff[m]) : zero_page;
+#ifdef LT_ABL_NO_A
+                    if (a.N < 0)
+#endif
+                    dma16h(src, dst + (wl + 4 * m) * 1024);
+                }
+            }
+            ++issued;
+            if (++ig == ngc) {
+                ig = 0;
+                if (++icol < ncol) enter_col(blockIdx.x + icol * gridDim.x);
+            }
+        };
+        const int mine = (NI_G - wl + 3) / 4;             // DMA pieces of one group requested by this wave
+        for (int k = 0; k < 4 && issued < total_groups; ++k) issue_next();
+        int sidx = 0, k = 0;
+        const int ntile = ncol * tpc;
+        for (int ti = 0; ti < ntile; ++ti) {
+            const int ahead = issued - sidx - 2;          // groups requested beyond the two this tile reads: 0, 1 or 2
+            wait_vmcnt_h(ahead > 0 ? ahead * mine : 0);
+            asm volatile("s_barrier" ::: "memory");       // A: groups sidx, sidx + 1 landed; the consumers are done with tile ti - 1
+            while (issued <= sidx + 3 && issued < total_groups) issue_next();
+            ++sidx;
+            if (++k == tpc) { k = 0; ++sidx; }
+        }
+        return;
+    }
+
+    // ================================= consumer waves =================================
+    // wave = output plane td of the tile; fragment i covers rows th = 4 i + v / 8, tw = v % 8 of that plane
+    const int lvb = lane >> 5;
+    int abase[KS][G][SM];                                 // in-plane byte offset of (voxel, k-vector), per kw
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+        const int r = i * MF + (lane & (MF - 1));
+        const int tw = r % TW, th = r / TW;
+        const int own = (th * C::PW + tw) * CINB;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+            const int f = C::fswz(0, th, tw + kw);
+#pragma unroll
+            for (int g = 0; g < G; ++g) abase[kw][g][i] = own + (((lvb + 2 * g) ^ f) << 4);
+        }
+    }
+    // MFMA row r of the transposed product (= the weight row this lane feeds) carries output channel chan(r), chosen so that
+    // the 16 result registers of lane (voxel, h) are channels 8h .. 8h+7 and 16+8h .. 16+8h+7: two 16-byte runs, loaded
+    // (residual) and stored as such.  The MFMA's own row order (r = 8q + 4h + j in register 4q + j) would give four 8-byte runs
+    // per lane: twice the vector-memory instructions, and their issue (~65 cycles each for 64 scattered lanes) is paid by the
+    // wave that also issues the MFMAs.
+    unsigned bbase[G][SN];
+    {
+        const int r = lane & 31;
+        const int chan = 16 * (r >> 4) + 8 * ((r >> 2) & 1) + 4 * ((r >> 3) & 1) + (r & 3);
+        const int bsw = (-(chan / VPR)) & (NVV - 1);
+#pragma unroll
+        for (int g = 0; g < G; ++g) bbase[g][0] = lds0 + chan * CINB + (((lvb + 2 * g) ^ bsw) << 4);
+    }
+    constexpr int RPU = SM + SN;
+    constexpr int PDU = 4;
+    constexpr int RING = PDU + 1;
+    constexpr int NU = C::NTAPS * G;
+    static_assert((PDU + 1) * RPU <= 15, "lookahead exceeds the lgkmcnt counter");
+
+    // transposed product D[co][voxel]: lane (voxel v = lane & 31 of fragment i, half h = lane >> 5) holds channels
+    // c(e) = 8 h + e (e < 8) and 16 + 8 h + (e - 8) of its voxel; (acc + bias) * scale + shift folded into one fma per value
+    const int vl = lane & 31, hh = lane >> 5;
+    float esc[16], esf[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = 16 * (e >> 3) + 8 * hh + (e & 7);
+        const float bi = a.bias ? a.bias[c] : 0.f, sc = a.scale ? a.scale[c] : 1.f, sf = a.shift ? a.shift[c] : 0.f;
+        esc[e] = sc;
+        esf[e] = bi * sc + sf;
+    }
+    const EpiFloors fl = epi_floors(a.flags);
+    const bool has_res = a.res != nullptr;
+    const unsigned no_res = has_res ? 0u : 0x80008000u;  // zeros -> -0.0 pairs: v + -0.0 == v
+    const size_t ldc = (size_t)a.ldc;
+    const size_t voff0 = (((size_t)wave * a.H + (vl >> 3)) * a.W + (vl & 7)) * ldc + 8 * hh;
+    const size_t vstep = (size_t)4 * a.W * ldc;          // fragment i -> th + 4
+    const size_t dstep = (size_t)TD * a.H * a.W * ldc;   // next tile of the column
+    const size_t rstep = has_res ? vstep : 0;            // without a residual every piece reads the zero page
+
+    int n, h0, w0;
+    col_of(blockIdx.x, n, h0, w0);
+    size_t tbase = (((size_t)n * a.D * a.H + h0) * a.W + w0) * ldc + voff0;
+    size_t pbase = 0;                                    // output offset of the tile whose epilogue is pending
+
+    acc_t acc[SM], pacc[SM];
+    uint4 rq[4], rqn[4];                                  // residual of the pending tile / of the tile being computed
+    unsigned ha[KS][G][SM];
+    unsigned hd1 = 0, hd2 = 0;                            // plane base of kd = 1 minus kd = 0, kd = 2 minus kd = 1
+    V16 fa[RING][SM], fb[RING][SN];
+
+    auto load_unit = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int tap = u / G, g = u % G, slot = u % RING;
+        constexpr int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        constexpr int imm = (kh * C::PW + kw) * CINB;
+        if constexpr (u > 0 && u % (9 * G) == 0) {       // first unit of the next kd: move the twelve fragment bases one plane on
+            const unsigned dlt = kd == 1 ? hd1 : hd2;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+                    for (int ii = 0; ii < SM; ++ii) ha[kk][gg][ii] += dlt;
+        }
+        static_for<0, SM>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            lds_read16<imm>(fa[slot][i], ha[kw][g][i]);
+        });
+        lds_read16<tap * C::SLAB>(fb[slot][0], bbase[g][0]);
+    };
+    auto epi_piece = [&](auto pc) {                       // piece p of the pending tile: fragment p / 2, 8-channel run p % 2
+        constexpr int p = decltype(pc)::value, I = p >> 1, Q = p & 1;
+        const unsigned rr[4] = {rq[p].x | no_res, rq[p].y | no_res, rq[p].z | no_res, rq[p].w | no_res};
+        unsigned o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int e = 8 * Q + 2 * d;
+            float v0 = fmaf(pacc[I][e], esc[e], esf[e]);
+            float v1 = fmaf(pacc[I][e + 1], esc[e + 1], esf[e + 1]);
+            v0 = epi_apply(v0, fl, __uint_as_float(rr[d] << 16));
+            v1 = epi_apply(v1, fl, __uint_as_float(rr[d] & 0xffff0000u));
+            o[d] = pack_bf16x2(v0, v1);
+        }
+#ifdef LT_ABL_NO_STORE
+        if (a.N < 0)
+#endif
+        *(uint4*)((T*)a.y + pbase + I * vstep + 16 * Q) = make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    auto tap_loop = [&](auto epi_c) {
+        constexpr bool EPI = decltype(epi_c)::value;
+        static_for<0, PDU>([&](auto uc) { load_unit(uc); });
+        static_for<0, NU>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int slot = u % RING;
+            constexpr int ahead = (u + PDU < NU) ? PDU : NU - 1 - u;
+            if constexpr (u + PDU < NU) load_unit(std::integral_constant<int, u + PDU>{});
+            lgkm_wait<ahead * RPU>();
+#pragma unroll
+            for (int i = 0; i < SM; ++i) frag_ready(fa[slot][i]);
+            frag_ready(fb[slot][0]);
+#pragma unroll
+            for (int i = 0; i < SM; ++i) Mma<T, MF>::run(acc[i], fb[slot][0], fa[slot][i]);   // D[co][voxel]: weights first
+#ifndef LT_ABL_NO_EPI
+            if constexpr (EPI && u >= 2 && u < 26 && (u - 2) % 6 == 0) epi_piece(std::integral_constant<int, (u - 2) / 6>{});
+#endif
+            if constexpr (u == 0) {
+                // residual of THIS tile, requested a whole tap loop before the pieces under the next tile consume it (requested
+                // at unit 30 it arrived late: the first piece stalled ~1.3k cycles per tile).  Explicitly GLOBAL loads: a
+                // pointer selected between the residual and the zero page is a flat pointer to the compiler, and flat loads
+                // also count in lgkmcnt, which the fragment pipeline counts by hand
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                typedef const __attribute__((address_space(1))) u32x4* gq_t;
+                const unsigned long long rb = has_res ? (unsigned long long)(size_t)((const T*)a.res + tbase) : zp_bits;
+                static_for<0, 4>([&](auto pc) {
+                    constexpr int p = decltype(pc)::value;
+                    const u32x4 rv = *(gq_t)(rb + ((p >> 1) * rstep + 16 * (p & 1)) * sizeof(T));
+                    rqn[p] = make_uint4(rv[0], rv[1], rv[2], rv[3]);
+                });
+            }
+        });
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the weight slabs (and the constants)
+#ifdef LT_TRACE
+    long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
+    const long long tr_begin = LT_CLKH();
+    long long tr_last = tr_begin;
+#define LT_TRC(k_) { const long long c_ = LT_CLKH(); tr[k_] += c_ - tr_last; tr_last = c_; }
+#else
+#define LT_TRC(k_)
+#endif
+    int sidx = 0, k = 0, icol = 0;
+    const int ntile = ncol * tpc;
+    for (int ti = 0; ti < ntile; ++ti) {
+        // A: plane groups sidx, sidx + 1 have landed; every consumer is done with the tap loop of the previous tile
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        LT_TRC(1)
+        {
+            const unsigned p0 = lds_halo + ((sidx + (wave >> 2)) & 3) * GROUP_B + (wave & 3) * PLANE_B;
+            const unsigned p1 = lds_halo + ((sidx + ((wave + 1) >> 2)) & 3) * GROUP_B + ((wave + 1) & 3) * PLANE_B;
+            const unsigned p2 = lds_halo + ((sidx + ((wave + 2) >> 2)) & 3) * GROUP_B + ((wave + 2) & 3) * PLANE_B;
+            hd1 = p1 - p0; hd2 = p2 - p1;
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int i = 0; i < SM; ++i) ha[kw][g][i] = p0 + abase[kw][g][i];
+        }
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+            for (int e = 0; e < NACC; ++e) acc[i][e] = 0.f;
+        LT_TRC(2)
+        if (ti == 0) tap_loop(std::false_type{});
+        else tap_loop(std::true_type{});
+        LT_TRC(4)
+#pragma unroll
+        for (int i = 0; i < SM; ++i) pacc[i] = acc[i];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) rq[p] = rqn[p];
+        pbase = tbase;
+        ++sidx;
+        tbase += dstep;
+        if (++k == tpc) {                                // next column
+            k = 0; ++sidx;
+            if (++icol < ncol) {
+                col_of(blockIdx.x + icol * gridDim.x, n, h0, w0);
+                tbase = (((size_t)n * a.D * a.H + h0) * a.W + w0) * ldc + voff0;
+            }
+        }
+        LT_TRC(6)
+    }
+    static_for<0, 4>([&](auto pc) { epi_piece(pc); });   // the last tile's epilogue has nothing to hide under
+#ifdef LT_TRACE
+    if (wave == 0 && lane == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64) {   // same record as the persistent kernel
+        long long* o = g_trace_h + (blockIdx.x >> 3) * 8;
+        o[0] = LT_CLKH() - tr_begin;
+        for (int q = 1; q < 7; ++q) o[q] = tr[q];
+        o[7] = ntile;
+    }
+#endif
+#undef LT_TRC
+}
+
 // ---- 7^3 kernel with loader waves -------------------------------------------------------------------------------------------
 // PMC on the ring version above (7^3 32->16 at 64^3): 3.3 VALU + 3.4 SALU + 1.3 LDS instructions per MFMA and no LDS bank
 // conflicts -- with one workgroup per CU (the halo takes 123 KB) and so one compute wave per SIMD, the kernel was bound by
@@ -1423,6 +1766,30 @@ int launch_halo_persist(const HaloArgs& a, hipStream_t s) {
     return LT_OK;
 }
 
+template <typename T>
+int launch_halo_col(const HaloArgs& a, hipStream_t s) {
+    typedef HaloCfg<T, 3, 32, 32, 4, 8, 8, 9, 2> C;
+    constexpr int W_BYTES = ((C::NTAPS * C::SLAB + 1023) / 1024) * 1024;
+    constexpr int LDS = W_BYTES + 4 * 4 * C::HH * C::PW * C::CINB;
+    auto kern = conv3d_halo_col_kernel<T>;
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+        n_cu -= n_cu % 8;   // the column dealing assumes workgroup b runs on XCD b % 8
+        attr_set = true;
+    }
+    const int total_cols = a.N * a.tiles_h * a.tiles_w;  // % 8 == 0 (checked by the caller)
+    const int grid = total_cols < n_cu ? total_cols : n_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, total_cols);
+    LT_CHECK_LAUNCH("lt_conv_fwd(halo, column walk)");
+    return LT_OK;
+}
+
 template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF, int PD, bool LDR>
 int launch_halo(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF> C;
@@ -1476,6 +1843,13 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     // persistent variant: needs a few tiles per workgroup to amortise the weight load, and total % 8 == 0 for the XCD dealing
     static const bool no_persist = getenv("LT_HALO_NO_PERSIST") != nullptr;   // A/B
     if (bf && ks == 3 && cout_pad == 32 && c.Cout == 32 && c.ldc % 4 == 0 && c.Cin == 32 && nblk >= 1024 && nblk % 8 == 0 && !no_persist) {
+        // column walk (sliding plane window + overlapped epilogue) when every workgroup gets whole columns of >= 2 tiles
+        const char* nocol = getenv("LT_HALO_NO_COL");    // A/B, read per call
+        const long long cols = (long long)c.N * a.tiles_h * a.tiles_w;
+        if (!nocol && a.tiles_d >= 2 && cols % 8 == 0 && cols >= 256 && c.ldc % 8 == 0) {
+            int rc = launch_halo_col<bf16_t>(a, s);
+            return rc == LT_OK ? 1 : rc;
+        }
         int rc = launch_halo_persist<bf16_t, 32, 32>(a, s);
         return rc == LT_OK ? 1 : rc;
     }

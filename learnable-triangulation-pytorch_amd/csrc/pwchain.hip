@@ -14,8 +14,11 @@
 //     index (K slot s of block kb' <-> channel 16 kb' + 8 (s >> 2) + 4 h + (s & 3)); the contraction does not care about
 //     the order as long as the weights use the same one, so layers >= 2 load their weights with that permutation and the
 //     activations never leave the registers between layers;
-//   * the fp32 logits of 64 voxels go through a wave-private LDS tile to become one contiguous 64*J*4-byte run of
-//     16-byte stores (rows of J = 17 floats are not vector aligned on their own).
+//   * channels-last output: the fp32 logits of 64 voxels go through a wave-private LDS tile to become one contiguous
+//     64*J*4-byte run of 16-byte stores (rows of J = 17 floats are not vector aligned on their own);
+//   * planar output (desc.plane > 0, what the soft-argmax wants: one contiguous volume per joint): the same wave-private
+//     tile, laid out [J][64 voxels]: every channel of the tile is a 256-byte run = 16 lanes x 16 bytes (storing the result
+//     registers directly, 4 bytes per lane in 128-byte runs, measured 0.34 ms against 0.19 ms for the channels-last tile).
 // Intermediate activations are rounded to bf16 exactly where the separate launches would store them.
 #include "conv_common.h"
 
@@ -33,10 +36,11 @@ struct PwArgs {
     int k_pad[LT_PWCHAIN_MAX];
     int relu[LT_PWCHAIN_MAX];
     long long ntile;   // tiles of 64 voxels
+    long long plane;   // planar output: voxels per sample (a multiple of 64), else 0
     int cout_last;
 };
 
-template <int L>
+template <int L, bool PLANAR>
 __global__ __launch_bounds__(256) void pwchain_kernel(const PwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,6 +86,11 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const PwArgs a) {
     if (gw < a.ntile) load_tile(gw, xf);
     for (long long t = gw; t < a.ntile; t += nw) {
         const bool more = t + nw < a.ntile;
+        float* yp = nullptr;                             // planar: voxel 0 of tile t, channel 0
+        if (PLANAR) {
+            const long long smp = (t * 64) / a.plane;
+            yp = a.y + smp * J * a.plane + (t * 64 - smp * a.plane);
+        }
         if (more) load_tile(t + nw, xn);                 // next tile's 4 KB in flight under this tile's MFMAs
         f32x16 acc[2];
 #pragma unroll
@@ -120,6 +129,12 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const PwArgs a) {
                         for (int i = 0; i < 4; ++i) u[i] = pack_bf16x2(val[8 * kb + 2 * i], val[8 * kb + 2 * i + 1]);
                         xf[nt][kb].u = make_uint4(u[0], u[1], u[2], u[3]);
                     }
+                } else if (PLANAR) {                     // fp32 logits -> wave-private LDS tile [J][64 voxels]
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int c = (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (c < J) ep[c * 64 + 32 * nt + vl] = val[e];
+                    }
                 } else {                                 // fp32 logits -> wave-private LDS tile [64 voxels][J]
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
@@ -130,9 +145,14 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const PwArgs a) {
             }
         }
         // 64 * J floats = 16 J vectors of 16 bytes, contiguous in y (ldy == J, 64 voxels * J * 4 B is a multiple of 16)
-        float4* dst = (float4*)(a.y + (size_t)t * 64 * J);
-        const float4* src = (const float4*)ep;
-        for (int i = lane; i < 16 * J; i += 64) dst[i] = src[i];
+        if (PLANAR) {                                    // channel c of the tile: 64 floats = lanes 16 c .. 16 c + 15 of the sweep
+            for (int i = lane; i < 16 * J; i += 64)
+                *(float4*)(yp + (long long)(i >> 4) * a.plane + 4 * (i & 15)) = *(const float4*)(ep + 4 * i);
+        } else {
+            float4* dst = (float4*)(a.y + (size_t)t * 64 * J);
+            const float4* src = (const float4*)ep;
+            for (int i = lane; i < 16 * J; i += 64) dst[i] = src[i];
+        }
         if (more) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -142,9 +162,9 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const PwArgs a) {
     }
 }
 
-template <int L>
+template <int L, bool PLANAR>
 int launch_pw(const PwArgs& a, hipStream_t s) {
-    auto kern = pwchain_kernel<L>;
+    auto kern = pwchain_kernel<L, PLANAR>;
     const size_t lds = ((size_t)L * 96 + (size_t)4 * 64 * a.cout_last) * sizeof(float);
     long long blocks = (a.ntile + 3) / 4;
     if (blocks > 2048) blocks = 2048;                    // several tiles per wave: the weight/constant setup is amortised
@@ -178,13 +198,23 @@ extern "C" int lt_pwchain_fwd(const lt_pwchain_desc* d, const void* x, void* y, 
     }
     a.cout_last = d->cout[d->nlayers - 1];
     LT_REQUIRE(d->ldy == a.cout_last, LT_ERR_UNSUPPORTED, "lt_pwchain_fwd: ldy %d != width %d", d->ldy, a.cout_last);
+    LT_REQUIRE(d->plane >= 0 && d->plane % 64 == 0 && (d->plane == 0 || d->rows % d->plane == 0), LT_ERR_INVALID,
+               "lt_pwchain_fwd: plane %lld (planar output needs a multiple of 64 voxels per sample that divides rows)", (long long)d->plane);
+    a.plane = d->plane;
     a.x = (const bf16_t*)x;
     a.y = (float*)y;
     a.ntile = d->rows / 64;
     hipStream_t s = (hipStream_t)stream;
+    if (a.plane) {
+        switch (d->nlayers) {
+            case 1: return launch_pw<1, true>(a, s);
+            case 2: return launch_pw<2, true>(a, s);
+            default: return launch_pw<3, true>(a, s);
+        }
+    }
     switch (d->nlayers) {
-        case 1: return launch_pw<1>(a, s);
-        case 2: return launch_pw<2>(a, s);
-        default: return launch_pw<3>(a, s);
+        case 1: return launch_pw<1, false>(a, s);
+        case 2: return launch_pw<2, false>(a, s);
+        default: return launch_pw<3, false>(a, s);
     }
 }

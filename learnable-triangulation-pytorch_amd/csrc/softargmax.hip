@@ -6,6 +6,9 @@
 // (max, sum, sum*coord) state per joint in registers, so the voxel's coordinates are read once for all
 // joints; channels-last logits are staged through an LDS tile with an odd row stride, which turns the
 // strided per-joint walk into conflict-free LDS reads while global loads stay fully coalesced.
+// Planar logits ((B, J, V^3), what lt_pwchain_fwd writes for the bf16 V2V tail) need no staging: a lane owns FOUR consecutive
+// voxels, every joint is one 16-byte load per lane (all J of them in flight at once) and the probabilities are written by a
+// plain vectorised elementwise pass.
 #include "lt_common.h"
 
 using namespace lt;
@@ -15,6 +18,7 @@ namespace {
 constexpr int SA_ITERS = 8;                  // voxels per lane
 constexpr int SA_CHUNK = 256 * SA_ITERS;     // voxels per workgroup
 constexpr int SA_REC = 5;                    // partial record: m, s, sx, sy, sz
+typedef float sa_f32x4 __attribute__((ext_vector_type(4)));
 
 struct SA3Args {
     const float* logits;
@@ -126,6 +130,125 @@ __global__ __launch_bounds__(256, (JP <= 17 ? 3 : 2)) void sa3_partial_kernel(co
     }
 }
 
+// Planar logits, nvox % 4 == 0: a lane owns SAP_V groups of four consecutive voxels (their coordinates stay in registers for
+// all joints), the workgroup walks the joints: per joint one 16-byte load per group (the next joint's loads are in flight
+// under this joint's arithmetic), an exact two-step softmax over the lane's 16 values, then one wave reduction
+// (max -> rescale -> sums).  Register state is independent of J, so this kernel runs at 3+ waves per SIMD.
+constexpr int SAP_V = 4;
+constexpr int SAP_CHUNK = 256 * 4 * SAP_V;   // voxels per workgroup
+
+__global__ __launch_bounds__(256, 3) void sa3_partial_planar_kernel(const SA3Args a) {
+    __shared__ float red[32 * 4 * SA_REC];    // [J][wave][5]
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const float* lg = a.logits + (long long)b * a.J * a.nvox;
+    const float* cd = a.coords + (long long)b * a.nvox * 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long vox[SAP_V];
+    float wgt[SAP_V];
+    sa_f32x4 ca[SAP_V], cb[SAP_V], cc[SAP_V];   // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3
+#pragma unroll
+    for (int k = 0; k < SAP_V; ++k) {
+        const long long v = (long long)chunk * SAP_CHUNK + k * 1024 + threadIdx.x * 4;
+        const bool ok = v < a.nvox;          // nvox % 4 == 0: a group is inside or outside as a whole
+        wgt[k] = ok ? 1.f : 0.f;             // outside: re-read group 0 (finite values of the same volume) with weight 0
+        vox[k] = ok ? v : 0;
+        const sa_f32x4* c4 = (const sa_f32x4*)(cd + vox[k] * 3);
+        ca[k] = c4[0]; cb[k] = c4[1]; cc[k] = c4[2];
+    }
+    sa_f32x4 cur[SAP_V], nxt[SAP_V];
+#pragma unroll
+    for (int k = 0; k < SAP_V; ++k) cur[k] = *(const sa_f32x4*)(lg + vox[k]);
+#pragma unroll 1
+    for (int j = 0; j < a.J; ++j) {
+        const float* nl = lg + (long long)min(j + 1, a.J - 1) * a.nvox;
+#pragma unroll
+        for (int k = 0; k < SAP_V; ++k) nxt[k] = *(const sa_f32x4*)(nl + vox[k]);
+        float m = 0.f;
+        if (a.softmax) {
+            m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < SAP_V; ++k) {
+                cur[k] *= a.mult;
+                m = fmaxf(fmaxf(m, fmaxf(cur[k][0], cur[k][1])), fmaxf(cur[k][2], cur[k][3]));
+            }
+        }
+        float s = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+        for (int k = 0; k < SAP_V; ++k) {
+            float e0, e1, e2, e3;
+            if (a.softmax) {
+                e0 = expf(cur[k][0] - m); e1 = expf(cur[k][1] - m); e2 = expf(cur[k][2] - m); e3 = expf(cur[k][3] - m);
+            } else {
+                e0 = fmaxf(a.mult * cur[k][0], 0.f); e1 = fmaxf(a.mult * cur[k][1], 0.f);
+                e2 = fmaxf(a.mult * cur[k][2], 0.f); e3 = fmaxf(a.mult * cur[k][3], 0.f);
+            }
+            e0 *= wgt[k]; e1 *= wgt[k]; e2 *= wgt[k]; e3 *= wgt[k];
+            s += (e0 + e1) + (e2 + e3);
+            sx += (e0 * ca[k][0] + e1 * ca[k][3]) + (e2 * cb[k][2] + e3 * cc[k][1]);
+            sy += (e0 * ca[k][1] + e1 * cb[k][0]) + (e2 * cb[k][3] + e3 * cc[k][2]);
+            sz += (e0 * ca[k][2] + e1 * cb[k][1]) + (e2 * cc[k][0] + e3 * cc[k][3]);
+        }
+        float M = m;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
+        if (a.softmax) {
+            const float c = expf(m - M);
+            s *= c; sx *= c; sy *= c; sz *= c;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s += __shfl_xor(s, off); sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off);
+        }
+        if (lane == 0) {
+            float* r = red + (j * 4 + wave) * SA_REC;
+            r[0] = M; r[1] = s; r[2] = sx; r[3] = sy; r[4] = sz;
+        }
+#pragma unroll
+        for (int k = 0; k < SAP_V; ++k) cur[k] = nxt[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < a.J) {
+        const int j = threadIdx.x;
+        float M = -INFINITY;
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, red[(j * 4 + w) * SA_REC]);
+        float S = 0.f, X = 0.f, Y = 0.f, Z = 0.f;
+        for (int w = 0; w < 4; ++w) {
+            const float* r = red + (j * 4 + w) * SA_REC;
+            const float c = expf(r[0] - M);
+            S += r[1] * c; X += r[2] * c; Y += r[3] * c; Z += r[4] * c;
+        }
+        float* o = a.partial + (((long long)b * a.J + j) * a.nchunks + chunk) * SA_REC;
+        o[0] = M; o[1] = S; o[2] = X; o[3] = Y; o[4] = Z;
+    }
+}
+
+// planar logits -> planar probabilities: elementwise with per-(b, joint) statistics, four 16-byte vectors per lane in flight
+__global__ __launch_bounds__(256) void sa3_probs_planar_kernel(const SA3Args a) {
+    const long long plane = blockIdx.y;       // b * J + joint
+    const float M = a.stats[plane * 2], S = a.stats[plane * 2 + 1];
+    const float4* src = (const float4*)(a.logits + plane * a.nvox);
+    float4* dst = (float4*)(a.probs + plane * a.nvox);
+    const long long n4 = a.nvox / 4, i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k * 256 < n4) v[k] = src[i0 + k * 256];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k * 256 < n4) {
+            float4 p;
+            if (a.softmax) {
+                p.x = __fdiv_rn(expf(a.mult * v[k].x - M), S); p.y = __fdiv_rn(expf(a.mult * v[k].y - M), S);
+                p.z = __fdiv_rn(expf(a.mult * v[k].z - M), S); p.w = __fdiv_rn(expf(a.mult * v[k].w - M), S);
+            } else {
+                p.x = fmaxf(a.mult * v[k].x, 0.f); p.y = fmaxf(a.mult * v[k].y, 0.f);
+                p.z = fmaxf(a.mult * v[k].z, 0.f); p.w = fmaxf(a.mult * v[k].w, 0.f);
+            }
+            dst[i0 + k * 256] = p;
+        }
+    }
+}
+
 // one wave per (b, joint): combine the chunk partials in fp64
 __global__ void sa3_finalize_kernel(const SA3Args a, int B) {
     const int bj = blockIdx.x;
@@ -181,6 +304,13 @@ __global__ __launch_bounds__(256) void sa3_probs_kernel(const SA3Args a) {
             }
         }
     }
+}
+
+// planar logits whose volumes are float4-addressable take the vectorised kernels
+bool sa3_planar_vec(const SA3Args& a) {
+    static const bool off = getenv("LT_SA3_NO_VEC") != nullptr;
+    return !off && a.nvox % 4 == 0 && ((uintptr_t)a.logits & 15) == 0 && ((uintptr_t)a.coords & 15) == 0 &&
+           (!a.probs || ((uintptr_t)a.probs & 15) == 0);
 }
 
 template <bool CL>
@@ -321,15 +451,25 @@ extern "C" int lt_softargmax3d_fwd(const float* logits, const float* coords, flo
     a.logits = logits; a.coords = coords; a.kp = kp; a.probs = probs; a.mult = mult; a.softmax = softmax; a.J = J; a.ld = ld; a.nvox = nvox;
     a.nchunks = (int)((nvox + SA_CHUNK - 1) / SA_CHUNK);
     a.partial = (float*)workspace;
-    a.stats = a.partial + (long long)B * J * a.nchunks * SA_REC;
+    a.stats = a.partial + (long long)B * J * a.nchunks * SA_REC;   // the workspace layout is sized for SA_CHUNK chunks
     hipStream_t st = (hipStream_t)stream;
-    int rc = channels_last ? sa3_launch_partial<true>(a, B, st) : sa3_launch_partial<false>(a, B, st);
+    const bool vec = !channels_last && sa3_planar_vec(a);
+    int rc = LT_OK;
+    if (vec) {
+        a.nchunks = (int)((nvox + SAP_CHUNK - 1) / SAP_CHUNK);    // fewer, larger chunks: the records fit a fortiori
+        hipLaunchKernelGGL(sa3_partial_planar_kernel, dim3(a.nchunks, B), dim3(256), 0, st, a);
+        LT_CHECK_LAUNCH("lt_softargmax3d_fwd(partial, planar)");
+    } else {
+        rc = channels_last ? sa3_launch_partial<true>(a, B, st) : sa3_launch_partial<false>(a, B, st);
+    }
     if (rc != LT_OK) return rc;
     hipLaunchKernelGGL(sa3_finalize_kernel, dim3(B * J), dim3(64), 0, st, a, B);
     LT_CHECK_LAUNCH("lt_softargmax3d_fwd(finalize)");
     if (probs) {
         const dim3 grid(a.nchunks, B);
         if (channels_last) hipLaunchKernelGGL(sa3_probs_kernel<true>, grid, dim3(256), 256 * (J | 1) * sizeof(float), st, a);
+        else if (vec)
+            hipLaunchKernelGGL(sa3_probs_planar_kernel, dim3((unsigned)((nvox / 4 + 1023) / 1024), B * J), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(sa3_probs_kernel<false>, grid, dim3(256), 0, st, a);
         LT_CHECK_LAUNCH("lt_softargmax3d_fwd(probs)");
     }

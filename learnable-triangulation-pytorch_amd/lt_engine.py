@@ -299,9 +299,11 @@ class PlanBuilder:
             cin = w.shape[0]
         return True
 
-    def pwchain(self, x, layers):
+    def pwchain(self, x, layers, planar=False):
         """Chain of pointwise convolutions in one pass over the volume (lt_pwchain_fwd); the last layer's output is fp32.
-        layers: [(weight [Cout,Cin,1,1,1], bias, bn-tuple-or-None, relu), ...].  Returns the output Act [N,D,H,W,Cout_last]."""
+        layers: [(weight [Cout,Cin,1,1,1], bias, bn-tuple-or-None, relu), ...].  Returns the output Act [N,D,H,W,Cout_last];
+        planar=True stores it as (N, Cout, D, H, W) -- the Act's tensor is then the channels-last VIEW of that storage
+        (not contiguous; `.t.permute(0, 4, 1, 2, 3)` is), which is the layout lt_softargmax3d_fwd streams fastest."""
         assert self.can_chain_pointwise(x, layers)
         N, D, Hh, W, _ = x.shape
         d = H.PwChainDesc()
@@ -321,7 +323,13 @@ class PlanBuilder:
             flops += 2 * d.rows * spec.Cout * w.shape[1]
             shape = (N, D, Hh, W, spec.Cout)
         d.ldy = specs[-1].Cout
-        y = self.alloc(shape, torch.float32)
+        planar = bool(planar) and (D * Hh * W) % 64 == 0
+        if planar:
+            d.plane = D * Hh * W
+            y = Act(self.alloc((N, shape[-1], D, Hh, W), torch.float32).t.permute(0, 2, 3, 4, 1))
+            y.pooled = False
+        else:
+            y = self.alloc(shape, torch.float32)
         self.keep.append(x.t)
         self.keep.append(d)
         self.flops += flops

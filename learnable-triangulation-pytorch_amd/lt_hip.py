@@ -43,7 +43,8 @@ PWCHAIN_MAX = 3
 class PwChainDesc(C.Structure):
     _fields_ = [("dtype", i32), ("nlayers", i32), ("rows", i64), ("cin", i32), ("ldy", i32),
                 ("cout", i32 * PWCHAIN_MAX), ("k_pad", i32 * PWCHAIN_MAX), ("flags", i32 * PWCHAIN_MAX),
-                ("weight", vp * PWCHAIN_MAX), ("bias", vp * PWCHAIN_MAX), ("scale", vp * PWCHAIN_MAX), ("shift", vp * PWCHAIN_MAX)]
+                ("weight", vp * PWCHAIN_MAX), ("bias", vp * PWCHAIN_MAX), ("scale", vp * PWCHAIN_MAX), ("shift", vp * PWCHAIN_MAX),
+                ("plane", i64)]
 
 
 # symbol -> (restype, argtypes); must list every symbol include/lt_hip.h declares

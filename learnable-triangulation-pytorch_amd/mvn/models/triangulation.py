@@ -136,7 +136,9 @@ class VolumetricTriangulationNet(_PlannedNet):
         probs = torch.empty(B, J, V, V, V, dtype=torch.float32, device=device)
         ws = torch.empty(1 if dry_run else max(1, lib.lt_softargmax3d_workspace(B, J, V ** 3)), dtype=torch.uint8, device=device)
         mult, sm = float(self.volume_multiplier), int(bool(self.volume_softmax))
-        b.custom(lambda st: H.check(lib.lt_softargmax3d_fwd(logits.t.data_ptr(), coords.data_ptr(), mult, sm, 1, J, kp.data_ptr(),
+        cl = int(logits.t.is_contiguous())   # channels-last rows of J floats, or planar (N, J, V, V, V) storage (bf16 pwchain tail)
+        assert cl or logits.t.permute(0, 4, 1, 2, 3).is_contiguous()
+        b.custom(lambda st: H.check(lib.lt_softargmax3d_fwd(logits.t.data_ptr(), coords.data_ptr(), mult, sm, cl, J, kp.data_ptr(),
                                                             probs.data_ptr(), B, J, V ** 3, ws.data_ptr(), st), "lt_softargmax3d_fwd"),
                  "softargmax3d", nbytes=2 * B * J * V ** 3 * 4,  # read logits + write probabilities
                  info={"logits": logits, "coords": coords, "mult": mult, "softmax": sm, "kp": kp, "probs": probs})

@@ -118,7 +118,8 @@ class V2VModel(nn.Module):
         self.register_load_state_dict_post_hook(lambda m, k: m._plans.clear())
 
     def record(self, b, x):
-        """x: Act [N,V,V,V,Cin] -> logits Act [N,V,V,V,Cout], always fp32 (they feed the soft-argmax)."""
+        """x: Act [N,V,V,V,Cin] -> logits Act [N,V,V,V,Cout], always fp32 (they feed the soft-argmax); the bf16 tail stores
+        them planar (the Act's tensor is a channels-last view of (N,Cout,V,V,V) storage, see PlanBuilder.pwchain)."""
         for m in self.front_layers:
             y = m.record(b, x); b.release(x); x = y
         x = self.encoder_decoder.record(b, x)
@@ -128,7 +129,7 @@ class V2VModel(nn.Module):
         chain = [(m.block[0].weight, m.block[0].bias, bn_tuple(m.block[1]), True) for m in tail] + [(o.weight, o.bias, None, False)]
         y = self.back_layers[0].record(b, x); b.release(x); x = y
         if all(isinstance(m, Basic3DBlock) and m.block[0].kernel_size == (1, 1, 1) for m in tail) and b.can_chain_pointwise(x, chain):
-            y = b.pwchain(x, chain)
+            y = b.pwchain(x, chain, planar=True)   # (N, J, V, V, V) storage: the soft-argmax reads whole volumes per joint
             b.release(x)
             return y
         for m in tail:

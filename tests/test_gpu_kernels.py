@@ -292,6 +292,27 @@ def test_softargmax3d_large_sharp():
     c0, p0 = op.integrate_tensor_3d_with_coordinates(v, cv.to(DEV), softmax=False)
     check("integrate3d/64^3 relu/channels_last coords", c0.cpu(), rc0.float(), 2e-4)
     check("integrate3d/64^3 relu/channels_last volumes", p0.cpu(), rv0.float(), 1e-6)
+    c1, p1 = op.integrate_tensor_3d_with_coordinates((lg * 0.01).to(DEV), cv.to(DEV), softmax=False)
+    check("integrate3d/64^3 relu/joint_major coords", c1.cpu(), rc0.float(), 2e-4)
+    check("integrate3d/64^3 relu/joint_major volumes", p1.cpu(), rv0.float(), 1e-6)
+
+
+@pytest.mark.parametrize("V,J", [(24, 17), (8, 3), (20, 32)])
+def test_softargmax3d_planar_ragged(V, J):
+    """Joint-major volumes whose voxel count is not a multiple of the 4096-voxel chunk of the vectorised planar kernels (ragged last
+    workgroup, lanes without voxels), 1..32 joints, multiplier != 1."""
+    from mvn.utils import op
+    g = torch.Generator().manual_seed(V * 100 + J)
+    lg = torch.randn(3, J, V, V, V, generator=g) * 3
+    cv = torch.stack([O.coord_volume(np.array([100.0 * b, 50.0, -30.0]), 2000.0, V) for b in range(3)])
+    for sm in (True, False):
+        x = lg if sm else lg * 0.01
+        rc, rv = O.integrate_tensor_3d_with_coordinates((x * 2.0).double(), cv.double(), softmax=sm)
+        c, p = op.integrate_tensor_3d_with_coordinates(x.to(DEV) * 2.0, cv.to(DEV), softmax=sm)
+        rel = ((c.cpu().double() - rc).abs() / rc.abs().clamp(min=1.0)).max()
+        record("integrate3d/%d^3 J=%d softmax=%d planar coords max rel (1mm floor)" % (V, J, sm), float(rel))
+        assert float(rel) < (2e-5 if sm else 2e-4)
+        check("integrate3d/%d^3 J=%d softmax=%d planar volumes" % (V, J, sm), p.cpu(), rv.float(), 1e-5)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -352,9 +373,45 @@ def test_conv3d_halo_kernel(case):
             check("conv3d_halo_nores/%s/%s" % (case, dname), out3, ref3, 1.5e-2)
 
 
+COL_CASES = {  # name: (N, (D,H,W)): 3^3 32->32 bf16 with >= 256 columns of >= 2 tiles -> the column-walking kernel
+    "pin_1col_4deep": (8, (16, 32, 64)),        # XCD-pinned samples, one column per workgroup
+    "pin_2col_2deep": (16, (8, 32, 64)),        # two columns per workgroup, two tiles per column (ring wraps between columns)
+    "raster_uneven": (5, (16, 64, 64)),         # 320 columns on 256 workgroups, raster dealing
+}
+
+
+@pytest.mark.parametrize("col", ["1", "0"], ids=["column_walk", "persistent"])
+@pytest.mark.parametrize("case", list(COL_CASES))
+def test_conv3d_halo_column_walk(case, col, monkeypatch):
+    """conv3d_halo_col_kernel (sliding window of halo planes, epilogue deferred under the next tile's MFMAs) and the persistent
+    kernel it replaces (LT_HALO_NO_COL=1) vs torch conv3d: residual + ReLU, affine only, ReLU only."""
+    if col == "0":
+        monkeypatch.setenv("LT_HALO_NO_COL", "1")
+    else:
+        monkeypatch.delenv("LT_HALO_NO_COL", raising=False)
+    N, sp = COL_CASES[case]
+    g = torch.Generator().manual_seed(len(case) + 11)
+    x = torch.randn(N, 32, *sp, generator=g)
+    w = torch.randn(32, 32, 3, 3, 3, generator=g) * (1.0 / (32 * 27) ** 0.5)
+    bias = torch.randn(32, generator=g) * 0.1
+    bn = _bn(32, g)
+    res = torch.randn(N, 32, *sp, generator=g)
+    rd = bf16_round
+    conv = F.conv3d(rd(x), rd(w), bias, 1, 1)
+    ref = torch.relu(_bn_ref(conv, bn) + rd(res))
+    out = run_conv(x, w, bias, bn, 1, 1, torch.bfloat16, H.TILE_HALO, relu=True, residual=res)
+    check("conv3d_halo_col=%s/%s/res" % (col, case), out, ref, 1.5e-2)
+    out2 = run_conv(x, w, bias, bn, 1, 1, torch.bfloat16, 0, relu=False, residual=None)
+    check("conv3d_halo_col=%s/%s/plain" % (col, case), out2, _bn_ref(conv, bn), 1.5e-2)
+    out3 = run_conv(x, w, None, None, 1, 1, torch.bfloat16, 0, relu=True, residual=None)
+    check("conv3d_halo_col=%s/%s/relu_only" % (col, case), out3, torch.relu(F.conv3d(rd(x), rd(w), None, 1, 1)), 1.5e-2)
+
+
+@pytest.mark.parametrize("planar", [False, True], ids=["channels_last", "planar"])
 @pytest.mark.parametrize("nlayers,J", [(3, 17), (2, 32), (1, 17), (3, 5)])
-def test_pwchain(nlayers, J):
-    """lt_pwchain_fwd (pointwise chain in registers) vs torch: every layer's output rounded to bf16 except the fp32 last one."""
+def test_pwchain(nlayers, J, planar):
+    """lt_pwchain_fwd (pointwise chain in registers) vs torch: every layer's output rounded to bf16 except the fp32 last one;
+    channels-last rows or planar (N, J, D, H, W) storage behind the same channels-last Act view."""
     g = torch.Generator().manual_seed(40 + nlayers + J)
     x = torch.randn(2, 8, 8, 16, 32, generator=g)                      # 2048 voxels, channels last
     widths = [32] * (nlayers - 1) + [J]
@@ -369,7 +426,8 @@ def test_pwchain(nlayers, J):
     b = E.PlanBuilder(DEV, torch.bfloat16)
     xa = E.Act(x.to(DEV).to(torch.bfloat16))
     assert b.can_chain_pointwise(xa, layers)
-    y = b.pwchain(xa, layers)
+    y = b.pwchain(xa, layers, planar=planar)
+    assert y.t.is_contiguous() != planar and (not planar or y.t.permute(0, 4, 1, 2, 3).is_contiguous())
     b.finish().run_eager(torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     cur = bf16_round(x).permute(0, 4, 1, 2, 3)
@@ -383,7 +441,7 @@ def test_pwchain(nlayers, J):
             cur = bf16_round(cur)
     ref = cur.permute(0, 2, 3, 4, 1)
     assert y.t.dtype == torch.float32 and tuple(y.t.shape) == tuple(ref.shape)
-    check("pwchain/L%d_J%d" % (nlayers, J), y.t.cpu(), ref, 1e-2)
+    check("pwchain/L%d_J%d%s" % (nlayers, J, "/planar" if planar else ""), y.t.cpu(), ref, 1e-2)
 
 
 @pytest.mark.parametrize("staged", ["0", "1"])

@@ -215,3 +215,6 @@ def test_c_abi_exports_every_declared_symbol():
     assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -2 and b"inner layers" in l.lt_last_error()
     pd.cout[0] = 32
     assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -2 and b"last layer stores fp32" in l.lt_last_error()
+    # planar output: voxels per sample must be a multiple of 64 that divides rows
+    pd.flags[1], pd.rows, pd.plane = H.EPI_STORE_F32, 128, 96
+    assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -1 and b"plane" in l.lt_last_error()

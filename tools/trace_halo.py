@@ -6,11 +6,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "learnable-triangulation-pytorch_amd")
-os.environ["LT_HIP_LIB"] = os.path.join(PKG, "lib", "liblt_hip_trace.so")
+# LT_TRACE_DEFS="LT_ABL_NO_STORE": extra defines for an ablation of the traced kernel (results wrong by design, timing only)
+EXTRA = os.environ.get("LT_TRACE_DEFS", "").split()
+VARIANT = "trace" + "".join("_" + d.lower() for d in EXTRA)
+os.environ["LT_HIP_LIB"] = os.path.join(PKG, "lib", "liblt_hip_%s.so" % VARIANT)
 sys.path.insert(0, PKG)
 if not os.path.exists(os.environ["LT_HIP_LIB"]):   # profiling build of the same sources (hipcc is on the GPU box too)
     import lt_build
-    lt_build.build_variant("trace", ["LT_TRACE"])
+    lt_build.build_variant(VARIANT, ["LT_TRACE"] + EXTRA)
 import numpy as np
 import torch
 
@@ -44,10 +47,11 @@ def main():
     r = buf.reshape(-1, 8)
     r = r[r[:, 7] > 0]
     nt = r[:, 7].mean()
-    names = ["total", "wait+barrier", "halo issue", "res issue", "tap loop", "barrier", "epilogue"]
-    print("persistent 3^3 32->32 @64^3 B=%d: %.0f us, %d workgroups sampled, %.1f tiles each" % (B, us, len(r), nt))
+    names = ["total", "wait+barrier", "halo issue / tile setup", "res issue", "tap loop (+ deferred epilogue)", "barrier", "epilogue / bookkeeping"]
+    kern = "persistent" if os.environ.get("LT_HALO_NO_COL") else "column-walk"
+    print(kern + (" [" + " ".join(EXTRA) + "]" if EXTRA else "") + " 3^3 32->32 @64^3 B=%d: %.0f us, %d workgroups sampled, %.1f tiles each" % (B, us, len(r), nt))
     for k, nm in enumerate(names):
-        print("  %-14s %9.0f cycles/tile" % (nm, r[:, k].mean() / nt))
+        print("  %-32s %9.0f cycles/tile" % (nm, r[:, k].mean() / nt))
 
 
 if __name__ == "__main__":
