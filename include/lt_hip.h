@@ -215,6 +215,30 @@ typedef struct {
 int lt_pwchain_fwd(const lt_pwchain_desc* desc, const void* x, void* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The stem of the 2D backbone in one pass: conv 7x7 / stride 2 / pad 3 -> (acc + bias) * scale +
+ * shift (eval BatchNorm folded) -> ReLU -> max pool 3x3 / stride 2 / pad 1.  Replaces the first four
+ * lines of PoseResNet.forward (mvn/models/pose_resnet.py:293-297: conv1, bn1, relu, maxpool): the
+ * half-resolution 64-channel map never goes to HBM.  bf16 only (fp32 plans record lt_conv_fwd +
+ * lt_maxpool_fwd); results are identical to those two launches (max commutes with the bf16 rounding).
+ * x: N,H,W,8 channels-last (3 image channels zero-padded to 8); y: N,Hp,Wp,64 with Hc = (H-1)/2 + 1,
+ * Hp = (Hc-1)/2 + 1.  weight: lt_stem_packed_bytes() bytes filled ONCE per model by
+ * lt_stem_pack_weights from the lt_conv_fwd packing [64][k_pad] (k = (kh*7 + kw)*8 + ci, bf16): the
+ * kernel's MFMA fragment order, so that a wave reads 1 KB contiguous per K step.
+ * -------------------------------------------------------------------------------------------*/
+typedef struct {
+    int32_t dtype;                       /* LT_BF16 */
+    int32_t N, H, W;
+    int32_t Cin, Cout;                   /* 8, 64 */
+    const void* weight;                  /* packed by lt_stem_pack_weights, 16-byte aligned */
+    const float* bias;                   /* 64 entries each, or NULL */
+    const float* scale;
+    const float* shift;
+} lt_stem_desc;
+size_t lt_stem_packed_bytes(void);
+int lt_stem_pack_weights(const void* weight, int32_t k_pad, void* packed, void* stream);
+int lt_stem_pool_fwd(const lt_stem_desc* desc, const void* x, void* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * hipGraph + event helpers (the forward is ~230 launches: replay it as one graph)
  * -------------------------------------------------------------------------------------------*/
 int lt_graph_begin(void* stream);

@@ -340,6 +340,43 @@ class PlanBuilder:
                   "pwchain", label, flops, nbytes, {"specs": specs, "x": x, "y": y})
         return y
 
+    def can_stem_pool(self, x, weight, stride, pad, pool):
+        """True when lt_stem_pool_fwd covers conv -> BN -> ReLU -> max pool: bf16 plan, 2D map with 8 (padded) channels,
+        7x7 / stride 2 / pad 3 convolution to 64 channels, 3x3 / stride 2 / pad 1 pool."""
+        return (self.dtype == torch.bfloat16 and x.shape[1] == 1 and x.shape[-1] == 8 and weight.dim() == 4
+                and tuple(weight.shape[2:]) == (7, 7) and weight.shape[0] == 64 and weight.shape[1] <= 8
+                and stride == 2 and pad == 3 and tuple(pool) == (3, 2, 1))
+
+    def stem_pool(self, x, weight, bn):
+        """conv 7x7/2 (no bias) + eval BN + ReLU + max pool 3x3/2 in one pass (lt_stem_pool_fwd).  x: Act [N,1,H,W,8];
+        returns Act [N,1,Hp,Wp,64]."""
+        assert self.can_stem_pool(x, weight, 2, 3, (3, 2, 1))
+        N, _, Hh, W, _ = x.shape
+        spec = make_conv_spec(weight, None, bn, x.shape, 2, 3, self.dtype, False, H.EPI_RELU_POST)
+        Hp, Wp = (spec.Ho - 1) // 2 + 1, (spec.Wo - 1) // 2 + 1
+        y = self.alloc((N, 1, Hp, Wp, 64))
+        wdev = self.const(spec.phases[0].weight, self.dtype)
+        bi, sc, sh = self.const(spec.bias), self.const(spec.scale), self.const(spec.shift)
+        lib = None if self.dry_run else H.lib()
+        # the kernel reads its weights in MFMA fragment order: packed once, here (on the plan's device, legacy stream)
+        wpk = torch.empty(57344 if self.dry_run else lib.lt_stem_packed_bytes(), dtype=torch.uint8, device=self.device)
+        if not self.dry_run:
+            H.check(lib.lt_stem_pack_weights(wdev.data_ptr(), spec.k_pad, wpk.data_ptr(), H.cur_stream()), "lt_stem_pack_weights")
+            torch.cuda.current_stream().synchronize()
+        d = H.StemDesc()
+        d.dtype, d.N, d.H, d.W, d.Cin, d.Cout = self.code, N, Hh, W, 8, 64
+        d.weight, d.bias, d.scale, d.shift = wpk.data_ptr(), bi.data_ptr(), sc.data_ptr(), sh.data_ptr()
+        self.keep.append(x.t)
+        self.keep.append(d)
+        self.keep.append(wpk)
+        flops = 2 * N * spec.Ho * spec.Wo * 64 * 49 * weight.shape[1]
+        self.flops += flops
+        esz = x.t.element_size()
+        self._add(lambda s, d=d, xp=x.t.data_ptr(), yp=y.t.data_ptr(): H.check(lib.lt_stem_pool_fwd(C.byref(d), xp, yp, s), "lt_stem_pool_fwd"),
+                  "stem", "stem conv7x7/2+pool3x3/2 8->64 @%s" % "x".join(str(v) for v in (N, Hh, W)), flops,
+                  (x.t.numel() + y.t.numel()) * esz + spec.phases[0].weight.numel() * esz, {"spec": spec, "x": x, "y": y})
+        return y
+
     def maxpool(self, x, k, s, p, nd):
         N, D, Hh, W, Cc = x.shape
         kk = (1, k, k) if nd == 2 else (k, k, k)

@@ -47,6 +47,11 @@ class PwChainDesc(C.Structure):
                 ("plane", i64)]
 
 
+class StemDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("N", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32),
+                ("weight", vp), ("bias", vp), ("scale", vp), ("shift", vp)]
+
+
 # symbol -> (restype, argtypes); must list every symbol include/lt_hip.h declares
 SIGNATURES = {
     "lt_last_error": (C.c_char_p, []),
@@ -55,6 +60,9 @@ SIGNATURES = {
     "lt_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
     "lt_conv_cout_pad": (C.c_int, [i32]),
     "lt_pwchain_fwd": (C.c_int, [C.POINTER(PwChainDesc), vp, vp, vp]),
+    "lt_stem_pool_fwd": (C.c_int, [C.POINTER(StemDesc), vp, vp, vp]),
+    "lt_stem_packed_bytes": (C.c_size_t, []),
+    "lt_stem_pack_weights": (C.c_int, [vp, i32, vp, vp]),
     "lt_maxpool_fwd": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32 * 3, vp]),
     "lt_global_avgpool": (C.c_int, [i32, vp, vp, i32, i32, i32, vp]),
     "lt_nchw_to_nhwc": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, vp]),

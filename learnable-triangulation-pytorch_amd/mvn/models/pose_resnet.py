@@ -136,9 +136,12 @@ class PoseResNet(nn.Module):
     def record(self, b, x, want_heatmaps=True):
         """x: Act [N,1,H,W,Cpad] (zero-padded input channels).  Returns (heatmaps Act fp32 | None,
         features Act, alg_conf Act | None, vol_conf Act | None)."""
-        y = b.conv(x, self.conv1.weight, None, bn_tuple(self.bn1), stride=2, pad=3, relu=True)
-        p = b.maxpool(y, 3, 2, 1, nd=2); b.release(y)
-        y = p
+        if b.can_stem_pool(x, self.conv1.weight, 2, 3, (3, 2, 1)):   # bf16: conv1 + bn1 + relu + maxpool in one pass
+            y = b.stem_pool(x, self.conv1.weight, bn_tuple(self.bn1))
+        else:
+            y = b.conv(x, self.conv1.weight, None, bn_tuple(self.bn1), stride=2, pad=3, relu=True)
+            p = b.maxpool(y, 3, 2, 1, nd=2); b.release(y)
+            y = p
         for li in range(1, 5):
             for blk in getattr(self, "layer%d" % li):
                 z = blk.record(b, y)

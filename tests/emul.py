@@ -72,6 +72,10 @@ def run_plan_on_cpu(plan):
                 if i + 1 < len(info["specs"]):
                     cur = cur.to(info["x"].t.dtype).float()
             info["y"].t.copy_(cur)
+        elif kind == "stem":      # lt_stem_pool_fwd: conv + affine + ReLU rounded to the plan dtype, then the 3x3/2 max pool
+            cur = emulate_conv(info["spec"], info["x"].t.float().clone()).to(info["x"].t.dtype).float()
+            pooled = F.max_pool3d(cur.permute(0, 4, 1, 2, 3), (1, 3, 3), (1, 2, 2), (0, 1, 1))
+            info["y"].t.copy_(pooled.permute(0, 2, 3, 4, 1))
         elif kind == "maxpool":
             x = info["x"].t.float().permute(0, 4, 1, 2, 3)
             y = F.max_pool3d(x, tuple(info["k"]), tuple(info["s"]), tuple(info["p"]))

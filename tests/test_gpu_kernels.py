@@ -373,6 +373,32 @@ def test_conv3d_halo_kernel(case):
             check("conv3d_halo_nores/%s/%s" % (case, dname), out3, ref3, 1.5e-2)
 
 
+@pytest.mark.parametrize("N,hw,cin", [(2, (64, 128), 3), (1, (100, 84), 3), (3, (37, 53), 1), (1, (384, 384), 3)])
+def test_stem_pool(N, hw, cin):
+    """lt_stem_pool_fwd (conv 7x7/2 + BN + ReLU + max pool 3x3/2 in one pass) vs torch, and bit-identical to the two separate
+    launches (conv then pool) it replaces; ragged tiles, odd sizes, pool windows and conv taps over every border."""
+    g = torch.Generator().manual_seed(N * 1000 + hw[0])
+    x = torch.randn(N, cin, *hw, generator=g)
+    w = torch.randn(64, cin, 7, 7, generator=g) * (1.0 / (cin * 49) ** 0.5)
+    bn = _bn(64, g)
+    b = E.PlanBuilder(DEV, torch.bfloat16)
+    xa = E.Act(to_cl(x, 8, torch.bfloat16))
+    assert b.can_stem_pool(xa, w, 2, 3, (3, 2, 1))
+    y = b.stem_pool(xa, w, bn)
+    y1 = b.conv(xa, w, None, bn, stride=2, pad=3, relu=True)
+    y2 = b.maxpool(y1, 3, 2, 1, nd=2)
+    b.finish().run_eager(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = F.max_pool2d(bf16_round(torch.relu(_bn_ref(F.conv2d(bf16_round(x), bf16_round(w), None, 2, 3), bn))), 3, 2, 1)
+    out = from_cl(y.t, 2)
+    assert tuple(out.shape) == tuple(ref.shape)
+    check("stem_pool/%dx%dx%d" % (N, hw[0], hw[1]), out, ref, 1.5e-2)
+    two = from_cl(y2.t, 2)
+    record("stem_pool/%dx%dx%d vs conv+pool max abs diff" % (N, hw[0], hw[1]), float((out - two).abs().max()))
+    # same bf16 inputs, fp32 accumulation in a different order: a rounding boundary may flip the last bf16 bit
+    assert float((out - two).abs().max()) <= 2 ** -7 * float(two.abs().max())
+
+
 COL_CASES = {  # name: (N, (D,H,W)): 3^3 32->32 bf16 with >= 256 columns of >= 2 tiles -> the column-walking kernel
     "pin_1col_4deep": (8, (16, 32, 64)),        # XCD-pinned samples, one column per workgroup
     "pin_2col_2deep": (16, (8, 32, 64)),        # two columns per workgroup, two tiles per column (ring wraps between columns)

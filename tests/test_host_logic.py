@@ -215,6 +215,16 @@ def test_c_abi_exports_every_declared_symbol():
     assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -2 and b"inner layers" in l.lt_last_error()
     pd.cout[0] = 32
     assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -2 and b"last layer stores fp32" in l.lt_last_error()
+    # lt_stem_pool_fwd: bf16, 8 -> 64 channels, weights packed by lt_stem_pack_weights from [64][k_pad >= 392]
+    sd = H.StemDesc()
+    sd.dtype, sd.N, sd.H, sd.W, sd.Cin, sd.Cout = 0, 1, 32, 32, 8, 64
+    assert l.lt_stem_pool_fwd(ctypes.byref(sd), 1, 1, None) == -2 and b"bf16" in l.lt_last_error()
+    sd.dtype, sd.Cin = 1, 3
+    assert l.lt_stem_pool_fwd(ctypes.byref(sd), 1, 1, None) == -2 and b"channels" in l.lt_last_error()
+    sd.Cin, sd.weight = 8, 8
+    assert l.lt_stem_pool_fwd(ctypes.byref(sd), 1, 1, None) == -1 and b"packed weights" in l.lt_last_error()
+    assert l.lt_stem_packed_bytes() == 2 * 28 * 64 * 16
+    assert l.lt_stem_pack_weights(1, 64, 1, None) == -1 and b"k_pad" in l.lt_last_error()
     # planar output: voxels per sample must be a multiple of 64 that divides rows
     pd.flags[1], pd.rows, pd.plane = H.EPI_STORE_F32, 128, 96
     assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -1 and b"plane" in l.lt_last_error()
