@@ -88,6 +88,8 @@ constexpr int LT_EPI_NO_XCD_REMAP = 1 << 17;      // internal A/B switch (env LT
 int conv2_dispatch(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile, hipStream_t s);
 // conv_igemm3.hip (288-row tile, 8 waves): 1 = launched, 0 = not applicable (fall back), < 0 = error
 int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, bool forced, hipStream_t s);
+// conv_pw.hip (streaming kernel for single-tap phases: 1x1x1 convs, 2x2x2 stride-2 deconvs): 1 / 0 / < 0 as above
+int conv_pw_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, hipStream_t s);
 // conv3d_halo.hip: 1 = launched, 0 = not applicable (fall back), < 0 = error
 int conv3d_halo_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, bool forced, hipStream_t s);
 

@@ -399,6 +399,47 @@ def test_stem_pool(N, hw, cin):
     assert float((out - two).abs().max()) <= 2 ** -7 * float(two.abs().max())
 
 
+PW_CASES = {  # name: (N, cin, cout, (D,H,W), deconv)
+    "pw_16_32": (2, 16, 32, (8, 8, 16), False),
+    "pw_32_64": (1, 32, 64, (4, 8, 8), False),
+    "pw_64_32": (3, 64, 32, (4, 4, 8), False),
+    "pw_128_64": (1, 128, 64, (4, 4, 4), False),
+    "deconv2_64_32": (2, 64, 32, (4, 8, 8), True),
+    "deconv2_128_64": (1, 128, 32, (2, 4, 8), True),     # 8 phases x 64 x 128 weights would not fit the 64 KB budget at Cout = 64
+    "deconv2_32_32_odd": (1, 32, 32, (2, 4, 8), True),
+}
+
+
+@pytest.mark.parametrize("stream", ["1", "0"], ids=["pw_stream", "igemm"])
+@pytest.mark.parametrize("case", list(PW_CASES))
+def test_conv_pointwise_stream(case, stream, monkeypatch):
+    """conv_pw (streaming kernel of the single-tap layers: 1x1x1 convs and 2x2x2 stride-2 deconvs of V2V, bf16) and the implicit
+    GEMM it replaces (LT_CONV_NO_PW=1) vs torch: affine only, ReLU + residual."""
+    if stream == "0":
+        monkeypatch.setenv("LT_CONV_NO_PW", "1")
+    else:
+        monkeypatch.delenv("LT_CONV_NO_PW", raising=False)
+    N, cin, cout, sp, deconv = PW_CASES[case]
+    g = torch.Generator().manual_seed(len(case) + 5)
+    x = torch.randn(N, cin, *sp, generator=g)
+    rd = bf16_round
+    bias = torch.randn(cout, generator=g) * 0.1
+    bn = _bn(cout, g)
+    if deconv:
+        w = torch.randn(cin, cout, 2, 2, 2, generator=g) * (1.0 / cin ** 0.5)
+        conv = F.conv_transpose3d(rd(x), rd(w), bias, 2, 0)
+        osp = tuple(2 * v for v in sp)
+    else:
+        w = torch.randn(cout, cin, 1, 1, 1, generator=g) * (1.0 / cin ** 0.5)
+        conv = F.conv3d(rd(x), rd(w), bias)
+        osp = sp
+    res = torch.randn(N, cout, *osp, generator=g)
+    out = run_conv(x, w, bias, bn, 2 if deconv else 1, 0, torch.bfloat16, 0, transposed=deconv)
+    check("conv_pw=%s/%s/affine" % (stream, case), out, _bn_ref(conv, bn), 1.5e-2)
+    out2 = run_conv(x, w, bias, bn, 2 if deconv else 1, 0, torch.bfloat16, 0, transposed=deconv, relu=True, residual=res)
+    check("conv_pw=%s/%s/relu_res" % (stream, case), out2, torch.relu(_bn_ref(conv, bn) + rd(res)), 1.5e-2)
+
+
 COL_CASES = {  # name: (N, (D,H,W)): 3^3 32->32 bf16 with >= 256 columns of >= 2 tiles -> the column-walking kernel
     "pin_1col_4deep": (8, (16, 32, 64)),        # XCD-pinned samples, one column per workgroup
     "pin_2col_2deep": (16, (8, 32, 64)),        # two columns per workgroup, two tiles per column (ring wraps between columns)
