@@ -192,10 +192,11 @@ def main():
                     traffic = pm["conv_family_bytes_per_step"]
             except (OSError, ValueError, KeyError):
                 pass
-            if "pwchain" in fam:   # the fused pointwise tail is convolution work too
-                conv = {k: conv[k] + fam["pwchain"][k] for k in conv}
+            for extra in ("pwchain", "stem"):   # the fused pointwise tail and the fused stem are convolution work too
+                if extra in fam:
+                    conv = {k: conv[k] + fam[extra][k] for k in conv}
             ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-            result["roofline"] = {"kernel": "conv family: conv_igemm2/3, conv3d_halo*, pwchain (all %d launches of one step)" % conv["launches"], "bound": "mfma",
+            result["roofline"] = {"kernel": "conv family: conv_igemm2/3/5, conv3d_halo*, conv_pw, stem_pool, pwchain (all %d launches of one step)" % conv["launches"], "bound": "mfma",
                                   "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                   "flop_per_step": conv["flops"], "ms_per_step_in_kernel": conv["ms"]}
             hb = {}

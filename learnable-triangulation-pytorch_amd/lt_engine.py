@@ -205,6 +205,7 @@ class PlanBuilder:
         self.stages = stages
         self.flops = 0         # 2*MAC of the recorded convolutions
         self.bytes_alloc = 0
+        self.ntail = 0         # trailing ops kept out of the captured graph (PlanBuilder.custom(tail=True))
 
     # ---- memory ---------------------------------------------------------------------------
     def alloc(self, shape, dtype=None):
@@ -403,20 +404,25 @@ class PlanBuilder:
                   info={"x": x, "y": y})
         return y
 
-    def custom(self, fn, kind="op", label="", flops=0, nbytes=0, info=None):
-        """fn(stream) -> None: any other liblt_hip launch; nbytes = its ALGORITHMIC HBM bytes (roofline numerator)."""
+    def custom(self, fn, kind="op", label="", flops=0, nbytes=0, info=None, tail=False):
+        """fn(stream) -> None: any other liblt_hip launch; nbytes = its ALGORITHMIC HBM bytes (roofline numerator).
+        tail=True: fn(stream, outs=None) is one of the LAST ops of the plan and writes the tensors the caller returns; it stays
+        outside the captured graph so that Plan.run can point it at freshly allocated outputs (no clone of the results)."""
+        assert tail or not self.ntail, "tail ops must be recorded last"
         self._add(fn, kind, label or kind, flops, nbytes, info)
+        self.ntail += 1 if tail else 0
 
     def finish(self):
-        return Plan(self.ops, self.keep, self.device, self.flops, self.bytes_alloc, self.dry_run)
+        return Plan(self.ops, self.keep, self.device, self.flops, self.bytes_alloc, self.dry_run, self.ntail)
 
 
 class Plan:
-    def __init__(self, ops, keep, device, flops, bytes_alloc, dry_run=False):
+    def __init__(self, ops, keep, device, flops, bytes_alloc, dry_run=False, ntail=0):
         self.ops, self.keep, self.device = ops, keep, device
         self.flops, self.bytes_alloc = flops, bytes_alloc
         self.graph = None
         self.dry_run = dry_run
+        self.nhead = len(ops) - ntail   # ops[nhead:] are tail ops: launched eagerly after the graph, fn(stream, outs)
 
     def run_eager(self, stream):
         if self.dry_run:
@@ -441,11 +447,18 @@ class Plan:
 
     def capture(self, stream):
         g = H.Graph()
-        g.capture(stream, lambda: self.run_eager(stream))
+        g.capture(stream, lambda: [fn(stream) for fn, _ in self.ops[:self.nhead]])
         self.graph = g
 
-    def run(self, stream):
+    def run(self, stream, outs=None):
+        """Replays the captured graph (or launches eagerly), then the tail ops; outs: passed to every tail op (the tensors they
+        should write instead of their recorded outputs), None = the recorded ones."""
+        if self.dry_run:
+            raise RuntimeError("a dry-run plan cannot execute: liblt_hip runs on the GPU only")
         if self.graph is not None:
             self.graph.launch(stream)
         else:
-            self.run_eager(stream)
+            for fn, _ in self.ops[:self.nhead]:
+                fn(stream)
+        for fn, _ in self.ops[self.nhead:]:
+            fn(stream, outs)

@@ -35,7 +35,7 @@ def main():
     for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0])[0] * 2 + write.get(k, [0])[0])):
         f, nf = fetch.get(k, [0.0, 0]); w, _ = write.get(k, [0.0, 0])
         per[k] = {"launches_per_step": nf / steps, "fetch_bytes_per_step_corrected": f * 1024 * 2 / steps, "write_bytes_per_step": w * 1024 / steps}
-    conv = [v for k, v in per.items() if k.startswith("conv") or k.startswith("pwchain")]
+    conv = [v for k, v in per.items() if k.startswith("conv") or k.startswith("pwchain") or k.startswith("stem_pool")]
     res = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 3 --warmup 1 --no-graph; FETCH_SIZE x2 "
                    "(gfx950 counts 64 B per 128-B request), KiB -> bytes; Infinity-Cache hits are included in both counters",
            "per_gpu_batch": batch,
