@@ -233,6 +233,8 @@ typedef struct {
     const float* bias;                   /* 64 entries each, or NULL */
     const float* scale;
     const float* shift;
+    int32_t x_layout;                    /* 0: x = N,H,W,8 bf16 (Cin = 8); 1: x = N,3,H,W fp32, the reference's image
+                                            tensor (Cin = 3), rounded to bf16 on the fly like lt_nchw_to_nhwc would */
 } lt_stem_desc;
 size_t lt_stem_packed_bytes(void);
 int lt_stem_pack_weights(const void* weight, int32_t k_pad, void* packed, void* stream);

@@ -5,7 +5,8 @@
 // of 384x384) is written by the convolution and read back by the pool, and the implicit GEMM gathers its A operand in 16-byte
 // pieces (Cin = 3 padded to 8 = one vector per tap): measured 0.56 + 0.19 ms.  Here a workgroup owns a 4 x 16 tile of POOLED
 // pixels:
-//   * the 23 x 72-pixel input patch under it is copied to LDS once (rows are contiguous 16-byte pixels), split by column
+//   * the 23 x 72-pixel input patch under it is copied to LDS once (rows are contiguous 16-byte pixels -- or, x_layout 1, read
+//     straight from the reference's fp32 (N, 3, H, W) images and rounded here: no separate layout pass), split by column
 //     parity so that the stride-2 walk of the convolution reads consecutive 16-byte slots (no bank conflicts);
 //   * the 9 x 33 convolution outputs the pool needs are 10 MFMA fragments of 32 pixels; the kernel window is padded to 7 x 8
 //     taps (the 8th column has zero weights) so that one 32x32x16 MFMA consumes the tap pair (kh, 2kp), (kh, 2kp+1): lanes
@@ -40,7 +41,7 @@ constexpr int SP_LDS = SP_PATCH_B > SP_OUT_B ? SP_PATCH_B : SP_OUT_B;
 static_assert(SP_NFRAG == 10, "two M halves of five fragments");
 
 struct StemArgs {
-    const bf16_t* x;       // N, H, W, 8
+    const void* x;         // N, H, W, 8 bf16 -- or N, 3, H, W fp32 (the reference's image tensor, converted in the patch copy)
     const bf16_t* w;       // fragment-packed: [2 channel blocks][28 K steps][64 lanes][8]
     bf16_t* y;             // N, Hp, Wp, 64
     const float* bias;
@@ -52,6 +53,7 @@ struct StemArgs {
 
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
+template <bool NCHW>
 __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -68,20 +70,49 @@ __global__ __launch_bounds__(256, 3) void stem_pool_kernel(const StemArgs a) {
     // cleared, the surplus items of the last round redo the last slot ----
     {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const bf16_t* xs = a.x + (size_t)n * a.H * a.W * 8;
         constexpr int NIT = (SP_IH * SP_IW + 255) / 256;
         u32x4 v[NIT];
         int slot[NIT];
+        if (NCHW) {
+            // fp32 planes of the reference's (N, 3, H, W) images: three coalesced 4-byte loads per pixel, rounded to bf16
+            // (nearest even, exactly what lt_nchw_to_nhwc + the 8-channel path do) into channels 0-2 of the pixel's slot
+            const float* xs = (const float*)a.x + (size_t)n * 3 * a.H * a.W;
+            const size_t plane = (size_t)a.H * a.W;
+            float f[NIT][3];
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            int i = t + 256 * k;
-            i = i < SP_IH * SP_IW ? i : SP_IH * SP_IW - 1;
-            const int r = i / SP_IW, c = i - r * SP_IW;
-            const int gy = iy0 + r, gx = ix0 + c;
-            const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            const u32x4 ld = *(const u32x4*)(xs + (ok ? ((size_t)gy * a.W + gx) * 8 : 0));
-            v[k] = ok ? ld : (u32x4)(0u);
-            slot[k] = ((r * 2 + (c & 1)) * SP_HALF + (c >> 1)) * 16;
+            for (int k = 0; k < NIT; ++k) {
+                int i = t + 256 * k;
+                i = i < SP_IH * SP_IW ? i : SP_IH * SP_IW - 1;
+                const int r = i / SP_IW, c = i - r * SP_IW;
+                const int gy = iy0 + r, gx = ix0 + c;
+                const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                const size_t off = ok ? (size_t)gy * a.W + gx : 0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float ld = xs[ch * plane + off];
+                    f[k][ch] = ok ? ld : 0.f;
+                }
+                slot[k] = ((r * 2 + (c & 1)) * SP_HALF + (c >> 1)) * 16;
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                v[k] = (u32x4)(0u);
+                v[k][0] = pack_bf16x2(f[k][0], f[k][1]);
+                v[k][1] = pack_bf16x2(f[k][2], 0.f);
+            }
+        } else {
+            const bf16_t* xs = (const bf16_t*)a.x + (size_t)n * a.H * a.W * 8;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                int i = t + 256 * k;
+                i = i < SP_IH * SP_IW ? i : SP_IH * SP_IW - 1;
+                const int r = i / SP_IW, c = i - r * SP_IW;
+                const int gy = iy0 + r, gx = ix0 + c;
+                const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                const u32x4 ld = *(const u32x4*)(xs + (ok ? ((size_t)gy * a.W + gx) * 8 : 0));
+                v[k] = ok ? ld : (u32x4)(0u);
+                slot[k] = ((r * 2 + (c & 1)) * SP_HALF + (c >> 1)) * 16;
+            }
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) *(u32x4*)(smem + slot[k]) = v[k];
@@ -213,10 +244,12 @@ extern "C" int lt_stem_pool_fwd(const lt_stem_desc* d, const void* x, void* y, v
     LT_REQUIRE(d && x && y, LT_ERR_INVALID, "lt_stem_pool_fwd: null argument");
     LT_REQUIRE(d->dtype == LT_BF16, LT_ERR_UNSUPPORTED, "lt_stem_pool_fwd: bf16 only (fp32 plans record conv + max pool)");
     LT_REQUIRE(d->N >= 1 && d->H >= 1 && d->W >= 1, LT_ERR_INVALID, "lt_stem_pool_fwd: bad shape");
-    LT_REQUIRE(d->Cin == 8 && d->Cout == 64, LT_ERR_UNSUPPORTED, "lt_stem_pool_fwd: %d -> %d channels (8 padded input channels -> 64)", d->Cin, d->Cout);
+    LT_REQUIRE(d->x_layout == 0 || d->x_layout == 1, LT_ERR_INVALID, "lt_stem_pool_fwd: x_layout %d", d->x_layout);
+    LT_REQUIRE(d->Cin == (d->x_layout ? 3 : 8) && d->Cout == 64, LT_ERR_UNSUPPORTED,
+               "lt_stem_pool_fwd: %d -> %d channels (8 padded bf16 channels, or the 3 fp32 planes of x_layout 1, -> 64)", d->Cin, d->Cout);
     LT_REQUIRE(d->weight && ((uintptr_t)d->weight & 15) == 0, LT_ERR_INVALID, "lt_stem_pool_fwd: packed weights (lt_stem_pack_weights) missing or misaligned");
     StemArgs a;
-    a.x = (const bf16_t*)x; a.w = (const bf16_t*)d->weight; a.y = (bf16_t*)y;
+    a.x = x; a.w = (const bf16_t*)d->weight; a.y = (bf16_t*)y;
     a.bias = d->bias; a.scale = d->scale; a.shift = d->shift;
     a.N = d->N; a.H = d->H; a.W = d->W;
     a.Hc = (d->H + 6 - 7) / 2 + 1; a.Wc = (d->W + 6 - 7) / 2 + 1;
@@ -224,7 +257,8 @@ extern "C" int lt_stem_pool_fwd(const lt_stem_desc* d, const void* x, void* y, v
     a.tiles_y = (a.Hp + SP_PH - 1) / SP_PH; a.tiles_x = (a.Wp + SP_PW - 1) / SP_PW;
     const long long nblk = (long long)a.N * a.tiles_y * a.tiles_x;
     LT_REQUIRE(nblk < (1ll << 31), LT_ERR_UNSUPPORTED, "lt_stem_pool_fwd: too many tiles");
-    hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)nblk), dim3(256), SP_LDS, (hipStream_t)stream, a);
+    if (d->x_layout) hipLaunchKernelGGL(stem_pool_kernel<true>, dim3((unsigned)nblk), dim3(256), SP_LDS, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(stem_pool_kernel<false>, dim3((unsigned)nblk), dim3(256), SP_LDS, (hipStream_t)stream, a);
     LT_CHECK_LAUNCH("lt_stem_pool_fwd");
     return LT_OK;
 }

@@ -206,6 +206,7 @@ class PlanBuilder:
         self.flops = 0         # 2*MAC of the recorded convolutions
         self.bytes_alloc = 0
         self.ntail = 0         # trailing ops kept out of the captured graph (PlanBuilder.custom(tail=True))
+        self.npre = 0          # leading ops kept out of the captured graph (they read a caller-owned tensor: stem_pool(image_cell=...))
 
     # ---- memory ---------------------------------------------------------------------------
     def alloc(self, shape, dtype=None):
@@ -348,10 +349,16 @@ class PlanBuilder:
                 and tuple(weight.shape[2:]) == (7, 7) and weight.shape[0] == 64 and weight.shape[1] <= 8
                 and stride == 2 and pad == 3 and tuple(pool) == (3, 2, 1))
 
-    def stem_pool(self, x, weight, bn):
+    def stem_pool(self, x, weight, bn, image_cell=None):
         """conv 7x7/2 (no bias) + eval BN + ReLU + max pool 3x3/2 in one pass (lt_stem_pool_fwd).  x: Act [N,1,H,W,8];
-        returns Act [N,1,Hp,Wp,64]."""
+        returns Act [N,1,Hp,Wp,64].  image_cell: a dict whose "ptr" the caller sets, before every Plan.run, to the data
+        pointer of its contiguous fp32 (N,3,H,W) images: the kernel then reads THAT tensor (rounding to bf16 on the fly) instead
+        of x, the op stays outside the captured graph (its input address changes per call), and the separate layout pass into x
+        is not needed.  Must be the first op of the plan; ignored by dry-run plans (their interpreter reads x)."""
         assert self.can_stem_pool(x, weight, 2, 3, (3, 2, 1))
+        if self.dry_run or weight.shape[1] != 3:
+            image_cell = None
+        assert image_cell is None or not self.ops, "an op reading the caller's tensor must be the first of the plan"
         N, _, Hh, W, _ = x.shape
         spec = make_conv_spec(weight, None, bn, x.shape, 2, 3, self.dtype, False, H.EPI_RELU_POST)
         Hp, Wp = (spec.Ho - 1) // 2 + 1, (spec.Wo - 1) // 2 + 1
@@ -365,17 +372,28 @@ class PlanBuilder:
             H.check(lib.lt_stem_pack_weights(wdev.data_ptr(), spec.k_pad, wpk.data_ptr(), H.cur_stream()), "lt_stem_pack_weights")
             torch.cuda.current_stream().synchronize()
         d = H.StemDesc()
-        d.dtype, d.N, d.H, d.W, d.Cin, d.Cout = self.code, N, Hh, W, 8, 64
+        d.dtype, d.N, d.H, d.W, d.Cin, d.Cout = self.code, N, Hh, W, (3 if image_cell is not None else 8), 64
         d.weight, d.bias, d.scale, d.shift = wpk.data_ptr(), bi.data_ptr(), sc.data_ptr(), sh.data_ptr()
+        d.x_layout = 1 if image_cell is not None else 0
         self.keep.append(x.t)
         self.keep.append(d)
         self.keep.append(wpk)
         flops = 2 * N * spec.Ho * spec.Wo * 64 * 49 * weight.shape[1]
         self.flops += flops
         esz = x.t.element_size()
-        self._add(lambda s, d=d, xp=x.t.data_ptr(), yp=y.t.data_ptr(): H.check(lib.lt_stem_pool_fwd(C.byref(d), xp, yp, s), "lt_stem_pool_fwd"),
-                  "stem", "stem conv7x7/2+pool3x3/2 8->64 @%s" % "x".join(str(v) for v in (N, Hh, W)), flops,
-                  (x.t.numel() + y.t.numel()) * esz + spec.phases[0].weight.numel() * esz, {"spec": spec, "x": x, "y": y})
+        if image_cell is not None:
+            def launch(s, d=d, yp=y.t.data_ptr(), cell=image_cell):
+                if not cell.get("ptr"):
+                    raise RuntimeError("stem_pool: the plan reads the caller's images; set image_cell['ptr'] before Plan.run")
+                H.check(lib.lt_stem_pool_fwd(C.byref(d), cell["ptr"], yp, s), "lt_stem_pool_fwd")
+            nbytes = N * 3 * Hh * W * 4 + y.t.numel() * esz + spec.phases[0].weight.numel() * esz
+            self.npre += 1
+        else:
+            def launch(s, d=d, xp=x.t.data_ptr(), yp=y.t.data_ptr()):
+                H.check(lib.lt_stem_pool_fwd(C.byref(d), xp, yp, s), "lt_stem_pool_fwd")
+            nbytes = (x.t.numel() + y.t.numel()) * esz + spec.phases[0].weight.numel() * esz
+        self._add(launch, "stem", "stem conv7x7/2+pool3x3/2 %d->64 @%s" % (d.Cin, "x".join(str(v) for v in (N, Hh, W))), flops, nbytes,
+                  {"spec": spec, "x": x, "y": y})
         return y
 
     def maxpool(self, x, k, s, p, nd):
@@ -413,16 +431,19 @@ class PlanBuilder:
         self.ntail += 1 if tail else 0
 
     def finish(self):
-        return Plan(self.ops, self.keep, self.device, self.flops, self.bytes_alloc, self.dry_run, self.ntail)
+        return Plan(self.ops, self.keep, self.device, self.flops, self.bytes_alloc, self.dry_run, self.ntail, self.npre)
 
 
 class Plan:
-    def __init__(self, ops, keep, device, flops, bytes_alloc, dry_run=False, ntail=0):
+    def __init__(self, ops, keep, device, flops, bytes_alloc, dry_run=False, ntail=0, npre=0):
         self.ops, self.keep, self.device = ops, keep, device
         self.flops, self.bytes_alloc = flops, bytes_alloc
         self.graph = None
         self.dry_run = dry_run
-        self.nhead = len(ops) - ntail   # ops[nhead:] are tail ops: launched eagerly after the graph, fn(stream, outs)
+        # ops[:npre] read a caller-owned tensor and ops[nhead:] write the caller's result tensors: both are launched eagerly
+        # around the captured graph of ops[npre:nhead]
+        self.npre = npre
+        self.nhead = len(ops) - ntail
 
     def run_eager(self, stream):
         if self.dry_run:
@@ -447,18 +468,20 @@ class Plan:
 
     def capture(self, stream):
         g = H.Graph()
-        g.capture(stream, lambda: [fn(stream) for fn, _ in self.ops[:self.nhead]])
+        g.capture(stream, lambda: [fn(stream) for fn, _ in self.ops[self.npre:self.nhead]])
         self.graph = g
 
     def run(self, stream, outs=None):
-        """Replays the captured graph (or launches eagerly), then the tail ops; outs: passed to every tail op (the tensors they
-        should write instead of their recorded outputs), None = the recorded ones."""
+        """Launches the pre ops, replays the captured graph (or launches eagerly), then the tail ops; outs: passed to every
+        tail op (the tensors they should write instead of their recorded outputs), None = the recorded ones."""
         if self.dry_run:
             raise RuntimeError("a dry-run plan cannot execute: liblt_hip runs on the GPU only")
+        for fn, _ in self.ops[:self.npre]:
+            fn(stream)
         if self.graph is not None:
             self.graph.launch(stream)
         else:
-            for fn, _ in self.ops[:self.nhead]:
+            for fn, _ in self.ops[self.npre:self.nhead]:
                 fn(stream)
         for fn, _ in self.ops[self.nhead:]:
             fn(stream, outs)

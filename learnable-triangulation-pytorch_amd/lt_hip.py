@@ -49,7 +49,7 @@ class PwChainDesc(C.Structure):
 
 class StemDesc(C.Structure):
     _fields_ = [("dtype", i32), ("N", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32),
-                ("weight", vp), ("bias", vp), ("scale", vp), ("shift", vp)]
+                ("weight", vp), ("bias", vp), ("scale", vp), ("shift", vp), ("x_layout", i32)]
 
 
 # symbol -> (restype, argtypes); must list every symbol include/lt_hip.h declares

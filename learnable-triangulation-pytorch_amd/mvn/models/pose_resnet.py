@@ -133,11 +133,12 @@ class PoseResNet(nn.Module):
         self.register_load_state_dict_post_hook(lambda m, k: m._plans.clear())
 
     # ---- plan recording -------------------------------------------------------------------
-    def record(self, b, x, want_heatmaps=True):
+    def record(self, b, x, want_heatmaps=True, image_cell=None):
         """x: Act [N,1,H,W,Cpad] (zero-padded input channels).  Returns (heatmaps Act fp32 | None,
-        features Act, alg_conf Act | None, vol_conf Act | None)."""
+        features Act, alg_conf Act | None, vol_conf Act | None).  image_cell: see PlanBuilder.stem_pool (the fused stem reads
+        the caller's fp32 images directly; x is then only a shape)."""
         if b.can_stem_pool(x, self.conv1.weight, 2, 3, (3, 2, 1)):   # bf16: conv1 + bn1 + relu + maxpool in one pass
-            y = b.stem_pool(x, self.conv1.weight, bn_tuple(self.bn1))
+            y = b.stem_pool(x, self.conv1.weight, bn_tuple(self.bn1), image_cell=image_cell)
         else:
             y = b.conv(x, self.conv1.weight, None, bn_tuple(self.bn1), stride=2, pad=3, relu=True)
             p = b.maxpool(y, 3, 2, 1, nd=2); b.release(y)

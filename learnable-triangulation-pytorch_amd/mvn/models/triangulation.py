@@ -101,7 +101,11 @@ class VolumetricTriangulationNet(_PlannedNet):
         x_in = b.alloc((B * NV, 1, Hh, W, E.min_cin_of(dt)))
         x_in.pooled = False
         # the 1x1 heatmap head is dead in the volumetric path: only its SHAPE is used (reference :264)
-        _, feats256, _, volc = self.backbone.record(b, x_in, want_heatmaps=False)
+        # bf16 plans: the fused stem reads the caller's fp32 images (pointer handed over per forward through this cell)
+        image_cell = {"ptr": None, "ref": None}
+        _, feats256, _, volc = self.backbone.record(b, x_in, want_heatmaps=False, image_cell=image_cell)
+        if not b.npre:
+            image_cell = None
         pf = self.process_features[0]
         feats = b.conv(feats256, pf.weight, pf.bias, None)
         b.release(feats256)
@@ -147,7 +151,7 @@ class VolumetricTriangulationNet(_PlannedNet):
                  info={"logits": logits, "coords": coords, "mult": mult, "softmax": sm, "kp": kp, "probs": probs}, tail=True)
         plan = b.finish()
         plan.keep += [geo, geo_host, coords, kp, probs, ws]
-        return {"plan": plan, "x_in": x_in, "feats": feats, "geo": geo, "geo_host": geo_host, "coords": coords, "kp": kp,
+        return {"plan": plan, "x_in": x_in, "image_cell": image_cell, "feats": feats, "geo": geo, "geo_host": geo_host, "coords": coords, "kp": kp,
                 "probs": probs, "conf": conf, "logits": logits, "vol": vol, "hw": (h, w), "offs": (o_pos, o_cen, o_rot),
                 "captured": False}
 
@@ -203,8 +207,11 @@ class VolumetricTriangulationNet(_PlannedNet):
         with torch.cuda.stream(side):
             st = side.cuda_stream
             P["geo"].copy_(P["geo_host"], non_blocking=True)
-            H.check(H.lib().lt_nchw_to_nhwc(H.dtype_code(self.compute_dtype), x.data_ptr(), P["x_in"].t.data_ptr(), B * NV, 3, Hh * W,
-                                            P["x_in"].t.shape[-1], st), "lt_nchw_to_nhwc")
+            if P["image_cell"] is not None:     # the plan's first op reads the images where they are
+                P["image_cell"]["ptr"], P["image_cell"]["ref"] = x.data_ptr(), x
+            else:
+                H.check(H.lib().lt_nchw_to_nhwc(H.dtype_code(self.compute_dtype), x.data_ptr(), P["x_in"].t.data_ptr(), B * NV, 3, Hh * W,
+                                                P["x_in"].t.shape[-1], st), "lt_nchw_to_nhwc")
             plan = P["plan"]
             if self.use_graph and not P["captured"]:
                 plan.run_eager(st)          # warm-up launch outside capture (sets func attributes, loads code objects)

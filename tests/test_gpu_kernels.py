@@ -397,6 +397,19 @@ def test_stem_pool(N, hw, cin):
     record("stem_pool/%dx%dx%d vs conv+pool max abs diff" % (N, hw[0], hw[1]), float((out - two).abs().max()))
     # same bf16 inputs, fp32 accumulation in a different order: a rounding boundary may flip the last bf16 bit
     assert float((out - two).abs().max()) <= 2 ** -7 * float(two.abs().max())
+    if cin == 3:   # x_layout 1: the same kernel reading the fp32 (N, 3, H, W) images where they are (a pre op of the plan)
+        b2 = E.PlanBuilder(DEV, torch.bfloat16)
+        cell = {"ptr": None}
+        y3 = b2.stem_pool(E.Act(torch.empty(N, 1, hw[0], hw[1], 8, dtype=torch.bfloat16, device=DEV)), w, bn, image_cell=cell)
+        plan = b2.finish()
+        assert plan.npre == 1
+        with pytest.raises(RuntimeError, match="image_cell"):
+            plan.run(torch.cuda.current_stream().cuda_stream)
+        xd = x.to(DEV).contiguous()
+        cell["ptr"] = xd.data_ptr()
+        plan.run(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(from_cl(y3.t, 2), out), "fp32-image path must round exactly like lt_nchw_to_nhwc + the bf16 path"
 
 
 PW_CASES = {  # name: (N, cin, cout, (D,H,W), deconv)

@@ -223,6 +223,10 @@ def test_c_abi_exports_every_declared_symbol():
     assert l.lt_stem_pool_fwd(ctypes.byref(sd), 1, 1, None) == -2 and b"channels" in l.lt_last_error()
     sd.Cin, sd.weight = 8, 8
     assert l.lt_stem_pool_fwd(ctypes.byref(sd), 1, 1, None) == -1 and b"packed weights" in l.lt_last_error()
+    sd.x_layout = 1       # fp32 (N, 3, H, W) images: Cin must then be 3
+    assert l.lt_stem_pool_fwd(ctypes.byref(sd), 1, 1, None) == -2 and b"channels" in l.lt_last_error()
+    sd.x_layout = 2
+    assert l.lt_stem_pool_fwd(ctypes.byref(sd), 1, 1, None) == -1 and b"x_layout" in l.lt_last_error()
     assert l.lt_stem_packed_bytes() == 2 * 28 * 64 * 16
     assert l.lt_stem_pack_weights(1, 64, 1, None) == -1 and b"k_pad" in l.lt_last_error()
     # planar output: voxels per sample must be a multiple of 64 that divides rows
