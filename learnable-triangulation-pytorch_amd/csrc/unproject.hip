@@ -13,6 +13,8 @@
 //     feature maps occupy one private L2 instead of being replicated into all eight.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "lt_common.h"
 
 using namespace lt;
@@ -421,6 +423,121 @@ __global__ __launch_bounds__(1024) void unproject_lds_kernel(const UnprojArgs a)
     ChVec<T, CH>::st(out + vox * C + c0, res);
 }
 
+// ---- quad kernel: bf16, C = 32, exactly 4 views, softmax aggregation, bricked volumes (the BASELINE configuration) -----------------
+// The generic kernel above is VALU-bound (~700 instructions per lane-item; PMC: 40 % of the cycles waiting on instruction
+// issue): every one of the four lanes of a voxel (one per 8-channel vector) redoes the projection of the voxel into all four
+// views.  Here the four lanes of a voxel's quad split the VIEWS for the projection (lane j projects into view j and keeps that
+// view's 3x4 matrix in registers for the whole kernel), fold the zero-padding rules into the four bilinear weights (an invalid
+// corner gets weight 0 and a clamped, readable address), and hand the four tap offsets + four weights of their view to the
+// other three lanes with DPP quad broadcasts; the bilinear blend and the view softmax run on packed fp32 pairs (v_pk_fma_f32).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+template <int Q>
+__device__ __forceinline__ int quad_bcast_i(int v) {   // value of lane Q of this lane's quad
+    return __builtin_amdgcn_mov_dpp(v, Q | (Q << 2) | (Q << 4) | (Q << 6), 0xf, 0xf, true);
+}
+template <int Q>
+__device__ __forceinline__ float quad_bcast_f(float v) { return __int_as_float(quad_bcast_i<Q>(__float_as_int(v))); }
+
+__global__ __launch_bounds__(256) void unproject_q4_kernel(const UnprojArgs a) {
+    typedef bf16_t T;
+    constexpr int C = 32;
+    int b, chunk;
+    if (a.xcd_pin) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        b = xcd + 8 * (j / a.chunks);
+        chunk = j % a.chunks;
+    } else {
+        b = blockIdx.x / a.chunks;
+        chunk = blockIdx.x % a.chunks;
+    }
+    const long long nvox = (long long)a.v0 * a.v1 * a.v2;
+    const T* feats = (const T*)a.feats + (long long)b * 4 * a.h * a.w * C;
+    const float* coords = a.coords + (long long)b * nvox * 3;
+    T* out = (T*)a.out + (long long)b * nvox * C;
+    const int nk = a.v2 >> 4, nj = a.v1 >> 2;
+    const int bk = (chunk % nk) << 4, bj = ((chunk / nk) % nj) << 2, bi = (chunk / (nk * nj)) << 2;
+    const int t = threadIdx.x, qv = t & 3;               // qv: the view this lane projects into AND its 8-channel vector
+    const int h = a.h, w = a.w;
+    float P[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) P[i] = a.proj[((long long)b * 4 + qv) * 12 + i];
+    const float inv_h = __builtin_amdgcn_rcpf((float)h), inv_w = __builtin_amdgcn_rcpf((float)w);
+    const int vbase = qv * h * w * C + 0;                // element offset of view qv's map (this lane's projection)
+
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+        const int vb = it * 64 + (t >> 2);
+        const long long vox = ((long long)(bi + (vb >> 6)) * a.v1 + bj + ((vb >> 4) & 3)) * a.v2 + bk + (vb & 15);
+        const float X0 = coords[vox * 3], X1 = coords[vox * 3 + 1], X2 = coords[vox * 3 + 2];
+        // ---- projection of the voxel into view qv (the arithmetic of sample_view<bf16>) ----
+        const float px = __fadd_rn(fmaf(X2, P[2], fmaf(X1, P[1], __fmul_rn(X0, P[0]))), P[3]);
+        const float py = __fadd_rn(fmaf(X2, P[6], fmaf(X1, P[5], __fmul_rn(X0, P[4]))), P[7]);
+        float pz = __fadd_rn(fmaf(X2, P[10], fmaf(X1, P[9], __fmul_rn(X0, P[8]))), P[11]);
+        const bool invalid = pz <= 0.0f;
+        if (pz == 0.0f) pz = 1.0f;
+        const float rz = __builtin_amdgcn_rcpf(pz);
+        const float u = px * rz, vv = py * rz;
+        const float gx = __fmul_rn(2.0f, __fsub_rn(u * inv_h, 0.5f));      // op.py:128-129: x by h, y by w
+        const float gy = __fmul_rn(2.0f, __fsub_rn(vv * inv_w, 0.5f));
+        const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), 0.5f * (float)(w - 1));
+        const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), 0.5f * (float)(h - 1));
+        const float xw = floorf(ix), yn = floorf(iy);
+        const float we = __fsub_rn(ix, xw), ww = __fsub_rn(1.0f, we);
+        const float ws = __fsub_rn(iy, yn), wn = __fsub_rn(1.0f, ws);
+        const bool xw_ok = xw >= 0.f && xw <= (float)(w - 1), xe_ok = xw >= -1.f && xw <= (float)(w - 2);
+        const bool yn_ok = yn >= 0.f && yn <= (float)(h - 1), ys_ok = yn >= -1.f && yn <= (float)(h - 2);
+        const bool act = !invalid && (xw_ok || xe_ok) && (yn_ok || ys_ok);
+        const int x0 = act ? (int)xw : 0, y0 = act ? (int)yn : 0;
+        const int xwc = min(max(x0, 0), w - 1), xec = min(max(x0 + 1, 0), w - 1);
+        const int rn = min(max(y0, 0), h - 1) * w, rs = min(max(y0 + 1, 0), h - 1) * w;
+        // my view's four corners: element offsets (clamped into the map) and weights (0 where the corner is padding)
+        const int o00 = vbase + (rn + xwc) * C, o01 = vbase + (rn + xec) * C, o10 = vbase + (rs + xwc) * C, o11 = vbase + (rs + xec) * C;
+        const float k00 = (act && yn_ok && xw_ok) ? __fmul_rn(wn, ww) : 0.f, k01 = (act && yn_ok && xe_ok) ? __fmul_rn(wn, we) : 0.f;
+        const float k10 = (act && ys_ok && xw_ok) ? __fmul_rn(ws, ww) : 0.f, k11 = (act && ys_ok && xe_ok) ? __fmul_rn(ws, we) : 0.f;
+
+        f32x2_t val[4][4];                                // [view][channel pair] of this lane's 8 channels
+        auto view = [&](auto vc) {
+            constexpr int V = decltype(vc)::value;
+            const int p00 = quad_bcast_i<V>(o00), p01 = quad_bcast_i<V>(o01), p10 = quad_bcast_i<V>(o10), p11 = quad_bcast_i<V>(o11);
+            const float w00 = quad_bcast_f<V>(k00), w01 = quad_bcast_f<V>(k01), w10 = quad_bcast_f<V>(k10), w11 = quad_bcast_f<V>(k11);
+            const uint4 t00 = *(const uint4*)(feats + p00 + qv * 8), t01 = *(const uint4*)(feats + p01 + qv * 8);
+            const uint4 t10 = *(const uint4*)(feats + p10 + qv * 8), t11 = *(const uint4*)(feats + p11 + qv * 8);
+            const unsigned u00[4] = {t00.x, t00.y, t00.z, t00.w}, u01[4] = {t01.x, t01.y, t01.z, t01.w};
+            const unsigned u10[4] = {t10.x, t10.y, t10.z, t10.w}, u11[4] = {t11.x, t11.y, t11.z, t11.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const f32x2_t f00 = {__uint_as_float(u00[d] << 16), __uint_as_float(u00[d] & 0xffff0000u)};
+                const f32x2_t f01 = {__uint_as_float(u01[d] << 16), __uint_as_float(u01[d] & 0xffff0000u)};
+                const f32x2_t f10 = {__uint_as_float(u10[d] << 16), __uint_as_float(u10[d] & 0xffff0000u)};
+                const f32x2_t f11 = {__uint_as_float(u11[d] << 16), __uint_as_float(u11[d] & 0xffff0000u)};
+                val[V][d] = f00 * w00 + f01 * w01 + f10 * w10 + f11 * w11;
+            }
+        };
+        view(std::integral_constant<int, 0>{}); view(std::integral_constant<int, 1>{});
+        view(std::integral_constant<int, 2>{}); view(std::integral_constant<int, 3>{});
+
+        // ---- softmax over the views per channel: sum_v x_v softmax_v(x) = (sum_v x_v e_v) / (sum_v e_v) ----
+        unsigned o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            f32x2_t m = val[0][d];
+#pragma unroll
+            for (int v = 1; v < 4; ++v) { m[0] = fmaxf(m[0], val[v][d][0]); m[1] = fmaxf(m[1], val[v][d][1]); }
+            f32x2_t s = {0.f, 0.f}, tt = {0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x2_t dl = (val[v][d] - m) * 1.4426950408889634f;
+                const f32x2_t ex = {__builtin_amdgcn_exp2f(dl[0]), __builtin_amdgcn_exp2f(dl[1])};
+                s += ex;
+                tt += val[v][d] * ex;
+            }
+            o[d] = pack_bf16x2(tt[0] * __builtin_amdgcn_rcpf(s[0]), tt[1] * __builtin_amdgcn_rcpf(s[1]));
+        }
+        *(uint4*)(out + vox * C + qv * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 template <typename T, int CH>
 int launch_unproject(const UnprojArgs& a, hipStream_t st) {
     const unsigned grid = (unsigned)((long long)a.B * a.chunks);
@@ -473,6 +590,12 @@ extern "C" int lt_unproject_fwd(int32_t dtype, const void* feats, const float* p
     if (C == 32 && NV <= UP_NV && a.bricked && use_lds && use_lds[0] == '1') {
         hipLaunchKernelGGL(unproject_lds_kernel, dim3((unsigned)((long long)a.B * a.chunks)), dim3(1024), 0, st, a);
         LT_CHECK_LAUNCH("lt_unproject_fwd(lds)");
+        return LT_OK;
+    }
+    const char* no_q4 = getenv("LT_UNPROJ_NO_Q4");       // A/B, read per call
+    if (C == 32 && NV == 4 && a.bricked && agg == LT_AGG_SOFTMAX && !no_q4 && (long long)4 * h * w * C < (1ll << 30)) {
+        hipLaunchKernelGGL(unproject_q4_kernel, dim3((unsigned)((long long)a.B * a.chunks)), dim3(256), 0, st, a);
+        LT_CHECK_LAUNCH("lt_unproject_fwd(q4)");
         return LT_OK;
     }
     if (C % 8 == 0) return launch_unproject<bf16_t, 8>(a, st);

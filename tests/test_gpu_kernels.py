@@ -533,8 +533,9 @@ def test_unproject_bf16_lds_staged(staged, monkeypatch):
     monkeypatch.setenv("LT_UNPROJ_LDS", staged)
     synth = __import__("oracle.synth", fromlist=["x"])
     g = torch.Generator().manual_seed(21)
-    for B, NV, V, hw in ((8, 4, 32, 24), (2, 3, 16, 96), (1, 8, 16, 24)):
-        K, R, t = synth.ring_cameras(NV, 96, inside=(NV == 3))
+    # (B, views, volume, map size, a camera inside the cube): NV == 4 + softmax takes the quad kernel (unproject_q4_kernel)
+    for B, NV, V, hw, inside in ((8, 4, 32, 24, False), (2, 3, 16, 96, True), (1, 8, 16, 24, False), (3, 4, 16, 96, True)):
+        K, R, t = synth.ring_cameras(NV, 96, inside=inside)
         P = torch.from_numpy(O.resized_projection(K, R, t, (96, 96), (hw, hw))).float()[None].repeat(B, 1, 1, 1).contiguous()
         hm = torch.randn(B, NV, 32, hw, hw, generator=g)
         conf = torch.rand(B, NV, 32, generator=g) + 0.1
@@ -544,6 +545,12 @@ def test_unproject_bf16_lds_staged(staged, monkeypatch):
             out = op.unproject_heatmaps(hm.to(DEV).bfloat16(), P.to(DEV), cv.to(DEV), method, conf.to(DEV))
             ref = O.unproject_heatmaps(bf16_round(hm), P, cv, method, conf)
             check("unproject_bf16/staged=%s/B%d_NV%d_V%d_hw%d/%s" % (staged, B, NV, V, hw, method), out.float().cpu(), ref, 1e-2)
+        if NV == 4 and staged == "0":   # the quad kernel against the generic gather kernel it replaces
+            out = op.unproject_heatmaps(hm.to(DEV).bfloat16(), P.to(DEV), cv.to(DEV), "softmax")
+            monkeypatch.setenv("LT_UNPROJ_NO_Q4", "1")
+            gen = op.unproject_heatmaps(hm.to(DEV).bfloat16(), P.to(DEV), cv.to(DEV), "softmax")
+            monkeypatch.delenv("LT_UNPROJ_NO_Q4")
+            check("unproject_bf16/q4 vs generic/B%d_V%d_hw%d" % (B, V, hw), out.float().cpu(), gen.float().cpu(), 1e-2)
 
 
 V5_CASES = {  # name: (nd, N, cin, cout, k, stride, pad, spatial, residual)
