@@ -79,6 +79,9 @@ typedef struct lt_conv_phase {
     const int32_t* taps; /* ntaps x 4 int32: dd, dh, dw, element offset ((dd*H + dh)*W + dw)*Cin     */
     int32_t ntaps;
     int32_t out_off[3];  /* ood, ooh, oow                                                            */
+    const void* weight_frag; /* optional (NULL = none): the same bf16 weights in MFMA fragment order, written by
+                                lt_conv_pack_weights -- lets the 288 x 256 kernel read its B operand with coalesced
+                                loads instead of staging it through LDS (Cout % 256 == 0 layers)                  */
 } lt_conv_phase;
 
 typedef struct lt_conv_desc {
@@ -96,6 +99,10 @@ typedef struct lt_conv_desc {
     int32_t stages;             /* 0 = choose; 2 or 3 = LDS-DMA ring depth of the v2 kernels (tuning)       */
     lt_conv_phase phase[LT_CONV_MAX_PHASES];
 } lt_conv_desc;
+
+/* bf16 weights [cout_pad][k_pad] (cout_pad % 16 == 0, k_pad % 32 == 0) -> cout_pad * k_pad elements in fragment order
+ * ([k_pad / 32][cout_pad / 16][64 lanes][8]: lane l holds column 16 t + (l & 15), K elements 32 s + 8 (l >> 4) .. + 7). */
+int lt_conv_pack_weights(const void* weight, int32_t cout_pad, int32_t k_pad, void* packed, void* stream);
 
 enum { LT_TILE_AUTO = 0,
        /* v1: register-staged tiles (kept for A/B runs and as a cross-check) */

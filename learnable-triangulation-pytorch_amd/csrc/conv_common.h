@@ -11,6 +11,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct PhaseArg {
     const void* w;
+    const void* wfrag;   // the same weights in MFMA B-fragment order (lt_conv_pack_weights), or null
     const int4* taps;
     int ntaps;
     int ood, ooh, oow;

@@ -945,6 +945,288 @@ __global__ __launch_bounds__(512) void conv_igemm5_kernel(const ConvArgs a) {
     }
 }
 
+// ---- 288 x 256 tile with the B operand (weights) read straight from global memory in fragment order ---------------------------
+// What bounds conv_igemm5 is the number of LDS-DMA pieces a CU can push per unit of time (each piece = 16 rows of 64 bytes = 16
+// separate segments for the address path): 34 per K step, 18 of activations and 16 of weights.  The weights need no gather at
+// all: lt_conv_pack_weights stores them once per model in MFMA fragment order ([K / 32][Cout / 16][lane] x 16 bytes), so a wave
+// reads each of its four B fragments with ONE fully coalesced 1 KB global load (L1 / L2 resident: every workgroup of the same
+// N tile reads the same bytes) into registers, one K step ahead.  The ring then carries activations only: 18 pieces and 18 KB
+// per stage, six stages in 108 KB, and half the LDS fragment reads.  Everything else (tile, waves, sliced DMA issue, read
+// stream with counted lgkmcnt, epilogue) is conv_igemm5's.  The K loop is unrolled by two because the two B register sets
+// alternate (k_pad is a multiple of 64, so the number of 32-element steps is even).
+// wave-uniform base in SGPRs + 32-bit lane offset + immediate: no 64-bit address arithmetic in VGPRs
+template <int IMM>
+__device__ __forceinline__ void gload16(V16& d, const void* sbase, unsigned voff) {
+    static_assert(IMM >= 0 && IMM < 4096, "global_load immediate offset");
+    f32x4 t;
+    const unsigned long long b = (unsigned long long)(size_t)sbase;
+    const unsigned long long ub = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)b);   // uniform by construction; make it provable
+    // s_nop: the base may have just been written by v_readfirstlane, and a VALU write of an SGPR needs 5 wait states before a
+    // vector-memory instruction reads it -- the hazard recognizer does not look inside inline asm (seen: the load took the
+    // stale low dword and faulted)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(t) : "v"(voff), "s"(ub), "n"(IMM) : "memory");
+    d.f = t;
+}
+__device__ __forceinline__ void wait_vmcnt6(int n) {
+    switch (n) {
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: wait_vmcnt3(n); break;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void conv_igemm6_kernel(const ConvArgs a) {
+    typedef bf16_t T;
+    constexpr bool PW = MODE == 1;
+    constexpr int BM = BM3, BN = 256, NW = 8, WM = 144, WN = 64, MF = 16, SM = WM / MF, SN = WN / MF, NST = 6, VEC = 8, BK = 32, ROWB = 64;
+    constexpr int NPA = BM / 16;                          // 18 DMA pieces of 1 KiB per stage (16 rows of 64 B each)
+    constexpr int A_IT = (NPA + NW - 1) / NW;             // 3 (waves 0, 1) / 2
+    constexpr int STAGE = BM * ROWB;                      // 18432 B: activations only
+    constexpr int REGION = NST * STAGE;
+    constexpr int EP_ROWS = 48, EP_LD = WN + 4, EP_WAVE = EP_ROWS * EP_LD * 4, NPASS = WM / EP_ROWS;
+    static_assert(NW * EP_WAVE <= REGION && NPASS == 3, "epilogue staging");
+    typedef typename Mma<T, MF>::acc_t acc_t;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int4* s_taps = (int4*)(smem + REGION);               // [ntaps] (unused when PW)
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page3;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int lin = blockIdx.x;
+    if (!(a.flags & LT_EPI_NO_XCD_REMAP)) {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = lin & 7, j = lin >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tile_n = lin % a.tiles_n;
+    const int tile_m = lin / a.tiles_n;
+    const PhaseArg ph = a.phase[0];
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const T* __restrict__ x = (const T*)a.x;
+
+    const int prow = lane >> 2;
+    const int kv = (lane & 3) ^ swz64(prow);
+    const bool a_tail = wave < NPA % NW;                 // waves 0, 1 own a third piece
+    const int dps = (A_IT - 1) + (a_tail ? 1 : 0);       // 3 or 2 DMA pieces per wave and stage
+    int id0[PW ? 1 : A_IT], ih0[PW ? 1 : A_IT], iw0[PW ? 1 : A_IT], baseC[A_IT], cur[PW ? 1 : A_IT];
+    if (!PW)
+        for (int i = t; i < ph.ntaps; i += 64 * NW) s_taps[i] = ph.taps[i];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + 16 * (wave + NW * i) + prow;
+        const bool own = i < A_IT - 1 || a_tail;
+        if (PW) baseC[i] = (own && m < a.M) ? m * a.Cin + kv * VEC : -1;
+        else if (own && m < a.M) {
+            int n, od, oh, ow;
+            decode_row(a, m, n, od, oh, ow);
+            id0[i] = od * a.sd - a.pd;
+            ih0[i] = oh * a.sh - a.ph;
+            iw0[i] = ow * a.sw - a.pw;
+            baseC[i] = (((n * a.D + id0[i]) * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
+        } else {
+            id0[i] = -(1 << 24);
+            ih0[i] = iw0[i] = baseC[i] = 0;
+        }
+    }
+    // B fragments of this wave: N tiles n0 / 16 + 4 wn + j, K step ks -> ((ks * cout_pad / 16 + tile) * 64 + lane) * 16 bytes
+    const size_t wstep = (size_t)a.tiles_n * (BN / 16) * 64 * VEC;   // elements per K step
+    const T* wfrag = (const T*)ph.wfrag + (size_t)(n0 / 16 + SN * wn) * 64 * VEC;   // wave-uniform; lane l reads + 16 l bytes
+    const unsigned wlane = lane * 16;
+    __syncthreads();
+
+    const int nk = a.k_pad / BK;
+    int c0s = 0;
+    auto stage_prep = [&](int ks) {
+        if (!PW) {
+            const int k0 = ks * BK;
+            c0s = k0 & (a.Cin - 1);
+            if (c0s == 0) {                              // the tap changes every Cin / 32 steps
+                const int tap = k0 >> a.log2Cin;
+                int4 tp = make_int4(-(1 << 24), 0, 0, 0);
+                if (tap < ph.ntaps) tp = s_taps[tap];
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) {
+                    const int id = id0[i] + tp.x, ih = ih0[i] + tp.y, iw = iw0[i] + tp.z;
+                    const bool ok = ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+                    cur[i] = ok ? baseC[i] + tp.w + kv * VEC : -1;
+                }
+            }
+        }
+    };
+    auto stage_piece = [&](int ks, unsigned sbuf, auto pc) {
+        constexpr int P = decltype(pc)::value;
+        if (P == A_IT - 1 && !a_tail) return;
+        const void* src;
+        if (PW) src = baseC[P] >= 0 ? (const void*)(x + (baseC[P] + ks * BK)) : zero_page;
+        else src = cur[P] >= 0 ? (const void*)(x + (cur[P] + c0s)) : zero_page;
+        dma16(src, lds0 + sbuf + (wave + NW * P) * 1024);
+    };
+
+    const int r15 = lane & 15;
+    const unsigned fo = r15 * ROWB + (((lane >> 4) ^ swz64(r15)) << 4);
+    const unsigned aoff = lds0 + wm * WM * ROWB + fo;
+
+    acc_t acc[SM][SN];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    V16 fb[2][SN];                                        // B fragments of steps ks (set ks & 1) and ks + 1
+    static_for<0, SN>([&](auto jc) { gload16<decltype(jc)::value * 1024>(fb[0][decltype(jc)::value], wfrag, wlane); });
+#pragma unroll
+    for (int sgi = 0; sgi < NST - 1; ++sgi)
+        if (sgi < nk) {
+            stage_prep(sgi);
+            static_for<0, A_IT>([&](auto pc) { stage_piece(sgi, sgi * STAGE, pc); });
+        }
+
+    constexpr int LOOK = 3, RA = LOOK + 1;               // read stream of a step: the SM A fragments
+    unsigned rbuf = 0, wbuf = (NST - 1) * STAGE;          // ring offsets of the stage being read / being requested
+    auto step = [&](int ks, auto rc) {
+        constexpr int R = decltype(rc)::value;           // ks & 1: which B register set this step multiplies with
+        // needed now: B(ks) (requested at the start of step ks-1) and, older, stage ks.  Requested after B(ks): the pieces of stage
+        // ks+NST-2 (step ks-1), if that stage exists; before the first step: stages 1 .. NST-2 after stage 0
+        const int after = ks == 0 ? ((nk < NST - 1 ? nk : NST - 1) - 1) * dps : (ks + NST - 2 < nk ? dps : 0);
+        wait_vmcnt6(after);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage ks landed for every wave; stage ks-1 fully consumed
+#pragma unroll
+        for (int j = 0; j < SN; ++j) frag_ready(fb[R][j]);
+        {   // B(ks+1): the last step re-reads its own fragments (a valid address; never used)
+            const T* wn1 = wfrag + (size_t)(ks + 1 < nk ? ks + 1 : ks) * wstep;
+            static_for<0, SN>([&](auto jc) { gload16<decltype(jc)::value * 1024>(fb[R ^ 1][decltype(jc)::value], wn1, wlane); });
+        }
+        const bool more = ks + NST - 1 < nk;
+        if (more) stage_prep(ks + NST - 1);
+        const unsigned abase = aoff + rbuf;
+        V16 fa[RA];
+        auto issue = [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
+            lds_read16<K * 16 * ROWB>(fa[K % RA], abase);
+        };
+        static_for<0, SM>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int prev_target = u == 0 ? 0 : (u + LOOK < SM ? u + LOOK : SM);
+            constexpr int target = u + 1 + LOOK < SM ? u + 1 + LOOK : SM;
+            static_for<prev_target, target>([&](auto kc) { issue(kc); });
+            lgkm_wait<target - u - 1>();
+            frag_ready(fa[u % RA]);
+#pragma unroll
+            for (int j = 0; j < SN; ++j) LT3_MMA(acc[u][j], fa[u % RA], fb[R][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (u % 2 == 0 && u / 2 < A_IT) {   // one DMA piece of stage ks+NST-1 behind every second fragment
+                if (more) stage_piece(ks + NST - 1, wbuf, std::integral_constant<int, u / 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        rbuf = rbuf + STAGE == REGION ? 0 : rbuf + STAGE;
+        wbuf = wbuf + STAGE == REGION ? 0 : wbuf + STAGE;
+    };
+    for (int ks = 0; ks < nk; ks += 2) {
+        step(ks, std::integral_constant<int, 0>{});
+        step(ks + 1, std::integral_constant<int, 1>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring becomes the epilogue staging area
+#ifdef LT_ABL_NO_EPI
+    if (a.M >= 0) return;
+#endif
+    // ---- epilogue: three passes of 48 rows through this wave's private fp32 LDS tile -> 16-byte vectors (as conv_igemm5) ----
+    constexpr int LPR = WN / 8, RPP = 64 / LPR, ITP = EP_ROWS / RPP;
+    const int colv = n0 + wn * WN + (lane % LPR) * 8;
+    auto out_off = [&](int p, int k) -> long long {
+        const int m = m0 + wm * WM + p * EP_ROWS + k * RPP + lane / LPR;
+        if (m >= a.M || colv >= a.Cout) return -1;
+        long long pix = m;
+        if (!PW) {
+            int n, od, oh, ow;
+            decode_row(a, m, n, od, oh, ow);
+            pix = ((long long)(n * a.OD + od * a.osd + ph.ood) * a.OH + oh * a.osh + ph.ooh) * a.OW + ow * a.osw + ph.oow;
+        }
+        return pix * a.ldc + colv;
+    };
+    const EpiFloors fl = epi_floors(a.flags);
+    const bool has_res = a.res != nullptr;
+    float* ep = (float*)(smem + wave * EP_WAVE);
+    float bi[SN], sc[SN], sf[SN];
+#pragma unroll
+    for (int j = 0; j < SN; ++j) {
+        const int colj = n0 + wn * WN + j * MF + r15;    // < cout_pad: the constant arrays are padded
+        bi[j] = a.bias ? a.bias[colj] : 0.f;
+        sc[j] = a.scale ? a.scale[colj] : 1.f;
+        sf[j] = a.shift ? a.shift[colj] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        long long off[ITP];
+        uint4 rv[ITP];
+#pragma unroll
+        for (int k = 0; k < ITP; ++k) {                  // this pass's residual vectors first: independent round trips
+            off[k] = out_off(p, k);
+            rv[k] = (has_res && off[k] >= 0) ? *(const uint4*)((const T*)a.res + off[k]) : make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+            for (int j = 0; j < SN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    ep[(ii * MF + (lane >> 4) * 4 + e) * EP_LD + j * MF + r15] = (acc[3 * p + ii][j][e] + bi[j]) * sc[j] + sf[j];
+#pragma unroll
+        for (int k = 0; k < ITP; ++k) {
+            if (off[k] < 0) continue;
+            const float* src = ep + (k * RPP + lane / LPR) * EP_LD + (lane % LPR) * 8;
+            const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
+            const float vv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const unsigned ru[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+            unsigned ou[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                ou[e] = pack_bf16x2(epi_apply(vv[2 * e], fl, __uint_as_float(ru[e] << 16)), epi_apply(vv[2 * e + 1], fl, __uint_as_float(ru[e] & 0xffff0000u)));
+            *(uint4*)((T*)a.y + off[k]) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+        }
+    }
+}
+
+// lt_conv_fwd packing [cout_pad][k_pad] -> MFMA B-fragment order [k_pad / 32][cout_pad / 16][64 lanes][8]: lane l of a fragment
+// holds column 16 tile + (l & 15), K elements 32 step + 8 (l >> 4) .. + 7
+__global__ void conv_pack_b_kernel(const bf16_t* __restrict__ w, int cout_pad, int k_pad, bf16_t* __restrict__ out) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (step * cout_pad / 16 + tile) * 64 + lane
+    const long long total = (long long)(k_pad / 32) * (cout_pad / 16) * 64;
+    if (g >= total) return;
+    const int l = (int)(g & 63);
+    const long long ft = g >> 6;
+    const int tile = (int)(ft % (cout_pad / 16)), stepk = (int)(ft / (cout_pad / 16));
+    *(uint4*)(out + g * 8) = *(const uint4*)(w + (size_t)(16 * tile + (l & 15)) * k_pad + 32 * stepk + 8 * (l >> 4));
+}
+
+template <int MODE>
+int launch6(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
+    a.tiles_n = cout_pad / 256;
+    const long long nblk = cdiv(a.M, BM3) * a.tiles_n;
+    LT_REQUIRE(nblk < (1ll << 31), LT_ERR_INVALID, "lt_conv_fwd: grid too large");
+    const size_t lds = 6 * (size_t)BM3 * 64 + (size_t)max_taps * sizeof(int4);
+    LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: 288x256 tile needs %zu B of LDS", lds);
+    auto kern = conv_igemm6_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, s, a);
+    LT_CHECK_LAUNCH("lt_conv_fwd(v6)");
+    return LT_OK;
+}
+
 template <int MODE>
 int launch5(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
     a.tiles_n = cout_pad / 256;
@@ -1007,6 +1289,11 @@ int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_ta
             const bool pw5 = q0.ntaps == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.pd == 0 && a.ph == 0 && a.pw == 0 && a.osd == 1 &&
                              a.osh == 1 && a.osw == 1 && q0.ood == 0 && q0.ooh == 0 && q0.oow == 0 && a.OD == a.Do && a.OH == a.Ho &&
                              a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
+            const char* no6 = getenv("LT_CONV_NO_V6");   // A/B, read per call
+            if (q0.wfrag && !no6 && a.k_pad % 64 == 0) {  // weights also available in fragment order: B operand from registers
+                const int rc6 = pw5 ? launch6<1>(a, cout_pad, max_taps, s) : launch6<2>(a, cout_pad, max_taps, s);
+                return rc6 == LT_OK ? 1 : rc6;
+            }
             const int rc5 = pw5 ? launch5<1>(a, cout_pad, max_taps, s) : launch5<2>(a, cout_pad, max_taps, s);
             return rc5 == LT_OK ? 1 : rc5;
         }
@@ -1046,6 +1333,17 @@ int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_ta
 }
 
 }  // namespace lt
+
+extern "C" int lt_conv_pack_weights(const void* weight, int32_t cout_pad, int32_t k_pad, void* packed, void* stream) {
+    LT_REQUIRE(weight && packed, LT_ERR_INVALID, "lt_conv_pack_weights: null argument");
+    LT_REQUIRE(cout_pad >= 16 && cout_pad % 16 == 0 && k_pad >= 32 && k_pad % 32 == 0, LT_ERR_INVALID,
+               "lt_conv_pack_weights: cout_pad %d / k_pad %d (multiples of 16 / 32; bf16 weights [cout_pad][k_pad])", cout_pad, k_pad);
+    const long long total = (long long)(k_pad / 32) * (cout_pad / 16) * 64;
+    hipLaunchKernelGGL(conv_pack_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)weight,
+                       cout_pad, k_pad, (bf16_t*)packed);
+    LT_CHECK_LAUNCH("lt_conv_pack_weights");
+    return LT_OK;
+}
 
 #ifdef LT_TRACE
 extern "C" int lt_trace_read3(long long* dst, int n, int clear) {

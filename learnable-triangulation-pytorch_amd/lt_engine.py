@@ -267,6 +267,15 @@ class PlanBuilder:
             tdev = self.const(ph.taps)
             d.phase[i].weight = wdev.data_ptr(); d.phase[i].taps = tdev.data_ptr()
             d.phase[i].ntaps = ph.taps.shape[0]; d.phase[i].out_off = H.i3(ph.out_off)
+            # wide bf16 layers also get their weights in MFMA fragment order (B operand read straight from global memory by
+            # the 288 x 256 kernel); packed once, here
+            if (self.dtype == torch.bfloat16 and not self.dry_run and len(spec.phases) == 1 and spec.cout_pad % 256 == 0
+                    and spec.k_pad % 64 == 0):
+                wfr = torch.empty_like(wdev)
+                H.check(H.lib().lt_conv_pack_weights(wdev.data_ptr(), spec.cout_pad, spec.k_pad, wfr.data_ptr(), H.cur_stream()),
+                        "lt_conv_pack_weights")
+                self.keep.append(wfr)
+                d.phase[i].weight_frag = wfr.data_ptr()
         bi, sc, sh = self.const(spec.bias), self.const(spec.scale), self.const(spec.shift)
         self.keep.append(d)
         macs = spec.N * spec.Do * spec.Ho * spec.Wo * spec.Cout * sum(int(p.taps.shape[0]) for p in spec.phases) * (

@@ -25,7 +25,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 
 class ConvPhase(C.Structure):
-    _fields_ = [("weight", vp), ("taps", vp), ("ntaps", i32), ("out_off", i32 * 3)]
+    _fields_ = [("weight", vp), ("taps", vp), ("ntaps", i32), ("out_off", i32 * 3), ("weight_frag", vp)]
 
 
 class ConvDesc(C.Structure):
@@ -59,6 +59,7 @@ SIGNATURES = {
     "lt_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "lt_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
     "lt_conv_cout_pad": (C.c_int, [i32]),
+    "lt_conv_pack_weights": (C.c_int, [vp, i32, i32, vp, vp]),
     "lt_pwchain_fwd": (C.c_int, [C.POINTER(PwChainDesc), vp, vp, vp]),
     "lt_stem_pool_fwd": (C.c_int, [C.POINTER(StemDesc), vp, vp, vp]),
     "lt_stem_packed_bytes": (C.c_size_t, []),

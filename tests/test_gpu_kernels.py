@@ -564,10 +564,16 @@ V5_CASES = {  # name: (nd, N, cin, cout, k, stride, pad, spatial, residual)
 }
 
 
+@pytest.mark.parametrize("bsrc", ["registers", "lds"])
 @pytest.mark.parametrize("case", list(V5_CASES))
-def test_conv_v5_288x256(case, monkeypatch):
-    """288x256 tile / 32-element K steps / four stages (Cout % 256 == 0), forced with LT_CONV_V5=1, vs torch (bf16)."""
+def test_conv_v5_288x256(case, bsrc, monkeypatch):
+    """288x256 tile / 32-element K steps (Cout % 256 == 0), forced with LT_CONV_V5=1, vs torch (bf16): conv_igemm6 (weights read
+    from global memory in fragment order, activations in a six-stage ring) and conv_igemm5 (both operands staged, LT_CONV_NO_V6=1)."""
     monkeypatch.setenv("LT_CONV_V5", "1")
+    if bsrc == "lds":
+        monkeypatch.setenv("LT_CONV_NO_V6", "1")
+    else:
+        monkeypatch.delenv("LT_CONV_NO_V6", raising=False)
     nd, N, cin, cout, k, s, p, sp, with_res = V5_CASES[case]
     g = torch.Generator().manual_seed(len(case) * 5 + cin)
     x = torch.randn(N, cin, *sp, generator=g)
@@ -579,7 +585,7 @@ def test_conv_v5_288x256(case, monkeypatch):
     res = torch.randn(pre.shape, generator=g) if with_res else None
     ref = torch.relu(pre + bf16_round(res)) if with_res else torch.relu(pre)
     out = run_conv(x, w, bias, bn, s, p, torch.bfloat16, H.TILE3_288, relu=True, residual=res)
-    check("conv_v5/%s/forced" % case, out, ref, 1.5e-2)
+    check("conv_v5/%s/%s/forced" % (bsrc, case), out, ref, 1.5e-2)
     out3 = run_conv(x, w, bias, bn, s, p, torch.bfloat16, H.TILE3_288, relu=False, relu_pre=True, residual=res)
     ref3 = torch.relu(pre) + bf16_round(res) if with_res else torch.relu(pre)
     check("conv_v5/%s/relu_pre" % case, out3, ref3, 1.5e-2)
