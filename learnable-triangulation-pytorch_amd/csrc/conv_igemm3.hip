@@ -1269,7 +1269,23 @@ namespace lt {
 
 // 1 = launched, 0 = not applicable (caller falls back to conv_igemm2), < 0 = error
 int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, bool forced, hipStream_t s) {
-    if (dtype != LT_BF16 || nphase != 1) return 0;
+    if (dtype != LT_BF16) return 0;
+    if (nphase > 1) {
+        // a stride-2 transposed convolution = one convolution per output parity over the same iteration space: the phases differ
+        // only in taps, weights and output offset, so the first one decides for all (the 4x4 deconvolutions of the backbone head)
+        for (int p = 0; p < nphase; ++p) {
+            ConvArgs b = a;
+            b.phase[0] = a.phase[p];
+            const int rc = conv3_try(dtype, b, cout_pad, 1, max_taps, forced, s);
+            if (rc < 0) return rc;
+            if (rc == 0) {
+                if (p == 0) return 0;
+                set_error("lt_conv_fwd: phase %d of a transposed convolution is not supported by the kernel that took phase 0", p);
+                return LT_ERR_UNSUPPORTED;
+            }
+        }
+        return 1;
+    }
     if (a.flags & (LT_EPI_STORE_F32 | LT_EPI_SIGMOID)) return 0;
     if ((a.Cout % 8) || (a.ldc % 8) || (a.k_pad % 64)) return 0;
     if ((a.Cin * 2) % ROW_BYTES || (a.Cin & (a.Cin - 1))) return 0;   // a 128-byte K step must lie inside one tap; Cin = 2^k

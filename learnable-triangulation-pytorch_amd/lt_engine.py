@@ -269,8 +269,7 @@ class PlanBuilder:
             d.phase[i].ntaps = ph.taps.shape[0]; d.phase[i].out_off = H.i3(ph.out_off)
             # wide bf16 layers also get their weights in MFMA fragment order (B operand read straight from global memory by
             # the 288 x 256 kernel); packed once, here
-            if (self.dtype == torch.bfloat16 and not self.dry_run and len(spec.phases) == 1 and spec.cout_pad % 256 == 0
-                    and spec.k_pad % 64 == 0):
+            if self.dtype == torch.bfloat16 and not self.dry_run and spec.cout_pad % 256 == 0 and spec.k_pad % 64 == 0:
                 wfr = torch.empty_like(wdev)
                 H.check(H.lib().lt_conv_pack_weights(wdev.data_ptr(), spec.cout_pad, spec.k_pad, wfr.data_ptr(), H.cur_stream()),
                         "lt_conv_pack_weights")

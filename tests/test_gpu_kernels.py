@@ -591,6 +591,26 @@ def test_conv_v5_288x256(case, bsrc, monkeypatch):
     check("conv_v5/%s/relu_pre" % case, out3, ref3, 1.5e-2)
 
 
+@pytest.mark.parametrize("bsrc", ["registers", "lds"])
+def test_deconv4x4_phases_288x256(bsrc, monkeypatch):
+    """ConvTranspose2d 4x4 / stride 2 / pad 1 (the backbone's deconv head) through the 288x256 kernels: every output parity is one
+    launch of the single-phase kernel (conv3_try loops over the phases); vs torch and vs the implicit GEMM that took all phases."""
+    monkeypatch.setenv("LT_CONV_V5", "1")
+    if bsrc == "lds":
+        monkeypatch.setenv("LT_CONV_NO_V6", "1")
+    else:
+        monkeypatch.delenv("LT_CONV_NO_V6", raising=False)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 256, 12, 12, generator=g)
+    w = torch.randn(256, 256, 4, 4, generator=g) * (1.0 / (256 * 4) ** 0.5)
+    bn = _bn(256, g)
+    ref = torch.relu(_bn_ref(F.conv_transpose2d(bf16_round(x), bf16_round(w), None, 2, 1), bn))
+    out = run_conv(x, w, None, bn, 2, 1, torch.bfloat16, H.TILE3_288, transposed=True, relu=True)
+    check("deconv4x4_288x256/%s" % bsrc, out, ref, 1.5e-2)
+    gen = run_conv(x, w, None, bn, 2, 1, torch.bfloat16, TILES["v2_128x128"], transposed=True, relu=True)
+    check("deconv4x4_288x256/%s vs igemm2" % bsrc, out, gen, 1.5e-2)
+
+
 @pytest.mark.parametrize("kdb", ["1", "0"])
 @pytest.mark.parametrize("case", ["halo_7x7_32_16", "halo_7x7_32_16_big"])
 def test_conv3d_halo7_variants(case, kdb, monkeypatch):
