@@ -103,6 +103,13 @@ typedef struct lt_conv_desc {
 /* bf16 weights [cout_pad][k_pad] (cout_pad % 16 == 0, k_pad % 32 == 0) -> cout_pad * k_pad elements in fragment order
  * ([k_pad / 32][cout_pad / 16][64 lanes][8]: lane l holds column 16 t + (l & 15), K elements 32 s + 8 (l >> 4) .. + 7). */
 int lt_conv_pack_weights(const void* weight, int32_t cout_pad, int32_t k_pad, void* packed, void* stream);
+/* The fragment order of the TRANSPOSED product (weights as the first MFMA operand), used by the 3x3x3 64 -> 64 halo kernel:
+ * [tap][cin / 16][cout_pad / 32][64 lanes][8]; lane (r = l & 31, h = l >> 5) holds output channel
+ * 32 b + 16 (r >> 4) + 8 ((r >> 2) & 1) + 4 ((r >> 3) & 1) + (r & 3), K elements 16 g + 8 h .. + 7 of the tap.
+ * Which of the two orders lt_conv_phase.weight_frag must have follows from the layer: Cout % 256 == 0 -> lt_conv_pack_weights;
+ * 3x3x3, stride 1, 64 -> 64 channels -> this one; any other layer ignores the field. */
+int lt_conv_pack_weights_t32(const void* weight, int32_t cout_pad, int32_t k_pad, int32_t cin, int32_t ntaps, void* packed,
+                             void* stream);
 
 enum { LT_TILE_AUTO = 0,
        /* v1: register-staged tiles (kept for A/B runs and as a cross-check) */

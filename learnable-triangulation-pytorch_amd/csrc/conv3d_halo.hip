@@ -153,6 +153,7 @@ __device__ __forceinline__ void wait_vmcnt_h(int n) {
 struct HaloArgs {
     const void* x;
     const void* w;      // [cout_pad][k_pad], k = tap*Cin + ci (the lt_conv_fwd packing)
+    const void* wfrag;  // the same weights packed by lt_conv_pack_weights_t32 (conv3d_halo_wreg_kernel), or null
     void* y;
     const void* res;
     const float* bias;
@@ -1276,6 +1277,178 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
 #undef LT_TRC
 }
 
+// ---- 3^3 64 -> 64: halo in LDS, weights from global memory in fragment order, two workgroups per CU ----------------------------
+// The loader-wave kernel spends 37k cycles on a 64 -> 64 tile whose MFMAs take 13.8k: with the 77 KB halo AND a 72 KB weight ring
+// in LDS only one workgroup fits a CU, so the halo round trip, the nine weight chunks (a barrier and an L2 round trip each) and
+// the epilogue are all exposed.  Here the weights never touch LDS: lt_conv_pack_weights_t32 stores them once in the fragment
+// order of the transposed product ([tap][16-channel K block][32-row Cout block][lane] x 16 bytes), a wave reads the one fragment
+// it needs per (tap, K block) with a coalesced 1 KB global load (L1/L2 resident: 221 KB shared by every workgroup), and LDS
+// holds the halo alone -- 75 KB, TWO workgroups per CU, whose load / MFMA / store phases overlap each other.  Wave = (Cout half,
+// pair of output planes): four voxel fragments x one weight fragment per unit = four MFMAs per global load.  Voxel fragments keep
+// the 128-byte-voxel swizzle of the kernels above (slot ^ f(row, column)); the K block enters the address as XOR (g << 5), one
+// v_xor per read instead of 72 precomputed address registers.  Transposed product with permuted weight rows: the epilogue moves
+// 16-byte channel runs straight from the accumulators (see conv3d_halo_col_kernel).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(const HaloArgs a) {
+    constexpr int KS = 3, CIN = 64, CP = 64, TD = 4, TH = 8, TW = 8, G = 4;
+    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, 3, 3> C;
+    static_assert(sizeof(T) == 2 && C::CINB == 128 && C::NVV == 8 && C::SW::FB == 0, "bf16, 128-byte voxels, plane-independent swizzle");
+    constexpr int PLANE_B = C::HH * C::PW * C::CINB;      // 12800
+    constexpr int NI_H = C::HALO_BYTES / 1024;            // 75
+    static_assert(3 * PLANE_B + 2 * C::PW * C::CINB < 65536, "plane offsets must fit the ds_read immediate");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page_h;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tps = a.tiles_d * a.tiles_h * a.tiles_w;
+    int n, tix;
+    if (a.xcd_pin) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        n = xcd + 8 * (j / tps);
+        tix = j % tps;
+    } else {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        n = lin / tps;
+        tix = lin % tps;
+    }
+    const int w0 = (tix % a.tiles_w) * TW;
+    const int h0 = ((tix / a.tiles_w) % a.tiles_h) * TH;
+    const int d0 = (tix / (a.tiles_w * a.tiles_h)) * TD;
+    const T* __restrict__ x = (const T*)a.x + (size_t)n * a.D * a.H * a.W * CIN;
+
+    // ---- halo DMA, all four waves ----
+    for (int i = wave; i < NI_H; i += 4) {
+        const int q = i * 64 + lane;
+        const int hv = q / C::NVV, pv = q % C::NVV;
+        const int hw_ = hv % C::PW, hh_ = (hv / C::PW) % C::HH, hd_ = hv / (C::PW * C::HH);
+        const int lv = pv ^ C::fswz(hd_, hh_, hw_);
+        const int id = d0 - 1 + hd_, ih = h0 - 1 + hh_, iw = w0 - 1 + hw_;
+        const bool ok = ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+        const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : zero_page;
+        dma16h(src, lds0 + i * 1024);
+    }
+
+    // ---- roles ----
+    const int ch = wave & 1, pp = wave >> 1;              // Cout half, pair of output planes (2 pp, 2 pp + 1)
+    const int vl = lane & 31, hh = lane >> 5;
+    // voxel-fragment addresses: fragment (tdl, i) = plane 2 pp + tdl, rows 4 i + vl / 8, column vl % 8; tap (kd, kh, kw), K block g:
+    //   lp[kh*3+kw][i] ^ (g << 5), + (tdl + kd) planes as immediate
+    unsigned lp[9][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int th = 4 * i + (vl >> 3), tw = vl & 7;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                lp[kh * 3 + kw][i] = lds0 + ((2 * pp * C::HH + th + kh) * C::PW + tw + kw) * C::CINB + ((hh ^ C::fswz(0, th + kh, tw + kw)) << 4);
+    }
+    // weight fragments: unit u = tap * G + g -> 1 KB at ((u * 2 + ch) * 64 + lane) * 16 bytes
+    const T* wl = (const T*)a.wfrag + ((size_t)ch * 64 + lane) * 8;
+    auto load_w = [&](int u) -> V16 {
+        V16 v;
+        v.u = *(const uint4*)(wl + (size_t)u * 2 * 64 * 8);
+        return v;
+    };
+    constexpr int NU = 27 * G, WD = 4;
+    V16 wf[WD + 1];
+#pragma unroll
+    for (int u = 0; u < WD; ++u) wf[u] = load_w(u);
+
+    // ---- residual of this lane's outputs, requested before the tap loop ----
+    const size_t ldc = (size_t)a.ldc;
+    const bool has_res = a.res != nullptr;
+    size_t ooff[4];
+    uint4 rq[4][2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int td = 2 * pp + (f >> 1), th = 4 * (f & 1) + (vl >> 3), tw = vl & 7;
+        ooff[f] = ((((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw) * ldc + 32 * ch + 8 * hh;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            rq[f][q] = has_res ? *(const uint4*)((const T*)a.res + ooff[f] + 16 * q) : make_uint4(0, 0, 0, 0);
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
+
+    // the halo pieces are the oldest vector-memory operations of this wave: wait for everything once (weights and residual are
+    // needed soon anyway), then the workgroup barrier publishes the image
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    V16 xa[2][4];
+    auto load_x = [&](auto uc, V16 (&dst)[4]) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int tap = u / G, g = u % G;
+        constexpr int kd = tap / 9, khkw = tap % 9;
+        const unsigned a0 = lp[khkw][0] ^ (g << 5), a1 = lp[khkw][1] ^ (g << 5);
+        dst[0].u = *(const uint4*)((lptr_t)(size_t)(a0 + (0 + kd) * PLANE_B));
+        dst[1].u = *(const uint4*)((lptr_t)(size_t)(a1 + (0 + kd) * PLANE_B));
+        dst[2].u = *(const uint4*)((lptr_t)(size_t)(a0 + (1 + kd) * PLANE_B));
+        dst[3].u = *(const uint4*)((lptr_t)(size_t)(a1 + (1 + kd) * PLANE_B));
+    };
+    load_x(std::integral_constant<int, 0>{}, xa[0]);
+    static_for<0, NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (u + WD < NU) wf[(u + WD) % (WD + 1)] = load_w(u + WD);
+        if constexpr (u + 1 < NU) load_x(std::integral_constant<int, u + 1>{}, xa[(u + 1) & 1]);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % (WD + 1)].h, xa[u & 1][f].h, acc[f], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch distances (the scheduler sinks the loads otherwise)
+    });
+
+    // ---- epilogue from the accumulators: lane (voxel, h) holds channels 32 ch + 8 h + e (e < 8) and 32 ch + 16 + 8 h + (e - 8) ----
+    float esc[16], esf[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = 32 * ch + 16 * (e >> 3) + 8 * hh + (e & 7);
+        const float bi = a.bias ? a.bias[c] : 0.f, sc = a.scale ? a.scale[c] : 1.f, sf = a.shift ? a.shift[c] : 0.f;
+        esc[e] = sc; esf[e] = bi * sc + sf;
+    }
+    const EpiFloors fl = epi_floors(a.flags);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned rr[4] = {rq[f][q].x, rq[f][q].y, rq[f][q].z, rq[f][q].w};
+            unsigned o[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int e = 8 * q + 2 * d;
+                const float v0 = epi_apply(fmaf(acc[f][e], esc[e], esf[e]), fl, __uint_as_float(rr[d] << 16));
+                const float v1 = epi_apply(fmaf(acc[f][e + 1], esc[e + 1], esf[e + 1]), fl, __uint_as_float(rr[d] & 0xffff0000u));
+                o[d] = pack_bf16x2(v0, v1);
+            }
+            *(uint4*)((T*)a.y + ooff[f] + 16 * q) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+}
+
+// lt_conv_fwd packing [cout_pad][k_pad] (k = tap * cin + ci) -> fragments of the transposed product:
+// [tap][cin / 16][cout_pad / 32][64 lanes][8]; lane (r = l & 31, h = l >> 5) holds row chan(r) + 32 block, K elements 16 g + 8 h .. + 7
+__global__ void conv_pack_t32_kernel(const bf16_t* __restrict__ w, int cout_pad, int k_pad, int cin, int ntaps, bf16_t* __restrict__ out) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nbk = cout_pad / 32, ng = cin / 16;
+    if (g >= (long long)ntaps * ng * nbk * 64) return;
+    const int l = (int)(g & 63);
+    long long ft = g >> 6;
+    const int nb = (int)(ft % nbk); ft /= nbk;
+    const int kg = (int)(ft % ng);
+    const int tap = (int)(ft / ng);
+    const int r = l & 31, h = l >> 5;
+    const int chan = 32 * nb + 16 * (r >> 4) + 8 * ((r >> 2) & 1) + 4 * ((r >> 3) & 1) + (r & 3);
+    *(uint4*)(out + g * 8) = *(const uint4*)(w + (size_t)chan * k_pad + (size_t)tap * cin + 16 * kg + 8 * h);
+}
+
 // ---- 7^3 kernel with loader waves -------------------------------------------------------------------------------------------
 // PMC on the ring version above (7^3 32->16 at 64^3): 3.3 VALU + 3.4 SALU + 1.3 LDS instructions per MFMA and no LDS bank
 // conflicts -- with one workgroup per CU (the halo takes 123 KB) and so one compute wave per SIMD, the kernel was bound by
@@ -1767,6 +1940,21 @@ int launch_halo_persist(const HaloArgs& a, hipStream_t s) {
 }
 
 template <typename T>
+int launch_halo_wreg(const HaloArgs& a, hipStream_t s) {
+    typedef HaloCfg<T, 3, 64, 64, 4, 8, 8, 3, 3> C;
+    auto kern = conv3d_halo_wreg_kernel<T>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const long long nblk = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), C::HALO_BYTES, s, a);
+    LT_CHECK_LAUNCH("lt_conv_fwd(halo, weights from registers)");
+    return LT_OK;
+}
+
+template <typename T>
 int launch_halo_col(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<T, 3, 32, 32, 4, 8, 8, 9, 2> C;
     constexpr int W_BYTES = ((C::NTAPS * C::SLAB + 1023) / 1024) * 1024;
@@ -1825,7 +2013,7 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     const long long nblk = (long long)c.N * (c.D / 4) * (c.H / 8) * (c.W / 8);
     if (nblk < 256 && !forced) return 0;   // too few workgroups: the 64x64 implicit-GEMM tile fills the chip better
     HaloArgs a;
-    a.x = c.x; a.w = p0.w; a.y = c.y; a.res = c.res; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
+    a.x = c.x; a.w = p0.w; a.wfrag = p0.wfrag; a.y = c.y; a.res = c.res; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
     a.N = c.N; a.D = c.D; a.H = c.H; a.W = c.W; a.Cout = c.Cout; a.ldc = c.ldc; a.k_pad = c.k_pad; a.flags = c.flags;
     a.tiles_d = c.D / 4; a.tiles_h = c.H / 8; a.tiles_w = c.W / 8;
     a.xcd_pin = (c.N % 8 == 0) ? 1 : 0;
@@ -1851,6 +2039,11 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
             return rc == LT_OK ? 1 : rc;
         }
         int rc = launch_halo_persist<bf16_t, 32, 32>(a, s);
+        return rc == LT_OK ? 1 : rc;
+    }
+    // 64 -> 64: halo-only LDS, weights as fragments from global memory, two workgroups per CU
+    if (bf && ks == 3 && c.Cin == 64 && cout_pad == 64 && c.Cout == 64 && c.ldc % 8 == 0 && a.wfrag && !getenv("LT_HALO_NO_WREG")) {
+        int rc = launch_halo_wreg<bf16_t>(a, s);
         return rc == LT_OK ? 1 : rc;
     }
     static const bool row_chunks = getenv("LT_HALO_ROW") != nullptr;   // A/B: 3-tap weight chunks -> 51 KB of LDS -> 3 workgroups per CU
@@ -1894,3 +2087,15 @@ extern "C" int lt_trace_read_halo(long long* dst, int n) {
     return n;
 }
 #endif
+
+extern "C" int lt_conv_pack_weights_t32(const void* weight, int32_t cout_pad, int32_t k_pad, int32_t cin, int32_t ntaps, void* packed,
+                                        void* stream) {
+    LT_REQUIRE(weight && packed, LT_ERR_INVALID, "lt_conv_pack_weights_t32: null argument");
+    LT_REQUIRE(cout_pad >= 32 && cout_pad % 32 == 0 && cin >= 16 && cin % 16 == 0 && ntaps >= 1 && (long long)ntaps * cin <= k_pad && k_pad % 8 == 0,
+               LT_ERR_INVALID, "lt_conv_pack_weights_t32: cout_pad %d / cin %d / ntaps %d / k_pad %d", cout_pad, cin, ntaps, k_pad);
+    const long long total = (long long)ntaps * (cin / 16) * (cout_pad / 32) * 64;
+    hipLaunchKernelGGL(conv_pack_t32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)weight,
+                       cout_pad, k_pad, cin, ntaps, (bf16_t*)packed);
+    LT_CHECK_LAUNCH("lt_conv_pack_weights_t32");
+    return LT_OK;
+}

@@ -229,6 +229,8 @@ def test_c_abi_exports_every_declared_symbol():
     assert l.lt_stem_pool_fwd(ctypes.byref(sd), 1, 1, None) == -1 and b"x_layout" in l.lt_last_error()
     assert l.lt_stem_packed_bytes() == 2 * 28 * 64 * 16
     assert l.lt_stem_pack_weights(1, 64, 1, None) == -1 and b"k_pad" in l.lt_last_error()
+    assert l.lt_conv_pack_weights(1, 100, 64, 1, None) == -1 and b"cout_pad" in l.lt_last_error()
+    assert l.lt_conv_pack_weights_t32(1, 64, 1728, 64, 28, 1, None) == -1 and b"ntaps" in l.lt_last_error()
     # planar output: voxels per sample must be a multiple of 64 that divides rows
     pd.flags[1], pd.rows, pd.plane = H.EPI_STORE_F32, 128, 96
     assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -1 and b"plane" in l.lt_last_error()
