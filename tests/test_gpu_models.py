@@ -199,6 +199,31 @@ def test_bf16_kernel_set_of_the_benchmark_vs_fp32_kernels():
     assert float((outs["bf16"][2].sum(dim=(2, 3, 4)) - 1).abs().max()) < 1e-3
 
 
+def test_panoptic_shape_8_views_128_cube():
+    """BASELINE config 4 (8 synthetic views, 128^3 voxel cube): every volumetric kernel at 8x the voxel count and with the generic
+    (not the 4-view quad) unprojection; bf16 kernels against the fp32 parity kernels, ResNet-50 backbone to keep the test short."""
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    B, NV, V = 2, 8, 128
+    cfg = synth.vol_config(50, V, "softmax", 1.0)
+    sd = synth.make_state_dict(spec.vol_net_spec(50, 17), seed=4, sharpen=False)
+    inp = synth.make_inputs(B, NV, 256, seed=9)
+    images = inp["images"].to(DEV)
+    outs = {}
+    for name, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        m = VolumetricTriangulationNet(cfg, device=DEV); m.load_state_dict(sd); m.eval(); m.compute_dtype = dtype
+        batch = {"cameras": _cameras(inp, B), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+        o = m(images, None, batch)
+        outs[name] = [t.float().cpu() if torch.is_tensor(t) else t for t in o]
+        del m
+        torch.cuda.empty_cache()
+    kp32, kp16 = outs["f32"][0], outs["bf16"][0]
+    assert tuple(outs["bf16"][2].shape) == (B, 17, V, V, V)
+    record("8 views / 128^3: joints bf16 kernels vs fp32 kernels, MPJPE (mm)", float((kp16 - kp32).norm(dim=-1).mean()))
+    record("8 views / 128^3: volumes bf16 vs fp32 (max|d|/max|ref|)", rel_err(outs["bf16"][2], outs["f32"][2]))
+    assert torch.isfinite(kp16).all() and float((kp16 - kp32).norm(dim=-1).mean()) < 0.1
+    assert float((outs["bf16"][2].sum(dim=(2, 3, 4)) - 1).abs().max()) < 1e-3
+
+
 def test_algebraic_c1_vs_reference_golden(golden_dir):
     """BASELINE config 1: algebraic triangulation, 4 x 256^2, ResNet-50 with confidences."""
     from mvn.models.triangulation import AlgebraicTriangulationNet
