@@ -1288,14 +1288,22 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
 // the 128-byte-voxel swizzle of the kernels above (slot ^ f(row, column)); the K block enters the address as XOR (g << 5), one
 // v_xor per read instead of 72 precomputed address registers.  Transposed product with permuted weight rows: the epilogue moves
 // 16-byte channel runs straight from the accumulators (see conv3d_halo_col_kernel).
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(const HaloArgs a) {
-    constexpr int KS = 3, CIN = 64, CP = 64, TD = 4, TH = 8, TW = 8, G = 4;
+// Instantiated for 64 -> 64 (two Cout blocks: wave = (Cout half, pair of output planes), four voxel fragments), 32 -> 64 (same
+// roles, two K blocks) and 128 -> 128 (four Cout blocks: wave = Cout block, all eight voxel fragments; 256-byte voxels fill
+// LDS with the halo alone, one workgroup per CU with up to 512 registers per wave).
+template <typename T, int CIN, int CP>
+__global__ __launch_bounds__(256, (CIN == 128 ? 1 : 2)) void conv3d_halo_wreg_kernel(const HaloArgs a) {
+    constexpr int KS = 3, TD = 4, TH = 8, TW = 8, G = CIN / 16, NB = CP / 32;
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, 3, 3> C;
-    static_assert(sizeof(T) == 2 && C::CINB == 128 && C::NVV == 8 && C::SW::FB == 0, "bf16, 128-byte voxels, plane-independent swizzle");
-    constexpr int PLANE_B = C::HH * C::PW * C::CINB;      // 12800
-    constexpr int NI_H = C::HALO_BYTES / 1024;            // 75
-    static_assert(3 * PLANE_B + 2 * C::PW * C::CINB < 65536, "plane offsets must fit the ds_read immediate");
+    static_assert(sizeof(T) == 2 && (NB == 2 || NB == 4) && (C::CINB == 64 || C::CINB == 128 || C::CINB == 256), "bf16; 32/64/128 -> 64/128");
+    static_assert(C::SW::FB == 0, "plane-independent swizzle");
+    constexpr int PLANE_B = C::HH * C::PW * C::CINB;
+    constexpr int NI_H = C::HALO_BYTES / 1024;
+    constexpr int FR = NB == 2 ? 4 : 8;                   // voxel fragments per wave
+    constexpr bool PRE_RES = FR == 4;                     // residual requested before the tap loop (register budget)
+    // swizzle of the 16-byte vectors of a voxel: the searched ones for 64- and 128-byte voxels; 256-byte voxels start at bank 0
+    // each, so the 16 lanes of a read phase (2 rows x 8 columns) must use 16 different slots: column & 7 | (row & 1) << 3
+    auto wswz = [](int hh_, int hw_) -> int { return C::CINB == 256 ? ((hw_ & 7) | ((hh_ & 1) << 3)) : C::fswz(0, hh_, hw_); };
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
@@ -1327,18 +1335,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(const HaloArgs
         const int q = i * 64 + lane;
         const int hv = q / C::NVV, pv = q % C::NVV;
         const int hw_ = hv % C::PW, hh_ = (hv / C::PW) % C::HH, hd_ = hv / (C::PW * C::HH);
-        const int lv = pv ^ C::fswz(hd_, hh_, hw_);
+        const int lv = pv ^ wswz(hh_, hw_);
         const int id = d0 - 1 + hd_, ih = h0 - 1 + hh_, iw = w0 - 1 + hw_;
-        const bool ok = ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+        const bool ok = hv < C::HV && ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
         const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : zero_page;
         dma16h(src, lds0 + i * 1024);
     }
 
     // ---- roles ----
-    const int ch = wave & 1, pp = wave >> 1;              // Cout half, pair of output planes (2 pp, 2 pp + 1)
+    const int cb = NB == 2 ? (wave & 1) : wave;           // Cout block of 32
+    const int p0 = NB == 2 ? 2 * (wave >> 1) : 0;         // first output plane of this wave's fragments
     const int vl = lane & 31, hh = lane >> 5;
-    // voxel-fragment addresses: fragment (tdl, i) = plane 2 pp + tdl, rows 4 i + vl / 8, column vl % 8; tap (kd, kh, kw), K block g:
-    //   lp[kh*3+kw][i] ^ (g << 5), + (tdl + kd) planes as immediate
+    // voxel-fragment addresses: fragment f = (plane p0 + f / 2, rows 4 (f & 1) + vl / 8, column vl % 8); tap (kd, kh, kw), K block g:
+    //   (lp[kh*3+kw][f & 1] ^ (g << 5)) + (f / 2 + kd) planes
     unsigned lp[9][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1347,13 +1356,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(const HaloArgs
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)
-                lp[kh * 3 + kw][i] = lds0 + ((2 * pp * C::HH + th + kh) * C::PW + tw + kw) * C::CINB + ((hh ^ C::fswz(0, th + kh, tw + kw)) << 4);
+                lp[kh * 3 + kw][i] = lds0 + ((p0 * C::HH + th + kh) * C::PW + tw + kw) * C::CINB + ((hh ^ wswz(th + kh, tw + kw)) << 4);
     }
-    // weight fragments: unit u = tap * G + g -> 1 KB at ((u * 2 + ch) * 64 + lane) * 16 bytes
-    const T* wl = (const T*)a.wfrag + ((size_t)ch * 64 + lane) * 8;
+    // weight fragments: unit u = tap * G + g -> 1 KB at ((u * NB + cb) * 64 + lane) * 16 bytes
+    const T* wl = (const T*)a.wfrag + ((size_t)cb * 64 + lane) * 8;
     auto load_w = [&](int u) -> V16 {
         V16 v;
-        v.u = *(const uint4*)(wl + (size_t)u * 2 * 64 * 8);
+        v.u = *(const uint4*)(wl + (size_t)u * NB * 64 * 8);
         return v;
     };
     constexpr int NU = 27 * G, WD = 4;
@@ -1361,23 +1370,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(const HaloArgs
 #pragma unroll
     for (int u = 0; u < WD; ++u) wf[u] = load_w(u);
 
-    // ---- residual of this lane's outputs, requested before the tap loop ----
+    // ---- output offsets; the residual is requested before the tap loop when the register budget allows ----
     const size_t ldc = (size_t)a.ldc;
     const bool has_res = a.res != nullptr;
-    size_t ooff[4];
-    uint4 rq[4][2];
+    auto out_off = [&](int f) -> size_t {
+        const int td = p0 + (f >> 1), th = 4 * (f & 1) + (vl >> 3), tw = vl & 7;
+        return ((((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw) * ldc + 32 * cb + 8 * hh;
+    };
+    uint4 rq[PRE_RES ? FR : 1][2];
+    if (PRE_RES) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const int td = 2 * pp + (f >> 1), th = 4 * (f & 1) + (vl >> 3), tw = vl & 7;
-        ooff[f] = ((((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw) * ldc + 32 * ch + 8 * hh;
+        for (int f = 0; f < FR; ++f)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-            rq[f][q] = has_res ? *(const uint4*)((const T*)a.res + ooff[f] + 16 * q) : make_uint4(0, 0, 0, 0);
+            for (int q = 0; q < 2; ++q)
+                rq[PRE_RES ? f : 0][q] = has_res ? *(const uint4*)((const T*)a.res + out_off(f) + 16 * q) : make_uint4(0, 0, 0, 0);
     }
 
-    f32x16 acc[4];
+    f32x16 acc[FR];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < FR; ++f)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
 
@@ -1385,16 +1396,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(const HaloArgs
     // needed soon anyway), then the workgroup barrier publishes the image
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-    V16 xa[2][4];
-    auto load_x = [&](auto uc, V16 (&dst)[4]) {
+    V16 xa[2][FR];
+    auto load_x = [&](auto uc, V16 (&dst)[FR]) {
         constexpr int u = decltype(uc)::value;
         constexpr int tap = u / G, g = u % G;
         constexpr int kd = tap / 9, khkw = tap % 9;
         const unsigned a0 = lp[khkw][0] ^ (g << 5), a1 = lp[khkw][1] ^ (g << 5);
-        dst[0].u = *(const uint4*)((lptr_t)(size_t)(a0 + (0 + kd) * PLANE_B));
-        dst[1].u = *(const uint4*)((lptr_t)(size_t)(a1 + (0 + kd) * PLANE_B));
-        dst[2].u = *(const uint4*)((lptr_t)(size_t)(a0 + (1 + kd) * PLANE_B));
-        dst[3].u = *(const uint4*)((lptr_t)(size_t)(a1 + (1 + kd) * PLANE_B));
+        // planes whose offset does not fit the 16-bit ds_read immediate (256-byte voxels: 25600 B per plane) go through a
+        // second base three planes up, so that no read needs its own address register
+        constexpr int HI = 3 * PLANE_B;
+        const unsigned b0 = a0 + HI, b1 = a1 + HI;
+        static_for<0, FR>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int off = ((f >> 1) + kd) * PLANE_B;
+            if constexpr (off + 16 <= 65536) dst[f].u = *(const uint4*)((lptr_t)(size_t)(((f & 1) ? a1 : a0) + off));
+            else dst[f].u = *(const uint4*)((lptr_t)(size_t)(((f & 1) ? b1 : b0) + (off - HI)));
+        });
     };
     load_x(std::integral_constant<int, 0>{}, xa[0]);
     static_for<0, NU>([&](auto uc) {
@@ -1402,25 +1419,29 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(const HaloArgs
         if constexpr (u + WD < NU) wf[(u + WD) % (WD + 1)] = load_w(u + WD);
         if constexpr (u + 1 < NU) load_x(std::integral_constant<int, u + 1>{}, xa[(u + 1) & 1]);
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < FR; ++f)
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % (WD + 1)].h, xa[u & 1][f].h, acc[f], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);               // keep the prefetch distances (the scheduler sinks the loads otherwise)
     });
 
-    // ---- epilogue from the accumulators: lane (voxel, h) holds channels 32 ch + 8 h + e (e < 8) and 32 ch + 16 + 8 h + (e - 8) ----
+    // ---- epilogue from the accumulators: lane (voxel, h) holds channels 32 cb + 8 h + e (e < 8) and 32 cb + 16 + 8 h + (e - 8) ----
     float esc[16], esf[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int c = 32 * ch + 16 * (e >> 3) + 8 * hh + (e & 7);
+        const int c = 32 * cb + 16 * (e >> 3) + 8 * hh + (e & 7);
         const float bi = a.bias ? a.bias[c] : 0.f, sc = a.scale ? a.scale[c] : 1.f, sf = a.shift ? a.shift[c] : 0.f;
         esc[e] = sc; esf[e] = bi * sc + sf;
     }
     const EpiFloors fl = epi_floors(a.flags);
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < FR; ++f) {
+        const size_t oo = out_off(f);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const unsigned rr[4] = {rq[f][q].x, rq[f][q].y, rq[f][q].z, rq[f][q].w};
+            uint4 rv;
+            if (PRE_RES) rv = rq[PRE_RES ? f : 0][q];
+            else rv = has_res ? *(const uint4*)((const T*)a.res + oo + 16 * q) : make_uint4(0, 0, 0, 0);
+            const unsigned rr[4] = {rv.x, rv.y, rv.z, rv.w};
             unsigned o[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -1429,8 +1450,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_halo_wreg_kernel(const HaloArgs
                 const float v1 = epi_apply(fmaf(acc[f][e + 1], esc[e + 1], esf[e + 1]), fl, __uint_as_float(rr[d] & 0xffff0000u));
                 o[d] = pack_bf16x2(v0, v1);
             }
-            *(uint4*)((T*)a.y + ooff[f] + 16 * q) = make_uint4(o[0], o[1], o[2], o[3]);
+            *(uint4*)((T*)a.y + oo + 16 * q) = make_uint4(o[0], o[1], o[2], o[3]);
         }
+    }
 }
 
 // lt_conv_fwd packing [cout_pad][k_pad] (k = tap * cin + ci) -> fragments of the transposed product:
@@ -1939,10 +1961,11 @@ int launch_halo_persist(const HaloArgs& a, hipStream_t s) {
     return LT_OK;
 }
 
-template <typename T>
+template <typename T, int CIN, int CP>
 int launch_halo_wreg(const HaloArgs& a, hipStream_t s) {
-    typedef HaloCfg<T, 3, 64, 64, 4, 8, 8, 3, 3> C;
-    auto kern = conv3d_halo_wreg_kernel<T>;
+    typedef HaloCfg<T, 3, CIN, CP, 4, 8, 8, 3, 3> C;
+    static_assert(C::HALO_BYTES <= 160 * 1024, "the halo must fit LDS");
+    auto kern = conv3d_halo_wreg_kernel<T, CIN, CP>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2041,10 +2064,13 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
         int rc = launch_halo_persist<bf16_t, 32, 32>(a, s);
         return rc == LT_OK ? 1 : rc;
     }
-    // 64 -> 64: halo-only LDS, weights as fragments from global memory, two workgroups per CU
-    if (bf && ks == 3 && c.Cin == 64 && cout_pad == 64 && c.Cout == 64 && c.ldc % 8 == 0 && a.wfrag && !getenv("LT_HALO_NO_WREG")) {
-        int rc = launch_halo_wreg<bf16_t>(a, s);
-        return rc == LT_OK ? 1 : rc;
+    // halo-only LDS, weights as fragments from global memory (lt_conv_pack_weights_t32): 64 -> 64, 32 -> 64, 128 -> 128
+    if (bf && ks == 3 && c.Cout == cout_pad && c.ldc % 8 == 0 && a.wfrag && !getenv("LT_HALO_NO_WREG")) {
+        int rc = 1;
+        if (c.Cin == 64 && cout_pad == 64) rc = launch_halo_wreg<bf16_t, 64, 64>(a, s);
+        else if (c.Cin == 32 && cout_pad == 64) rc = launch_halo_wreg<bf16_t, 32, 64>(a, s);
+        else if (c.Cin == 128 && cout_pad == 128) rc = launch_halo_wreg<bf16_t, 128, 128>(a, s);
+        if (rc != 1) return rc == LT_OK ? 1 : rc;
     }
     static const bool row_chunks = getenv("LT_HALO_ROW") != nullptr;   // A/B: 3-tap weight chunks -> 51 KB of LDS -> 3 workgroups per CU
     if (bf) {

@@ -275,12 +275,13 @@ class PlanBuilder:
                         "lt_conv_pack_weights")
                 self.keep.append(wfr)
                 d.phase[i].weight_frag = wfr.data_ptr()
-            elif (self.dtype == torch.bfloat16 and not self.dry_run and not transposed and tuple(weight.shape) == (64, 64, 3, 3, 3)
-                  and x.shape[-1] == 64 and spec.stride == (1, 1, 1) and spec.pad == (1, 1, 1)):
-                # 3x3x3 64 -> 64 (V2V at 32^3): fragments of the transposed product for conv3d_halo_wreg_kernel
+            elif (self.dtype == torch.bfloat16 and not self.dry_run and not transposed and x.shape[-1] == weight.shape[1]
+                  and tuple(weight.shape) in ((64, 64, 3, 3, 3), (64, 32, 3, 3, 3), (128, 128, 3, 3, 3))
+                  and spec.stride == (1, 1, 1) and spec.pad == (1, 1, 1)):
+                # 3x3x3 64 -> 64, 32 -> 64, 128 -> 128 (V2V): fragments of the transposed product for conv3d_halo_wreg_kernel
                 wfr = torch.empty_like(wdev)
-                H.check(H.lib().lt_conv_pack_weights_t32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, 64, 27, wfr.data_ptr(), H.cur_stream()),
-                        "lt_conv_pack_weights_t32")
+                H.check(H.lib().lt_conv_pack_weights_t32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, weight.shape[1], 27, wfr.data_ptr(),
+                                                         H.cur_stream()), "lt_conv_pack_weights_t32")
                 self.keep.append(wfr)
                 d.phase[i].weight_frag = wfr.data_ptr()
         bi, sc, sh = self.const(spec.bias), self.const(spec.scale), self.const(spec.shift)

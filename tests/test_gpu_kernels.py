@@ -612,26 +612,29 @@ def test_deconv4x4_phases_288x256(bsrc, monkeypatch):
 
 
 @pytest.mark.parametrize("wsrc", ["registers", "lds"])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 64), (128, 128)])
 @pytest.mark.parametrize("N,sp", [(1, (8, 8, 16)), (3, (4, 16, 8)), (8, (8, 16, 16))])
-def test_conv3d_halo_64_64_weight_source(N, sp, wsrc, monkeypatch):
-    """3^3 64 -> 64 bf16: conv3d_halo_wreg_kernel (weights as fragments from global memory, halo-only LDS, two workgroups per CU) and the
-    loader-wave kernel with its LDS weight ring (LT_HALO_NO_WREG=1) vs torch: residual + ReLU, affine only; padding at every face."""
+def test_conv3d_halo_64_64_weight_source(N, sp, cin, cout, wsrc, monkeypatch):
+    """3^3 64 -> 64 / 32 -> 64 / 128 -> 128 bf16: conv3d_halo_wreg_kernel (weights as fragments from global memory, halo-only LDS) and
+    the kernels it replaces (LT_HALO_NO_WREG=1: loader-wave halo kernel or implicit GEMM) vs torch: residual + ReLU, affine only;
+    padding at every face."""
     if wsrc == "lds":
         monkeypatch.setenv("LT_HALO_NO_WREG", "1")
     else:
         monkeypatch.delenv("LT_HALO_NO_WREG", raising=False)
-    g = torch.Generator().manual_seed(N * 31 + sp[0])
-    x = torch.randn(N, 64, *sp, generator=g)
-    w = torch.randn(64, 64, 3, 3, 3, generator=g) * (1.0 / (64 * 27) ** 0.5)
-    bias = torch.randn(64, generator=g) * 0.1
-    bn = _bn(64, g)
-    res = torch.randn(N, 64, *sp, generator=g)
+    g = torch.Generator().manual_seed(N * 31 + sp[0] + cin)
+    x = torch.randn(N, cin, *sp, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (1.0 / (cin * 27) ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    bn = _bn(cout, g)
+    res = torch.randn(N, cout, *sp, generator=g)
     rd = bf16_round
     conv = F.conv3d(rd(x), rd(w), bias, 1, 1)
-    out = run_conv(x, w, bias, bn, 1, 1, torch.bfloat16, H.TILE_HALO, relu=True, residual=res)
-    check("conv3d_halo_64_64/%s/N%d/res" % (wsrc, N), out, torch.relu(_bn_ref(conv, bn) + rd(res)), 1.5e-2)
-    out2 = run_conv(x, w, bias, bn, 1, 1, torch.bfloat16, H.TILE_HALO, relu=False, residual=None)
-    check("conv3d_halo_64_64/%s/N%d/plain" % (wsrc, N), out2, _bn_ref(conv, bn), 1.5e-2)
+    tile = H.TILE_HALO if (wsrc == "registers" or cin != 128) else 0     # no LDS-weight halo kernel for 128 -> 128: implicit GEMM
+    out = run_conv(x, w, bias, bn, 1, 1, torch.bfloat16, tile, relu=True, residual=res)
+    check("conv3d_halo_%d_%d/%s/N%d/res" % (cin, cout, wsrc, N), out, torch.relu(_bn_ref(conv, bn) + rd(res)), 1.5e-2)
+    out2 = run_conv(x, w, bias, bn, 1, 1, torch.bfloat16, tile, relu=False, residual=None)
+    check("conv3d_halo_%d_%d/%s/N%d/plain" % (cin, cout, wsrc, N), out2, _bn_ref(conv, bn), 1.5e-2)
 
 
 @pytest.mark.parametrize("kdb", ["1", "0"])
