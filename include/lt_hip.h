@@ -79,9 +79,10 @@ typedef struct lt_conv_phase {
     const int32_t* taps; /* ntaps x 4 int32: dd, dh, dw, element offset ((dd*H + dh)*W + dw)*Cin     */
     int32_t ntaps;
     int32_t out_off[3];  /* ood, ooh, oow                                                            */
-    const void* weight_frag; /* optional (NULL = none): the same bf16 weights in MFMA fragment order, written by
-                                lt_conv_pack_weights -- lets the 288 x 256 kernel read its B operand with coalesced
-                                loads instead of staging it through LDS (Cout % 256 == 0 layers)                  */
+    const void* weight_frag; /* optional (NULL = none): the same bf16 weights in an MFMA fragment order, so that a kernel can read
+                                its weight operand with coalesced loads instead of staging it through LDS */
+    int32_t weight_frag_layout; /* 0 = none; 1 = lt_conv_pack_weights (Cout % 256 == 0 layers, 288 x 256 kernel);
+                                   2 = lt_conv_pack_weights_t32 (3x3x3 64->64 / 32->64 / 128->128 halo kernel, 3x3 256->256 band kernel) */
 } lt_conv_phase;
 
 typedef struct lt_conv_desc {
@@ -106,8 +107,7 @@ int lt_conv_pack_weights(const void* weight, int32_t cout_pad, int32_t k_pad, vo
 /* The fragment order of the TRANSPOSED product (weights as the first MFMA operand), used by the 3x3x3 64 -> 64 halo kernel:
  * [tap][cin / 16][cout_pad / 32][64 lanes][8]; lane (r = l & 31, h = l >> 5) holds output channel
  * 32 b + 16 (r >> 4) + 8 ((r >> 2) & 1) + 4 ((r >> 3) & 1) + (r & 3), K elements 16 g + 8 h .. + 7 of the tap.
- * Which of the two orders lt_conv_phase.weight_frag must have follows from the layer: Cout % 256 == 0 -> lt_conv_pack_weights;
- * 3x3x3, stride 1, 64 -> 64 channels -> this one; any other layer ignores the field. */
+ * lt_conv_phase.weight_frag_layout says which of the two orders weight_frag holds; a kernel only uses the one it was written for. */
 int lt_conv_pack_weights_t32(const void* weight, int32_t cout_pad, int32_t k_pad, int32_t cin, int32_t ntaps, void* packed,
                              void* stream);
 

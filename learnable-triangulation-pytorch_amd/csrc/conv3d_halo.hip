@@ -1455,6 +1455,187 @@ __global__ __launch_bounds__(256, (CIN == 128 ? 1 : 2)) void conv3d_halo_wreg_ke
     }
 }
 
+// ---- 2D 3x3, 256 -> 256 on 24-wide maps (the 36 bottleneck convs of ResNet-152 layer3): row bands in LDS, weights from global ----
+// The implicit GEMM gathers its A operand nine times (once per tap) through LDS-DMA and runs this layer at ~53 % of the MFMA rate
+// the chip sustains.  Here a workgroup owns a BAND of 12 rows x 24 columns = 288 pixels of one image and half of the output
+// channels (128 = one 32-channel block per compute wave): the band's halo (14 x 26 pixels) is staged ONCE per 64-channel K chunk
+// (46 KB; two buffers: loader waves request chunk q+1 while the compute waves multiply chunk q), every tap reads its voxel
+// fragments from that image with immediates, and the weights come from global memory as fragments of the transposed product
+// (lt_conv_pack_weights_t32), one coalesced 1 KB load per nine MFMAs.  256 bands x 2 channel halves = two workgroups per CU
+// in sequence, the two halves of a band on the same XCD.  OPT-IN (the plan packs the weights for it only with LT_CONV_BAND=1):
+// per layer it measures 83 us against 90 us for conv_igemm6, but inside the replayed forward the step is 1 % slower (two rounds
+// of workgroups, each with an exposed first-chunk load and epilogue, against one round).  Slot swizzle of the 128-byte pixel chunks: (column / 2 + 4 row) & 7 --
+// 16 consecutive pixels of a fragment read (also across the row wrap at column 24) then hit 16 different (bank half, slot) pairs;
+// a tap moves it by XOR constants, the K block by (g << 5), so a read is one v_xor + ds_read with an immediate.
+struct BandArgs {
+    const void* x;
+    const void* wfrag;
+    void* y;
+    const void* res;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    int N, H, W, ldc, flags, bands;   // bands per image
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv2d_band_kernel(const BandArgs a) {
+    constexpr int CIN = 256, KC = 64, NQ = CIN / KC, W_ = 24, RB = 12, PWID = W_ + 2, HROWS = RB + 2;
+    constexpr int HV = HROWS * PWID;                      // 364 halo pixels
+    constexpr int CHUNK_B = ((HV * KC * 2 + 1023) / 1024) * 1024;   // 47104
+    constexpr int NI = CHUNK_B / 1024;                    // 46 DMA pieces per chunk
+    constexpr int NF = RB * W_ / 32;                      // 9 pixel fragments
+    constexpr int G = KC / 16;                            // 4 K blocks per chunk
+    static_assert(sizeof(T) == 2 && RB * W_ == 288 && 2 * CHUNK_B <= 160 * 1024, "bf16, 288-pixel band, two chunk buffers");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page_h;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // workgroup -> (band tile, channel half): b and b + 8 (same XCD) are the two halves of one band
+    const int lin = blockIdx.x;
+    const int chalf = (lin >> 3) & 1;
+    const int tile = (lin & 7) + 8 * (lin >> 4);
+    const int n = tile / a.bands, r0 = (tile % a.bands) * RB;
+    const T* __restrict__ x = (const T*)a.x + (size_t)n * a.H * a.W * CIN;
+    auto sw = [](int hrow, int hcol) -> int { return ((hcol >> 1) + 4 * hrow) & 7; };
+
+    if (wave >= 4) {
+        // ================================= loader waves =================================
+        const int wl = wave & 3;
+        constexpr int MAXP = (NI + 3) / 4;
+        int poff[MAXP];                                   // element offset of this lane's 16 bytes of piece m inside chunk 0, or -1
+#pragma unroll
+        for (int m = 0; m < MAXP; ++m) {
+            const int q = (wl + 4 * m) * 64 + lane;
+            const int hv = q >> 3, pv = q & 7;
+            const int hrow = hv / PWID, hcol = hv - hrow * PWID;
+            const int lv = pv ^ sw(hrow, hcol);
+            const int gy = r0 - 1 + hrow, gx = hcol - 1;
+            const bool ok = hv < HV && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            poff[m] = ok ? (gy * a.W + gx) * CIN + lv * 8 : -1;
+        }
+        auto issue = [&](int q) {
+#pragma unroll
+            for (int m = 0; m < MAXP; ++m)
+                if (wl + 4 * m < NI) {
+                    const void* src = poff[m] >= 0 ? (const void*)(x + poff[m] + q * KC) : zero_page;
+                    dma16h(src, lds0 + (q & 1) * CHUNK_B + (wl + 4 * m) * 1024);
+                }
+        };
+        issue(0);
+        for (int q = 0; q < NQ; ++q) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // chunk q landed; the compute waves are done with chunk q-1
+            if (q + 1 < NQ) issue(q + 1);
+        }
+        return;
+    }
+
+    // ================================= compute waves =================================
+    const int cb = 4 * chalf + wave;                      // 32-channel output block
+    const int vl = lane & 31, hh = lane >> 5;
+    // pixel fragment f: pixel m = 32 f + vl = (row m / 24, column m % 24).  Read address of tap (kh, kw), K block g, buffer b:
+    //   (A[f][kw] ^ ((g << 5) ^ ((kh & 1) << 6))) + kh * PWID * 128 + b * CHUNK_B, the last two as the immediate
+    unsigned A[NF][3];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int m = 32 * f + vl;
+        const int row = m / W_, col = m - row * W_;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) A[f][kw] = lds0 + (row * PWID + col + kw) * (KC * 2) + ((hh ^ sw(row, col + kw)) << 4);
+    }
+    // weight fragments: (tap, 16-channel K block kb of 16, Cout block of 8) -> 1 KB at (((tap * 16 + kb) * 8 + cb) * 64 + lane) * 16 B
+    // (wave-uniform base + 32-bit lane offset: the loads take the SGPR-base form, no 64-bit address per unit in VGPRs)
+    const T* wb = (const T*)a.wfrag + (size_t)cb * 64 * 8;
+    const unsigned wlane = lane * 8;
+    constexpr size_t WKB = (size_t)8 * 64 * 8;            // elements per K block
+    constexpr int UPC = 9 * G, WD = 2;                    // units per chunk (tap-major, then K block); weight prefetch distance
+                                                          // (2 x 288 MFMA cycles; 3 already spills at the 256-register limit)
+    auto wptr = [&](int q, int u) -> const T* {           // unit u of chunk q
+        const int tap = u / G, gl = u % G;
+        return wb + ((size_t)tap * 16 + 4 * q + gl) * WKB + wlane;
+    };
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
+
+    V16 wf[WD + 1];
+    V16 xa[NF];
+    auto read_x = [&](auto bc, auto uc, auto fc) {
+        constexpr int b = decltype(bc)::value, u = decltype(uc)::value, f = decltype(fc)::value;
+        constexpr int tap = u / G, g = u % G, kh = tap / 3, kw = tap % 3;
+        constexpr unsigned XC = (unsigned)((g << 5) ^ ((kh & 1) << 6));
+        // the XOR as volatile asm: left to the compiler, all 216 distinct (fragment, kw, constant) addresses are computed up
+        // front and live in (spilled) registers
+        unsigned ad = A[f][kw];
+        if constexpr (XC != 0) asm volatile("v_xor_b32 %0, %2, %1" : "=v"(ad) : "v"(A[f][kw]), "n"(XC));
+        xa[f].u = *(const uint4*)((lptr_t)(size_t)(ad + kh * PWID * (KC * 2) + b * CHUNK_B));
+    };
+    // one K chunk out of buffer B: 36 units of (1 weight fragment, 9 pixel fragments, 9 MFMAs); the pixel fragments of unit u+1 are
+    // read into the registers unit u has just multiplied with, the weight fragments WD units ahead
+    auto chunk = [&](auto bc, int q) {
+        constexpr int b = decltype(bc)::value;
+#pragma unroll
+        for (int u = 0; u < WD; ++u) wf[u] = *(const V16*)wptr(q, u);
+        static_for<0, NF>([&](auto fc) { read_x(bc, std::integral_constant<int, 0>{}, fc); });
+        static_for<0, UPC>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if constexpr (u + WD < UPC) wf[(u + WD) % (WD + 1)] = *(const V16*)wptr(q, u + WD);
+            static_for<0, NF>([&](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % (WD + 1)].h, xa[f].h, acc[f], 0, 0, 0);
+                if constexpr (u + 1 < UPC) read_x(bc, std::integral_constant<int, u + 1>{}, fc);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+#pragma unroll 1
+    for (int q = 0; q < NQ; q += 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // chunk q is in buffer 0
+        chunk(std::integral_constant<int, 0>{}, q);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // chunk q + 1 is in buffer 1
+        chunk(std::integral_constant<int, 1>{}, q + 1);
+    }
+
+    // ---- epilogue from the accumulators: lane (pixel, h) holds channels 32 cb + 8 h + e (e < 8) and 32 cb + 16 + 8 h + (e - 8) ----
+    float esc[16], esf[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = 32 * cb + 16 * (e >> 3) + 8 * hh + (e & 7);
+        const float bi = a.bias ? a.bias[c] : 0.f, sc = a.scale ? a.scale[c] : 1.f, sf = a.shift ? a.shift[c] : 0.f;
+        esc[e] = sc; esf[e] = bi * sc + sf;
+    }
+    const EpiFloors fl = epi_floors(a.flags);
+    const bool has_res = a.res != nullptr;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int m = 32 * f + vl;
+        const int row = m / W_, col = m - row * W_;
+        const size_t oo = (((size_t)n * a.H + r0 + row) * a.W + col) * (size_t)a.ldc + 32 * cb + 8 * hh;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint4 rv = has_res ? *(const uint4*)((const T*)a.res + oo + 16 * q) : make_uint4(0, 0, 0, 0);
+            const unsigned rr[4] = {rv.x, rv.y, rv.z, rv.w};
+            unsigned o[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int e = 8 * q + 2 * d;
+                const float v0 = epi_apply(fmaf(acc[f][e], esc[e], esf[e]), fl, __uint_as_float(rr[d] << 16));
+                const float v1 = epi_apply(fmaf(acc[f][e + 1], esc[e + 1], esf[e + 1]), fl, __uint_as_float(rr[d] & 0xffff0000u));
+                o[d] = pack_bf16x2(v0, v1);
+            }
+            *(uint4*)((T*)a.y + oo + 16 * q) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // lt_conv_fwd packing [cout_pad][k_pad] (k = tap * cin + ci) -> fragments of the transposed product:
 // [tap][cin / 16][cout_pad / 32][64 lanes][8]; lane (r = l & 31, h = l >> 5) holds row chan(r) + 32 block, K elements 16 g + 8 h .. + 7
 __global__ void conv_pack_t32_kernel(const bf16_t* __restrict__ w, int cout_pad, int k_pad, int cin, int ntaps, bf16_t* __restrict__ out) {
@@ -2021,6 +2202,32 @@ int launch_halo(const HaloArgs& a, hipStream_t s) {
 
 namespace lt {
 
+// 2D 3x3 / stride 1 / pad 1, 256 -> 256 on 24-wide maps, weights available in the transposed fragment order: row-band kernel.
+// 1 = launched, 0 = not applicable, < 0 = error.
+int conv2d_band_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, hipStream_t s) {
+    if (dtype != LT_BF16 || nphase != 1 || getenv("LT_CONV_NO_BAND")) return 0;
+    const PhaseArg& p0 = c.phase[0];
+    if (!p0.wfrag_t || p0.ntaps != 9 || c.D != 1 || c.Do != 1 || c.OD != 1 || c.pd != 0 || c.ph != 1 || c.pw != 1) return 0;
+    if (c.sd != 1 || c.sh != 1 || c.sw != 1 || c.osd != 1 || c.osh != 1 || c.osw != 1 || p0.ood || p0.ooh || p0.oow) return 0;
+    if (c.H != c.Ho || c.W != c.Wo || c.OH != c.Ho || c.OW != c.Wo) return 0;
+    if (c.Cin != 256 || c.Cout != 256 || cout_pad != 256 || c.ldc % 8 || c.W != 24 || c.H % 12) return 0;
+    if (c.flags & (LT_EPI_STORE_F32 | LT_EPI_SIGMOID)) return 0;
+    const long long tiles = (long long)c.N * (c.H / 12);
+    if (tiles % 8 || tiles < 128) return 0;               // the two channel halves of a band are dealt to one XCD; fill the chip
+    BandArgs a;
+    a.x = c.x; a.wfrag = p0.wfrag_t; a.y = c.y; a.res = c.res; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
+    a.N = c.N; a.H = c.H; a.W = c.W; a.ldc = c.ldc; a.flags = c.flags; a.bands = c.H / 12;
+    auto kern = conv2d_band_kernel<bf16_t>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * 2)), dim3(512), 2 * 47104, s, a);
+    LT_CHECK_LAUNCH("lt_conv_fwd(2D band)");
+    return 1;
+}
+
 // Returns 1 and launches when the problem matches one of the instantiated halo configurations, 0 when the caller should
 // fall back to the implicit-GEMM path, negative on error.
 int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool forced, hipStream_t s) {
@@ -2036,7 +2243,7 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     const long long nblk = (long long)c.N * (c.D / 4) * (c.H / 8) * (c.W / 8);
     if (nblk < 256 && !forced) return 0;   // too few workgroups: the 64x64 implicit-GEMM tile fills the chip better
     HaloArgs a;
-    a.x = c.x; a.w = p0.w; a.wfrag = p0.wfrag; a.y = c.y; a.res = c.res; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
+    a.x = c.x; a.w = p0.w; a.wfrag = p0.wfrag_t; a.y = c.y; a.res = c.res; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
     a.N = c.N; a.D = c.D; a.H = c.H; a.W = c.W; a.Cout = c.Cout; a.ldc = c.ldc; a.k_pad = c.k_pad; a.flags = c.flags;
     a.tiles_d = c.D / 4; a.tiles_h = c.H / 8; a.tiles_w = c.W / 8;
     a.xcd_pin = (c.N % 8 == 0) ? 1 : 0;

@@ -11,7 +11,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct PhaseArg {
     const void* w;
-    const void* wfrag;   // the same weights in MFMA B-fragment order (lt_conv_pack_weights), or null
+    const void* wfrag;   // the same weights in MFMA B-fragment order (lt_conv_pack_weights, layout 1), or null
+    const void* wfrag_t; // ... in the order of the transposed product (lt_conv_pack_weights_t32, layout 2), or null
     const int4* taps;
     int ntaps;
     int ood, ooh, oow;
@@ -93,5 +94,7 @@ int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_ta
 int conv_pw_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, hipStream_t s);
 // conv3d_halo.hip: 1 = launched, 0 = not applicable (fall back), < 0 = error
 int conv3d_halo_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, bool forced, hipStream_t s);
+// conv3d_halo.hip, 2D row-band kernel (3x3 256->256 on 24-wide maps, weights in the transposed fragment order): 1 / 0 / < 0
+int conv2d_band_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, hipStream_t s);
 
 }  // namespace lt

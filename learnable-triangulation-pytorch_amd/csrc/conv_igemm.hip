@@ -278,6 +278,11 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
             return LT_ERR_UNSUPPORTED;
         }
     }
+    if (tile == LT_TILE_AUTO && !force_v1) {             // 2D 3x3 256 -> 256 on 24-wide maps: row bands in LDS, weights from global memory
+        const int rc = conv2d_band_try(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, s);
+        if (rc < 0) return rc;
+        if (rc == 1) return LT_OK;
+    }
     if (tile == LT_TILE_AUTO && !force_v1) {             // narrow single-tap layers (V2V skip convs, 2x2x2 deconvs): streaming kernel
         const int rc = conv_pw_try(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, s);
         if (rc < 0) return rc;
@@ -346,7 +351,8 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bi
         const lt_conv_phase& ph = d->phase[p];
         LT_REQUIRE(ph.weight && ph.taps && ph.ntaps >= 1, LT_ERR_INVALID, "lt_conv_fwd: phase %d incomplete", p);
         LT_REQUIRE((long long)ph.ntaps * d->Cin <= d->k_pad, LT_ERR_INVALID, "lt_conv_fwd: phase %d: ntaps*Cin > k_pad", p);
-        a.phase[p].w = ph.weight; a.phase[p].wfrag = ph.weight_frag; a.phase[p].taps = (const int4*)ph.taps; a.phase[p].ntaps = ph.ntaps;
+        a.phase[p].w = ph.weight; a.phase[p].wfrag = ph.weight_frag_layout == 1 ? ph.weight_frag : nullptr;
+        a.phase[p].wfrag_t = ph.weight_frag_layout == 2 ? ph.weight_frag : nullptr; a.phase[p].taps = (const int4*)ph.taps; a.phase[p].ntaps = ph.ntaps;
         a.phase[p].ood = ph.out_off[0]; a.phase[p].ooh = ph.out_off[1]; a.phase[p].oow = ph.out_off[2];
         if (ph.ntaps > max_taps) max_taps = ph.ntaps;
     }

@@ -25,7 +25,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 
 class ConvPhase(C.Structure):
-    _fields_ = [("weight", vp), ("taps", vp), ("ntaps", i32), ("out_off", i32 * 3), ("weight_frag", vp)]
+    _fields_ = [("weight", vp), ("taps", vp), ("ntaps", i32), ("out_off", i32 * 3), ("weight_frag", vp), ("weight_frag_layout", i32)]
 
 
 class ConvDesc(C.Structure):

@@ -611,6 +611,28 @@ def test_deconv4x4_phases_288x256(bsrc, monkeypatch):
     check("deconv4x4_288x256/%s vs igemm2" % bsrc, out, gen, 1.5e-2)
 
 
+@pytest.mark.parametrize("band", ["1", "0"], ids=["band", "igemm"])
+@pytest.mark.parametrize("N,H_", [(64, 24), (128, 24), (32, 48)])
+def test_conv2d_band_256_256(N, H_, band, monkeypatch):
+    """3x3 / stride 1 / pad 1, 256 -> 256 on 24-wide maps (ResNet-152 layer3 at 384^2 inputs): conv2d_band_kernel (row bands in LDS,
+    weights as fragments from global memory; opt-in with LT_CONV_BAND=1) and the implicit GEMM (default) vs torch: ReLU, residual + ReLU."""
+    if band == "1":
+        monkeypatch.setenv("LT_CONV_BAND", "1")      # opt-in: read when the plan packs the layer's weights
+    else:
+        monkeypatch.delenv("LT_CONV_BAND", raising=False)
+    g = torch.Generator().manual_seed(N + H_)
+    x = torch.randn(N, 256, H_, 24, generator=g)
+    w = torch.randn(256, 256, 3, 3, generator=g) * (1.0 / (256 * 9) ** 0.5)
+    bn = _bn(256, g)
+    res = torch.randn(N, 256, H_, 24, generator=g)
+    rd = bf16_round
+    conv = _bn_ref(F.conv2d(rd(x), rd(w), None, 1, 1), bn)
+    out = run_conv(x, w, None, bn, 1, 1, torch.bfloat16, 0, relu=True)
+    check("conv2d_band=%s/N%d_H%d/relu" % (band, N, H_), out, torch.relu(conv), 1.5e-2)
+    out2 = run_conv(x, w, None, bn, 1, 1, torch.bfloat16, 0, relu=True, residual=res)
+    check("conv2d_band=%s/N%d_H%d/res" % (band, N, H_), out2, torch.relu(conv + rd(res)), 1.5e-2)
+
+
 @pytest.mark.parametrize("wsrc", ["registers", "lds"])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (32, 64), (128, 128)])
 @pytest.mark.parametrize("N,sp", [(1, (8, 8, 16)), (3, (4, 16, 8)), (8, (8, 16, 16))])
