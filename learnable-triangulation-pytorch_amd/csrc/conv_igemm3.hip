@@ -976,11 +976,13 @@ __device__ __forceinline__ void wait_vmcnt6(int n) {
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(512) void conv_igemm6_kernel(const ConvArgs a) {
+// NWM = 2: 288-row tile, eight waves, one workgroup per CU; NWM = 1: 144-row tile, four waves, TWO workgroups per CU (55 KB ring each):
+// the short-K pointwise layers are mostly epilogue traffic, and a second workgroup's K loop overlaps it.
+template <int MODE, int NWM>
+__global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArgs a) {
     typedef bf16_t T;
     constexpr bool PW = MODE == 1;
-    constexpr int BM = BM3, BN = 256, NW = 8, WM = 144, WN = 64, MF = 16, SM = WM / MF, SN = WN / MF, NST = 6, VEC = 8, BK = 32, ROWB = 64;
+    constexpr int BM = 144 * NWM, BN = 256, NW = 4 * NWM, WM = 144, WN = 64, MF = 16, SM = WM / MF, SN = WN / MF, NST = 6, VEC = 8, BK = 32, ROWB = 64;
     constexpr int NPA = BM / 16;                          // 18 DMA pieces of 1 KiB per stage (16 rows of 64 B each)
     constexpr int A_IT = (NPA + NW - 1) / NW;             // 3 (waves 0, 1) / 2
     constexpr int STAGE = BM * ROWB;                      // 18432 B: activations only
@@ -1014,7 +1016,7 @@ __global__ __launch_bounds__(512) void conv_igemm6_kernel(const ConvArgs a) {
 
     const int prow = lane >> 2;
     const int kv = (lane & 3) ^ swz64(prow);
-    const bool a_tail = wave < NPA % NW;                 // waves 0, 1 own a third piece
+    const bool a_tail = wave < NPA % NW;                 // waves 0, 1 (wave 0 of the four-wave variant) own a third piece
     const int dps = (A_IT - 1) + (a_tail ? 1 : 0);       // 3 or 2 DMA pieces per wave and stage
     int id0[PW ? 1 : A_IT], ih0[PW ? 1 : A_IT], iw0[PW ? 1 : A_IT], baseC[A_IT], cur[PW ? 1 : A_IT];
     if (!PW)
@@ -1209,20 +1211,20 @@ __global__ void conv_pack_b_kernel(const bf16_t* __restrict__ w, int cout_pad, i
     *(uint4*)(out + g * 8) = *(const uint4*)(w + (size_t)(16 * tile + (l & 15)) * k_pad + 32 * stepk + 8 * (l >> 4));
 }
 
-template <int MODE>
+template <int MODE, int NWM>
 int launch6(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
     a.tiles_n = cout_pad / 256;
-    const long long nblk = cdiv(a.M, BM3) * a.tiles_n;
+    const long long nblk = cdiv(a.M, 144 * NWM) * a.tiles_n;
     LT_REQUIRE(nblk < (1ll << 31), LT_ERR_INVALID, "lt_conv_fwd: grid too large");
-    const size_t lds = 6 * (size_t)BM3 * 64 + (size_t)max_taps * sizeof(int4);
+    const size_t lds = 6 * (size_t)(144 * NWM) * 64 + (size_t)max_taps * sizeof(int4);
     LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: 288x256 tile needs %zu B of LDS", lds);
-    auto kern = conv_igemm6_kernel<MODE>;
+    auto kern = conv_igemm6_kernel<MODE, NWM>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256 * NWM), lds, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(v6)");
     return LT_OK;
 }
@@ -1307,7 +1309,12 @@ int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_ta
                              a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
             const char* no6 = getenv("LT_CONV_NO_V6");   // A/B, read per call
             if (q0.wfrag && !no6 && a.k_pad % 64 == 0) {  // weights also available in fragment order: B operand from registers
-                const int rc6 = pw5 ? launch6<1>(a, cout_pad, max_taps, s) : launch6<2>(a, cout_pad, max_taps, s);
+                // short-K pointwise layers (the 1x1 expands): 144-row tiles, two workgroups per CU (LT_CONV_V6_BM144=0/1 forces it off/on)
+                const char* e144 = getenv("LT_CONV_V6_BM144");
+                const bool bm144 = e144 ? e144[0] == '1' : (pw5 && a.k_pad <= 256 && a.M % 144 == 0);
+                int rc6;
+                if (bm144) rc6 = pw5 ? launch6<1, 1>(a, cout_pad, max_taps, s) : launch6<2, 1>(a, cout_pad, max_taps, s);
+                else rc6 = pw5 ? launch6<1, 2>(a, cout_pad, max_taps, s) : launch6<2, 2>(a, cout_pad, max_taps, s);
                 return rc6 == LT_OK ? 1 : rc6;
             }
             const int rc5 = pw5 ? launch5<1>(a, cout_pad, max_taps, s) : launch5<2>(a, cout_pad, max_taps, s);

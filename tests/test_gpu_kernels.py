@@ -564,7 +564,7 @@ V5_CASES = {  # name: (nd, N, cin, cout, k, stride, pad, spatial, residual)
 }
 
 
-@pytest.mark.parametrize("bsrc", ["registers", "lds"])
+@pytest.mark.parametrize("bsrc", ["registers", "registers_144", "lds"])
 @pytest.mark.parametrize("case", list(V5_CASES))
 def test_conv_v5_288x256(case, bsrc, monkeypatch):
     """288x256 tile / 32-element K steps (Cout % 256 == 0), forced with LT_CONV_V5=1, vs torch (bf16): conv_igemm6 (weights read
@@ -574,6 +574,7 @@ def test_conv_v5_288x256(case, bsrc, monkeypatch):
         monkeypatch.setenv("LT_CONV_NO_V6", "1")
     else:
         monkeypatch.delenv("LT_CONV_NO_V6", raising=False)
+    monkeypatch.setenv("LT_CONV_V6_BM144", "1" if bsrc == "registers_144" else "0")   # 144-row tiles, two workgroups per CU
     nd, N, cin, cout, k, s, p, sp, with_res = V5_CASES[case]
     g = torch.Generator().manual_seed(len(case) * 5 + cin)
     x = torch.randn(N, cin, *sp, generator=g)
