@@ -982,7 +982,11 @@ template <int MODE, int NWM>
 __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArgs a) {
     typedef bf16_t T;
     constexpr bool PW = MODE == 1;
-    constexpr int BM = 144 * NWM, BN = 256, NW = 4 * NWM, WM = 144, WN = 64, MF = 16, SM = WM / MF, SN = WN / MF, NST = 6, VEC = 8, BK = 32, ROWB = 64;
+    constexpr int BM = 144 * NWM, BN = 256, NW = 4 * NWM, WM = 144, WN = 64, MF = 16, SM = WM / MF, SN = WN / MF, VEC = 8, BK = 32, ROWB = 64;
+#ifndef LT6_NST
+#define LT6_NST 6
+#endif
+    constexpr int NST = LT6_NST;                          // 6 x 18 KB, five stages in flight (8 stages measured no faster: the loop is not waiting for data)
     constexpr int NPA = BM / 16;                          // 18 DMA pieces of 1 KiB per stage (16 rows of 64 B each)
     constexpr int A_IT = (NPA + NW - 1) / NW;             // 3 (waves 0, 1) / 2
     constexpr int STAGE = BM * ROWB;                      // 18432 B: activations only
@@ -1003,6 +1007,10 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+#ifdef LT6_STAGGER
+    // A/B: the two co-resident workgroups of the four-wave variant start half a K step apart (they stay in lock step otherwise)
+    if (NWM == 1 && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(LT6_STAGGER);
+#endif
     int lin = blockIdx.x;
     if (!(a.flags & LT_EPI_NO_XCD_REMAP)) {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = lin & 7, j = lin >> 3;
@@ -1095,13 +1103,30 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
 
     constexpr int LOOK = 3, RA = LOOK + 1;               // read stream of a step: the SM A fragments
     unsigned rbuf = 0, wbuf = (NST - 1) * STAGE;          // ring offsets of the stage being read / being requested
+#ifdef LT_TRACE
+    long long tr_vm = 0, tr_bar = 0, tr_iss = 0, tr_cmp = 0, tr_prev = 0;
+    const long long tr_begin = LT_CLK3();
+    const long long tr_rt0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     auto step = [&](int ks, auto rc) {
         constexpr int R = decltype(rc)::value;           // ks & 1: which B register set this step multiplies with
+#ifdef LT_TRACE
+        const long long tr0 = LT_CLK3();
+        if (ks > 0) tr_cmp += tr0 - tr_prev;
+#endif
         // needed now: B(ks) (requested at the start of step ks-1) and, older, stage ks.  Requested after B(ks): the pieces of stage
         // ks+NST-2 (step ks-1), if that stage exists; before the first step: stages 1 .. NST-2 after stage 0
         const int after = ks == 0 ? ((nk < NST - 1 ? nk : NST - 1) - 1) * dps : (ks + NST - 2 < nk ? dps : 0);
         wait_vmcnt6(after);
+#ifdef LT_TRACE
+        const long long tr1 = LT_CLK3();
+        tr_vm += tr1 - tr0;
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage ks landed for every wave; stage ks-1 fully consumed
+#ifdef LT_TRACE
+        const long long tr2 = LT_CLK3();
+        tr_bar += tr2 - tr1;
+#endif
 #pragma unroll
         for (int j = 0; j < SN; ++j) frag_ready(fb[R][j]);
         {   // B(ks+1): the last step re-reads its own fragments (a valid address; never used)
@@ -1110,6 +1135,11 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
         }
         const bool more = ks + NST - 1 < nk;
         if (more) stage_prep(ks + NST - 1);
+#ifdef LT_TRACE
+        const long long tr3 = LT_CLK3();                  // B loads + tap bookkeeping
+        tr_iss += tr3 - tr2;
+        tr_prev = tr3;
+#endif
         const unsigned abase = aoff + rbuf;
         V16 fa[RA];
         auto issue = [&](auto kc) {
@@ -1138,6 +1168,17 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
         step(ks, std::integral_constant<int, 0>{});
         step(ks + 1, std::integral_constant<int, 1>{});
     }
+#ifdef LT_TRACE
+    {   // same record as conv_igemm3_kernel: total, vmcnt wait, barrier, issue (B loads), fragment reads + MFMAs + DMA issue, steps, 100 MHz ticks
+        const long long tr_end = LT_CLK3();
+        tr_cmp += tr_end - tr_prev;
+        const long long tr_rt1 = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wave == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 1024 && lane == 0) {
+            long long* o = g_trace3 + (blockIdx.x >> 3) * 8;
+            o[0] = tr_end - tr_begin; o[1] = tr_vm; o[2] = tr_bar; o[3] = tr_iss; o[4] = tr_cmp; o[5] = nk; o[6] = tr_rt1 - tr_rt0; o[7] = blockIdx.x;
+        }
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring becomes the epilogue staging area
 #ifdef LT_ABL_NO_EPI
     if (a.M >= 0) return;
@@ -1216,7 +1257,7 @@ int launch6(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
     a.tiles_n = cout_pad / 256;
     const long long nblk = cdiv(a.M, 144 * NWM) * a.tiles_n;
     LT_REQUIRE(nblk < (1ll << 31), LT_ERR_INVALID, "lt_conv_fwd: grid too large");
-    const size_t lds = 6 * (size_t)(144 * NWM) * 64 + (size_t)max_taps * sizeof(int4);
+    const size_t lds = LT6_NST * (size_t)(144 * NWM) * 64 + (size_t)max_taps * sizeof(int4);
     LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: 288x256 tile needs %zu B of LDS", lds);
     auto kern = conv_igemm6_kernel<MODE, NWM>;
     static bool attr_set = false;
