@@ -53,6 +53,29 @@ def test_recorded_plan_matches_oracle(nl, method, kind, Himg):
     assert P["plan"].flops > 0 and len(P["plan"].ops) > 50
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_plan_structure_pre_graph_tail(dt):
+    """What is captured into the hipGraph and what stays outside: the soft-argmax is the plan's only tail op (it writes the tensors
+    forward() returns); bf16 plans fuse the stem (one 'stem' op instead of conv + max pool) and chain the V2V tail; a dry-run plan
+    records no pre op (its interpreter reads the layout buffer, not the caller's images)."""
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    cfg = synth.vol_config(18, 32, "softmax")     # 32^3 is the smallest cube V2V's five poolings accept
+    m = VolumetricTriangulationNet(cfg, device="cpu")
+    m.eval()
+    m.compute_dtype = dt
+    P = m._build_plan(1, 2, 64, 64, "cpu", dry_run=True)
+    plan = P["plan"]
+    kinds = [meta["kind"] for _, meta in plan.ops]
+    assert plan.npre == 0 and P["image_cell"] is None
+    assert plan.nhead == len(plan.ops) - 1 and kinds[-1] == "softargmax3d" and kinds.count("softargmax3d") == 1
+    if dt == torch.bfloat16:
+        assert kinds[0] == "stem" and kinds.count("pwchain") == 1 and kinds.count("maxpool") == 5   # the five 3D pools of V2V
+    else:
+        assert kinds[0] == "conv" and kinds[1] == "maxpool" and "stem" not in kinds and "pwchain" not in kinds
+    with pytest.raises(RuntimeError):
+        plan.run(None)
+
+
 def test_pointwise_chain_is_recorded_for_bf16_and_matches_the_layers():
     """bf16 plans run V2V's pointwise tail (back_layers[1:] + output_layer) as ONE lt_pwchain_fwd; the recorded chain must
     be the same function as the three lt_conv_fwd launches an fp32 plan records (interpreted on the CPU)."""
