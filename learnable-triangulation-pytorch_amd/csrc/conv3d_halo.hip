@@ -17,6 +17,14 @@
 //            lines of the tile, not 16 consecutive voxels);
 //   weights: per tap a [cout_pad][CINB] slab, slot lv ^ ((-(col/VPR)) % NVV) (conflict free for both MFMA shapes).
 // Weight ring: NBUF chunk buffers, NBUF-1 chunks of DMA in flight (counted vmcnt), one barrier per chunk.
+//
+// Kernels in this file (dispatch: conv3d_halo_try / conv2d_band_try at the end):
+//   conv3d_halo_kernel          one tile per workgroup, weight ring in LDS, optional loader waves: fp32, and the bf16 shapes below miss
+//   conv3d_halo_persist_kernel  3^3 32->32: persistent, weights resident, double-buffered halo (small grids)
+//   conv3d_halo_col_kernel      3^3 32->32: column walk, ring of 4-plane halo groups, epilogue under the next tile's MFMAs
+//   conv3d_halo7_kernel / 7b    7^3 32->16: loader waves; tap-major / kd-register-blocked (default)
+//   conv3d_halo_wreg_kernel     3^3 64->64, 32->64, 128->128: halo-only LDS, weights as fragments from global memory
+//   conv2d_band_kernel          2D 3x3 256->256 on 24-wide maps (opt-in): row bands in LDS, weights from global memory
 #include <stdlib.h>
 
 #include <type_traits>

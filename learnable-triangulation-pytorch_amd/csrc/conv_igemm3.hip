@@ -15,6 +15,10 @@
 //     cycles; the other wave of its SIMD feeds the matrix pipe meanwhile);
 //   * fragments: hand-issued ds_read_b128 with counted lgkmcnt (hipcc falls back to lgkmcnt(0) beyond one group in flight).
 // bf16 only (the fp32 parity mode stays on conv_igemm2), one phase, pointwise or uniform-tap addressing, vector epilogue.
+//
+// Kernels in this file (dispatch: conv3_try at the end): conv_igemm3_kernel (288 x 128 / 64, 8 or 12 waves), conv_igemm4_kernel
+// (opt-in: four compute + four loader waves), conv_igemm5_kernel (288 x 256, 32-element K steps, both operands staged),
+// conv_igemm6_kernel (288 x 256 or 144 x 256, weights from global memory in fragment order: the default for Cout % 256 == 0).
 #include <stdlib.h>
 
 #include <type_traits>
