@@ -93,7 +93,7 @@ class GlobalAveragePoolingHead(nn.Module):
         return o
 
 
-class PoseResNet(nn.Module):
+class PoseResNet(E.PlanCache):
     def __init__(self, block_kind, layers, num_joints, num_input_channels=3, deconv_with_bias=False, num_deconv_layers=3,
                  num_deconv_filters=(256, 256, 256), num_deconv_kernels=(4, 4, 4), final_conv_kernel=1,
                  alg_confidences=False, vol_confidences=False, caffe=False):
@@ -129,8 +129,7 @@ class PoseResNet(nn.Module):
         self.final_layer = nn.Conv2d(inplanes, num_joints, kernel_size=final_conv_kernel, stride=1,
                                      padding=1 if final_conv_kernel == 3 else 0)
         self.compute_dtype = torch.float32
-        self._plans = {}
-        self.register_load_state_dict_post_hook(lambda m, k: m._plans.clear())
+        self._init_plan_cache()
 
     # ---- plan recording -------------------------------------------------------------------
     def record(self, b, x, want_heatmaps=True, image_cell=None):
@@ -176,22 +175,25 @@ class PoseResNet(nn.Module):
         if self.training:
             raise NotImplementedError("train-mode BatchNorm / backward are not built yet (SURVEY.md section 8f row 1); call .eval()")
         key = (tuple(x.shape), self.compute_dtype, x.device)
-        st = torch.cuda.current_stream().cuda_stream
-        if key not in self._plans:
-            N, Cc, Hh, W = x.shape
+        N, Cc, Hh, W = x.shape
+
+        def build():
             b = E.PlanBuilder(x.device, self.compute_dtype)
             inp = b.alloc((N, 1, Hh, W, E.min_cin_of(self.compute_dtype)))
             outs = self.record(b, inp, True)
-            self._plans[key] = (b.finish(), inp, outs)
-        plan, inp, (hm, feats, alg, vol) = self._plans[key]
-        N, Cc, Hh, W = x.shape
-        xin = x.float().contiguous()
-        H.check(H.lib().lt_nchw_to_nhwc(plan_dtype_code(self.compute_dtype), xin.data_ptr(), inp.t.data_ptr(), N, Cc, Hh * W,
-                                        inp.t.shape[-1], st), "lt_nchw_to_nhwc")
-        plan.run_eager(st)
-        to_nchw = lambda a: a.t[:, 0].permute(0, 3, 1, 2).to(torch.float32, copy=True)
-        conf = lambda a: None if a is None else a.t.reshape(N, -1).clone()
-        return to_nchw(hm), to_nchw(feats), conf(alg), conf(vol)
+            return {"plan": b.finish(), "inp": inp, "outs": outs}
+
+        with torch.cuda.device(x.device):    # launches go to x's device whatever the caller's current device is
+            P = self._plan_for(key, build)
+            plan, inp, (hm, feats, alg, vol) = P["plan"], P["inp"], P["outs"]
+            st = torch.cuda.current_stream(x.device).cuda_stream
+            xin = x.float().contiguous()
+            H.check(H.lib().lt_nchw_to_nhwc(plan_dtype_code(self.compute_dtype), xin.data_ptr(), inp.t.data_ptr(), N, Cc, Hh * W,
+                                            inp.t.shape[-1], st), "lt_nchw_to_nhwc")
+            plan.run_eager(st)
+            to_nchw = lambda a: a.t[:, 0].permute(0, 3, 1, 2).to(torch.float32, copy=True)
+            conf = lambda a: None if a is None else a.t.reshape(N, -1).clone()
+            return to_nchw(hm), to_nchw(feats), conf(alg), conf(vol)
 
 
 def plan_dtype_code(dt):
@@ -203,6 +205,8 @@ def get_pose_net(config, device="cuda:0"):
     ``config.num_layers`` / ``config.style`` and optionally loads a pretrained checkpoint, keeping only
     shape-compatible tensors, stripping ``module.`` and partially copying the final layer."""
     kind, layers = resnet_spec[config.num_layers]
+    if config.style == "caffe":
+        kind = "bottleneck"   # the reference swaps in Bottleneck_CAFFE (expansion 4) at EVERY depth, 18 and 34 included (:322-324)
     model = PoseResNet(kind, layers, config.num_joints, num_input_channels=3, deconv_with_bias=False, num_deconv_layers=3,
                        num_deconv_filters=(256, 256, 256), num_deconv_kernels=(4, 4, 4), final_conv_kernel=1,
                        alg_confidences=config.alg_confidences, vol_confidences=config.vol_confidences,

@@ -25,6 +25,10 @@ from mvn.models.v2v import V2VModel
 from mvn.utils import multiview, op, volumetric
 
 
+GEO_RING = 4          # pinned geometry staging slots per plan (forwards the host may run ahead of the GPU)
+MAX_LAUNCH_ELEMS = 2 ** 31   # liblt_hip indexes activations with 32-bit element offsets (conv_igemm.hip guard)
+
+
 def _bn_in_train_mode(m):
     return any(isinstance(c, nn.modules.batchnorm._BatchNorm) and c.training for c in m.modules())
 
@@ -35,8 +39,8 @@ def _no_training(m):
                                   "(SURVEY.md section 8f row 1); call model.eval()")
 
 
-class _PlannedNet(nn.Module):
-    """Shared plan cache: one recorded + graph-captured launch list per (shape, dtype, device)."""
+class _PlannedNet(E.PlanCache):
+    """A whole triangulation net behind one plan cache (lt_engine.PlanCache: LRU + weights fingerprint)."""
 
     def __init__(self):
         super().__init__()
@@ -44,18 +48,13 @@ class _PlannedNet(nn.Module):
         self.use_graph = True
         self.copy_outputs = True             # False: return views of plan-owned buffers (valid until the next forward)
         self.tile_override = 0
-        self._plans = {}
         self._stream = None
-        self.register_load_state_dict_post_hook(lambda m, k: m._plans.clear())
+        self._init_plan_cache()
 
     def set_compute_dtype(self, dtype):
         H.dtype_code(dtype)
         self.compute_dtype = dtype
         return self
-
-    def invalidate_plans(self):
-        """Call after changing weights in place (load_state_dict does it automatically)."""
-        self._plans.clear()
 
     def _side_stream(self, device):
         if self._stream is None or self._stream.device != device:
@@ -114,9 +113,12 @@ class VolumetricTriangulationNet(_PlannedNet):
         # geometry block (fp32, one H2D copy per forward): proj B*NV*12 | pos B*3 | center B*3 | rot B*9
         n_geo = B * NV * 12 + B * 15
         geo = torch.zeros(n_geo, dtype=torch.float32, device=device)
-        geo_host = torch.zeros(n_geo, dtype=torch.float32)
+        # pinned staging RING: forward N+1 fills the next slot while forward N's copy may still be queued; a slot is rewritten only
+        # after the event recorded behind its last copy has completed (forward never blocks on the GPU otherwise)
+        geo_ring = [torch.zeros(n_geo, dtype=torch.float32) for _ in range(1 if dry_run else GEO_RING)]
         if not dry_run:
-            geo_host = geo_host.pin_memory()
+            geo_ring = [g.pin_memory() for g in geo_ring]
+        geo_host = geo_ring[0]
         o_pos, o_cen, o_rot = B * NV * 12, B * NV * 12 + 3 * B, B * NV * 12 + 6 * B
         coords = torch.empty(B, V, V, V, 3, dtype=torch.float32, device=device)
         step = float(np.float32(self.cuboid_side / (V - 1)))
@@ -150,8 +152,11 @@ class VolumetricTriangulationNet(_PlannedNet):
                  "softargmax3d", nbytes=2 * B * J * V ** 3 * 4,  # read logits + write probabilities
                  info={"logits": logits, "coords": coords, "mult": mult, "softmax": sm, "kp": kp, "probs": probs}, tail=True)
         plan = b.finish()
-        plan.keep += [geo, geo_host, coords, kp, probs, ws]
-        return {"plan": plan, "x_in": x_in, "image_cell": image_cell, "feats": feats, "geo": geo, "geo_host": geo_host, "coords": coords, "kp": kp,
+        plan.keep += [geo, geo_ring, coords, kp, probs, ws]
+        if image_cell is not None and not dry_run:
+            x_in.t.untyped_storage().resize_(0)   # the fused stem reads the caller's images: x_in is only a shape (150 MB at B = 32)
+        return {"plan": plan, "x_in": x_in, "image_cell": image_cell, "feats": feats, "geo": geo, "geo_host": geo_host, "geo_ring": geo_ring,
+                "geo_events": [None] * len(geo_ring), "geo_slot": 0, "coords": coords, "kp": kp,
                 "probs": probs, "conf": conf, "logits": logits, "vol": vol, "hw": (h, w), "offs": (o_pos, o_cen, o_rot),
                 "captured": False}
 
@@ -174,7 +179,11 @@ class VolumetricTriangulationNet(_PlannedNet):
             theta = np.random.uniform(0.0, 2 * np.pi) if self.training else 0.0
             rot[i] = volumetric.get_rotation_matrix(axis, theta).reshape(-1)
         o_pos, o_cen, o_rot = P["offs"]
-        gh = P["geo_host"]
+        slot = P["geo_slot"] = (P["geo_slot"] + 1) % len(P["geo_ring"])
+        ev = P["geo_events"][slot]
+        if ev is not None:
+            ev.synchronize()         # the copy that last read this slot (GEO_RING forwards ago) has completed
+        gh = P["geo_host"] = P["geo_ring"][slot]
         gh[:o_pos] = torch.from_numpy(proj.astype(np.float32).reshape(-1))
         gh[o_pos:o_cen] = torch.from_numpy(position.astype(np.float32).reshape(-1))
         gh[o_cen:o_rot] = torch.from_numpy(base.astype(np.float32).reshape(-1))
@@ -182,19 +191,54 @@ class VolumetricTriangulationNet(_PlannedNet):
         return position, base, sides
 
     # ---------------------------------------------------------------------------------------
+    def max_samples_per_launch(self, NV, Hh, W):
+        """Largest per-launch batch: every activation must stay below 2^31 elements (32-bit element offsets in liblt_hip).  The
+        widest ones are the 32-channel V^3 volume and the 64-channel half-resolution map behind the stem."""
+        V = self.volume_size
+        per_sample = max(32 * V ** 3, NV * 64 * ((Hh + 1) // 2) * ((W + 1) // 2), NV * 256 * ((Hh + 3) // 4) * ((W + 3) // 4))
+        return max(1, (MAX_LAUNCH_ELEMS - 1) // per_sample)
+
     def forward(self, images, proj_matricies, batch):
         """images (B,NV,3,H,W) fp32 on the GPU; ``proj_matricies`` is ignored exactly as in the reference
         (overwritten at :277); ``batch`` as built by datasets/utils.py:14-37 (``cameras``, and
-        ``pred_keypoints_3d`` or ``keypoints_3d``).  Returns the reference's 7-tuple (:355)."""
+        ``pred_keypoints_3d`` or ``keypoints_3d``).  Returns the reference's 7-tuple (:355).
+
+        Asynchronous like the reference's CUDA forward: nothing here waits for the GPU (results are ordered on the current
+        stream).  Batches beyond ``max_samples_per_launch`` (BASELINE config 4: 32 samples of 128^3 voxels are exactly 2^31
+        elements) run as consecutive sub-batches of one plan."""
         H.require_gpu(images, "images")
         _no_training(self)
-        device = images.device
         B, NV = images.shape[:2]
+        cap = self.max_samples_per_launch(NV, images.shape[3], images.shape[4])
+        if B <= cap:
+            with torch.cuda.device(images.device):
+                return self._forward_chunk(images, batch, 0, B)
+        n = -(-B // cap)
+        size = -(-B // n)            # equal-sized chunks (one plan), a shorter last one only if B does not divide
+        parts = []
+        with torch.cuda.device(images.device):
+            for lo in range(0, B, size):
+                parts.append(self._forward_chunk(images, batch, lo, min(B, lo + size)))
+        cat = lambda i: torch.cat([p[i] for p in parts], dim=0)
+        conf = None if parts[0][3] is None else cat(3)
+        return cat(0), cat(1), cat(2), conf, [c for p in parts for c in p[4]], cat(5), cat(6)
+
+    def _forward_chunk(self, images, batch, lo, hi):
+        device = images.device
+        NV = images.shape[1]
         Hh, W = images.shape[3:]
-        key = (B, NV, Hh, W, self.compute_dtype, device, self.use_graph)
-        if key not in self._plans:
-            self._plans[key] = self._build_plan(B, NV, Hh, W, device)
-        P = self._plans[key]
+        if lo != 0 or hi != images.shape[0]:
+            images = images[lo:hi]
+            batch = dict(batch, cameras=[cams[lo:hi] for cams in batch["cameras"]])
+            for k in ("keypoints_3d", "pred_keypoints_3d"):
+                if k in batch:
+                    batch[k] = batch[k][lo:hi]
+        B = hi - lo
+        # everything a plan bakes in besides the weights (those: the fingerprint inside _plan_for)
+        key = (B, NV, Hh, W, self.compute_dtype, device, self.use_graph, self.volume_size, float(self.cuboid_side),
+               float(self.volume_multiplier), bool(self.volume_softmax), self.volume_aggregation_method,
+               bool(self.transfer_cmu_to_human36m), self.tile_override, self.num_joints)
+        P = self._plan_for(key, lambda: self._build_plan(B, NV, Hh, W, device))
         h, w = P["hw"]
         position, base, sides = self._host_geometry(batch, B, (Hh, W), P)
         # ---- device side ----
@@ -207,6 +251,8 @@ class VolumetricTriangulationNet(_PlannedNet):
         with torch.cuda.stream(side):
             st = side.cuda_stream
             P["geo"].copy_(P["geo_host"], non_blocking=True)
+            ev = P["geo_events"][P["geo_slot"]] = P["geo_events"][P["geo_slot"]] or torch.cuda.Event()
+            ev.record(side)
             if P["image_cell"] is not None:     # the plan's first op reads the images where they are
                 P["image_cell"]["ptr"], P["image_cell"]["ref"] = x.data_ptr(), x
             else:
@@ -226,16 +272,20 @@ class VolumetricTriangulationNet(_PlannedNet):
                 plan.run(st)
             feats = P["feats"].t.reshape(B, NV, h, w, 32).permute(0, 1, 4, 2, 3)
             conf = P["conf"]
+            o_pos, o_cen, o_rot = P["offs"]
+            base_points = P["geo"][o_cen:o_rot].reshape(B, 3).clone()    # fp32(base), from the block that was just copied in
             if self.copy_outputs:
                 coords = coords.clone()
                 feats = feats.to(torch.float32, copy=True)
                 conf = None if conf is None else conf.clone()
             if conf is not None and self.volume_aggregation_method == "conf_norm":
                 conf = conf / conf.sum(dim=1, keepdim=True)   # the RETURNED confidences are the normalised ones (reference :268-269, :355)
+            for t in (kp, probs, coords, feats, base_points, conf):
+                if t is not None:
+                    t.record_stream(cur)     # allocated on the side stream, handed to the caller's stream
         x.record_stream(side)
         cur.wait_stream(side)
         cuboids = [volumetric.Cuboid3D(position[i], sides) for i in range(B)]
-        base_points = torch.from_numpy(base.astype(np.float32)).to(device)
         return kp, feats, probs, conf, cuboids, coords, base_points
 
 
@@ -279,10 +329,12 @@ class AlgebraicTriangulationNet(_PlannedNet):
         device = images.device
         B, NV = images.shape[:2]
         Hh, W = images.shape[3:]
-        key = (B, NV, Hh, W, self.compute_dtype, device)
-        if key not in self._plans:
-            self._plans[key] = self._build_plan(B, NV, Hh, W, device)
-        P = self._plans[key]
+        key = (B, NV, Hh, W, self.compute_dtype, device, float(self.heatmap_multiplier), bool(self.heatmap_softmax), self.tile_override)
+        with torch.cuda.device(device):
+            P = self._plan_for(key, lambda: self._build_plan(B, NV, Hh, W, device))
+            return self._run(P, images, proj_matricies, B, NV, Hh, W, device)
+
+    def _run(self, P, images, proj_matricies, B, NV, Hh, W, device):
         h, w = P["hw"]; J = P["J"]
         st = torch.cuda.current_stream(device).cuda_stream
         x = images.reshape(B * NV, 3, Hh, W).float().contiguous()

@@ -102,7 +102,7 @@ class EncoderDecorder(nn.Module):  # (sic) reference :69-138
         return x
 
 
-class V2VModel(nn.Module):
+class V2VModel(E.PlanCache):
     def __init__(self, input_channels, output_channels):
         super().__init__()
         self.front_layers = nn.Sequential(Basic3DBlock(input_channels, 16, 7), Res3DBlock(16, 32), Res3DBlock(32, 32), Res3DBlock(32, 32))
@@ -114,8 +114,7 @@ class V2VModel(nn.Module):
                 nn.init.xavier_normal_(m.weight)
                 nn.init.constant_(m.bias, 0)
         self.compute_dtype = torch.float32
-        self._plans = {}
-        self.register_load_state_dict_post_hook(lambda m, k: m._plans.clear())
+        self._init_plan_cache()
 
     def record(self, b, x):
         """x: Act [N,V,V,V,Cin] -> logits Act [N,V,V,V,Cout], always fp32 (they feed the soft-argmax); the bf16 tail stores
@@ -144,13 +143,15 @@ class V2VModel(nn.Module):
         if self.training:
             raise NotImplementedError("train-mode BatchNorm / backward are not built yet (SURVEY.md section 8f row 1); call .eval()")
         key = (tuple(x.shape), self.compute_dtype, x.device)
-        if key not in self._plans:
+
+        def build():
             b = E.PlanBuilder(x.device, self.compute_dtype)
             inp = b.alloc((x.shape[0],) + tuple(x.shape[2:]) + (x.shape[1],))
             inp.pooled = False
-            out = self.record(b, inp)
-            self._plans[key] = (b.finish(), inp, out)
-        plan, inp, out = self._plans[key]
-        inp.t.copy_(x.permute(0, 2, 3, 4, 1))
-        plan.run_eager(torch.cuda.current_stream().cuda_stream)
-        return out.t.permute(0, 4, 1, 2, 3).clone(memory_format=torch.preserve_format)
+            return {"plan": b.finish_after(self.record(b, inp)), "inp": inp}
+
+        with torch.cuda.device(x.device):    # launches go to x's device whatever the caller's current device is
+            P = self._plan_for(key, build)
+            P["inp"].t.copy_(x.permute(0, 2, 3, 4, 1))
+            P["plan"].run_eager(torch.cuda.current_stream(x.device).cuda_stream)
+            return P["plan"].result.t.permute(0, 4, 1, 2, 3).clone(memory_format=torch.preserve_format)

@@ -177,6 +177,73 @@ def gen_nets(mvn):
     np.savez_compressed(os.path.join(GOLD, "nets.npz"), **out)
 
 
+def gen_caffe(mvn):
+    """style == 'caffe' (pose_resnet.py:322-324, Bottleneck_CAFFE :98-137): at a bottleneck depth (50) and at a basic-block
+    depth (18), where the reference still swaps in the expansion-4 caffe bottleneck."""
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    for nl, hw in ((50, 128), (18, 64)):
+        sp = spec.pose_resnet_spec(nl, 17, False, False, "", caffe=True)
+        cfg = synth.AttrDict(num_layers=nl, style="caffe", num_joints=17, alg_confidences=False, vol_confidences=False,
+                             init_weights=False, checkpoint="")
+        ref = mvn.models.pose_resnet.get_pose_net(cfg, device="cpu")
+        rsd = ref.state_dict()
+        assert list(rsd.keys()) == list(sp.keys()), "caffe resnet%d key order" % nl
+        assert all(tuple(rsd[k].shape) == sp[k][0] for k in sp)
+        sd = synth.make_state_dict(sp, seed=700 + nl)
+        ref.load_state_dict(sd, strict=True); ref.eval()
+        x = torch.randn(2, 3, hw, hw, generator=g)
+        with torch.no_grad():
+            hm, ft, _, _ = ref(x)
+        ohm, oft, _, _ = O.pose_resnet(sd, x, nl, prefix="", caffe=True)
+        _check("caffe resnet%d features" % nl, oft, ft, 2e-5); _check("caffe resnet%d heatmaps" % nl, ohm, hm, 2e-5)
+        # the two styles really differ on the same weights (otherwise this fixture would pin nothing)
+        _, sft, _, _ = O.pose_resnet(sd, x, nl if nl >= 50 else 50, prefix="", caffe=False) if nl >= 50 else (None, None, None, None)
+        if sft is not None:
+            assert _maxrel(sft, ft) > 1e-2
+        out["rn%d_feat_s2" % nl] = sub(ft, 2); out["rn%d_hm" % nl] = hm.numpy()
+        out["rn%d_sd_digest" % nl] = np.array(synth.state_dict_checksum(sd))
+        out["rn%d_nkeys" % nl] = np.array(len(sp))
+    np.savez_compressed(os.path.join(GOLD, "nets_caffe.npz"), **out)
+
+
+def gen_pipe2d(mvn):
+    """Well-conditioned algebraic tail (triangulation.py:164-191): heatmaps RENDERED from a projected skeleton (Gaussian blobs
+    at the projections of known 3D joints + noise), through op.integrate_tensor_2d (x100, softmax), the heatmap->image scaling
+    and multiview.triangulate_batch_of_points.  Unlike random-weight heatmaps the four views agree on a 3D point, so the
+    DLT is well conditioned and the END-TO-END 3D output can be gated."""
+    op, mv = mvn.utils.op, mvn.utils.multiview
+    g = torch.Generator().manual_seed(77)
+    B, NV, J, H, h = 2, 4, 17, 256, 64
+    K, R, t = synth.ring_cameras(NV, H)
+    P = torch.from_numpy(K @ np.concatenate([R, t], -1)).float()                      # image-resolution projections
+    X = (torch.rand(B, J, 3, generator=g) - 0.5) * torch.tensor([800.0, 800.0, 1600.0])  # a "skeleton" inside the capture volume
+    hm = torch.zeros(B, NV, J, h, h)
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(h, dtype=torch.float32), indexing="ij")
+    for b in range(B):
+        for v in range(NV):
+            uv = mv.project_3d_points_to_image_plane_without_distortion(P[v], X[b]) * (h / H)   # heatmap pixels
+            for j in range(J):
+                hm[b, v, j] = 0.12 * torch.exp(-((xx - uv[j, 0]) ** 2 + (yy - uv[j, 1]) ** 2) / (2 * 1.5 ** 2))
+    hm = hm + 0.002 * torch.randn(hm.shape, generator=g)
+    conf = torch.rand(B, NV, J, generator=g) + 0.2
+    kp2d, hm_sm = op.integrate_tensor_2d(hm.reshape(B * NV, J, h, h) * 100.0, True)
+    kp2d = kp2d.reshape(B, NV, J, 2)
+    cn = conf / conf.sum(dim=1, keepdim=True) + 1e-5
+    kp2d_img = torch.stack([kp2d[..., 0] * (H / h), kp2d[..., 1] * (H / h)], dim=-1)
+    Pb = P[None].repeat(B, 1, 1, 1).contiguous()
+    kp3d = mv.triangulate_batch_of_points(Pb, kp2d_img, cn)
+    err = float((kp3d - X).norm(dim=-1).max())
+    print("  rendered-heatmap pipeline: triangulated vs true joints max %.2f mm" % err)
+    assert err < 30.0, err       # soft-argmax of a blob on a 64-pixel grid: a few mm, i.e. the views AGREE
+    o2, _ = O.integrate_tensor_2d(hm.reshape(B * NV, J, h, h) * 100.0, True)
+    _check("pipe2d kp2d", o2.reshape(B, NV, J, 2), kp2d, 2e-6)
+    _check("pipe2d kp3d", O.triangulate_batch_of_points(Pb, kp2d_img, cn), kp3d, 1e-5)
+    np.savez_compressed(os.path.join(GOLD, "pipe2d.npz"), hm=hm.numpy(),
+                        conf=conf.numpy(), P=Pb.numpy(), kp2d=kp2d_img.numpy(), kp3d=kp3d.numpy(), X=X.numpy(),
+                        hm_sm_sub=sub(hm_sm, 4))
+
+
 def run_vol_case(mvn, tag, num_layers, B, NV, H, V, method="softmax", multiplier=1.0, sharpen=False,
                  inside=False, rotate=False, kind="mpii", seed=0, stride=4, cmu=False):
     cfg = synth.vol_config(num_layers, V, method, multiplier, kind)
@@ -252,7 +319,7 @@ def main():
     torch.manual_seed(0)
     os.makedirs(GOLD, exist_ok=True)
     mvn = ref_loader.load()
-    which = sys.argv[1:] or ["ops", "nets", "vol", "alg"]
+    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d"]
     if "ops" in which:
         print("[ops]"); gen_ops(mvn)
     if "nets" in which:
@@ -269,8 +336,18 @@ def main():
         run_vol_case(mvn, "c2_default", 152, 1, 4, 384, 64, "softmax", sharpen=False, seed=0, stride=4)
         std = run_vol_case(mvn, "c2_sharp", 152, 1, 4, 384, 64, "softmax", sharpen=True, seed=0, stride=4)
         print("  (calibration) sharpened logit std = %.3f with SHARPEN_GAIN=%.1f" % (std, synth.SHARPEN_GAIN))
+    if "vol2" in which:
+        print("[vol2]")
+        # BASELINE config 2 shape at B = 4 (four different samples; batch kernels and XCD pinning see a real batch)
+        run_vol_case(mvn, "c2_b4", 152, 4, 4, 384, 64, "softmax", sharpen=True, seed=6, stride=4)
+        # BASELINE config 4: 8 views, 128^3 voxels (Panoptic-shaped), ResNet-152, 384^2
+        run_vol_case(mvn, "c4_sharp", 152, 1, 8, 384, 128, "softmax", sharpen=True, seed=8, stride=8)
     if "alg" in which:
         print("[alg]"); gen_alg(mvn)
+    if "caffe" in which:
+        print("[caffe]"); gen_caffe(mvn)
+    if "pipe2d" in which:
+        print("[pipe2d]"); gen_pipe2d(mvn)
     digest = {k: [list(v[0]), v[1]] for k, v in spec.vol_net_spec(152, 17).items()}
     with open(os.path.join(GOLD, "spec_digest.json"), "w") as f:
         json.dump({"n_keys": len(digest), "n_params": int(sum(int(np.prod(v[0])) for v in digest.values())),

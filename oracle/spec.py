@@ -48,8 +48,10 @@ def _gap_head(spec, p, cin, ncls):
         spec[p + ".head.%d.bias" % i] = ((o,), "lin_b")
 
 
-def pose_resnet_spec(num_layers, num_joints, alg_conf=False, vol_conf=False, prefix=""):
+def pose_resnet_spec(num_layers, num_joints, alg_conf=False, vol_conf=False, prefix="", caffe=False):
     kind, blocks = RESNET_SPEC[num_layers]
+    if caffe:   # pose_resnet.py:322-324: style 'caffe' swaps in Bottleneck_CAFFE for ANY depth (same member names/shapes as Bottleneck)
+        kind = "bottleneck"
     exp = 4 if kind == "bottleneck" else 1
     s = OrderedDict()
     _conv(s, prefix + "conv1", 64, 3, 7, 2, False)

@@ -166,12 +166,15 @@ def _bn(sd, p, x):
                         sd[p + ".bias"], False, 0.1, BN_EPS)
 
 
-def pose_resnet(sd, x, num_layers, prefix="backbone."):
-    """PoseResNet.forward, mvn/models/pose_resnet.py:293-318 (eval mode).
+def pose_resnet(sd, x, num_layers, prefix="backbone.", caffe=False):
+    """PoseResNet.forward, mvn/models/pose_resnet.py:293-318 (eval mode).  caffe=True: config.style == 'caffe'
+    (pose_resnet.py:322-324, Bottleneck_CAFFE :98-137: bottleneck blocks at every depth, the block stride on the first 1x1).
 
     Returns (heatmaps, features, alg_confidences|None, vol_confidences|None).
     """
     kind, blocks = RESNET_SPEC[num_layers]
+    if caffe:
+        kind = "bottleneck"
     g = lambda k: sd[prefix + k]
     x = F.conv2d(x, g("conv1.weight"), None, 2, 3)
     x = F.relu(_bn(sd, prefix + "bn1", x))
@@ -182,8 +185,9 @@ def pose_resnet(sd, x, num_layers, prefix="backbone."):
             st = 2 if (li > 0 and bi == 0) else 1
             res = x
             if kind == "bottleneck":  # pose_resnet.py:75-95 ('simple' style: stride on the 3x3)
-                o = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"])))
-                o = F.relu(_bn(sd, p + ".bn2", F.conv2d(o, sd[p + ".conv2.weight"], None, st, 1)))
+                s1, s2 = (st, 1) if caffe else (1, st)
+                o = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, s1)))
+                o = F.relu(_bn(sd, p + ".bn2", F.conv2d(o, sd[p + ".conv2.weight"], None, s2, 1)))
                 o = _bn(sd, p + ".bn3", F.conv2d(o, sd[p + ".conv3.weight"]))
             else:                      # pose_resnet.py:37-54
                 o = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, st, 1)))

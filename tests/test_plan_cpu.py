@@ -122,3 +122,58 @@ def test_v2v_bf16_plan_uses_the_chain():
     kinds = [meta["kind"] for _, meta in b.finish().ops]
     assert kinds[-1] == "pwchain" and kinds.count("pwchain") == 1
     assert tuple(out.t.shape) == (1, 32, 32, 32, 17) and out.t.dtype == torch.float32
+
+
+def test_plan_cache_fingerprint_and_lru():
+    """lt_engine.PlanCache: a cached plan bakes copies of the weights, so it must be rebuilt when ANY weight of the tree
+    changes -- load_state_dict into a CHILD, an optimizer-style in-place update, a re-bound Parameter -- and the cache is a
+    bounded LRU.  The key carries every scalar the plan bakes in (see VolumetricTriangulationNet._forward_chunk)."""
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    m = VolumetricTriangulationNet(synth.vol_config(18, 32), device="cpu").eval()
+    built = []
+
+    def build(tag):
+        def f():
+            built.append(tag)
+            return {"tag": tag}
+        return f
+
+    assert m._plan_for("a", build("a1"))["tag"] == "a1" and m._plan_for("a", build("a2"))["tag"] == "a1"     # cache hit
+    fp0 = m.weights_fingerprint()
+    # (1) child load_state_dict: only the child's own hook fires, the parent's cache must still notice
+    m.backbone.load_state_dict(m.backbone.state_dict())
+    assert m.weights_fingerprint() != fp0
+    assert m._plan_for("a", build("a3"))["tag"] == "a3"
+    # (2) in-place update under no_grad (what optimizers and EMA swaps do)
+    with torch.no_grad():
+        m.volume_net.output_layer.bias.add_(1.0)
+    assert m._plan_for("a", build("a4"))["tag"] == "a4"
+    # (3) a buffer (BatchNorm running statistics feed the folded scale/shift)
+    with torch.no_grad():
+        m.backbone.bn1.running_var.mul_(2.0)
+    assert m._plan_for("a", build("a5"))["tag"] == "a5"
+    # (4) a re-bound Parameter object and a re-bound child module
+    m.process_features[0].bias = torch.nn.Parameter(torch.zeros(32))
+    assert m._plan_for("a", build("a6"))["tag"] == "a6"
+    m.process_features = torch.nn.Sequential(torch.nn.Conv2d(256, 32, 1))
+    assert m._plan_for("a", build("a7"))["tag"] == "a7"
+    assert m._plan_for("a", build("a8"))["tag"] == "a7"             # unchanged weights: still a hit
+    # LRU: at most max_plans entries, least recently used goes first
+    m.max_plans = 2
+    m._plan_for("b", build("b1")); m._plan_for("a", build("x")); m._plan_for("c", build("c1"))
+    assert list(m._plans) == ["a", "c"] and built[-2:] == ["b1", "c1"]
+    m.invalidate_plans()
+    assert not m._plans
+    # the documented blind spot: writes through .data do not bump the version counter
+    fp = m.weights_fingerprint()
+    m.volume_net.output_layer.bias.data.add_(1.0)
+    assert m.weights_fingerprint() == fp
+
+
+def test_sub_batching_limit():
+    """BASELINE config 4 at 32 samples is exactly 2^31 elements per 32-channel volume: forward() splits such batches."""
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    m = VolumetricTriangulationNet(synth.vol_config(18, 128), device="cpu")
+    assert m.max_samples_per_launch(8, 384, 384) == 31
+    m64 = VolumetricTriangulationNet(synth.vol_config(18, 64), device="cpu")
+    assert m64.max_samples_per_launch(4, 384, 384) == 227     # bounded by the 256-channel quarter-resolution maps of 4 views
