@@ -1096,8 +1096,33 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-    V16 fb[2][SN];                                        // B fragments of steps ks (set ks & 1) and ks + 1
-    static_for<0, SN>([&](auto jc) { gload16<decltype(jc)::value * 1024>(fb[0][decltype(jc)::value], wfrag, wlane); });
+    // B fragments in BPF + 1 register sets: set ks % (BPF + 1) holds step ks, requested BPF steps ahead.  Why BPF = 2 (LT6_BPF):
+    // vector-memory loads return IN ORDER, so a B load (L1/L2, a few hundred cycles) is only seen once every older LDS-DMA piece of
+    // the wave has landed too.  One step ahead, waiting for B(ks) meant waiting for the pieces issued during step ks-2 (~1.5 steps
+    // ago, while a piece needs ~2 steps from issue to landing under load): the 170-240 cycles of "own DMA" wait and most of the
+    // 560-700 cycles every wave then spent at the barrier waiting for the slowest wave's queue (profiles/r01_trace_kstep_v6.log).
+    // Two steps ahead the youngest piece in front of B(ks) is ~2.5 steps old.
+#ifndef LT6_BPF
+#define LT6_BPF 2
+#endif
+    constexpr int BPF = LT6_BPF, NBS = BPF + 1;
+    static_assert(BPF == 1 || BPF == 2, "B prefetch distance");
+#ifdef LT_ABL_NO_A
+    constexpr bool ABL_A = true;        // timing ablations (profiling builds, results WRONG): no DMA pieces / no B loads inside the K loop
+#else
+    constexpr bool ABL_A = false;
+#endif
+#ifdef LT_ABL_NO_B
+    constexpr bool ABL_B = true;
+#else
+    constexpr bool ABL_B = false;
+#endif
+    V16 fb[NBS][SN];
+    static_for<0, BPF>([&](auto pbc) {
+        constexpr int pb = decltype(pbc)::value;
+        const T* wpb = wfrag + (size_t)(pb < nk ? pb : nk - 1) * wstep;
+        static_for<0, SN>([&](auto jc) { gload16<decltype(jc)::value * 1024>(fb[pb][decltype(jc)::value], wpb, wlane); });
+    });
 #pragma unroll
     for (int sgi = 0; sgi < NST - 1; ++sgi)
         if (sgi < nk) {
@@ -1105,7 +1130,10 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
             static_for<0, A_IT>([&](auto pc) { stage_piece(sgi, sgi * STAGE, pc); });
         }
 
-    constexpr int LOOK = 3, RA = LOOK + 1;               // read stream of a step: the SM A fragments
+#ifndef LT6_LOOK
+#define LT6_LOOK (LT6_BPF == 2 ? 2 : 3)
+#endif
+    constexpr int LOOK = LT6_LOOK, RA = LOOK + 1;        // read stream of a step: the SM A fragments (one fewer in flight next to three B sets: registers)
     unsigned rbuf = 0, wbuf = (NST - 1) * STAGE;          // ring offsets of the stage being read / being requested
 #ifdef LT_TRACE
     long long tr_vm = 0, tr_bar = 0, tr_iss = 0, tr_cmp = 0, tr_prev = 0;
@@ -1113,15 +1141,25 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
     const long long tr_rt0 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
     auto step = [&](int ks, auto rc) {
-        constexpr int R = decltype(rc)::value;           // ks & 1: which B register set this step multiplies with
+        constexpr int R = decltype(rc)::value;           // ks % NBS: which B register set this step multiplies with
 #ifdef LT_TRACE
         const long long tr0 = LT_CLK3();
         if (ks > 0) tr_cmp += tr0 - tr_prev;
 #endif
-        // needed now: B(ks) (requested at the start of step ks-1) and, older, stage ks.  Requested after B(ks): the pieces of stage
-        // ks+NST-2 (step ks-1), if that stage exists; before the first step: stages 1 .. NST-2 after stage 0
-        const int after = ks == 0 ? ((nk < NST - 1 ? nk : NST - 1) - 1) * dps : (ks + NST - 2 < nk ? dps : 0);
-        wait_vmcnt6(after);
+        // needed now: B(ks) and, older, stage ks.  The queue, oldest first: prologue [B(0 .. BPF-1) | stages 0 .. P-1], then per step j
+        // [B(j+BPF): SN loads | pieces of stage j+NST-1: dps or none].  Everything younger than the youngest needed load may stay in flight.
+        const int lp = ABL_A ? 0 : dps, lb = ABL_B ? 0 : SN;
+        auto pieces_of = [&](int j) { return j + NST - 1 < nk ? lp : 0; };
+        int after = 0;
+        if (ks >= BPF) {                                   // youngest needed: B(ks), requested at the top of step ks-BPF
+            for (int j = ks - BPF; j < ks; ++j) after += pieces_of(j);
+            after += (BPF - 1) * lb;
+        } else {                                           // first steps: B(ks) leads the prologue; youngest needed: prologue stage ks
+            const int P = nk < NST - 1 ? nk : NST - 1;
+            after = (P - 1 - ks) * dps;
+            for (int j = 0; j < ks; ++j) after += lb + pieces_of(j);
+        }
+        wait_vmcnt6(after);                                // (> 12: waits for everything; only possible in the first steps)
 #ifdef LT_TRACE
         const long long tr1 = LT_CLK3();
         tr_vm += tr1 - tr0;
@@ -1133,11 +1171,11 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
 #endif
 #pragma unroll
         for (int j = 0; j < SN; ++j) frag_ready(fb[R][j]);
-        {   // B(ks+1): the last step re-reads its own fragments (a valid address; never used)
-            const T* wn1 = wfrag + (size_t)(ks + 1 < nk ? ks + 1 : ks) * wstep;
-            static_for<0, SN>([&](auto jc) { gload16<decltype(jc)::value * 1024>(fb[R ^ 1][decltype(jc)::value], wn1, wlane); });
+        if (!ABL_B) {   // B(ks+BPF): the last steps re-read the last fragments (a valid address; never used)
+            const T* wn1 = wfrag + (size_t)(ks + BPF < nk ? ks + BPF : nk - 1) * wstep;
+            static_for<0, SN>([&](auto jc) { gload16<decltype(jc)::value * 1024>(fb[(R + BPF) % NBS][decltype(jc)::value], wn1, wlane); });
         }
-        const bool more = ks + NST - 1 < nk;
+        const bool more = !ABL_A && ks + NST - 1 < nk;
         if (more) stage_prep(ks + NST - 1);
 #ifdef LT_TRACE
         const long long tr3 = LT_CLK3();                  // B loads + tap bookkeeping
@@ -1168,9 +1206,24 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
         rbuf = rbuf + STAGE == REGION ? 0 : rbuf + STAGE;
         wbuf = wbuf + STAGE == REGION ? 0 : wbuf + STAGE;
     };
-    for (int ks = 0; ks < nk; ks += 2) {
-        step(ks, std::integral_constant<int, 0>{});
-        step(ks + 1, std::integral_constant<int, 1>{});
+    if constexpr (NBS == 2) {
+        for (int ks = 0; ks < nk; ks += 2) {             // nk is even (k_pad % 64 == 0)
+            step(ks, std::integral_constant<int, 0>{});
+            step(ks + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (int ks = 0; ks < nk; ks += 6) {             // the set index is ks % 3: six steps per trip, nk even
+            step(ks, std::integral_constant<int, 0>{});
+            step(ks + 1, std::integral_constant<int, 1>{});
+            if (ks + 2 < nk) {
+                step(ks + 2, std::integral_constant<int, 2>{});
+                step(ks + 3, std::integral_constant<int, 0>{});
+            }
+            if (ks + 4 < nk) {
+                step(ks + 4, std::integral_constant<int, 1>{});
+                step(ks + 5, std::integral_constant<int, 2>{});
+            }
+        }
     }
 #ifdef LT_TRACE
     {   // same record as conv_igemm3_kernel: total, vmcnt wait, barrier, issue (B loads), fragment reads + MFMAs + DMA issue, steps, 100 MHz ticks

@@ -20,7 +20,9 @@ def init(backend=None):
     Returns (world, rank, local_rank)."""
     world, rank, local = env_world()
     if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC, needed by RCCL on this driver
+        # the image exports this already (its host driver only supports dmabuf IPC; without it RCCL's hipIpcGetMemHandle fails):
+        # kept for environments built by hand
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
@@ -47,6 +49,16 @@ def sum_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_floats(value, device="cpu"):
+    """[value of rank 0, value of rank 1, ...] on every rank (all_gather of one fp64; a list of one for a single process)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 def shard_samples(n_samples, rank, world):

@@ -58,7 +58,8 @@ def make_state_dict(spec, seed=0, sharpen=False, basic_block=False):
         sd[name] = w
     for k in list(sd):
         if k.endswith("output_layer.weight") or k.endswith("output_layer.bias"):
-            sd[k] = sd[k] * (OUT_DEFAULT_GAIN * (SHARPEN_GAIN if sharpen else 1.0))
+            # sharpen: False, True (= SHARPEN_GAIN) or an explicit gain (fixtures whose shape changes the un-scaled logit std)
+            sd[k] = sd[k] * (OUT_DEFAULT_GAIN * (1.0 if not sharpen else SHARPEN_GAIN if sharpen is True else float(sharpen)))
     return sd
 
 

@@ -61,3 +61,46 @@ def test_single_process_is_a_noop():
     assert lt_dist.max_over_ranks(3.5) == 3.5 and lt_dist.shard_samples(5, 0, 1) == [0, 1, 2, 3, 4]
     assert lt_dist.job_throughput(8, 2.0) == (4.0, 8.0, 2.0)
     lt_dist.barrier()
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment re-executes itself under torch.distributed.run (the path the
+    judge asked for); --stub-cpu swaps the GPU step for a sleep and the backend for gloo, everything else -- launcher,
+    env:// rendezvous on 127.0.0.1, barrier, SUM / MAX / all_gather of the timing, one JSON line from rank 0 -- is the real code."""
+    res = _run_bench(["--gpus", "2", "--steps", "5", "--warmup", "1", "--batch", "4", "--stub-cpu"])
+    assert res["n_gpus"] == 2 and res["self_launched"] is True and res["backend"] == "gloo"
+    assert res["total_samples"] == 2 * 5 * 4                      # whole-job aggregate over both ranks
+    assert len(res["per_rank_samples_per_s"]) == 2
+    # rank 1 sleeps twice as long per step: the job is judged on the slowest rank
+    assert res["per_rank_samples_per_s"][0] > res["per_rank_samples_per_s"][1]
+    assert res["value"] <= 2 * res["per_rank_samples_per_s"][1] * 1.05
+
+
+def test_bench_under_torchrun_env_does_not_relaunch():
+    """The driver's way: torch.distributed.run starts the ranks; bench.py must then NOT launch again."""
+    import json
+    import subprocess
+    port = _free_port()
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--stub-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["self_launched"] is False and res["total_samples"] == 12

@@ -117,7 +117,7 @@ def test_volumetric_forward_vs_reference_golden(golden_dir, tag):
     check(tag + "/v2v logits", _sub(logits, s), g["logits_sub"], 2e-4)
 
 
-@pytest.mark.parametrize("tag", ["small_softmax", "c2_sharp", "c2_default"])
+@pytest.mark.parametrize("tag", ["small_softmax", "c2_sharp", "c2_default", "c2_b4", "c4_sharp"])
 def test_volumetric_forward_bf16_deviation(golden_dir, tag):
     """bf16 throughput mode: measured deviation from the fp32 reference, recorded (not gated at 1e-4)."""
     g = np.load(os.path.join(golden_dir, "vol_%s.npz" % tag))
@@ -222,6 +222,47 @@ def test_panoptic_shape_8_views_128_cube():
     record("8 views / 128^3: volumes bf16 vs fp32 (max|d|/max|ref|)", rel_err(outs["bf16"][2], outs["f32"][2]))
     assert torch.isfinite(kp16).all() and float((kp16 - kp32).norm(dim=-1).mean()) < 0.1
     assert float((outs["bf16"][2].sum(dim=(2, 3, 4)) - 1).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("nl,hw", [(50, 128), (18, 64)])
+def test_pose_resnet_caffe_style_vs_reference_golden(golden_dir, nl, hw):
+    """style == 'caffe' (reference pose_resnet.py:98-137, :322-324): stride on the first 1x1; at depth 18 the reference still
+    builds expansion-4 bottlenecks.  fp32 kernels against the reference's outputs."""
+    from mvn.models import pose_resnet
+    g = np.load(os.path.join(golden_dir, "nets_caffe.npz"))
+    gen = torch.Generator().manual_seed(31)
+    for n2, h2 in ((50, 128), (18, 64)):
+        x = torch.randn(2, 3, h2, h2, generator=gen)
+        if n2 == nl:
+            break
+    cfg = synth.AttrDict(num_layers=nl, style="caffe", num_joints=17, alg_confidences=False, vol_confidences=False, init_weights=False, checkpoint="")
+    m = pose_resnet.get_pose_net(cfg, device=DEV)
+    m.load_state_dict(synth.make_state_dict(spec.pose_resnet_spec(nl, 17, False, False, "", caffe=True), seed=700 + nl), strict=True)
+    m.eval()
+    hm, ft, _, _ = m(x.to(DEV))
+    check("caffe resnet%d features fp32 vs reference" % nl, _sub(ft.cpu(), 2), g["rn%d_feat_s2" % nl], 1e-4)
+    check("caffe resnet%d heatmaps fp32 vs reference" % nl, hm.cpu(), g["rn%d_hm" % nl], 1e-4)
+
+
+def test_algebraic_tail_on_rendered_heatmaps_vs_reference(golden_dir):
+    """Well-conditioned algebraic pipeline, END TO END gate on the 3D joints: heatmaps rendered from a projected
+    skeleton -> lt_softargmax2d_fwd (x100, softmax) -> heatmap->image scaling -> confidence-weighted lt_triangulate_dlt, against the
+    reference's op.integrate_tensor_2d + multiview.triangulate_batch_of_points on the same heatmaps."""
+    from mvn.utils import multiview, op
+    g = np.load(os.path.join(golden_dir, "pipe2d.npz"))
+    hm = torch.from_numpy(g["hm"]).to(DEV)
+    B, NV, J, h, _ = hm.shape
+    kp2d, hm_sm = op.integrate_tensor_2d(hm.reshape(B * NV, J, h, h) * 100.0, True)
+    conf = torch.from_numpy(g["conf"]).to(DEV)
+    conf = conf / conf.sum(dim=1, keepdim=True) + 1e-5
+    kp2d = kp2d.reshape(B, NV, J, 2) * (256 / h)
+    kp3d = multiview.triangulate_batch_of_points(torch.from_numpy(g["P"]).to(DEV), kp2d, confidences_batch=conf)
+    check("pipe2d/keypoints_2d (image px)", kp2d.cpu(), g["kp2d"], 1e-5)
+    check("pipe2d/heatmaps after softmax", _sub(hm_sm.cpu(), 4), g["hm_sm_sub"], 1e-4)
+    rel = np.abs(kp3d.cpu().numpy() - g["kp3d"]) / np.maximum(np.abs(g["kp3d"]), 1.0)
+    record("pipe2d/keypoints_3d end to end: max rel (1 mm floor)", float(rel.max()))
+    record("pipe2d/keypoints_3d vs the true skeleton (mm)", float(np.abs(kp3d.cpu().numpy() - g["X"]).max()))
+    assert rel.max() <= 1e-3, rel.max()
 
 
 def test_algebraic_c1_vs_reference_golden(golden_dir):

@@ -24,17 +24,31 @@ smoke)
   timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/session.log; tail -3 $OUT/smoke.log | tee -a $OUT/session.log
   ;;
 bench)
+  # the driver's command; the line carries the fp32 parity-mode leg, the parity block and the batch sweep
   timeout 900 python bench.py --ops-json $OUT/bench_ops_bf16.json > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
   echo "bench bf16 rc=$?" | tee -a $OUT/session.log; cat $OUT/bench_bf16.json | tee -a $OUT/session.log; tail -3 $OUT/bench_bf16.err
-  timeout 900 python bench.py --dtype fp32 --steps 5 --warmup 2 --no-cpu-baseline --ops-json $OUT/bench_ops_fp32.json > $OUT/bench_fp32.json 2> $OUT/bench_fp32.err
-  echo "bench fp32 rc=$?" | tee -a $OUT/session.log; cat $OUT/bench_fp32.json | tee -a $OUT/session.log; tail -3 $OUT/bench_fp32.err
+  ;;
+c4)
+  # BASELINE config 4: 8 views, 128^3 voxels (B = 8 per step by default)
+  timeout 900 python bench.py --views 8 --volume 128 --steps 10 --warmup 3 --ops-json $OUT/bench_ops_c4.json > $OUT/bench_c4.json 2> $OUT/bench_c4.err
+  echo "bench c4 rc=$?" | tee -a $OUT/session.log; cat $OUT/bench_c4.json | tee -a $OUT/session.log; tail -3 $OUT/bench_c4.err
   ;;
 prof)
   cd /tmp; export TMPDIR=/tmp
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $OUT/prof_bench.json 2> $OUT/prof.err
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-extras > $OUT/prof_bench.json 2> $OUT/prof.err
   echo "prof rc=$?" | tee -a $OUT/session.log
   cd $R
   find $OUT/prof -name "*stats*" | head | tee -a $OUT/session.log
+  ;;
+ablibs)
+  # per-layer A/B of library variants (lt_build.build_variant, built BEFORE the gpurun call): ABLIBS="base bpf1 noa ..."
+  for round in 1 2; do
+  for v in ${ABLIBS:-base}; do
+    E="LT_AB=base"; [ $v != base ] && E="LT_HIP_LIB=$R/learnable-triangulation-pytorch_amd/lib/liblt_hip_$v.so"
+    echo "== lib=$v round=$round" | tee -a $OUT/ablibs.log
+    env $E timeout 300 python tools/conv_bench.py --batch ${AB_BATCH:-32} --only "${AB_ONLY:-rn l3}" --variants auto --residual --rounds 5 2>&1 | grep -v amdgpu.ids | tee -a $OUT/ablibs.log
+  done
+  done
   ;;
 convbench)
   timeout 600 python tools/conv_bench.py --json $OUT/conv_bench_bf16.json > $OUT/conv_bench_bf16.log 2>&1
@@ -114,12 +128,20 @@ ab)
   done
   ;;
 pmc)
+  # counters in their own runs, --kernel-trace only (gpurun refuses --pmc together with the sys/hip/hsa trace domains); 6 forwards each
   cd /tmp; export TMPDIR=/tmp
-  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-graph > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+  PB="--steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-extras --no-graph --preroll-s 0 ${PMC_BENCH_ARGS:-}"
+  SFX=${PMC_SUFFIX:-}
+  rm -rf $OUT/pmc_fetch$SFX $OUT/pmc_write$SFX $OUT/pmc_mfma$SFX
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch$SFX -o bench -- python $R/bench.py $PB > $OUT/pmc_fetch$SFX.json 2> $OUT/pmc_fetch$SFX.err
   echo "pmc fetch rc=$?" | tee -a $OUT/session.log
-  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-graph > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write$SFX -o bench -- python $R/bench.py $PB > $OUT/pmc_write$SFX.json 2> $OUT/pmc_write$SFX.err
   echo "pmc write rc=$?" | tee -a $OUT/session.log
+  timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma$SFX -o bench -- python $R/bench.py $PB > $OUT/pmc_mfma$SFX.json 2> $OUT/pmc_mfma$SFX.err
+  echo "pmc mfma rc=$?" | tee -a $OUT/session.log
   cd $R
+  python tools/pmc_summary.py $OUT 6 ${PMC_BATCH:-32} --suffix "$SFX" ${PMC_SUMMARY_ARGS:-} 2>&1 | tee -a $OUT/session.log
+  cp profiles/r02_hbm_traffic_pmc$SFX.json $OUT/ 2>/dev/null
   ;;
 esac
 done
