@@ -190,6 +190,37 @@ int lt_softargmax3d_fwd(const float* logits, const float* coords, float mult, in
 int lt_softargmax2d_fwd(const float* heatmaps, float mult, int32_t softmax, float* coords, float* probs, int32_t NJ,
                         int32_t h, int32_t w, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-step pieces outside the convolutions: what torch.autograd derives in the
+ * reference for op.unproject_heatmaps and op.integrate_tensor_3d_with_coordinates, the fused VolumetricCELoss
+ * (mvn/models/loss.py:52-80; the reference walks samples and joints in Python with a .cpu() per sample), and the
+ * batch statistics of training-mode BatchNorm.  All gradients are fp32.
+ *
+ * lt_unproject_bwd: grad_out B,nvox,C (channels-last, fp32) -> grad_feats B,NV,h,w,C fp32 (MUST be zeroed by the caller; the
+ *   bilinear scatter uses atomics, so the summation order -- not the result beyond fp32 rounding -- varies between runs),
+ *   grad_conf B,NV,C (zeroed) or NULL.  Autograd semantics of op.py:113-162: nothing flows to the grid / projections;
+ *   depth <= 0 samples pass no gradient but their zero takes part in the view softmax, d out/d x_v = w_v (1 + x_v - out);
+ *   'max': the first maximal view; LT_AGG_CONF: g * conf_v (conf_norm: normalise outside).  NV <= 8, C % 4 == 0.
+ * lt_softargmax3d_bwd: probs B,J,nvox and kp B,J,3 are the forward's outputs; grad_kp B,J,3; an optional SPARSE gradient on the
+ *   returned probabilities (one voxel per (b,j): gp_idx / gp_val, what lt_volumetric_ce_fwd produces) -> grad_logits
+ *   (planar B,J,nvox, or channels-last B,nvox,J when channels_last != 0):  mult * p_i * (a_i - sum_j p_j a_j), a_i = g_kp . X_i + gp_i.
+ * lt_volumetric_ce_fwd: per (b,j) the voxel nearest to keypoints_gt (first minimum, like torch.argmin), terms[b,j] =
+ *   validity * -log(p + 1e-6), idx[b,j], grad_val[b,j] = d(sum(terms) / (B J)) / d probs[b,j,idx].  The loss is sum(terms) / (B J).
+ * lt_bn_stats_fwd: x rows x C channels-last -> per-channel mean and BIASED variance (fp64 accumulation); running statistics
+ *   (may be NULL) are updated the way torch does: (1 - momentum) * running + momentum * stat, variance unbiased.
+ * -------------------------------------------------------------------------------------------*/
+int lt_unproject_bwd(int32_t dtype, const void* feats, const float* proj, const float* coords, const float* conf, const float* grad_out,
+                     float* grad_feats, float* grad_conf, int32_t B, int32_t NV, int32_t C, int32_t h, int32_t w, int64_t nvox,
+                     int32_t agg, void* stream);
+int lt_softargmax3d_bwd(const float* probs, const float* coords, const float* kp, const float* grad_kp, const int32_t* gp_idx,
+                        const float* gp_val, float multiplier, int32_t softmax, int32_t channels_last, float* grad_logits, int32_t B,
+                        int32_t J, int64_t nvox, void* stream);
+int lt_volumetric_ce_fwd(const float* coords, const float* probs, const float* keypoints_gt, const float* validity, float* terms,
+                         int32_t* idx, float* grad_val, int32_t B, int32_t J, int64_t nvox, void* stream);
+size_t lt_bn_stats_workspace(int64_t rows, int32_t C);
+int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32_t C, float* mean, float* var, float* running_mean,
+                    float* running_var, float momentum, void* workspace, void* stream);
+
 /* multiview.triangulate_batch_of_points (mvn/utils/multiview.py:141-183): confidence-weighted DLT.
  * proj B,NV,3,4; points B,NV,J,2; conf B,NV,J or NULL; out B,J,3.  Smallest right singular vector
  * of the (2NV x 4) system by Jacobi eigen-iteration on A^T A in fp64. */

@@ -990,7 +990,28 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
 #ifndef LT6_NST
 #define LT6_NST 6
 #endif
-    constexpr int NST = LT6_NST;                          // 6 x 18 KB, five stages in flight (8 stages measured no faster: the loop is not waiting for data)
+    constexpr int NST = LT6_NST;                          // 6 x 18 KB (8 stages measured no faster: the loop is not waiting for data)
+    // Ping-pong of the two waves of a SIMD (waves w and w+4 share one: a workgroup's waves go to the SIMDs cyclically).  Waves 4-7
+    // ("Y") take the per-step barrier in the MIDDLE of their MFMA sequence instead of at its top, so they run half a step behind waves
+    // 0-3 ("X"): when X leaves the barrier into its step start-up (wait for its B fragments, request the next ones, first A reads) the
+    // matrix pipe of the SIMD is fed by Y's second half, and Y's start-up falls into the middle of X's MFMAs.  Before, all eight waves
+    // did the same thing at the same time and the pipe idled through every start-up (-DLT_ABL_NO_A -DLT_ABL_NO_B: 75 us for the 3x3
+    // 256->256 layer with NO memory instruction in the loop, against 43 us of MFMA issue).  Price: Y may still read stage ks-1 when X
+    // requests new pieces after barrier ks, so a piece goes to the slot of stage ks-2: NST-2 stages ahead instead of NST-1.
+    // Measured (profiles/r02_ab_igemm6.txt): per layer on dense random data (tools/conv_bench.py, 128 images) 3x3 256->256
+    // 106-121 -> 92-96 us, 1x1 1024->256 51 -> 46-48 us; inside the forward (post-ReLU activations, half of them zero, higher
+    // clocks: the same 3x3 layer takes 91 us there WITHOUT the ping-pong) 91.1 -> 92.7 us and 1196 vs 1194 samples/s end to end --
+    // the in-model kernels run against the power / clock limit, not against issue bubbles.  Default off; -DLT6_PP=1 builds it.
+#ifndef LT6_PP
+#define LT6_PP 0
+#endif
+#ifndef LT6_BPF
+#define LT6_BPF 1
+#endif
+    constexpr bool PP = LT6_PP && NWM == 2;
+    constexpr int AHEAD = PP ? NST - 2 : NST - 1;         // a piece issued during step ks belongs to stage ks + AHEAD
+    constexpr int YBAR = 4;                               // Y's barrier sits behind A fragment YBAR of the 9
+    static_assert(!PP || AHEAD >= LT6_BPF + 2, "ping-pong: a Y wave vouches for stage ks+1 at the top of its step ks");
     constexpr int NPA = BM / 16;                          // 18 DMA pieces of 1 KiB per stage (16 rows of 64 B each)
     constexpr int A_IT = (NPA + NW - 1) / NW;             // 3 (waves 0, 1) / 2
     constexpr int STAGE = BM * ROWB;                      // 18432 B: activations only
@@ -1096,14 +1117,12 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-    // B fragments in BPF + 1 register sets: set ks % (BPF + 1) holds step ks, requested BPF steps ahead.  Why BPF = 2 (LT6_BPF):
-    // vector-memory loads return IN ORDER, so a B load (L1/L2, a few hundred cycles) is only seen once every older LDS-DMA piece of
-    // the wave has landed too.  One step ahead, waiting for B(ks) meant waiting for the pieces issued during step ks-2 (~1.5 steps
-    // ago, while a piece needs ~2 steps from issue to landing under load): the 170-240 cycles of "own DMA" wait and most of the
-    // 560-700 cycles every wave then spent at the barrier waiting for the slowest wave's queue (profiles/r01_trace_kstep_v6.log).
-    // Two steps ahead the youngest piece in front of B(ks) is ~2.5 steps old.
+    // B fragments in BPF + 1 register sets: set ks % (BPF + 1) holds step ks, requested BPF steps ahead.  BPF = 2 (-DLT6_BPF=2) was
+    // built to test whether the in-order return of vector-memory loads (a B load is only seen once every older LDS-DMA piece of the
+    // wave has landed) explains the wait in front of the barrier: per layer 110 / 104 us (BPF 1) vs 112 / 109 and 104 / 107 us (BPF 2,
+    // two A-fragment lookaheads) in one session -- it does not; kept as a switch (profiles/r02_ab_igemm6.txt).
 #ifndef LT6_BPF
-#define LT6_BPF 2
+#define LT6_BPF 1
 #endif
     constexpr int BPF = LT6_BPF, NBS = BPF + 1;
     static_assert(BPF == 1 || BPF == 2, "B prefetch distance");
@@ -1124,7 +1143,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
         static_for<0, SN>([&](auto jc) { gload16<decltype(jc)::value * 1024>(fb[pb][decltype(jc)::value], wpb, wlane); });
     });
 #pragma unroll
-    for (int sgi = 0; sgi < NST - 1; ++sgi)
+    for (int sgi = 0; sgi < AHEAD; ++sgi)
         if (sgi < nk) {
             stage_prep(sgi);
             static_for<0, A_IT>([&](auto pc) { stage_piece(sgi, sgi * STAGE, pc); });
@@ -1134,12 +1153,13 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
 #define LT6_LOOK (LT6_BPF == 2 ? 2 : 3)
 #endif
     constexpr int LOOK = LT6_LOOK, RA = LOOK + 1;        // read stream of a step: the SM A fragments (one fewer in flight next to three B sets: registers)
-    unsigned rbuf = 0, wbuf = (NST - 1) * STAGE;          // ring offsets of the stage being read / being requested
+    unsigned rbuf = 0, wbuf = AHEAD * STAGE;              // ring offsets of the stage being read / being requested
 #ifdef LT_TRACE
     long long tr_vm = 0, tr_bar = 0, tr_iss = 0, tr_cmp = 0, tr_prev = 0;
     const long long tr_begin = LT_CLK3();
     const long long tr_rt0 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+    const bool YW = PP && wm == 1;                        // a "Y" wave of the ping-pong (wave-uniform: scalar branches around the barriers)
     auto step = [&](int ks, auto rc) {
         constexpr int R = decltype(rc)::value;           // ks % NBS: which B register set this step multiplies with
 #ifdef LT_TRACE
@@ -1149,14 +1169,15 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
         // needed now: B(ks) and, older, stage ks.  The queue, oldest first: prologue [B(0 .. BPF-1) | stages 0 .. P-1], then per step j
         // [B(j+BPF): SN loads | pieces of stage j+NST-1: dps or none].  Everything younger than the youngest needed load may stay in flight.
         const int lp = ABL_A ? 0 : dps, lb = ABL_B ? 0 : SN;
-        auto pieces_of = [&](int j) { return j + NST - 1 < nk ? lp : 0; };
+        auto pieces_of = [&](int j) { return j + AHEAD < nk ? lp : 0; };
         int after = 0;
         if (ks >= BPF) {                                   // youngest needed: B(ks), requested at the top of step ks-BPF
             for (int j = ks - BPF; j < ks; ++j) after += pieces_of(j);
             after += (BPF - 1) * lb;
         } else {                                           // first steps: B(ks) leads the prologue; youngest needed: prologue stage ks
-            const int P = nk < NST - 1 ? nk : NST - 1;
-            after = (P - 1 - ks) * dps;
+            const int P = nk < AHEAD ? nk : AHEAD;
+            after = (P - 1 - ks - (YW ? 1 : 0)) * dps;     // a Y wave vouches for stage ks+1 here (its barrier ks+1 comes mid-step)
+            if (after < 0) after = 0;
             for (int j = 0; j < ks; ++j) after += lb + pieces_of(j);
         }
         wait_vmcnt6(after);                                // (> 12: waits for everything; only possible in the first steps)
@@ -1164,7 +1185,9 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
         const long long tr1 = LT_CLK3();
         tr_vm += tr1 - tr0;
 #endif
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage ks landed for every wave; stage ks-1 fully consumed
+        // X (and every wave without ping-pong): stage ks landed for every wave (each waited for its own pieces above; a wave's wait
+        // at the top of step j covers its pieces up to stage j + AHEAD - BPF, so Y's wait at the top of ITS step ks-1 covered stage ks)
+        if (!YW) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef LT_TRACE
         const long long tr2 = LT_CLK3();
         tr_bar += tr2 - tr1;
@@ -1175,8 +1198,8 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
             const T* wn1 = wfrag + (size_t)(ks + BPF < nk ? ks + BPF : nk - 1) * wstep;
             static_for<0, SN>([&](auto jc) { gload16<decltype(jc)::value * 1024>(fb[(R + BPF) % NBS][decltype(jc)::value], wn1, wlane); });
         }
-        const bool more = !ABL_A && ks + NST - 1 < nk;
-        if (more) stage_prep(ks + NST - 1);
+        const bool more = !ABL_A && ks + AHEAD < nk;
+        if (more) stage_prep(ks + AHEAD);
 #ifdef LT_TRACE
         const long long tr3 = LT_CLK3();                  // B loads + tap bookkeeping
         tr_iss += tr3 - tr2;
@@ -1198,14 +1221,22 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
 #pragma unroll
             for (int j = 0; j < SN; ++j) LT3_MMA(acc[u][j], fa[u % RA], fb[R][j]);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (u % 2 == 0 && u / 2 < A_IT) {   // one DMA piece of stage ks+NST-1 behind every second fragment
-                if (more) stage_piece(ks + NST - 1, wbuf, std::integral_constant<int, u / 2>{});
+            if constexpr (u % 2 == 0 && u / 2 < A_IT) {   // one DMA piece of stage ks+AHEAD behind every second fragment
+                if (more) stage_piece(ks + AHEAD, wbuf, std::integral_constant<int, u / 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (PP && u == YBAR) {              // Y's barrier ks+1 (X takes it at the top of its step ks+1); none in the last step
+                if (YW && ks + 1 < nk) asm volatile("s_barrier" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
         rbuf = rbuf + STAGE == REGION ? 0 : rbuf + STAGE;
         wbuf = wbuf + STAGE == REGION ? 0 : wbuf + STAGE;
     };
+    if (YW) {   // Y's barrier 0 (X: top of step 0): vouch for the own pieces of stage 0 first, like X does at the top of its step 0
+        wait_vmcnt6(((nk < AHEAD ? nk : AHEAD) - 1) * dps);
+        asm volatile("s_barrier" ::: "memory");
+    }
     if constexpr (NBS == 2) {
         for (int ks = 0; ks < nk; ks += 2) {             // nk is even (k_pad % 64 == 0)
             step(ks, std::integral_constant<int, 0>{});

@@ -42,14 +42,16 @@ def build(force=False, verbose=True):
     return _build(LIB, "build", [], verbose)
 
 
-def build_variant(name, defines, verbose=True):
+def build_variant(name, defines, verbose=True, only=None):
     """A/B build: lib/liblt_hip_<name>.so compiled with extra -D switches (kernel-scheduling experiments that must be
-    compile-time).  Selected at run time with LT_HIP_LIB=<path> (see lt_hip.py); never built or loaded by default."""
+    compile-time).  Selected at run time with LT_HIP_LIB=<path> (see lt_hip.py); never built or loaded by default.
+    only: source basenames the switches concern (e.g. ["conv_igemm3.hip"]); the other objects are taken from the default build
+    (which must be up to date) -- a variant then costs one file's compile instead of the whole library's."""
     lib = os.path.join(LIBDIR, "liblt_hip_%s.so" % name)
-    return _build(lib, "build_" + name, ["-D" + d for d in defines], verbose)
+    return _build(lib, "build_" + name, ["-D" + d for d in defines], verbose, only)
 
 
-def _build(LIB, objsub, extra, verbose):
+def _build(LIB, objsub, extra, verbose, only=None):
     FLAGS = globals()["FLAGS"] + list(extra)
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, objsub)
@@ -57,6 +59,11 @@ def _build(LIB, objsub, extra, verbose):
     hipcc = _hipcc()
 
     def compile_one(src):
+        if only is not None and os.path.basename(src) not in only:
+            base_obj = os.path.join(HERE, "build", os.path.basename(src)[:-4] + ".o")
+            if not os.path.exists(base_obj) or os.path.getmtime(base_obj) < os.path.getmtime(src):
+                raise RuntimeError("variant build: default object of %s is missing or stale, run lt_build.build() first" % src)
+            return base_obj
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -76,6 +76,11 @@ SIGNATURES = {
     "lt_softargmax3d_fwd": (C.c_int, [vp, vp, f32, i32, i32, i32, vp, vp, i32, i32, i64, vp, vp]),
     "lt_softargmax2d_fwd": (C.c_int, [vp, f32, i32, vp, vp, i32, i32, i32, vp]),
     "lt_triangulate_dlt": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "lt_unproject_bwd": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, vp]),
+    "lt_softargmax3d_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, i32, i32, i64, vp]),
+    "lt_volumetric_ce_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp]),
+    "lt_bn_stats_workspace": (C.c_size_t, [i64, i32]),
+    "lt_bn_stats_fwd": (C.c_int, [i32, vp, i64, i32, vp, vp, vp, vp, f32, vp, vp]),
     "lt_graph_begin": (C.c_int, [vp]),
     "lt_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
     "lt_graph_launch": (C.c_int, [vp, vp]),

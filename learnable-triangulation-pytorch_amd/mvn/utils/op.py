@@ -41,36 +41,67 @@ def build_coord_volumes(base_points, cuboid_side, volume_size, thetas=None, axis
     return out
 
 
+def _unproject_launch(feats_cl, P, cv, conf, method):
+    """feats_cl (B,NV,h,w,C) contiguous channels-last -> (B,v0,v1,v2,C) channels-last, same dtype."""
+    B, NV, h, w, Cc = feats_cl.shape
+    v0, v1, v2 = cv.shape[1:4]
+    out = torch.empty(B, v0, v1, v2, Cc, dtype=feats_cl.dtype, device=feats_cl.device)
+    H.check(H.lib().lt_unproject_fwd(H.dtype_code(feats_cl.dtype), feats_cl.data_ptr(), P.data_ptr(), cv.data_ptr(), H.ptr(conf), out.data_ptr(),
+                                     B, NV, Cc, h, w, v0, v1, v2, H.AGG["conf"] if conf is not None else H.AGG[method], H.cur_stream()), "lt_unproject_fwd")
+    return out
+
+
+class _UnprojectFn(torch.autograd.Function):
+    """lt_unproject_fwd / lt_unproject_bwd as one autograd node: what autograd builds in the reference from grid_sample, the
+    in-place depth mask and the view aggregation (op.py:113-162).  Gradients reach the heatmaps and (conf modes) the confidences;
+    projections and coordinates get none, exactly as in the reference (they do not require grad there)."""
+
+    @staticmethod
+    def forward(ctx, heatmaps, P, cv, conf, method):
+        feats = _as_channels_last(heatmaps, 2)
+        out = _unproject_launch(feats, P, cv, conf, method)
+        ctx.save_for_backward(feats, P, cv, conf if conf is not None else torch.empty(0, device=feats.device))
+        ctx.method, ctx.has_conf = method, conf is not None
+        return out.permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feats, P, cv, conf = ctx.saved_tensors
+        conf = conf if ctx.has_conf else None
+        B, NV, h, w, Cc = feats.shape
+        nvox = cv.shape[1] * cv.shape[2] * cv.shape[3]
+        g = grad_out.permute(0, 2, 3, 4, 1).float().contiguous()               # (B, v0, v1, v2, C) channels-last fp32
+        gfeats = torch.zeros(B, NV, h, w, Cc, dtype=torch.float32, device=feats.device)
+        gconf = torch.zeros_like(conf) if conf is not None else None
+        H.check(H.lib().lt_unproject_bwd(H.dtype_code(feats.dtype), feats.data_ptr(), P.data_ptr(), cv.data_ptr(), H.ptr(conf), g.data_ptr(),
+                                         gfeats.data_ptr(), H.ptr(gconf), B, NV, Cc, h, w, nvox,
+                                         H.AGG["conf"] if conf is not None else H.AGG[ctx.method], H.cur_stream()), "lt_unproject_bwd")
+        return gfeats.permute(0, 1, 4, 2, 3).to(feats.dtype), None, None, gconf, None
+
+
 def unproject_heatmaps(heatmaps, proj_matricies, coord_volumes, volume_aggregation_method="sum", vol_confidences=None):
     """heatmaps (B,NV,C,h,w), proj_matricies (B,NV,3,4), coord_volumes (B,V0,V1,V2,3),
-    vol_confidences (B,NV,C) for 'conf*' -> volumes (B,C,V0,V1,V2).  Reference: op.py:99-166."""
+    vol_confidences (B,NV,C) for 'conf*' -> volumes (B,C,V0,V1,V2).  Reference: op.py:99-166.  Differentiable with respect to the
+    heatmaps and the confidences (lt_unproject_bwd) whenever one of them requires grad."""
     if volume_aggregation_method not in _METHODS:
         raise ValueError("Unknown volume_aggregation_method: {}".format(volume_aggregation_method))
     H.require_gpu(heatmaps, "heatmaps")
-    code = H.dtype_code(heatmaps.dtype)
-    B, NV, Cc, h, w = heatmaps.shape
-    v0, v1, v2 = coord_volumes.shape[1:4]
-    feats = _as_channels_last(heatmaps, 2)
+    H.dtype_code(heatmaps.dtype)
     P = proj_matricies.to(heatmaps.device, torch.float32).contiguous()
     cv = coord_volumes.to(heatmaps.device, torch.float32).contiguous()
     conf = None
     if volume_aggregation_method.startswith("conf"):
         conf = vol_confidences.to(heatmaps.device, torch.float32).contiguous()
-    out = torch.empty(B, v0, v1, v2, Cc, dtype=heatmaps.dtype, device=heatmaps.device)
-    H.check(H.lib().lt_unproject_fwd(code, feats.data_ptr(), P.data_ptr(), cv.data_ptr(), H.ptr(conf), out.data_ptr(), B, NV, Cc, h, w,
-                                     v0, v1, v2, H.AGG['conf'] if conf is not None else H.AGG[volume_aggregation_method], H.cur_stream()), "lt_unproject_fwd")
-    return out.permute(0, 4, 1, 2, 3)
+    if torch.is_grad_enabled() and (heatmaps.requires_grad or (conf is not None and vol_confidences.requires_grad)):
+        return _UnprojectFn.apply(heatmaps, P, cv, conf, volume_aggregation_method)
+    return _unproject_launch(_as_channels_last(heatmaps, 2), P, cv, conf, volume_aggregation_method).permute(0, 4, 1, 2, 3)
 
 
-def integrate_tensor_3d_with_coordinates(volumes, coord_volumes, softmax=True):
-    """volumes (B,J,V0,V1,V2) logits, coord_volumes (B,V0,V1,V2,3) -> (coordinates (B,J,3), volumes after
-    softmax / ReLU).  Reference: op.py:84-96."""
-    H.require_gpu(volumes, "volumes")
+def _softargmax3d_launch(volumes, cv, softmax):
     B, J = volumes.shape[:2]
     nvox = int(np.prod(volumes.shape[2:]))
     cl = volumes.permute(0, 2, 3, 4, 1).is_contiguous() and not volumes.is_contiguous()
     lg = (volumes.permute(0, 2, 3, 4, 1) if cl else volumes).float().contiguous()
-    cv = coord_volumes.to(volumes.device, torch.float32).contiguous()
     kp = torch.empty(B, J, 3, dtype=torch.float32, device=volumes.device)
     probs = torch.empty((B, J) + tuple(volumes.shape[2:]), dtype=torch.float32, device=volumes.device)
     lib = H.lib()
@@ -78,6 +109,95 @@ def integrate_tensor_3d_with_coordinates(volumes, coord_volumes, softmax=True):
     H.check(lib.lt_softargmax3d_fwd(lg.data_ptr(), cv.data_ptr(), 1.0, int(bool(softmax)), int(cl), J, kp.data_ptr(), probs.data_ptr(),
                                     B, J, nvox, ws.data_ptr(), H.cur_stream()), "lt_softargmax3d_fwd")
     return kp, probs
+
+
+class _SoftArgmax3dFn(torch.autograd.Function):
+    """lt_softargmax3d_fwd / _bwd as one node with TWO outputs (coordinates, probabilities): a dense gradient on the
+    probabilities is folded in through its inner product with them; VolumetricCELoss (mvn/models/loss.py) instead hands over its
+    one-voxel-per-joint gradient in sparse form (``sparse_prob_grad``), so no (B,J,V^3) gradient tensor is ever materialised."""
+
+    @staticmethod
+    def forward(ctx, volumes, cv, softmax):
+        kp, probs = _softargmax3d_launch(volumes, cv, softmax)
+        ctx.save_for_backward(probs, cv, kp)
+        ctx.softmax, ctx.in_dtype = bool(softmax), volumes.dtype
+        return kp, probs
+
+    @staticmethod
+    def backward(ctx, g_kp, g_probs):
+        probs, cv, kp = ctx.saved_tensors
+        B, J = probs.shape[:2]
+        nvox = probs[0, 0].numel()
+        g_kp = torch.zeros_like(kp) if g_kp is None else g_kp.float().contiguous()
+        # sparse gradients on the probabilities left here by consumers that ran before us (VolumetricCELoss: one voxel per (b, j))
+        sparse = getattr(ctx, "_lt_sparse_prob_grads", [])
+        idx = val = None
+        if len(sparse) == 1:
+            idx, val = sparse[0]
+        gl = torch.empty_like(probs)
+        H.check(H.lib().lt_softargmax3d_bwd(probs.data_ptr(), cv.data_ptr(), kp.data_ptr(), g_kp.data_ptr(), H.ptr(idx), H.ptr(val), 1.0,
+                                            int(ctx.softmax), 0, gl.data_ptr(), B, J, nvox, H.cur_stream()), "lt_softargmax3d_bwd")
+        dense = None
+        if len(sparse) > 1:       # several sparse consumers: scatter them into one dense gradient (rare)
+            dense = torch.zeros(B, J, nvox, dtype=torch.float32, device=probs.device)
+            for i2, v2 in sparse:
+                dense.scatter_add_(2, i2.long()[..., None], v2[..., None])
+            dense = dense.reshape(probs.shape)
+        if g_probs is not None and g_probs.stride() != (0,) * g_probs.dim():   # a real dense gradient on the returned volumes
+            dense = g_probs.float() if dense is None else dense + g_probs.float()
+        if dense is not None:     # d/dl_i += p_i (gp_i - <p, gp>) (softmax) / gp_i [l_i > 0] (ReLU): small torch glue on a rare path
+            if ctx.softmax:
+                gl = gl + probs * (dense - (probs * dense).flatten(2).sum(-1)[..., None, None, None])
+            else:
+                gl = gl + dense * (probs > 0)
+        return gl.to(ctx.in_dtype), None, None
+
+
+def sparse_prob_grad(volumes, idx, val):
+    """Hands a one-voxel-per-(sample, joint) gradient on ``volumes`` -- the probabilities returned by
+    integrate_tensor_3d_with_coordinates -- to the node that produced them.  Returns the tensor the consumer's backward
+    should return for ``volumes``: an all-zero stride-0 view when the producer is our soft-argmax node (which then applies the sparse
+    part itself inside lt_softargmax3d_bwd), else the dense scatter."""
+    node = volumes.grad_fn
+    if isinstance(node, _SoftArgmax3dFn._backward_cls):
+        if not hasattr(node, "_lt_sparse_prob_grads"):
+            node._lt_sparse_prob_grads = []
+        node._lt_sparse_prob_grads.append((idx, val))
+        return torch.zeros((), dtype=volumes.dtype, device=volumes.device).expand(volumes.shape)
+    B, J = volumes.shape[:2]
+    dense = torch.zeros(B, J, volumes[0, 0].numel(), dtype=torch.float32, device=volumes.device)
+    dense.scatter_(2, idx.long()[..., None], val[..., None])
+    return dense.reshape(volumes.shape).to(volumes.dtype)
+
+
+def integrate_tensor_3d_with_coordinates(volumes, coord_volumes, softmax=True):
+    """volumes (B,J,V0,V1,V2) logits, coord_volumes (B,V0,V1,V2,3) -> (coordinates (B,J,3), volumes after
+    softmax / ReLU).  Reference: op.py:84-96.  Differentiable with respect to the logits (lt_softargmax3d_bwd)."""
+    H.require_gpu(volumes, "volumes")
+    cv = coord_volumes.to(volumes.device, torch.float32).contiguous()
+    if torch.is_grad_enabled() and volumes.requires_grad:
+        return _SoftArgmax3dFn.apply(volumes, cv, softmax)
+    return _softargmax3d_launch(volumes, cv, softmax)
+
+
+def batchnorm_batch_stats(x, running_mean=None, running_var=None, momentum=0.1):
+    """Training-mode BatchNorm statistics of x (N,C,*spatial; fp32 or bf16): per-channel batch mean and BIASED variance (what
+    F.batch_norm normalises with when training=True), fp64 accumulation (lt_bn_stats_fwd); running_mean / running_var (fp32, on the
+    GPU) are updated in place the way torch does (momentum, unbiased variance).  Channels-last inputs are consumed without a copy."""
+    H.require_gpu(x, "x")
+    xc = _as_channels_last(x, 1)
+    Cc = xc.shape[-1]
+    rows = xc.numel() // Cc
+    mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    var = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    lib = H.lib()
+    ws = torch.empty(max(16, lib.lt_bn_stats_workspace(rows, Cc)), dtype=torch.uint8, device=x.device)
+    if running_mean is not None:
+        assert running_mean.is_cuda and running_mean.dtype == torch.float32 and running_mean.is_contiguous()
+        assert running_var.is_cuda and running_var.dtype == torch.float32 and running_var.is_contiguous()
+    H.check(lib.lt_bn_stats_fwd(H.dtype_code(xc.dtype), xc.data_ptr(), rows, Cc, mean.data_ptr(), var.data_ptr(), H.ptr(running_mean),
+                                H.ptr(running_var), float(momentum), ws.data_ptr(), H.cur_stream()), "lt_bn_stats_fwd")
+    return mean, var
 
 
 def integrate_tensor_2d(heatmaps, softmax=True):

@@ -244,6 +244,73 @@ def gen_pipe2d(mvn):
                         hm_sm_sub=sub(hm_sm, 4))
 
 
+def gen_grad(mvn):
+    """Gradient fixtures for the non-convolution backward kernels: torch.autograd THROUGH THE REFERENCE'S OWN
+    op.unproject_heatmaps / op.integrate_tensor_3d_with_coordinates / loss.KeypointsMAELoss / loss.VolumetricCELoss on CPU.
+      (1) the small op fixtures of gen_ops (non-square maps, a camera inside the cube, rotated grids; C = 8), every aggregation;
+      (2) the small_softmax whole-pipeline case: d loss / d features through the unprojection for a random upstream gradient, and
+          d (MAE + 0.01 CE) / d logits through the 3D soft-argmax (train.py:217-230)."""
+    import mvn.models.loss as L
+    op = mvn.utils.op
+    ops = np.load(os.path.join(GOLD, "ops.npz"))
+    out = {}
+    g = torch.Generator().manual_seed(41)
+    P, cv = torch.from_numpy(ops["unproj_P"]), torch.from_numpy(ops["unproj_cv"])
+    hm0 = torch.from_numpy(ops["unproj_hm_C8"]); conf0 = torch.from_numpy(ops["unproj_cin_C8"])
+    G = torch.randn(2, 8, 7, 7, 7, generator=g)
+    out["u_G"] = G.numpy()
+    for method in ("sum", "max", "softmax", "conf"):
+        hm = hm0.clone().requires_grad_(True); conf = conf0.clone().requires_grad_(True)
+        vol = op.unproject_heatmaps(hm, P, cv, method, conf)
+        (vol * G).sum().backward()
+        out["u_ghm_" + method] = hm.grad.numpy()
+        if method == "conf":
+            out["u_gconf"] = conf.grad.numpy()
+        print("  unproject/%s: |grad| max %.3e" % (method, float(hm.grad.abs().max())))
+    # 3D soft-argmax + losses on the int3d fixture
+    vols0, cvs = torch.from_numpy(ops["int3d_in"]), torch.from_numpy(ops["int3d_cv"])
+    Gk = torch.randn(2, 5, 3, generator=g); Gp = torch.randn(2, 5, 6, 7, 8, generator=g) * 0.1
+    gt = torch.randn(2, 5, 3, generator=g) * 60; val = (torch.rand(2, 5, 1, generator=g) > 0.25).float()
+    out.update(s_Gk=Gk.numpy(), s_Gp=Gp.numpy(), s_gt=gt.numpy(), s_val=val.numpy())
+    for sm in (True, False):
+        v = vols0.clone().requires_grad_(True)
+        c, pv = op.integrate_tensor_3d_with_coordinates(v, cvs, softmax=sm)
+        ((c * Gk).sum() + (pv * Gp).sum()).backward()
+        out["s_glogits_dense_%d" % sm] = v.grad.numpy()
+    v = vols0.clone().requires_grad_(True)
+    c, pv = op.integrate_tensor_3d_with_coordinates(v, cvs, softmax=True)
+    mae = L.KeypointsMAELoss()(c * 0.1, gt * 0.1, val)
+    ce = L.VolumetricCELoss()(cvs, pv, gt, val)
+    (mae + 0.01 * ce).backward()
+    out.update(s_mae=np.array(float(mae)), s_ce=np.array(float(ce)), s_glogits_loss=v.grad.numpy())
+    for name, cls in (("mse", L.KeypointsMSELoss), ("mse_smooth", L.KeypointsMSESmoothLoss), ("l2", L.KeypointsL2Loss)):
+        out["s_" + name] = np.array(float(cls()(c.detach() * 0.1, gt * 0.1, val)))
+    # whole-pipeline shapes: the small_softmax case (2 samples, 3 views, camera 0 inside the cube, rotated cuboids)
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), ""))
+    c = dict(nl=18, B=2, NV=3, H=128, V=32, seed=2)
+    cfg = synth.vol_config(c["nl"], c["V"], "softmax", 1.0, "mpii")
+    sd = synth.make_state_dict(spec.vol_net_spec(c["nl"], 17, False), seed=c["seed"], sharpen=True, basic_block=True)
+    inp = synth.make_inputs(c["B"], c["NV"], c["H"], seed=c["seed"], inside=True)
+    gs = np.load(os.path.join(GOLD, "vol_small_softmax.npz"))
+    o = O.volumetric_forward(sd, cfg, inp["images"], inp["K"], inp["R"], inp["t"], inp["pred_keypoints_3d"], thetas=gs["thetas"], stages=True)
+    f = o["features"].clone().requires_grad_(True)
+    GV = torch.randn(o["unprojected"].shape, generator=g)
+    vol = op.unproject_heatmaps(f, o["proj"], o["coord_volumes"], "softmax")
+    _check("grad fixture: unprojected volume", vol.detach(), o["unprojected"], 2e-6)
+    (vol * GV).sum().backward()
+    out["p_gfeat"] = f.grad.numpy(); out["p_GV_seed"] = np.array(41)
+    lg = o["logits"].clone().requires_grad_(True)
+    kp, pv = op.integrate_tensor_3d_with_coordinates(lg * 1.0, o["coord_volumes"], softmax=True)
+    gt3 = kp.detach() + torch.randn(kp.shape, generator=g) * 30; val3 = torch.ones(2, 17, 1); val3[1, 3] = 0
+    mae = L.KeypointsMAELoss()(kp * 0.1, gt3 * 0.1, val3)
+    ce = L.VolumetricCELoss()(o["coord_volumes"], pv, gt3, val3)
+    (mae + 0.01 * ce).backward()
+    out.update(p_gt=gt3.numpy(), p_val=val3.numpy(), p_mae=np.array(float(mae)), p_ce=np.array(float(ce)), p_glogits_s2=sub(lg.grad, 2),
+               p_glogits_absmax=np.array(float(lg.grad.abs().max())))
+    print("  pipeline: mae %.4f ce %.4f |glogits| max %.3e |gfeat| max %.3e" % (float(mae), float(ce), float(lg.grad.abs().max()), float(f.grad.abs().max())))
+    np.savez_compressed(os.path.join(GOLD, "grads.npz"), **out)
+
+
 def gen_data(mvn):
     """Dataset/eval adjacency of the hot path: the reference's collate_fn / prepare_batch
     (datasets/utils.py:6-65) and Human36MMultiViewDataset.evaluate (human36m.py:190-273) on synthetic items / labels."""
@@ -363,7 +430,7 @@ def main():
     torch.manual_seed(0)
     os.makedirs(GOLD, exist_ok=True)
     mvn = ref_loader.load()
-    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data"]
+    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad"]
     if "ops" in which:
         print("[ops]"); gen_ops(mvn)
     if "nets" in which:
@@ -397,6 +464,8 @@ def main():
         print("[pipe2d]"); gen_pipe2d(mvn)
     if "data" in which:
         print("[data]"); gen_data(mvn)
+    if "grad" in which:
+        print("[grad]"); gen_grad(mvn)
     digest = {k: [list(v[0]), v[1]] for k, v in spec.vol_net_spec(152, 17).items()}
     with open(os.path.join(GOLD, "spec_digest.json"), "w") as f:
         json.dump({"n_keys": len(digest), "n_params": int(sum(int(np.prod(v[0])) for v in digest.values())),

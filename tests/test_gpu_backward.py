@@ -1,0 +1,130 @@
+"""GPU (-m gpu): the non-convolution backward kernels and training-mode BatchNorm statistics
+against gradients computed by torch.autograd THROUGH THE REFERENCE ITSELF (tests/golden/grads.npz, oracle/make_golden.py
+``grad``), through the product's autograd-facing API (mvn.utils.op / mvn.models.loss -> lt_unproject_bwd, lt_softargmax3d_bwd,
+lt_volumetric_ce_fwd, lt_bn_stats_fwd).  Gate: max|d| <= 1e-4 * max|ref| (fp32 kernels)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import check, record
+from oracle import spec, synth
+from oracle import vol_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def grads(golden_dir):
+    return np.load(os.path.join(golden_dir, "grads.npz"))
+
+
+@pytest.fixture(scope="module")
+def ops(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops.npz"))
+
+
+@pytest.mark.parametrize("method", ["sum", "max", "softmax", "conf"])
+def test_unproject_backward_vs_reference_autograd(ops, grads, method):
+    from mvn.utils import op
+    hm = torch.from_numpy(ops["unproj_hm_C8"]).to(DEV).requires_grad_(True)
+    conf = torch.from_numpy(ops["unproj_cin_C8"]).to(DEV).requires_grad_(True)
+    P, cv = torch.from_numpy(ops["unproj_P"]).to(DEV), torch.from_numpy(ops["unproj_cv"]).to(DEV)
+    G = torch.from_numpy(grads["u_G"]).to(DEV)
+    vol = op.unproject_heatmaps(hm, P, cv, method, conf)
+    check("bwd/unproject %s forward (autograd path)" % method, vol.detach().cpu(), ops["unproj_%s_C8" % method], 1e-5)
+    (vol * G).sum().backward()
+    check("bwd/unproject %s d/d heatmaps" % method, hm.grad.cpu(), grads["u_ghm_" + method], 1e-4)
+    if method == "conf":
+        check("bwd/unproject conf d/d confidences", conf.grad.cpu(), grads["u_gconf"], 1e-4)
+    else:
+        assert conf.grad is None
+
+
+def test_softargmax3d_backward_and_losses_vs_reference_autograd(ops, grads):
+    from mvn.models import loss as L
+    from mvn.utils import op
+    cvs = torch.from_numpy(ops["int3d_cv"]).to(DEV)
+    Gk, Gp = torch.from_numpy(grads["s_Gk"]).to(DEV), torch.from_numpy(grads["s_Gp"]).to(DEV)
+    gt, val = torch.from_numpy(grads["s_gt"]).to(DEV), torch.from_numpy(grads["s_val"]).to(DEV)
+    for sm in (True, False):     # dense gradients on both outputs (coordinates and the returned volumes)
+        v = torch.from_numpy(ops["int3d_in"]).to(DEV).requires_grad_(True)
+        c, pv = op.integrate_tensor_3d_with_coordinates(v, cvs, softmax=sm)
+        ((c * Gk).sum() + (pv * Gp).sum()).backward()
+        check("bwd/softargmax3d softmax=%d dense" % sm, v.grad.cpu(), grads["s_glogits_dense_%d" % sm], 1e-4)
+    # the training loss of train.py:217-230: MAE on the scaled joints + 0.01 x VolumetricCELoss on the returned volumes
+    v = torch.from_numpy(ops["int3d_in"]).to(DEV).requires_grad_(True)
+    c, pv = op.integrate_tensor_3d_with_coordinates(v, cvs, softmax=True)
+    mae = L.KeypointsMAELoss()(c * 0.1, gt * 0.1, val)
+    ce = L.VolumetricCELoss()(cvs, pv, gt, val)
+    assert float(mae) == pytest.approx(float(grads["s_mae"]), rel=1e-5) and float(ce) == pytest.approx(float(grads["s_ce"]), rel=1e-5)
+    (mae + 0.01 * ce).backward()
+    check("bwd/softargmax3d MAE + 0.01 CE (sparse CE gradient)", v.grad.cpu(), grads["s_glogits_loss"], 1e-4)
+    for name, cls in (("mse", L.KeypointsMSELoss), ("mse_smooth", L.KeypointsMSESmoothLoss), ("l2", L.KeypointsL2Loss)):
+        assert float(cls()(c.detach() * 0.1, gt * 0.1, val)) == pytest.approx(float(grads["s_" + name]), rel=1e-5), name
+    # CE on volumes that do not come from our soft-argmax node: dense scatter fallback, same numbers
+    pv2 = pv.detach().clone().requires_grad_(True)
+    L.VolumetricCELoss()(cvs, pv2, gt, val).backward()
+    assert int((pv2.grad != 0).sum()) <= pv2.shape[0] * pv2.shape[1]
+
+
+def test_pipeline_shape_gradients_vs_reference_autograd(golden_dir, grads):
+    """small_softmax whole-pipeline case (2 samples, 3 views, camera 0 inside the cube, rotated cuboids, 32 channels, 32^3 voxels):
+    d loss / d features through lt_unproject_bwd for a random upstream gradient, and d (MAE + 0.01 CE) / d logits."""
+    from mvn.models import loss as L
+    from mvn.utils import op
+    gs = np.load(os.path.join(golden_dir, "vol_small_softmax.npz"))
+    cfg = synth.vol_config(18, 32, "softmax", 1.0, "mpii")
+    sd = synth.make_state_dict(spec.vol_net_spec(18, 17, False), seed=2, sharpen=True, basic_block=True)
+    inp = synth.make_inputs(2, 3, 128, seed=2, inside=True)
+    o = O.volumetric_forward(sd, cfg, inp["images"], inp["K"], inp["R"], inp["t"], inp["pred_keypoints_3d"], thetas=gs["thetas"], stages=True)
+    g = torch.Generator().manual_seed(41)       # replay the generator of oracle/make_golden.py gen_grad up to GV
+    torch.randn(2, 8, 7, 7, 7, generator=g); torch.randn(2, 5, 3, generator=g); torch.randn(2, 5, 6, 7, 8, generator=g)
+    torch.randn(2, 5, 3, generator=g); torch.rand(2, 5, 1, generator=g)
+    GV = torch.randn(o["unprojected"].shape, generator=g)
+    f = o["features"].to(DEV).requires_grad_(True)
+    vol = op.unproject_heatmaps(f, o["proj"].to(DEV), o["coord_volumes"].to(DEV), "softmax")
+    (vol * GV.to(DEV)).sum().backward()
+    check("bwd/pipeline d/d features (fp32)", f.grad.cpu(), grads["p_gfeat"], 1e-4)
+    fb = o["features"].to(DEV).to(torch.bfloat16).requires_grad_(True)     # bf16 activations: recorded, not gated at 1e-4
+    (op.unproject_heatmaps(fb, o["proj"].to(DEV), o["coord_volumes"].to(DEV), "softmax").float() * GV.to(DEV)).sum().backward()
+    record("bwd/pipeline d/d features, bf16 feature maps (max|d|/max|ref|)",
+           float((fb.grad.float().cpu() - torch.from_numpy(grads["p_gfeat"])).abs().max() / np.abs(grads["p_gfeat"]).max()))
+    lg = o["logits"].to(DEV).requires_grad_(True)
+    cvd = o["coord_volumes"].to(DEV)
+    kp, pv = op.integrate_tensor_3d_with_coordinates(lg * 1.0, cvd, softmax=True)
+    gt3, val3 = torch.from_numpy(grads["p_gt"]).to(DEV), torch.from_numpy(grads["p_val"]).to(DEV)
+    mae = L.KeypointsMAELoss()(kp * 0.1, gt3 * 0.1, val3)
+    ce = L.VolumetricCELoss()(cvd, pv, gt3, val3)
+    assert float(mae) == pytest.approx(float(grads["p_mae"]), rel=1e-4) and float(ce) == pytest.approx(float(grads["p_ce"]), rel=1e-4)
+    (mae + 0.01 * ce).backward()
+    e = float((lg.grad.cpu()[:, :, ::2, ::2, ::2] - torch.from_numpy(grads["p_glogits_s2"])).abs().max() / float(grads["p_glogits_absmax"]))
+    record("bwd/pipeline d/d logits (max|d|/max|ref|)", e)
+    assert e <= 1e-4, e
+
+
+@pytest.mark.parametrize("shape,dtype", [((6, 17, 9, 11), torch.float32), ((3, 64, 24, 24), torch.bfloat16), ((2, 32, 8, 8, 8), torch.float32),
+                                         ((2, 300, 5, 7), torch.float32)])
+def test_batchnorm_batch_statistics_vs_torch(shape, dtype):
+    """Training-mode BatchNorm: per-channel batch mean / biased variance and the running-statistics update (momentum 0.1, unbiased
+    variance) against F.batch_norm(training=True) on the CPU."""
+    from mvn.utils import op
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(shape, generator=g) * 2 + 0.7).to(dtype)
+    C = shape[1]
+    rm, rv = torch.randn(C, generator=g) * 0.1, 0.5 + torch.rand(C, generator=g)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    xf = x.float()
+    F.batch_norm(xf, rm_ref, rv_ref, None, None, True, 0.1, 1e-5)
+    dims = [0] + list(range(2, xf.dim()))
+    mean_ref, var_ref = xf.mean(dim=dims), xf.var(dim=dims, unbiased=False)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    mean, var = op.batchnorm_batch_stats(x.to(DEV), rmd, rvd, momentum=0.1)
+    tol = 1e-5
+    check("bn stats mean %s %s" % (shape, dtype), mean.cpu(), mean_ref, tol)
+    check("bn stats var %s %s" % (shape, dtype), var.cpu(), var_ref, tol)
+    check("bn running_mean %s" % (shape,), rmd.cpu(), rm_ref, tol)
+    check("bn running_var %s" % (shape,), rvd.cpu(), rv_ref, tol)
