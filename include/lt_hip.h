@@ -171,6 +171,13 @@ int lt_rotate_points(const float* x, const float* rot, float* y, int64_t n, void
 int lt_unproject_fwd(int32_t dtype, const void* feats, const float* proj, const float* coords, const float* conf,
                      void* out, int32_t B, int32_t NV, int32_t C, int32_t h, int32_t w, int32_t v0, int32_t v1,
                      int32_t v2, int32_t agg, void* stream);
+/* The same over the cuboid grid of the model (triangulation.py:298-339) described by lt_coord_volumes' arguments instead of a
+ * coordinate tensor: the voxel centres are computed in registers (bit-identical to lt_coord_volumes) and WRITTEN to coords_out
+ * (B,V,V,V,3 fp32, a returned tensor of the forward) on the way -- the 12 bytes per voxel are never read back.  Fused for bf16,
+ * C = 32, 4 or 8 views, view softmax, V % 16 == 0; any other configuration runs lt_coord_volumes + lt_unproject_fwd inside. */
+int lt_unproject_grid_fwd(int32_t dtype, const void* feats, const float* proj, const float* pos, const float* center, const float* rot,
+                          float step, int32_t cmu_transfer, float* coords_out, const float* conf, void* out, int32_t B, int32_t NV,
+                          int32_t C, int32_t h, int32_t w, int32_t V, int32_t agg, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * op.integrate_tensor_3d_with_coordinates (mvn/utils/op.py:84-96):

@@ -21,6 +21,26 @@ using namespace lt;
 
 namespace {
 
+// One voxel centre of the (rotated, optionally CMU-permuted) cuboid grid: the loop body of triangulation.py:298-339, fp32 in the
+// reference's operation order (bit-exact in eval mode).  Shared by coord_volumes_kernel and the fused unprojection below.
+__device__ __forceinline__ void voxel_coord(const float* __restrict__ p, const float* __restrict__ c, const float* __restrict__ R, float step,
+                                            int i, int j, int k, int V, int cmu, float& o0, float& o1, float& o2) {
+    // triangulation.py:336-339: permute(0,2,1,3) then flip axis 1  ==> out[i][j][k] = cv[i][k][V-1-j]
+    const int a0 = i, a1 = cmu ? k : j, a2 = cmu ? (V - 1 - j) : k;
+    // f32(position) + f32(step) * idx, two roundings as in triangulation.py:311-313 (no FMA contraction)
+    const float x0 = __fadd_rn(p[0], __fmul_rn(step, (float)a0));
+    const float x1 = __fadd_rn(p[1], __fmul_rn(step, (float)a1));
+    const float x2 = __fadd_rn(p[2], __fmul_rn(step, (float)a2));
+    const float d0 = __fsub_rn(x0, c[0]), d1 = __fsub_rn(x1, c[1]), d2 = __fsub_rn(x2, c[2]);
+    // rot.mm(d): k-ordered multiply-adds (exact for theta = 0, where R is the identity)
+    const float r0 = fmaf(R[2], d2, fmaf(R[1], d1, __fmul_rn(R[0], d0)));
+    const float r1 = fmaf(R[5], d2, fmaf(R[4], d1, __fmul_rn(R[3], d0)));
+    const float r2 = fmaf(R[8], d2, fmaf(R[7], d1, __fmul_rn(R[6], d0)));
+    o0 = __fadd_rn(r0, c[0]);
+    o1 = __fadd_rn(r1, c[1]);
+    o2 = __fadd_rn(r2, c[2]);
+}
+
 __global__ void coord_volumes_kernel(const float* __restrict__ pos, const float* __restrict__ center,
                                      const float* __restrict__ rot, float step, int B, int V, int cmu, float* __restrict__ out) {
     const long long total = (long long)B * V * V * V;
@@ -30,24 +50,8 @@ __global__ void coord_volumes_kernel(const float* __restrict__ pos, const float*
         const int j = (int)(r % V); r /= V;
         const int i = (int)(r % V);
         const int b = (int)(r / V);
-        // triangulation.py:336-339: permute(0,2,1,3) then flip axis 1  ==> out[i][j][k] = cv[i][k][V-1-j]
-        const int a0 = i, a1 = cmu ? k : j, a2 = cmu ? (V - 1 - j) : k;
-        const float* p = pos + 3 * b;
-        const float* c = center + 3 * b;
-        const float* R = rot + 9 * b;
-        // f32(position) + f32(step) * idx, two roundings as in triangulation.py:311-313 (no FMA contraction)
-        const float x0 = __fadd_rn(p[0], __fmul_rn(step, (float)a0));
-        const float x1 = __fadd_rn(p[1], __fmul_rn(step, (float)a1));
-        const float x2 = __fadd_rn(p[2], __fmul_rn(step, (float)a2));
-        const float d0 = __fsub_rn(x0, c[0]), d1 = __fsub_rn(x1, c[1]), d2 = __fsub_rn(x2, c[2]);
-        // rot.mm(d): k-ordered multiply-adds (exact for theta = 0, where R is the identity)
-        const float r0 = fmaf(R[2], d2, fmaf(R[1], d1, __fmul_rn(R[0], d0)));
-        const float r1 = fmaf(R[5], d2, fmaf(R[4], d1, __fmul_rn(R[3], d0)));
-        const float r2 = fmaf(R[8], d2, fmaf(R[7], d1, __fmul_rn(R[6], d0)));
         float* o = out + g * 3;
-        o[0] = __fadd_rn(r0, c[0]);
-        o[1] = __fadd_rn(r1, c[1]);
-        o[2] = __fadd_rn(r2, c[2]);
+        voxel_coord(pos + 3 * b, center + 3 * b, rot + 9 * b, step, i, j, k, V, cmu, o[0], o[1], o[2]);
     }
 }
 
@@ -82,6 +86,14 @@ template <> struct ChVec<bf16_t, 1> {
     static __device__ __forceinline__ void st(bf16_t* p, const float (&f)[1]) { *p = f32_to_bf16(f[0]); }
 };
 
+template <int I0, int I1, typename F>
+__device__ __forceinline__ void static_for_views(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for_views<I0 + 1, I1>(f);
+    }
+}
+
 struct UnprojArgs {
     const void* feats;
     const float* proj;
@@ -92,6 +104,10 @@ struct UnprojArgs {
     int bricked;        // 4x4x16 bricks (v0%4 == v1%4 == v2%16 == 0) or linear 256-voxel chunks
     int chunks;         // workgroups per sample
     int xcd_pin;        // B % 8 == 0
+    // lt_unproject_grid_fwd: the voxel centres are COMPUTED (voxel_coord) from the cuboid description instead of read, and written to
+    // coords_out when that is not null (the coordinate volume is a returned tensor of the forward: written once, never read back)
+    const float* g_pos; const float* g_center; const float* g_rot;
+    float g_step; int g_cmu; float* coords_out;
 };
 
 // fp32 (parity) mode keeps IEEE divisions / expf; bf16 (throughput) mode uses v_rcp_f32 / v_exp_f32: the kernel was
@@ -423,13 +439,17 @@ __global__ __launch_bounds__(1024) void unproject_lds_kernel(const UnprojArgs a)
     ChVec<T, CH>::st(out + vox * C + c0, res);
 }
 
-// ---- quad kernel: bf16, C = 32, exactly 4 views, softmax aggregation, bricked volumes (the BASELINE configuration) -----------------
-// The generic kernel above is VALU-bound (~700 instructions per lane-item; PMC: 40 % of the cycles waiting on instruction
-// issue): every one of the four lanes of a voxel (one per 8-channel vector) redoes the projection of the voxel into all four
-// views.  Here the four lanes of a voxel's quad split the VIEWS for the projection (lane j projects into view j and keeps that
-// view's 3x4 matrix in registers for the whole kernel), fold the zero-padding rules into the four bilinear weights (an invalid
-// corner gets weight 0 and a clamped, readable address), and hand the four tap offsets + four weights of their view to the
-// other three lanes with DPP quad broadcasts; the bilinear blend and the view softmax run on packed fp32 pairs (v_pk_fma_f32).
+// ---- quad kernel: bf16, C = 32, 4 or 8 views, softmax aggregation, bricked volumes (BASELINE configurations 2 and 4) ------------------
+// The generic kernel above is VALU-bound (~700 instructions per lane-item at 4 views; PMC: 40 % of the cycles waiting on instruction
+// issue): every one of the four lanes of a voxel (one per 8-channel vector) redoes the projection of the voxel into all views.
+// Here the four lanes of a voxel's quad split the VIEWS for the projection (lane j projects into views j, j+4, ... and keeps those
+// 3x4 matrices in registers for the whole kernel), fold the zero-padding rules into the four bilinear weights (an invalid corner
+// gets weight 0 and a clamped, readable address), and hand the four tap offsets + four weights of their views to the other three
+// lanes with DPP quad broadcasts; the bilinear blend and the view softmax run on packed fp32 pairs with EXPLICIT fused
+// multiply-adds (the library is built with -ffp-contract=off for the bit-exact coordinate grid, which left this kernel with 109
+// v_pk_mul + 102 v_pk_add per voxel where 125 v_pk_fma do).  NVL = views per lane (1: 4 views, 2: 8 views).  GRID: the voxel centre
+// is computed in registers from the cuboid description (bit-identical to coord_volumes_kernel) instead of read from the 12-byte-
+// per-voxel coordinate volume, and lanes 0-2 of the quad write its three components to the returned tensor on the way.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 template <int Q>
@@ -438,10 +458,12 @@ __device__ __forceinline__ int quad_bcast_i(int v) {   // value of lane Q of thi
 }
 template <int Q>
 __device__ __forceinline__ float quad_bcast_f(float v) { return __int_as_float(quad_bcast_i<Q>(__float_as_int(v))); }
+__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
 
-__global__ __launch_bounds__(256) void unproject_q4_kernel(const UnprojArgs a) {
+template <int NVL, bool GRID>
+__global__ __launch_bounds__(256) void unproject_qn_kernel(const UnprojArgs a) {
     typedef bf16_t T;
-    constexpr int C = 32;
+    constexpr int C = 32, NV = 4 * NVL;
     int b, chunk;
     if (a.xcd_pin) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -452,70 +474,93 @@ __global__ __launch_bounds__(256) void unproject_q4_kernel(const UnprojArgs a) {
         chunk = blockIdx.x % a.chunks;
     }
     const long long nvox = (long long)a.v0 * a.v1 * a.v2;
-    const T* feats = (const T*)a.feats + (long long)b * 4 * a.h * a.w * C;
-    const float* coords = a.coords + (long long)b * nvox * 3;
+    const T* feats = (const T*)a.feats + (long long)b * NV * a.h * a.w * C;
+    const float* coords = GRID ? nullptr : a.coords + (long long)b * nvox * 3;
+    float* coords_out = (GRID && a.coords_out) ? a.coords_out + (long long)b * nvox * 3 : nullptr;
     T* out = (T*)a.out + (long long)b * nvox * C;
     const int nk = a.v2 >> 4, nj = a.v1 >> 2;
     const int bk = (chunk % nk) << 4, bj = ((chunk / nk) % nj) << 2, bi = (chunk / (nk * nj)) << 2;
-    const int t = threadIdx.x, qv = t & 3;               // qv: the view this lane projects into AND its 8-channel vector
+    const int t = threadIdx.x, qv = t & 3;               // qv: the views this lane projects into (qv, qv + 4) AND its 8-channel vector
     const int h = a.h, w = a.w;
-    float P[12];
+    float P[NVL][12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) P[i] = a.proj[((long long)b * 4 + qv) * 12 + i];
+    for (int s = 0; s < NVL; ++s)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) P[s][i] = a.proj[((long long)b * NV + qv + 4 * s) * 12 + i];
+    float gp[3], gc[3], gR[9];
+    if (GRID) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { gp[i] = a.g_pos[3 * b + i]; gc[i] = a.g_center[3 * b + i]; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) gR[i] = a.g_rot[9 * b + i];
+    }
     const float inv_h = __builtin_amdgcn_rcpf((float)h), inv_w = __builtin_amdgcn_rcpf((float)w);
-    const int vbase = qv * h * w * C + 0;                // element offset of view qv's map (this lane's projection)
 
 #pragma unroll 1
     for (int it = 0; it < 4; ++it) {
         const int vb = it * 64 + (t >> 2);
-        const long long vox = ((long long)(bi + (vb >> 6)) * a.v1 + bj + ((vb >> 4) & 3)) * a.v2 + bk + (vb & 15);
-        const float X0 = coords[vox * 3], X1 = coords[vox * 3 + 1], X2 = coords[vox * 3 + 2];
-        // ---- projection of the voxel into view qv (the arithmetic of sample_view<bf16>) ----
-        const float px = __fadd_rn(fmaf(X2, P[2], fmaf(X1, P[1], __fmul_rn(X0, P[0]))), P[3]);
-        const float py = __fadd_rn(fmaf(X2, P[6], fmaf(X1, P[5], __fmul_rn(X0, P[4]))), P[7]);
-        float pz = __fadd_rn(fmaf(X2, P[10], fmaf(X1, P[9], __fmul_rn(X0, P[8]))), P[11]);
-        const bool invalid = pz <= 0.0f;
-        if (pz == 0.0f) pz = 1.0f;
-        const float rz = __builtin_amdgcn_rcpf(pz);
-        const float u = px * rz, vv = py * rz;
-        const float gx = __fmul_rn(2.0f, __fsub_rn(u * inv_h, 0.5f));      // op.py:128-129: x by h, y by w
-        const float gy = __fmul_rn(2.0f, __fsub_rn(vv * inv_w, 0.5f));
-        const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), 0.5f * (float)(w - 1));
-        const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), 0.5f * (float)(h - 1));
-        const float xw = floorf(ix), yn = floorf(iy);
-        const float we = __fsub_rn(ix, xw), ww = __fsub_rn(1.0f, we);
-        const float ws = __fsub_rn(iy, yn), wn = __fsub_rn(1.0f, ws);
-        const bool xw_ok = xw >= 0.f && xw <= (float)(w - 1), xe_ok = xw >= -1.f && xw <= (float)(w - 2);
-        const bool yn_ok = yn >= 0.f && yn <= (float)(h - 1), ys_ok = yn >= -1.f && yn <= (float)(h - 2);
-        const bool act = !invalid && (xw_ok || xe_ok) && (yn_ok || ys_ok);
-        const int x0 = act ? (int)xw : 0, y0 = act ? (int)yn : 0;
-        const int xwc = min(max(x0, 0), w - 1), xec = min(max(x0 + 1, 0), w - 1);
-        const int rn = min(max(y0, 0), h - 1) * w, rs = min(max(y0 + 1, 0), h - 1) * w;
-        // my view's four corners: element offsets (clamped into the map) and weights (0 where the corner is padding)
-        const int o00 = vbase + (rn + xwc) * C, o01 = vbase + (rn + xec) * C, o10 = vbase + (rs + xwc) * C, o11 = vbase + (rs + xec) * C;
-        const float k00 = (act && yn_ok && xw_ok) ? __fmul_rn(wn, ww) : 0.f, k01 = (act && yn_ok && xe_ok) ? __fmul_rn(wn, we) : 0.f;
-        const float k10 = (act && ys_ok && xw_ok) ? __fmul_rn(ws, ww) : 0.f, k11 = (act && ys_ok && xe_ok) ? __fmul_rn(ws, we) : 0.f;
+        const int vi = bi + (vb >> 6), vj = bj + ((vb >> 4) & 3), vk = bk + (vb & 15);
+        const long long vox = ((long long)vi * a.v1 + vj) * a.v2 + vk;
+        float X0, X1, X2;
+        if (GRID) {
+            voxel_coord(gp, gc, gR, a.g_step, vi, vj, vk, a.v0, a.g_cmu, X0, X1, X2);
+            if (coords_out && qv < 3) coords_out[vox * 3 + qv] = qv == 0 ? X0 : (qv == 1 ? X1 : X2);
+        } else {
+            X0 = coords[vox * 3]; X1 = coords[vox * 3 + 1]; X2 = coords[vox * 3 + 2];
+        }
+        int o00[NVL], o01[NVL], o10[NVL], o11[NVL];
+        float k00[NVL], k01[NVL], k10[NVL], k11[NVL];
+#pragma unroll
+        for (int s = 0; s < NVL; ++s) {
+            // ---- projection of the voxel into view qv + 4 s (the arithmetic of sample_view<bf16>) ----
+            const float* Ps = P[s];
+            const float px = __fadd_rn(fmaf(X2, Ps[2], fmaf(X1, Ps[1], __fmul_rn(X0, Ps[0]))), Ps[3]);
+            const float py = __fadd_rn(fmaf(X2, Ps[6], fmaf(X1, Ps[5], __fmul_rn(X0, Ps[4]))), Ps[7]);
+            float pz = __fadd_rn(fmaf(X2, Ps[10], fmaf(X1, Ps[9], __fmul_rn(X0, Ps[8]))), Ps[11]);
+            const bool invalid = pz <= 0.0f;
+            if (pz == 0.0f) pz = 1.0f;
+            const float rz = __builtin_amdgcn_rcpf(pz);
+            const float u = px * rz, vv = py * rz;
+            const float gx = __fmul_rn(2.0f, __fsub_rn(u * inv_h, 0.5f));      // op.py:128-129: x by h, y by w
+            const float gy = __fmul_rn(2.0f, __fsub_rn(vv * inv_w, 0.5f));
+            const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), 0.5f * (float)(w - 1));
+            const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), 0.5f * (float)(h - 1));
+            const float xw = floorf(ix), yn = floorf(iy);
+            const float we = __fsub_rn(ix, xw), ww = __fsub_rn(1.0f, we);
+            const float ws = __fsub_rn(iy, yn), wn = __fsub_rn(1.0f, ws);
+            const bool xw_ok = xw >= 0.f && xw <= (float)(w - 1), xe_ok = xw >= -1.f && xw <= (float)(w - 2);
+            const bool yn_ok = yn >= 0.f && yn <= (float)(h - 1), ys_ok = yn >= -1.f && yn <= (float)(h - 2);
+            const bool act = !invalid && (xw_ok || xe_ok) && (yn_ok || ys_ok);
+            const int x0 = act ? (int)xw : 0, y0 = act ? (int)yn : 0;
+            const int xwc = min(max(x0, 0), w - 1), xec = min(max(x0 + 1, 0), w - 1);
+            const int rn = min(max(y0, 0), h - 1) * w, rs = min(max(y0 + 1, 0), h - 1) * w;
+            // this view's four corners: element offsets (clamped into the map) and weights (0 where the corner is padding)
+            const int vbase = (qv + 4 * s) * h * w * C;
+            o00[s] = vbase + (rn + xwc) * C; o01[s] = vbase + (rn + xec) * C; o10[s] = vbase + (rs + xwc) * C; o11[s] = vbase + (rs + xec) * C;
+            k00[s] = (act && yn_ok && xw_ok) ? __fmul_rn(wn, ww) : 0.f; k01[s] = (act && yn_ok && xe_ok) ? __fmul_rn(wn, we) : 0.f;
+            k10[s] = (act && ys_ok && xw_ok) ? __fmul_rn(ws, ww) : 0.f; k11[s] = (act && ys_ok && xe_ok) ? __fmul_rn(ws, we) : 0.f;
+        }
 
-        f32x2_t val[4][4];                                // [view][channel pair] of this lane's 8 channels
+        f32x2_t val[NV][4];                               // [view][channel pair] of this lane's 8 channels
         auto view = [&](auto vc) {
-            constexpr int V = decltype(vc)::value;
-            const int p00 = quad_bcast_i<V>(o00), p01 = quad_bcast_i<V>(o01), p10 = quad_bcast_i<V>(o10), p11 = quad_bcast_i<V>(o11);
-            const float w00 = quad_bcast_f<V>(k00), w01 = quad_bcast_f<V>(k01), w10 = quad_bcast_f<V>(k10), w11 = quad_bcast_f<V>(k11);
+            constexpr int V = decltype(vc)::value, Q = V & 3, S = V >> 2;
+            const int p00 = quad_bcast_i<Q>(o00[S]), p01 = quad_bcast_i<Q>(o01[S]), p10 = quad_bcast_i<Q>(o10[S]), p11 = quad_bcast_i<Q>(o11[S]);
+            const float w00 = quad_bcast_f<Q>(k00[S]), w01 = quad_bcast_f<Q>(k01[S]), w10 = quad_bcast_f<Q>(k10[S]), w11 = quad_bcast_f<Q>(k11[S]);
             const uint4 t00 = *(const uint4*)(feats + p00 + qv * 8), t01 = *(const uint4*)(feats + p01 + qv * 8);
             const uint4 t10 = *(const uint4*)(feats + p10 + qv * 8), t11 = *(const uint4*)(feats + p11 + qv * 8);
             const unsigned u00[4] = {t00.x, t00.y, t00.z, t00.w}, u01[4] = {t01.x, t01.y, t01.z, t01.w};
             const unsigned u10[4] = {t10.x, t10.y, t10.z, t10.w}, u11[4] = {t11.x, t11.y, t11.z, t11.w};
+            const f32x2_t W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const f32x2_t f00 = {__uint_as_float(u00[d] << 16), __uint_as_float(u00[d] & 0xffff0000u)};
                 const f32x2_t f01 = {__uint_as_float(u01[d] << 16), __uint_as_float(u01[d] & 0xffff0000u)};
                 const f32x2_t f10 = {__uint_as_float(u10[d] << 16), __uint_as_float(u10[d] & 0xffff0000u)};
                 const f32x2_t f11 = {__uint_as_float(u11[d] << 16), __uint_as_float(u11[d] & 0xffff0000u)};
-                val[V][d] = f00 * w00 + f01 * w01 + f10 * w10 + f11 * w11;
+                val[V][d] = pk_fma(f11, W11, pk_fma(f10, W10, pk_fma(f01, W01, f00 * W00)));
             }
         };
-        view(std::integral_constant<int, 0>{}); view(std::integral_constant<int, 1>{});
-        view(std::integral_constant<int, 2>{}); view(std::integral_constant<int, 3>{});
+        static_for_views<0, NV>(view);
 
         // ---- softmax over the views per channel: sum_v x_v softmax_v(x) = (sum_v x_v e_v) / (sum_v e_v) ----
         unsigned o[4];
@@ -523,14 +568,15 @@ __global__ __launch_bounds__(256) void unproject_q4_kernel(const UnprojArgs a) {
         for (int d = 0; d < 4; ++d) {
             f32x2_t m = val[0][d];
 #pragma unroll
-            for (int v = 1; v < 4; ++v) { m[0] = fmaxf(m[0], val[v][d][0]); m[1] = fmaxf(m[1], val[v][d][1]); }
+            for (int v = 1; v < NV; ++v) { m[0] = fmaxf(m[0], val[v][d][0]); m[1] = fmaxf(m[1], val[v][d][1]); }
             f32x2_t s = {0.f, 0.f}, tt = {0.f, 0.f};
+            const f32x2_t L2E = {1.4426950408889634f, 1.4426950408889634f}, mL = m * L2E;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const f32x2_t dl = (val[v][d] - m) * 1.4426950408889634f;
+            for (int v = 0; v < NV; ++v) {
+                const f32x2_t dl = pk_fma(val[v][d], L2E, -mL);                 // (x - m) log2(e)
                 const f32x2_t ex = {__builtin_amdgcn_exp2f(dl[0]), __builtin_amdgcn_exp2f(dl[1])};
                 s += ex;
-                tt += val[v][d] * ex;
+                tt = pk_fma(val[v][d], ex, tt);
             }
             o[d] = pack_bf16x2(tt[0] * __builtin_amdgcn_rcpf(s[0]), tt[1] * __builtin_amdgcn_rcpf(s[1]));
         }
@@ -560,6 +606,57 @@ extern "C" int lt_coord_volumes(const float* pos, const float* center, const flo
     return LT_OK;
 }
 
+namespace {
+// fills the launch geometry and picks the kernel; a.coords (read) or the a.g_* grid description must be set by the caller
+int unproject_dispatch(UnprojArgs& a, int dtype, bool grid, hipStream_t st) {
+    const long long nvox = (long long)a.v0 * a.v1 * a.v2;
+    a.bricked = (a.v0 % 4 == 0 && a.v1 % 4 == 0 && a.v2 % 16 == 0) ? 1 : 0;
+    a.chunks = (int)cdiv(nvox, 256);
+    a.xcd_pin = (a.B % 8 == 0) ? 1 : 0;
+    LT_REQUIRE((long long)a.B * a.chunks < (1ll << 31), LT_ERR_UNSUPPORTED, "lt_unproject_fwd: grid too large");
+    const unsigned nblk = (unsigned)((long long)a.B * a.chunks);
+    // quad kernel: bf16, 32 channels, 4 or 8 views, view softmax, bricked volume (BASELINE configurations 2 and 4)
+    const char* no_q4 = getenv("LT_UNPROJ_NO_Q4");       // A/B, read per call
+    const bool quad = dtype == LT_BF16 && a.C == 32 && (a.NV == 4 || a.NV == 8) && a.bricked && a.agg == LT_AGG_SOFTMAX && !no_q4 &&
+                      (long long)a.NV * a.h * a.w * a.C < (1ll << 30);
+    if (quad) {
+        if (a.NV == 4) {
+            if (grid) hipLaunchKernelGGL((unproject_qn_kernel<1, true>), dim3(nblk), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((unproject_qn_kernel<1, false>), dim3(nblk), dim3(256), 0, st, a);
+        } else {
+            if (grid) hipLaunchKernelGGL((unproject_qn_kernel<2, true>), dim3(nblk), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((unproject_qn_kernel<2, false>), dim3(nblk), dim3(256), 0, st, a);
+        }
+        LT_CHECK_LAUNCH("lt_unproject_fwd(quad)");
+        return LT_OK;
+    }
+    if (grid) {      // no fused kernel for this configuration: materialise the grid (it is a returned tensor anyway), then gather
+        const long long total = (long long)a.B * nvox;
+        const long long blocks = cdiv(total, 256);
+        hipLaunchKernelGGL(coord_volumes_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, a.g_pos, a.g_center, a.g_rot,
+                           a.g_step, a.B, a.v0, a.g_cmu, a.coords_out);
+        LT_CHECK_LAUNCH("lt_unproject_grid_fwd(coords)");
+        a.coords = a.coords_out;
+    }
+    if (dtype == LT_F32) {
+        if (a.C % 4 == 0) return launch_unproject<float, 4>(a, st);
+        return launch_unproject<float, 1>(a, st);
+    }
+    // LDS-staged variant: opt-in (LT_UNPROJ_LDS=1, read per call so that the tests can exercise both).  Measured at the BASELINE
+    // shape (16 samples, 4 views, 96x96x32 maps, 64^3 voxels): 0.90 ms staged vs 0.57 ms gathering -- the 37 MB of feature maps
+    // are L2-resident and the gather keeps 16 independent loads in flight per lane, while the staged copy exposes one load
+    // round trip per workgroup between its two barriers.
+    const char* use_lds = getenv("LT_UNPROJ_LDS");
+    if (a.C == 32 && a.NV <= UP_NV && a.bricked && use_lds && use_lds[0] == '1') {
+        hipLaunchKernelGGL(unproject_lds_kernel, dim3(nblk), dim3(1024), 0, st, a);
+        LT_CHECK_LAUNCH("lt_unproject_fwd(lds)");
+        return LT_OK;
+    }
+    if (a.C % 8 == 0) return launch_unproject<bf16_t, 8>(a, st);
+    return launch_unproject<bf16_t, 1>(a, st);
+}
+}  // namespace
+
 extern "C" int lt_unproject_fwd(int32_t dtype, const void* feats, const float* proj, const float* coords, const float* conf,
                                 void* out, int32_t B, int32_t NV, int32_t C, int32_t h, int32_t w, int32_t v0, int32_t v1,
                                 int32_t v2, int32_t agg, void* stream) {
@@ -569,37 +666,26 @@ extern "C" int lt_unproject_fwd(int32_t dtype, const void* feats, const float* p
     LT_REQUIRE((agg != LT_AGG_CONF && agg != LT_AGG_CONF_NORM) || conf, LT_ERR_INVALID, "lt_unproject_fwd: LT_AGG_CONF* needs confidences");
     LT_REQUIRE(B >= 1 && NV >= 1 && C >= 1 && h >= 2 && w >= 2 && v0 >= 1 && v1 >= 1 && v2 >= 1, LT_ERR_INVALID, "lt_unproject_fwd: bad shape");
     LT_REQUIRE((long long)NV * h * w * C < (1ll << 31), LT_ERR_UNSUPPORTED, "lt_unproject_fwd: feature maps too large");
-    UnprojArgs a;
+    UnprojArgs a = {};
     a.feats = feats; a.proj = proj; a.coords = coords; a.conf = conf; a.out = out;
     a.B = B; a.NV = NV; a.C = C; a.h = h; a.w = w; a.v0 = v0; a.v1 = v1; a.v2 = v2; a.agg = agg;
-    const long long nvox = (long long)v0 * v1 * v2;
-    a.bricked = (v0 % 4 == 0 && v1 % 4 == 0 && v2 % 16 == 0) ? 1 : 0;
-    a.chunks = (int)cdiv(nvox, 256);
-    a.xcd_pin = (B % 8 == 0) ? 1 : 0;
-    LT_REQUIRE((long long)B * a.chunks < (1ll << 31), LT_ERR_UNSUPPORTED, "lt_unproject_fwd: grid too large");
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == LT_F32) {
-        if (C % 4 == 0) return launch_unproject<float, 4>(a, st);
-        return launch_unproject<float, 1>(a, st);
-    }
-    // LDS-staged variant: opt-in (LT_UNPROJ_LDS=1, read per call so that the tests can exercise both).  Measured at the BASELINE
-    // shape (16 samples, 4 views, 96x96x32 maps, 64^3 voxels): 0.90 ms staged vs 0.57 ms gathering -- the 37 MB of feature maps
-    // are L2-resident and the gather keeps 16 independent loads in flight per lane, while the staged copy exposes one load
-    // round trip per workgroup between its two barriers.
-    const char* use_lds = getenv("LT_UNPROJ_LDS");
-    if (C == 32 && NV <= UP_NV && a.bricked && use_lds && use_lds[0] == '1') {
-        hipLaunchKernelGGL(unproject_lds_kernel, dim3((unsigned)((long long)a.B * a.chunks)), dim3(1024), 0, st, a);
-        LT_CHECK_LAUNCH("lt_unproject_fwd(lds)");
-        return LT_OK;
-    }
-    const char* no_q4 = getenv("LT_UNPROJ_NO_Q4");       // A/B, read per call
-    if (C == 32 && NV == 4 && a.bricked && agg == LT_AGG_SOFTMAX && !no_q4 && (long long)4 * h * w * C < (1ll << 30)) {
-        hipLaunchKernelGGL(unproject_q4_kernel, dim3((unsigned)((long long)a.B * a.chunks)), dim3(256), 0, st, a);
-        LT_CHECK_LAUNCH("lt_unproject_fwd(q4)");
-        return LT_OK;
-    }
-    if (C % 8 == 0) return launch_unproject<bf16_t, 8>(a, st);
-    return launch_unproject<bf16_t, 1>(a, st);
+    return unproject_dispatch(a, dtype, false, (hipStream_t)stream);
+}
+
+extern "C" int lt_unproject_grid_fwd(int32_t dtype, const void* feats, const float* proj, const float* pos, const float* center, const float* rot,
+                                     float step, int32_t cmu_transfer, float* coords_out, const float* conf, void* out, int32_t B, int32_t NV,
+                                     int32_t C, int32_t h, int32_t w, int32_t V, int32_t agg, void* stream) {
+    LT_REQUIRE(feats && proj && pos && center && rot && coords_out && out, LT_ERR_INVALID, "lt_unproject_grid_fwd: null argument");
+    LT_REQUIRE(dtype == LT_F32 || dtype == LT_BF16, LT_ERR_INVALID, "lt_unproject_grid_fwd: bad dtype %d", dtype);
+    LT_REQUIRE(agg >= LT_AGG_SUM && agg <= LT_AGG_CONF_NORM, LT_ERR_INVALID, "lt_unproject_grid_fwd: unknown aggregation %d", agg);
+    LT_REQUIRE((agg != LT_AGG_CONF && agg != LT_AGG_CONF_NORM) || conf, LT_ERR_INVALID, "lt_unproject_grid_fwd: LT_AGG_CONF* needs confidences");
+    LT_REQUIRE(B >= 1 && NV >= 1 && C >= 1 && h >= 2 && w >= 2 && V >= 2, LT_ERR_INVALID, "lt_unproject_grid_fwd: bad shape");
+    LT_REQUIRE((long long)NV * h * w * C < (1ll << 31), LT_ERR_UNSUPPORTED, "lt_unproject_grid_fwd: feature maps too large");
+    UnprojArgs a = {};
+    a.feats = feats; a.proj = proj; a.coords = nullptr; a.conf = conf; a.out = out;
+    a.B = B; a.NV = NV; a.C = C; a.h = h; a.w = w; a.v0 = V; a.v1 = V; a.v2 = V; a.agg = agg;
+    a.g_pos = pos; a.g_center = center; a.g_rot = rot; a.g_step = step; a.g_cmu = cmu_transfer; a.coords_out = coords_out;
+    return unproject_dispatch(a, dtype, true, (hipStream_t)stream);
 }
 
 namespace {

@@ -72,6 +72,7 @@ SIGNATURES = {
     "lt_coord_volumes": (C.c_int, [vp, vp, vp, f32, i32, i32, i32, vp, vp]),
     "lt_rotate_points": (C.c_int, [vp, vp, vp, i64, vp]),
     "lt_unproject_fwd": (C.c_int, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "lt_unproject_grid_fwd": (C.c_int, [i32, vp, vp, vp, vp, vp, f32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "lt_softargmax3d_workspace": (C.c_size_t, [i32, i32, i64]),
     "lt_softargmax3d_fwd": (C.c_int, [vp, vp, f32, i32, i32, i32, vp, vp, i32, i32, i64, vp, vp]),
     "lt_softargmax2d_fwd": (C.c_int, [vp, f32, i32, vp, vp, i32, i32, i32, vp]),

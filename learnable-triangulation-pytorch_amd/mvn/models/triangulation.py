@@ -124,19 +124,21 @@ class VolumetricTriangulationNet(_PlannedNet):
         step = float(np.float32(self.cuboid_side / (V - 1)))
         gp = geo.data_ptr()
         cmu = int(bool(self.transfer_cmu_to_human36m))
-        b.custom(lambda st: H.check(lib.lt_coord_volumes(gp + 4 * o_pos, gp + 4 * o_cen, gp + 4 * o_rot, step, B, V, cmu,
-                                                         coords.data_ptr(), st), "lt_coord_volumes"),
-                 "coord_volumes", nbytes=B * V ** 3 * 12, info={"geo": geo, "offs": (o_pos, o_cen, o_rot), "step": step, "cmu": cmu, "coords": coords})
         conf = None
         if volc is not None:
-            conf = volc.t.reshape(B, NV, 32)   # 'conf_norm' is normalised inside lt_unproject_fwd (LT_AGG_CONF_NORM)
+            conf = volc.t.reshape(B, NV, 32)   # 'conf_norm' is normalised inside the kernel (LT_AGG_CONF_NORM)
         vol = b.alloc((B, V, V, V, 32))
         esz = torch.empty((), dtype=dt).element_size()
         agg = H.AGG[self.volume_aggregation_method]
-        b.custom(lambda st: H.check(lib.lt_unproject_fwd(b.code, feats.t.data_ptr(), gp, coords.data_ptr(), H.ptr(conf), vol.t.data_ptr(),
-                                                         B, NV, 32, h, w, V, V, V, agg, st), "lt_unproject_fwd"),
-                 "unproject", nbytes=(B * NV * h * w * 32 + B * V ** 3 * 32) * esz,  # read feats once + write volume once
-                 info={"feats": feats, "geo": geo, "coords": coords, "conf": conf, "vol": vol, "agg": self.volume_aggregation_method, "NV": NV})
+        # ONE launch: the voxel centres are computed in registers from (position, centre, rotation, step) and written to the returned
+        # coordinate tensor on the way (reference :298-339 + op.py:99-166); configurations without a fused kernel run
+        # lt_coord_volumes + the generic gather inside the same call
+        b.custom(lambda st: H.check(lib.lt_unproject_grid_fwd(b.code, feats.t.data_ptr(), gp, gp + 4 * o_pos, gp + 4 * o_cen, gp + 4 * o_rot, step, cmu,
+                                                              coords.data_ptr(), H.ptr(conf), vol.t.data_ptr(), B, NV, 32, h, w, V, agg, st),
+                                    "lt_unproject_grid_fwd"),
+                 "unproject", nbytes=(B * NV * h * w * 32 + B * V ** 3 * 32) * esz + B * V ** 3 * 12,   # feats once + volume once + the returned coords
+                 info={"feats": feats, "geo": geo, "coords": coords, "conf": conf, "vol": vol, "agg": self.volume_aggregation_method, "NV": NV,
+                       "offs": (o_pos, o_cen, o_rot), "step": step, "cmu": cmu})
         logits = self.volume_net.record(b, vol)
         kp = torch.empty(B, J, 3, dtype=torch.float32, device=device)
         probs = torch.empty(B, J, V, V, V, dtype=torch.float32, device=device)

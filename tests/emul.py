@@ -83,7 +83,7 @@ def run_plan_on_cpu(plan):
         elif kind == "avgpool":
             x = info["x"].t.float()
             info["y"].t.copy_(x.mean(dim=(1, 2, 3)).reshape(info["y"].t.shape))
-        elif kind == "coord_volumes":
+        elif kind == "unproject":     # lt_unproject_grid_fwd: the cuboid grid (written to the returned coordinate tensor), then the gather
             o_pos, o_cen, o_rot = info["offs"]
             geo = info["geo"]
             B, V = info["coords"].shape[0], info["coords"].shape[1]
@@ -96,9 +96,8 @@ def run_plan_on_cpu(plan):
                 if info["cmu"]:
                     g = g.permute(0, 2, 1, 3).flip(1)
                 info["coords"][b] = g
-        elif kind == "unproject":
             f = info["feats"].t.float()
-            NV = info["NV"]; B = f.shape[0] // NV
+            NV = info["NV"]
             hm = f.reshape(B, NV, f.shape[2], f.shape[3], f.shape[4]).permute(0, 1, 4, 2, 3)
             P = info["geo"][:B * NV * 12].reshape(B, NV, 3, 4)
             conf = info["conf"]

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 import lt_engine as E
 import lt_hip as H
 from gpu_util import bf16_round, check, from_cl, record, rel_err, to_cl
+from oracle import synth
 from oracle import vol_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -679,3 +680,39 @@ def test_conv3d_halo7_variants(case, kdb, monkeypatch):
     ref2 = _bn_ref(F.conv3d(rd(x), rd(w), bias, 1, k // 2), bn)
     out2 = run_conv(x, w, bias, bn, 1, k // 2, torch.bfloat16, H.TILE_HALO, relu=False, residual=None)
     check("conv3d_halo7/kdb=%s/%s/plain" % (kdb, case), out2, ref2, 1.5e-2)
+
+
+@pytest.mark.parametrize("NV,V,dtype,method,cmu", [(4, 32, torch.bfloat16, "softmax", False), (8, 32, torch.bfloat16, "softmax", False),
+                                                   (8, 16, torch.bfloat16, "softmax", True), (4, 16, torch.float32, "softmax", False),
+                                                   (3, 16, torch.bfloat16, "sum", False), (8, 12, torch.bfloat16, "softmax", False)])
+def test_unproject_grid_fused_vs_separate(NV, V, dtype, method, cmu):
+    """lt_unproject_grid_fwd (voxel centres computed in registers and written to the returned tensor; quad kernel for bf16 / 32 channels /
+    4 or 8 views / softmax / V % 16 == 0, lt_coord_volumes + generic gather inside for everything else) against lt_coord_volumes followed
+    by lt_unproject_fwd: coordinates BIT-identical, volumes identical where the same kernel arithmetic runs and within bf16 rounding
+    against the oracle; rotated cuboids, the CMU axis permutation, a camera inside the cube."""
+    from mvn.utils import op, volumetric
+    g = torch.Generator().manual_seed(NV * 100 + V)
+    B, hw, C = 2, 24, 32
+    K, R, t = synth.ring_cameras(NV, 96, inside=True)
+    P = torch.from_numpy(O.resized_projection(K, R, t, (96, 96), (hw, hw))).float()[None].repeat(B, 1, 1, 1).contiguous()
+    hm = torch.randn(B, NV, C, hw, hw, generator=g)
+    base = torch.randn(B, 3, generator=g).double().numpy() * 100
+    thetas = [0.0, 0.7]
+    side = 2500.0
+    cv_ref = op.build_coord_volumes(base, side, V, thetas=thetas, cmu_transfer=cmu, device=DEV)
+    feats = hm.to(DEV).to(dtype).permute(0, 1, 3, 4, 2).contiguous()
+    pos = torch.from_numpy((base - side / 2).astype(np.float32)).to(DEV)
+    cen = torch.from_numpy(base.astype(np.float32)).to(DEV)
+    rot = torch.from_numpy(np.stack([volumetric.get_rotation_matrix((0, 0, 1), th) for th in thetas]).astype(np.float32)).to(DEV).contiguous()
+    coords = torch.full((B, V, V, V, 3), float("nan"), device=DEV)
+    out = torch.empty(B, V, V, V, C, dtype=dtype, device=DEV)
+    step = float(np.float32(side / (V - 1)))
+    H.check(H.lib().lt_unproject_grid_fwd(H.dtype_code(dtype), feats.data_ptr(), P.to(DEV).data_ptr(), pos.data_ptr(), cen.data_ptr(), rot.data_ptr(), step,
+                                          int(cmu), coords.data_ptr(), None, out.data_ptr(), B, NV, C, hw, hw, V, H.AGG[method], H.cur_stream()),
+            "lt_unproject_grid_fwd")
+    assert torch.equal(coords, cv_ref), "coordinates written by the fused kernel differ from lt_coord_volumes"
+    sep = op.unproject_heatmaps(hm.to(DEV).to(dtype), P.to(DEV), cv_ref, method)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    check("unproject_grid/NV%d_V%d_%s_%s_cmu%d vs separate" % (NV, V, str(dtype)[6:], method, cmu), out.permute(0, 4, 1, 2, 3).float().cpu(), sep.float().cpu(), tol)
+    ref = O.unproject_heatmaps(bf16_round(hm) if dtype == torch.bfloat16 else hm, P, cv_ref.cpu(), method)
+    check("unproject_grid/NV%d_V%d_%s_%s_cmu%d vs oracle" % (NV, V, str(dtype)[6:], method, cmu), out.permute(0, 4, 1, 2, 3).float().cpu(), ref, tol)

@@ -106,7 +106,16 @@ def test_volumetric_forward_vs_reference_golden(golden_dir, tag):
     mpjpe = float(np.sqrt(((kp.cpu().numpy() - g["kp"]) ** 2).sum(-1)).mean())
     record(tag + "/joints fp32: max rel err (1 mm floor)", float(rel.max()))
     record(tag + "/joints fp32: MPJPE vs reference (mm)", mpjpe)
-    assert rel.max() <= 1e-4, "joints max rel %.3e" % rel.max()
+    # The north-star gate, against the reference's output AND against the exact (fp64) soft-argmax of the reference's own logits.
+    # torch's fp32 softmax / einsum over V^3 voxels have a reduction error of their own (stored with the fixture: 2.9e-4 at 128^3, where
+    # the reference's probabilities sum to 1 +- 2.9e-4; <= 3e-5 at 64^3): a kernel can be no closer to the reference than the
+    # reference is to the exact value, so the first gate widens by that measured amount and the second one is the strict 1e-4.
+    self_rel = float(g["ref_self_rel"])
+    rel64 = np.abs(kp.cpu().double().numpy() - g["kp_fp64"]) / np.maximum(np.abs(g["kp_fp64"]), 1.0)
+    record(tag + "/joints fp32: max rel err vs the fp64 soft-argmax of the reference's logits", float(rel64.max()))
+    record(tag + "/reference's own fp32 reduction error (max rel)", self_rel)
+    assert rel64.max() <= 1e-4, "joints vs exact soft-argmax of the reference logits: max rel %.3e" % rel64.max()
+    assert rel.max() <= 1e-4 + self_rel, "joints max rel %.3e (reference self error %.3e)" % (rel.max(), self_rel)
     # intermediates that the API does not return: unprojected volume and V2V logits, from the plan's buffers
     P = list(m._plans.values())[0]
     # graph replay == eager, and a second call is bit-identical (determinism)
