@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=0, help="samples per GPU per step (default 32; 8 for 128^3 volumes)")
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU per step (default 32; 16 for 128^3 volumes: 128 images fill the 256 CUs with 288-row tiles)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--image", type=int, default=384)
@@ -205,7 +205,7 @@ def main():
     ap.add_argument("--stub-cpu", action="store_true", help="TEST ONLY: gloo backend, no GPU, step() is a sleep (exercises launcher + timing plumbing)")
     args = ap.parse_args()
     if not args.batch:
-        args.batch = 8 if args.volume >= 128 else 32
+        args.batch = 16 if args.volume >= 128 else 32
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)       # does not return

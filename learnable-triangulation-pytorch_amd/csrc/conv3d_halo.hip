@@ -2102,20 +2102,12 @@ int launch_halo7(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<bf16_t, 7, 32, 16, 4, 8, 8, 7, 4> C;
     constexpr int LDS = C::HALO_BYTES + 5 * C::WCH;
     auto kern = conv3d_halo7_kernel<bf16_t>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
     const long long nblk = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
     const char* kdb = getenv("LT_HALO_7B");              // kd-register-blocked variant: default; LT_HALO_7B=0 selects the tap-major kernel
     if (!kdb || kdb[0] != '0') {                         // (read per call: the tests run both)
         auto kern_b = conv3d_halo7b_kernel<bf16_t>;
-        static bool attr_b = false;
-        if (!attr_b) {
-            (void)hipFuncSetAttribute((const void*)kern_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_b = true;
-        }
+        LT_OPT_IN_LDS(kern_b, 160 * 1024);
         hipLaunchKernelGGL(kern_b, dim3((unsigned)nblk), dim3(512), LDS, s, a);
         LT_CHECK_LAUNCH("lt_conv_fwd(halo 7^3, kd-blocked)");
         return LT_OK;
@@ -2132,17 +2124,8 @@ int launch_halo_persist(const HaloArgs& a, hipStream_t s) {
     constexpr int LDS = W_BYTES + 2 * C::HALO_BYTES;
     static_assert(LDS <= 160 * 1024, "weights + two halo buffers do not fit LDS");
     auto kern = conv3d_halo_persist_kernel<T, CIN, CP>;
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-        n_cu -= n_cu % 8;   // the tile dealing assumes workgroup b runs on XCD b % 8
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
+    const int n_cu = lt::device_cu_count8();
     const long long total = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
     const int grid = (int)(total < n_cu ? total - total % 8 : n_cu);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, (int)total);
@@ -2155,11 +2138,7 @@ int launch_halo_wreg(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<T, 3, CIN, CP, 4, 8, 8, 3, 3> C;
     static_assert(C::HALO_BYTES <= 160 * 1024, "the halo must fit LDS");
     auto kern = conv3d_halo_wreg_kernel<T, CIN, CP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
     const long long nblk = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), C::HALO_BYTES, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(halo, weights from registers)");
@@ -2172,17 +2151,8 @@ int launch_halo_col(const HaloArgs& a, hipStream_t s) {
     constexpr int W_BYTES = ((C::NTAPS * C::SLAB + 1023) / 1024) * 1024;
     constexpr int LDS = W_BYTES + 4 * 4 * C::HH * C::PW * C::CINB;
     auto kern = conv3d_halo_col_kernel<T>;
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-        n_cu -= n_cu % 8;   // the column dealing assumes workgroup b runs on XCD b % 8
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
+    const int n_cu = lt::device_cu_count8();
     const int total_cols = a.N * a.tiles_h * a.tiles_w;  // % 8 == 0 (checked by the caller)
     const int grid = total_cols < n_cu ? total_cols : n_cu;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, total_cols);
@@ -2195,11 +2165,7 @@ int launch_halo(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF> C;
     static_assert(C::LDS_BYTES <= 160 * 1024, "halo tile does not fit LDS");
     auto kern = conv3d_halo_kernel<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF, PD, LDR>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
     const long long nblk = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(LDR ? 512 : 256), C::LDS_BYTES, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(halo)");
@@ -2226,11 +2192,7 @@ int conv2d_band_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, hipS
     a.x = c.x; a.wfrag = p0.wfrag_t; a.y = c.y; a.res = c.res; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
     a.N = c.N; a.H = c.H; a.W = c.W; a.ldc = c.ldc; a.flags = c.flags; a.bands = c.H / 12;
     auto kern = conv2d_band_kernel<bf16_t>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * 2)), dim3(512), 2 * 47104, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(2D band)");
     return 1;

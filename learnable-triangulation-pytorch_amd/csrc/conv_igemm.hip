@@ -245,11 +245,7 @@ int launch(ConvArgs a, int cout_pad, int nphase, int max_taps, hipStream_t s) {
     LT_REQUIRE(nblk < (1ll << 31), LT_ERR_INVALID, "lt_conv_fwd: grid too large");
     const size_t lds = 2 * (BM + BN) * ROW_BYTES + BM * sizeof(int) + (size_t)max_taps * sizeof(int4);
     auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, MF>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, nphase), dim3(256), lds, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd");
     return LT_OK;

@@ -574,11 +574,7 @@ int launch2(ConvArgs a, int cout_pad, int nphase, int max_taps, hipStream_t s) {
     const size_t lds = REGION + BM * sizeof(int) + (size_t)max_taps * sizeof(int4);
     LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: tile needs %zu B of LDS", lds);
     auto kern = conv_igemm2_kernel<T, BM, BN, WM, WN, MF, NST, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, nphase), dim3(256), lds, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(v2)");
     return LT_OK;

@@ -702,11 +702,7 @@ int launch4(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
     const size_t lds = 3 * (size_t)(BM3 + 128) * ROW_BYTES + (size_t)max_taps * sizeof(int4);
     LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: 288-row tile needs %zu B of LDS", lds);
     auto kern = conv_igemm4_kernel<MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(v4)");
     return LT_OK;
@@ -1348,11 +1344,7 @@ int launch6(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
     const size_t lds = LT6_NST * (size_t)(144 * NWM) * 64 + (size_t)max_taps * sizeof(int4);
     LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: 288x256 tile needs %zu B of LDS", lds);
     auto kern = conv_igemm6_kernel<MODE, NWM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256 * NWM), lds, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(v6)");
     return LT_OK;
@@ -1366,11 +1358,7 @@ int launch5(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
     const size_t lds = 4 * (size_t)(BM3 + 256) * 64 + (size_t)max_taps * sizeof(int4);
     LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: 288x256 tile needs %zu B of LDS", lds);
     auto kern = conv_igemm5_kernel<MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(v5)");
     return LT_OK;
@@ -1384,11 +1372,7 @@ int launch3(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
     const size_t lds = 3 * (size_t)(BM3 + BN) * ROW_BYTES + (size_t)max_taps * sizeof(int4);
     LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: 288-row tile needs %zu B of LDS", lds);
     auto kern = conv_igemm3_kernel<BN, MODE, NWM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256 * NWM), lds, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(v3)");
     return LT_OK;

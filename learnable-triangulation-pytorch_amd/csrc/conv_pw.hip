@@ -157,11 +157,7 @@ template <int KB, int NB>
 int launch_pw(const PwArgs& a, hipStream_t s) {
     auto kern = conv_pw_kernel<KB, NB>;
     const size_t lds = (size_t)a.nphase * NB * KB * 64 * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_set = true;
-    }
+    LT_OPT_IN_LDS(kern, 64 * 1024);
     long long blocks = (a.ntile + 3) / 4;
     if (blocks > 1024) blocks = 1024;                    // several tiles per wave: the weight staging is amortised
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, a);

@@ -1,6 +1,8 @@
 // Shared host/device helpers for liblt_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -28,6 +30,26 @@ void set_error(const char* fmt, ...);
             return LT_ERR_LAUNCH;                                                        \
         }                                                                                \
     } while (0)
+
+// Large dynamic LDS is an opt-in per kernel function AND per device: remembered per call site in a bitmask over the device ids
+// (a process-wide bool left every device but the first without the attribute: launches needing > 64 KB failed there), the return
+// code checked.  Cheap enough for the recording / eager paths (hipGetDevice); graph replays do not come through here.
+int current_device();
+#define LT_OPT_IN_LDS(kern, bytes)                                                                                  \
+    do {                                                                                                            \
+        static std::atomic<unsigned long long> done_{0};                                                            \
+        const unsigned long long bit_ = 1ull << (lt::current_device() & 63);                                        \
+        if (!(done_.load(std::memory_order_acquire) & bit_)) {                                                      \
+            hipError_t e_ = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
+            if (e_ != hipSuccess) {                                                                                 \
+                lt::set_error("hipFuncSetAttribute(max dynamic LDS %d): %s", (int)(bytes), hipGetErrorString(e_));  \
+                return LT_ERR_LAUNCH;                                                                               \
+            }                                                                                                       \
+            done_.fetch_or(bit_, std::memory_order_release);                                                        \
+        }                                                                                                           \
+    } while (0)
+// compute units of the current device, rounded down to a multiple of 8 (XCDs); cached per device id
+int device_cu_count8();
 
 typedef unsigned short bf16_t;  // raw bf16 bits
 

@@ -148,12 +148,10 @@ extern "C" int lt_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32
     const size_t lds = (size_t)64 * (C + 1) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == LT_F32) {
-        static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute((const void*)nhwc_to_nchw_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        LT_OPT_IN_LDS(nhwc_to_nchw_kernel<float>, 160 * 1024);
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, (const float*)x, y, N, C, HW, ld);
     } else if (dtype == LT_BF16) {
-        static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute((const void*)nhwc_to_nchw_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        LT_OPT_IN_LDS(nhwc_to_nchw_kernel<bf16_t>, 160 * 1024);
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), lds, st, (const bf16_t*)x, y, N, C, HW, ld);
     } else LT_REQUIRE(false, LT_ERR_INVALID, "lt_nhwc_to_nchw_f32: bad dtype");
     LT_CHECK_LAUNCH("lt_nhwc_to_nchw_f32");

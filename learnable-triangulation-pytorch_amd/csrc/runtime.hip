@@ -11,6 +11,24 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev;
+}
+int device_cu_count8() {
+    static std::atomic<int> cache[64];
+    const int dev = current_device() & 63;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        hipDeviceProp_t prop;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+        if (n <= 0) n = 256;
+        n -= n % 8;   // the tile dealing of the persistent kernels assumes workgroup b runs on XCD b % 8
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
 }  // namespace lt
 
 using namespace lt;
