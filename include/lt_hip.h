@@ -110,6 +110,9 @@ int lt_conv_pack_weights(const void* weight, int32_t cout_pad, int32_t k_pad, vo
  * lt_conv_phase.weight_frag_layout says which of the two orders weight_frag holds; a kernel only uses the one it was written for. */
 int lt_conv_pack_weights_t32(const void* weight, int32_t cout_pad, int32_t k_pad, int32_t cin, int32_t ntaps, void* packed,
                              void* stream);
+/* B-fragment order of the 32x32x16 MFMA (layout 3, conv_igemm7): [k_pad / 32][cout_pad / 32][2 K halves][64 lanes][8]; lane l of
+ * fragment (step, block, kk) holds column 32 block + (l & 31), K elements 32 step + 16 kk + 8 (l >> 5) .. + 7.  cout_pad % 32 == 0. */
+int lt_conv_pack_weights32(const void* weight, int32_t cout_pad, int32_t k_pad, void* packed, void* stream);
 
 enum { LT_TILE_AUTO = 0,
        /* v1: register-staged tiles (kept for A/B runs and as a cross-check) */

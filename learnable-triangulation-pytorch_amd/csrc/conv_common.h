@@ -13,6 +13,7 @@ struct PhaseArg {
     const void* w;
     const void* wfrag;   // the same weights in MFMA B-fragment order (lt_conv_pack_weights, layout 1), or null
     const void* wfrag_t; // ... in the order of the transposed product (lt_conv_pack_weights_t32, layout 2), or null
+    const void* wfrag32; // ... in B-fragment order of the 32x32x16 MFMA (lt_conv_pack_weights32, layout 3), or null
     const int4* taps;
     int ntaps;
     int ood, ooh, oow;
@@ -90,6 +91,8 @@ constexpr int LT_EPI_NO_XCD_REMAP = 1 << 17;      // internal A/B switch (env LT
 int conv2_dispatch(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile, hipStream_t s);
 // conv_igemm3.hip (288-row tile, 8 waves): 1 = launched, 0 = not applicable (fall back), < 0 = error
 int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, bool forced, hipStream_t s);
+// conv_igemm7.hip (288 x 256 tile on 32x32x16 MFMAs, weights in layout 3): 1 / 0 / < 0 as above
+int conv7_try(const ConvArgs& a, int cout_pad, int max_taps, bool pw, hipStream_t s);
 // conv_pw.hip (streaming kernel for single-tap phases: 1x1x1 convs, 2x2x2 stride-2 deconvs): 1 / 0 / < 0 as above
 int conv_pw_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, hipStream_t s);
 // conv3d_halo.hip: 1 = launched, 0 = not applicable (fall back), < 0 = error

@@ -348,7 +348,8 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bi
         LT_REQUIRE(ph.weight && ph.taps && ph.ntaps >= 1, LT_ERR_INVALID, "lt_conv_fwd: phase %d incomplete", p);
         LT_REQUIRE((long long)ph.ntaps * d->Cin <= d->k_pad, LT_ERR_INVALID, "lt_conv_fwd: phase %d: ntaps*Cin > k_pad", p);
         a.phase[p].w = ph.weight; a.phase[p].wfrag = ph.weight_frag_layout == 1 ? ph.weight_frag : nullptr;
-        a.phase[p].wfrag_t = ph.weight_frag_layout == 2 ? ph.weight_frag : nullptr; a.phase[p].taps = (const int4*)ph.taps; a.phase[p].ntaps = ph.ntaps;
+        a.phase[p].wfrag_t = ph.weight_frag_layout == 2 ? ph.weight_frag : nullptr;
+        a.phase[p].wfrag32 = ph.weight_frag_layout == 3 ? ph.weight_frag : nullptr; a.phase[p].taps = (const int4*)ph.taps; a.phase[p].ntaps = ph.ntaps;
         a.phase[p].ood = ph.out_off[0]; a.phase[p].ooh = ph.out_off[1]; a.phase[p].oow = ph.out_off[2];
         if (ph.ntaps > max_taps) max_taps = ph.ntaps;
     }

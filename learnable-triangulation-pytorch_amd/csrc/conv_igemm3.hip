@@ -1421,6 +1421,10 @@ int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_ta
                              a.osh == 1 && a.osw == 1 && q0.ood == 0 && q0.ooh == 0 && q0.oow == 0 && a.OD == a.Do && a.OH == a.Ho &&
                              a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
             const char* no6 = getenv("LT_CONV_NO_V6");   // A/B, read per call
+            if (q0.wfrag32 && a.k_pad % 64 == 0) {       // weights packed for the 32x32x16 MFMA (plan built with LT_CONV_V7=1): conv_igemm7
+                const int rc7 = conv7_try(a, cout_pad, max_taps, pw5, s);
+                if (rc7 != 0) return rc7;
+            }
             if (q0.wfrag && !no6 && a.k_pad % 64 == 0) {  // weights also available in fragment order: B operand from registers
                 // short-K pointwise layers (the 1x1 expands): 144-row tiles, two workgroups per CU (LT_CONV_V6_BM144=0/1 forces it off/on)
                 const char* e144 = getenv("LT_CONV_V6_BM144");

@@ -285,10 +285,21 @@ class PlanBuilder:
                 d.phase[i].weight_frag, d.phase[i].weight_frag_layout = wfr.data_ptr(), 2
             elif self.dtype == torch.bfloat16 and not self.dry_run and spec.cout_pad % 256 == 0 and spec.k_pad % 64 == 0:
                 wfr = torch.empty_like(wdev)
-                H.check(H.lib().lt_conv_pack_weights(wdev.data_ptr(), spec.cout_pad, spec.k_pad, wfr.data_ptr(), H.cur_stream()),
-                        "lt_conv_pack_weights")
+                # the 288-row layers get their weights in the fragment order of the 32x32x16 MFMA (conv_igemm7: +1 % end to end over
+                # conv_igemm6, 3x3 256->256 90.8 -> 87.4 us, 1x1 1024->256 50.9 -> 48.2 us inside the forward; LT_CONV_NO_V7=1 when the
+                # plan is built keeps conv_igemm6); the short-K pointwise layers stay on the 144-row variant of conv_igemm6 and its
+                # 16x16x32 order (measured: conv_igemm7 103.6 vs 85.6 us on 256->1024)
+                short_pw = all(k == 1 for k in weight.shape[2:]) and spec.k_pad <= 256 and not transposed
+                if os.environ.get("LT_CONV_NO_V7") != "1" and not short_pw:
+                    H.check(H.lib().lt_conv_pack_weights32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, wfr.data_ptr(), H.cur_stream()),
+                            "lt_conv_pack_weights32")
+                    layout = 3
+                else:
+                    H.check(H.lib().lt_conv_pack_weights(wdev.data_ptr(), spec.cout_pad, spec.k_pad, wfr.data_ptr(), H.cur_stream()),
+                            "lt_conv_pack_weights")
+                    layout = 1
                 self.keep.append(wfr)
-                d.phase[i].weight_frag, d.phase[i].weight_frag_layout = wfr.data_ptr(), 1
+                d.phase[i].weight_frag, d.phase[i].weight_frag_layout = wfr.data_ptr(), layout
             elif (self.dtype == torch.bfloat16 and not self.dry_run and not transposed and x.shape[-1] == weight.shape[1]
                   and tuple(weight.shape) in ((64, 64, 3, 3, 3), (64, 32, 3, 3, 3), (128, 128, 3, 3, 3))
                   and spec.stride == (1, 1, 1) and spec.pad == (1, 1, 1)):

@@ -61,6 +61,7 @@ SIGNATURES = {
     "lt_conv_cout_pad": (C.c_int, [i32]),
     "lt_conv_pack_weights": (C.c_int, [vp, i32, i32, vp, vp]),
     "lt_conv_pack_weights_t32": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
+    "lt_conv_pack_weights32": (C.c_int, [vp, i32, i32, vp, vp]),
     "lt_pwchain_fwd": (C.c_int, [C.POINTER(PwChainDesc), vp, vp, vp]),
     "lt_stem_pool_fwd": (C.c_int, [C.POINTER(StemDesc), vp, vp, vp]),
     "lt_stem_packed_bytes": (C.c_size_t, []),

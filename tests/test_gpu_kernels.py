@@ -565,7 +565,7 @@ V5_CASES = {  # name: (nd, N, cin, cout, k, stride, pad, spatial, residual)
 }
 
 
-@pytest.mark.parametrize("bsrc", ["registers", "registers_144", "lds"])
+@pytest.mark.parametrize("bsrc", ["registers", "registers_144", "lds", "v7_mfma32"])
 @pytest.mark.parametrize("case", list(V5_CASES))
 def test_conv_v5_288x256(case, bsrc, monkeypatch):
     """288x256 tile / 32-element K steps (Cout % 256 == 0), forced with LT_CONV_V5=1, vs torch (bf16): conv_igemm6 (weights read
@@ -576,6 +576,10 @@ def test_conv_v5_288x256(case, bsrc, monkeypatch):
     else:
         monkeypatch.delenv("LT_CONV_NO_V6", raising=False)
     monkeypatch.setenv("LT_CONV_V6_BM144", "1" if bsrc == "registers_144" else "0")   # 144-row tiles, two workgroups per CU
+    if bsrc == "v7_mfma32":     # conv_igemm7 (default): the same tile on 32x32x16 MFMAs (weights packed by lt_conv_pack_weights32 when the plan is built)
+        monkeypatch.delenv("LT_CONV_NO_V7", raising=False)
+    else:
+        monkeypatch.setenv("LT_CONV_NO_V7", "1")
     nd, N, cin, cout, k, s, p, sp, with_res = V5_CASES[case]
     g = torch.Generator().manual_seed(len(case) * 5 + cin)
     x = torch.randn(N, cin, *sp, generator=g)
@@ -593,7 +597,7 @@ def test_conv_v5_288x256(case, bsrc, monkeypatch):
     check("conv_v5/%s/relu_pre" % case, out3, ref3, 1.5e-2)
 
 
-@pytest.mark.parametrize("bsrc", ["registers", "lds"])
+@pytest.mark.parametrize("bsrc", ["registers", "lds", "v7_mfma32"])
 def test_deconv4x4_phases_288x256(bsrc, monkeypatch):
     """ConvTranspose2d 4x4 / stride 2 / pad 1 (the backbone's deconv head) through the 288x256 kernels: every output parity is one
     launch of the single-phase kernel (conv3_try loops over the phases); vs torch and vs the implicit GEMM that took all phases."""
@@ -602,6 +606,10 @@ def test_deconv4x4_phases_288x256(bsrc, monkeypatch):
         monkeypatch.setenv("LT_CONV_NO_V6", "1")
     else:
         monkeypatch.delenv("LT_CONV_NO_V6", raising=False)
+    if bsrc == "v7_mfma32":
+        monkeypatch.delenv("LT_CONV_NO_V7", raising=False)
+    else:
+        monkeypatch.setenv("LT_CONV_NO_V7", "1")
     g = torch.Generator().manual_seed(77)
     x = torch.randn(3, 256, 12, 12, generator=g)
     w = torch.randn(256, 256, 4, 4, generator=g) * (1.0 / (256 * 4) ** 0.5)
