@@ -231,6 +231,39 @@ size_t lt_bn_stats_workspace(int64_t rows, int32_t C);
 int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32_t C, float* mean, float* var, float* running_mean,
                     float* running_var, float momentum, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training step around the convolutions (fp32, channels-last rows x C): the reference's modules in training mode
+ * (train.py:233-243: zero_grad / backward / step) -- see lt_train.py for the tape that strings them together.
+ * lt_bn_act_fwd : z = act(gamma (y - mean) / sqrt(var + eps) + beta, residual) with lt_conv_fwd's LT_EPI_RELU_* flags; mean / var
+ *   from lt_bn_stats_fwd (batch statistics).  C % 4 == 0.
+ * lt_bn_act_bwd : its autograd: g = dz * relu mask; dbeta = sum g; dgamma = sum g x^; dy = gamma invstd (g - dbeta/n - x^ dgamma/n);
+ *   dres (may be NULL) = the residual input's gradient, added to the buffer when accumulate_res.  workspace: lt_bn_act_bwd_workspace.
+ * lt_act_bwd    : layers without BatchNorm: dy = dz * mask(z, residual, flags) (+ dres).
+ * lt_channel_sum: out[c] (+)= sum over rows of x[row][c] (bias gradients), fp64 accumulation.
+ * lt_maxpool_bwd: dx (pre-zeroed / accumulated) += dy at the first maximal element of every window (atomics).
+ * lt_conv_wgrad : dw[co][tap * Cin + ci] (=|+=) sum_m dy[m][co] * x[m @ tap][ci] over the GEMM rows m = (n, od, oh, ow) of the forward
+ *   convolution described by (N, D, H, W, Cin, Do, Ho, Wo, stride, pad, taps); exact-fp32 MFMA, no atomics.  For a transposed convolution
+ *   swap the roles (dy := the layer's INPUT at its own resolution, x := the output gradient, stride 2): dw[ci][tap * Cout + co].
+ * lt_adam_step  : torch.optim.Adam's single-tensor update (bias-corrected, eps outside the sqrt).
+ * -------------------------------------------------------------------------------------------*/
+int lt_bn_act_fwd(const float* y, const float* mean, const float* var, const float* gamma, const float* beta, const float* residual, float* z,
+                  int64_t rows, int32_t C, float eps, int32_t flags, void* stream);
+size_t lt_bn_act_bwd_workspace(int64_t rows, int32_t C);
+int lt_bn_act_bwd(const float* dz, const float* y, const float* residual, const float* mean, const float* var, const float* gamma, const float* beta,
+                  float* dy, float* dgamma, float* dbeta, float* dres, int32_t accumulate_res, int64_t rows, int32_t C, float eps, int32_t flags,
+                  void* workspace, void* stream);
+int lt_act_bwd(const float* dz, const float* z, const float* residual, float* dy, float* dres, int32_t accumulate_res, int64_t total, int32_t flags,
+               void* stream);
+size_t lt_channel_sum_workspace(int64_t rows, int32_t C);
+int lt_channel_sum(const float* x, int64_t rows, int32_t C, float* out, int32_t accumulate, void* workspace, void* stream);
+int lt_maxpool_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, const int32_t k[3],
+                   const int32_t s[3], const int32_t p[3], void* stream);
+int lt_conv_wgrad(const float* dy, const float* x, const int32_t* taps, float* dw, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin, int32_t Do,
+                  int32_t Ho, int32_t Wo, const int32_t stride[3], const int32_t pad[3], int32_t Cout, int32_t ldy, int32_t cout_pad, int32_t k_pad,
+                  int32_t ntaps, int32_t accumulate, void* stream);
+int lt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int32_t step, void* stream);
+
 /* multiview.triangulate_batch_of_points (mvn/utils/multiview.py:141-183): confidence-weighted DLT.
  * proj B,NV,3,4; points B,NV,J,2; conf B,NV,J or NULL; out B,J,3.  Smallest right singular vector
  * of the (2NV x 4) system by Jacobi eigen-iteration on A^T A in fp64. */

@@ -91,7 +91,7 @@ def _pad_k(wk, cout_pad, k_pad):
     return out
 
 
-def make_conv_spec(weight, bias, bn, in_shape, stride, pad, dtype, transposed=False, flags=0):
+def make_conv_spec(weight, bias, bn, in_shape, stride, pad, dtype, transposed=False, flags=0, output_padding=0):
     """Build the lt_conv_fwd description of one (transposed) convolution layer.
 
     weight: Conv{2,3}d [Cout,Cin,*k] or ConvTranspose{2,3}d [Cin,Cout,*k] (stride 2 only);
@@ -136,8 +136,8 @@ def make_conv_spec(weight, bias, bn, in_shape, stride, pad, dtype, transposed=Fa
         if not nd3 and i == 0:
             outs.append(1)
         else:
-            o = (dims[i] - 1) * 2 - 2 * pd[i] + ks[i]
-            assert o == 2 * dims[i], "transposed conv must exactly double the size (k=4,p=1 or k=2,p=0)"
+            o = (dims[i] - 1) * 2 - 2 * pd[i] + ks[i] + output_padding
+            assert o == 2 * dims[i], "transposed conv must exactly double the size (k=4,p=1 / k=2,p=0; with output_padding=1: k=3,p=1 / k=1,p=0 -- the input gradients of the stride-2 convolutions)"
             outs.append(o)
     cp = cout_pad_of(cout)
 
@@ -160,6 +160,8 @@ def make_conv_spec(weight, bias, bn, in_shape, stride, pad, dtype, transposed=Fa
                         for (kc, dc) in tc:
                             taps.append((da, db, dc, ((da * Hh + db) * W + dc) * cin))
                             cols.append(w[:, :, ka, kb, kc].t())  # [cout, cin]
+                if not taps:      # an output parity no tap reaches (1x1 / stride 2: the odd positions): one tap with zero weights writes the zeros
+                    taps, cols = [(0, 0, 0, 0)], [torch.zeros(cout, cin)]
                 wk = torch.cat(cols, dim=1)
                 phase_list.append((wk, taps, (pa, pb, pc)))
                 ntaps_max = max(ntaps_max, len(taps))
@@ -245,11 +247,11 @@ class PlanBuilder:
         self.ops.append((fn, meta))
 
     def conv(self, x, weight, bias=None, bn=None, stride=1, pad=0, transposed=False, relu=False, relu_pre=False,
-             residual=None, out_f32=False, out=None, sigmoid=False):
+             residual=None, out_f32=False, out=None, sigmoid=False, output_padding=0):
         """x: Act.  Returns the output Act [N, OD, OH, OW, Cout]."""
         flags = ((H.EPI_RELU_POST if relu else 0) | (H.EPI_RELU_PRE if relu_pre else 0) | (H.EPI_STORE_F32 if out_f32 else 0)
                  | (H.EPI_SIGMOID if sigmoid else 0))
-        spec = make_conv_spec(weight, bias, bn, x.shape, stride, pad, self.dtype, transposed, flags)
+        spec = make_conv_spec(weight, bias, bn, x.shape, stride, pad, self.dtype, transposed, flags, output_padding)
         y = out or self.alloc((spec.N, spec.OD, spec.OH, spec.OW, spec.Cout), torch.float32 if out_f32 else self.dtype)
         self.keep.append(x.t)   # the launch closure holds raw pointers only
         if residual is not None:

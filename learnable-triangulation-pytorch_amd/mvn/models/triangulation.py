@@ -35,8 +35,100 @@ def _bn_in_train_mode(m):
 
 def _no_training(m):
     if _bn_in_train_mode(m):
-        raise NotImplementedError("forward with BatchNorm in training mode (and backward) is not built yet "
+        raise NotImplementedError("forward with BatchNorm in training mode (and backward) is not built for this network "
                                   "(SURVEY.md section 8f row 1); call model.eval()")
+
+
+class _VolTrainFn(torch.autograd.Function):
+    """The whole training-mode forward of VolumetricTriangulationNet as ONE autograd node: forward runs the layers through an
+    lt_train.TrainTape (liblt_hip, fp32, BatchNorm on batch statistics), backward walks the tape and hands the parameter gradients
+    back to autograd -- so ``loss.backward()``, ``torch.optim`` / ``lt_train.Adam`` and DistributedDataParallel's gradient hooks work
+    as with the reference (train.py:233-243, :452-453).  Inputs: (model, images, batch, *parameters)."""
+    @staticmethod
+    def forward(ctx, model, images, batch, *params):
+        import lt_train
+        ctx.set_materialize_grads(False)              # an unused output arrives as None in backward, not as a dense zero tensor
+        ctx._lt_accepts_sparse_prob_grads = True      # VolumetricCELoss's one-voxel gradients are applied inside lt_softargmax3d_bwd
+        device = images.device
+        B, NV = images.shape[:2]
+        Hh, W = images.shape[3:]
+        V, J = model.volume_size, model.num_joints
+        lib = H.lib()
+        with torch.cuda.device(device):
+            tape = lt_train.TrainTape(device)
+            st = tape.stream
+            x = images.reshape(B * NV, 3, Hh, W).float().contiguous()
+            x_in = tape.alloc((B * NV, 1, Hh, W, E.min_cin_of(torch.float32)))
+            H.check(lib.lt_nchw_to_nhwc(H.LT_F32, x.data_ptr(), x_in.t.data_ptr(), B * NV, 3, Hh * W, x_in.t.shape[-1], st), "lt_nchw_to_nhwc")
+            tape.no_grad_ids.add(id(x_in))
+            _, feats256, _, volc = model.backbone.record(tape, x_in, want_heatmaps=False)
+            if volc is not None:
+                raise NotImplementedError("training with volume_aggregation_method conf* is not built")
+            pf = model.process_features[0]
+            feats = tape.conv(feats256, pf.weight, pf.bias, None)
+            h, w = feats.shape[2], feats.shape[3]
+            # host geometry exactly as in inference (numpy fp64; theta ~ U(0, 2 pi) because self.training), one H2D copy
+            n_geo = B * NV * 12 + B * 15
+            o_pos, o_cen, o_rot = B * NV * 12, B * NV * 12 + 3 * B, B * NV * 12 + 6 * B
+            G = {"hw": (h, w), "offs": (o_pos, o_cen, o_rot), "geo_ring": [torch.zeros(n_geo, dtype=torch.float32).pin_memory()],
+                 "geo_events": [None], "geo_slot": 0}
+            position, base, sides = model._host_geometry(batch, B, (Hh, W), G)
+            geo = G["geo_host"].to(device, non_blocking=False)
+            gp = geo.data_ptr()
+            coords = torch.empty(B, V, V, V, 3, dtype=torch.float32, device=device)
+            vol = tape.alloc((B, V, V, V, 32))
+            step = float(np.float32(model.cuboid_side / (V - 1)))
+            agg = H.AGG[model.volume_aggregation_method]
+            H.check(lib.lt_unproject_grid_fwd(H.LT_F32, feats.t.data_ptr(), gp, gp + 4 * o_pos, gp + 4 * o_cen, gp + 4 * o_rot, step,
+                                              int(bool(model.transfer_cmu_to_human36m)), coords.data_ptr(), None, vol.t.data_ptr(), B, NV, 32, h, w, V, agg, st),
+                    "lt_unproject_grid_fwd")
+
+            def unproject_bwd():
+                dvol = tape.grad_of(vol)
+                if dvol is None:
+                    return
+                gfe = torch.zeros_like(feats.t)
+                H.check(lib.lt_unproject_bwd(H.LT_F32, feats.t.data_ptr(), gp, coords.data_ptr(), None, dvol.data_ptr(), gfe.data_ptr(), None, B, NV, 32, h, w,
+                                             V ** 3, agg, st), "lt_unproject_bwd")
+                tape.seed(feats, gfe)
+            tape.add_backward(unproject_bwd)
+            logits = model.volume_net.record(tape, vol)          # channels-last (B,V,V,V,J) fp32
+            kp = torch.empty(B, J, 3, dtype=torch.float32, device=device)
+            probs = torch.empty(B, J, V, V, V, dtype=torch.float32, device=device)
+            ws = torch.empty(max(1, lib.lt_softargmax3d_workspace(B, J, V ** 3)), dtype=torch.uint8, device=device)
+            mult, sm = float(model.volume_multiplier), int(bool(model.volume_softmax))
+            H.check(lib.lt_softargmax3d_fwd(logits.t.data_ptr(), coords.data_ptr(), mult, sm, 1, J, kp.data_ptr(), probs.data_ptr(), B, J, V ** 3,
+                                            ws.data_ptr(), st), "lt_softargmax3d_fwd")
+        ctx.tape, ctx.logits, ctx.coords, ctx.kp, ctx.probs, ctx.params = tape, logits, coords, kp, probs, params
+        ctx.mult, ctx.sm, ctx.geo_keep = mult, sm, geo
+        feats_out = feats.t.reshape(B, NV, h, w, 32).permute(0, 1, 4, 2, 3).clone()
+        base_points = torch.from_numpy(base.astype(np.float32)).to(device)
+        ctx.mark_non_differentiable(feats_out, coords, base_points)
+        model._train_extra = (position, sides)
+        return kp, probs, feats_out, coords, base_points
+
+    @staticmethod
+    def backward(ctx, g_kp, g_probs, *unused):
+        tape, logits, coords, kp, probs = ctx.tape, ctx.logits, ctx.coords, ctx.kp, ctx.probs
+        B, J = probs.shape[:2]
+        nvox = probs[0, 0].numel()
+        dev = probs.device
+        with torch.cuda.device(dev):
+            g_kp = torch.zeros_like(kp) if g_kp is None else g_kp.float().contiguous()
+            sparse = getattr(ctx, "_lt_sparse_prob_grads", [])
+            idx = val = None
+            if len(sparse) == 1:
+                idx, val = sparse[0]
+            elif len(sparse) > 1 or (g_probs is not None and g_probs.stride() != (0,) * g_probs.dim()):
+                raise NotImplementedError("a dense gradient on the returned volumes in training (only VolumetricCELoss's sparse one is built)")
+            gl = torch.empty(B, nvox, J, dtype=torch.float32, device=dev)         # channels-last like the logits
+            H.check(H.lib().lt_softargmax3d_bwd(probs.data_ptr(), coords.data_ptr(), kp.data_ptr(), g_kp.data_ptr(), H.ptr(idx), H.ptr(val), ctx.mult, ctx.sm, 1,
+                                                gl.data_ptr(), B, J, nvox, tape.stream), "lt_softargmax3d_bwd")
+            tape.seed(logits, gl.reshape(logits.t.shape))
+            pg = tape.backward()
+        grads = tuple(pg.get(p) if p.requires_grad else None for p in ctx.params)
+        ctx.tape = None
+        return (None, None, None) + grads
 
 
 class _PlannedNet(E.PlanCache):
@@ -209,7 +301,8 @@ class VolumetricTriangulationNet(_PlannedNet):
         stream).  Batches beyond ``max_samples_per_launch`` (BASELINE config 4: 32 samples of 128^3 voxels are exactly 2^31
         elements) run as consecutive sub-batches of one plan."""
         H.require_gpu(images, "images")
-        _no_training(self)
+        if _bn_in_train_mode(self):
+            return self._forward_train(images, batch)
         B, NV = images.shape[:2]
         cap = self.max_samples_per_launch(NV, images.shape[3], images.shape[4])
         if B <= cap:
@@ -224,6 +317,19 @@ class VolumetricTriangulationNet(_PlannedNet):
         cat = lambda i: torch.cat([p[i] for p in parts], dim=0)
         conf = None if parts[0][3] is None else cat(3)
         return cat(0), cat(1), cat(2), conf, [c for p in parts for c in p[4]], cat(5), cat(6)
+
+    def _forward_train(self, images, batch):
+        """Training mode (any BatchNorm in train()): fp32, batch statistics, running statistics updated, random cuboid rotation; the
+        result carries the autograd node whose backward is liblt_hip's (lt_train.py).  Same 7-tuple as the inference forward."""
+        params = tuple(self.parameters())
+        off = [n for n, t in list(self.named_parameters()) + list(self.named_buffers()) if t.device != images.device]
+        if off:
+            raise RuntimeError("training updates the parameters where they live: move the model to %s first (model.to(device), as "
+                               "train.py:424 does); %d tensors are elsewhere, e.g. %s" % (images.device, len(off), off[0]))
+        kp, probs, feats, coords, base_points = _VolTrainFn.apply(self, images, batch, *params)
+        position, sides = self.__dict__.pop("_train_extra")
+        cuboids = [volumetric.Cuboid3D(position[i], sides) for i in range(images.shape[0])]
+        return kp, feats, probs, None, cuboids, coords, base_points
 
     def _forward_chunk(self, images, batch, lo, hi):
         device = images.device

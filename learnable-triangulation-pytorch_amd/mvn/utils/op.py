@@ -159,7 +159,7 @@ def sparse_prob_grad(volumes, idx, val):
     should return for ``volumes``: an all-zero stride-0 view when the producer is our soft-argmax node (which then applies the sparse
     part itself inside lt_softargmax3d_bwd), else the dense scatter."""
     node = volumes.grad_fn
-    if isinstance(node, _SoftArgmax3dFn._backward_cls):
+    if isinstance(node, _SoftArgmax3dFn._backward_cls) or getattr(node, "_lt_accepts_sparse_prob_grads", False):
         if not hasattr(node, "_lt_sparse_prob_grads"):
             node._lt_sparse_prob_grads = []
         node._lt_sparse_prob_grads.append((idx, val))

@@ -355,6 +355,98 @@ def gen_data(mvn):
     np.savez_compressed(os.path.join(GOLD, "data_eval.npz"), **out)
 
 
+def _train_sub(t, n=129):
+    """Strided sample of a parameter-shaped tensor (<= n values) -- the fixtures stay small; the norms cover the rest."""
+    f = t.detach().reshape(-1)
+    return f[::max(1, f.numel() // n)][:n].numpy().copy()
+
+
+def gen_train(mvn):
+    """One full training step of the reference's VolumetricTriangulationNet on CPU (train.py:148-243): model.train() (BatchNorm on batch
+    statistics, running statistics updated, random cuboid rotation), criterion MAE on keypoints * scale_keypoints_3d + 0.01 *
+    VolumetricCELoss, total_loss.backward(), torch.optim.Adam with the three learning-rate groups of train.py:430-437, opt.step().
+    Stored: losses, predictions, per-parameter gradient norms + strided samples, the BatchNorm running statistics and the parameters
+    after the step (samples).
+
+    Training-mode BatchNorm over few samples makes the step ILL-CONDITIONED (the V2V bottleneck normalises 2 x 2^3 = 16 values per
+    channel at V = 64; at V = 32 it would be 2, where a 1e-6 relative change of the images moves the reference's own gradients by
+    6 % median).  So the reference is run three times -- 8 threads, 1 thread (another fp32 summation order), and with the images
+    scaled by (1 + 1e-6) -- and the fixture stores, per parameter, how far the reference's gradient moves between them
+    (``noise/<name>``): the test gates ours against the reference within that measured self-noise."""
+    import mvn.models.loss as L
+    c = dict(nl=18, B=2, NV=3, H=128, V=64, seed=12)
+    cfg = synth.vol_config(c["nl"], c["V"], "softmax", 1.0, "mpii")
+    sp = spec.vol_net_spec(c["nl"], 17, False)
+    sd = synth.make_state_dict(sp, seed=c["seed"], sharpen=60.0, basic_block=True)
+    inp = synth.make_inputs(c["B"], c["NV"], c["H"], seed=c["seed"], inside=False)
+    lr, pf_lr, vn_lr = 1e-4, 1e-3, 1e-3          # experiments/human36m/train/human36m_vol_softmax.yaml
+    g = torch.Generator().manual_seed(43)
+    dgt = torch.randn(c["B"], 17, 3, generator=g) * 40
+    val = torch.ones(c["B"], 17, 1); val[1, 5] = 0
+
+    def step(eps=0.0, gt=None):
+        ref = mvn.models.triangulation.VolumetricTriangulationNet(cfg, device="cpu")
+        ref.load_state_dict(sd, strict=True)
+        ref.train()
+        opt = torch.optim.Adam([{"params": ref.backbone.parameters()}, {"params": ref.process_features.parameters(), "lr": pf_lr},
+                                {"params": ref.volume_net.parameters(), "lr": vn_lr}], lr=lr)
+        batch = {"cameras": _cameras(mvn, inp["K"], inp["R"], inp["t"], c["B"]), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+        np.random.seed(c["seed"] + 100)
+        kp, feats, vols, _, cuboids, cvs, bps = ref(inp["images"] * (1.0 + eps), torch.zeros(c["B"], c["NV"], 3, 4), batch)
+        if gt is None:
+            gt = kp.detach() + dgt
+        mae = L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val)
+        ce = L.VolumetricCELoss()(cvs, vols, gt, val)
+        opt.zero_grad()
+        (mae + 0.01 * ce).backward()
+        return ref, opt, dict(kp=kp.detach(), feats=feats.detach(), vols=vols.detach(), gt=gt, mae=float(mae), ce=float(ce))
+
+    np.random.seed(c["seed"] + 100)
+    thetas = np.random.uniform(0.0, 2 * np.pi, size=c["B"])
+    t0 = time.time()
+    ref, opt, r = step()
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)
+    ref1, _, r1 = step(gt=r["gt"])
+    torch.set_num_threads(nthr)
+    refp, _, rp = step(eps=1e-6, gt=r["gt"])
+    kp = r["kp"]
+    kp_noise = max(float(((o["kp"] - kp).abs() / kp.abs().clamp(min=1.0)).max()) for o in (r1, rp))
+    out = {"kp": kp.numpy(), "gt": r["gt"].numpy(), "val": val.numpy(), "mae": np.array(r["mae"]), "ce": np.array(r["ce"]),
+           "thetas": thetas, "lrs": np.array([lr, pf_lr, vn_lr]), "vol_sub": sub(r["vols"], 4), "kp_noise": np.array(kp_noise),
+           "loss_noise": np.array(max(abs(o["mae"] - r["mae"]) / r["mae"] for o in (r1, rp))),
+           "feat_sub": sub(r["feats"].reshape(c["B"] * c["NV"], *r["feats"].shape[2:]), 2)}
+    names, no_grad, noises = [], [], []
+    g1, gp = dict(ref1.named_parameters()), dict(refp.named_parameters())
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            no_grad.append(n)
+            continue
+        names.append(n)
+        gmax = float(p.grad.abs().max())
+        out["g/" + n] = _train_sub(p.grad)
+        out["gn/" + n] = np.array([float(p.grad.double().norm()), gmax, float(p.grad.double().sum())])
+        noise = max(float((o[n].grad - p.grad).abs().max()) for o in (g1, gp)) / max(gmax, 1e-30)
+        out["noise/" + n] = np.array(noise)
+        noises.append(noise)
+    opt.step()
+    for n, p in ref.named_parameters():
+        if n in names:
+            out["p1/" + n] = _train_sub(p)
+    for n, b_ in ref.named_buffers():
+        if n.endswith("running_mean") or n.endswith("running_var"):
+            out["rs/" + n] = _train_sub(b_)
+    out["names"] = np.array(names); out["no_grad"] = np.array(no_grad)
+    gn = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in ref.parameters() if p.grad is not None)))
+    out["grad_norm"] = np.array(gn)
+    noises = np.sort(np.array(noises))
+    print("  train step x3: %.1fs; mae %.4f ce %.4f; %d parameters with gradients (%d without), global grad norm %.4e" % (
+        time.time() - t0, r["mae"], r["ce"], len(names), len(no_grad), gn))
+    print("  reference self-noise (threads / 1e-6 perturbation): kp %.2e; gradients median %.2e, 90%% %.2e, max %.2e" % (
+        kp_noise, noises[len(noises) // 2], noises[int(len(noises) * 0.9)], noises[-1]))
+    np.savez_compressed(os.path.join(GOLD, "train_step.npz"), **out)
+
+
 def run_vol_case(mvn, tag, num_layers, B, NV, H, V, method="softmax", multiplier=1.0, sharpen=False,
                  inside=False, rotate=False, kind="mpii", seed=0, stride=4, cmu=False):
     cfg = synth.vol_config(num_layers, V, method, multiplier, kind)
@@ -438,7 +530,7 @@ def main():
     torch.manual_seed(0)
     os.makedirs(GOLD, exist_ok=True)
     mvn = ref_loader.load()
-    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad"]
+    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad", "train"]
     if "ops" in which:
         print("[ops]"); gen_ops(mvn)
     if "nets" in which:
@@ -464,6 +556,8 @@ def main():
         # and max prob 0.22 -- towards the near-argmax regime the survey says not to gate on (logit noise of 1e-6 of max then moves
         # the joints by > 1e-4; the reference's own 2-vs-8-thread deviation was 3e-5 there)
         run_vol_case(mvn, "c4_sharp", 152, 1, 8, 384, 128, "softmax", sharpen=157.0, seed=8, stride=8)
+    if "train" in which:
+        print("[train]"); gen_train(mvn)
     if "alg" in which:
         print("[alg]"); gen_alg(mvn)
     if "caffe" in which:

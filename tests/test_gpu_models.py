@@ -301,7 +301,7 @@ def test_algebraic_c1_vs_reference_golden(golden_dir):
 
 def test_loud_failure_modes():
     from mvn.models.triangulation import VolumetricTriangulationNet
-    m = VolumetricTriangulationNet(synth.vol_config(18, 32), device=DEV)
+    m = VolumetricTriangulationNet(synth.vol_config(18, 32, "conf_norm"), device=DEV)    # training is built for softmax / sum / max only
     inp = synth.make_inputs(1, 2, 64)
     m.train()
     with pytest.raises(NotImplementedError):

@@ -1,0 +1,365 @@
+"""GPU (-m gpu): the training step (BASELINE config 5).
+  * the training kernels of csrc/train.hip one by one against torch-CPU autograd of the same op (fp64 reference);
+  * single layers through lt_train.TrainTape (forward in training mode + input / weight / bias / BatchNorm gradients);
+  * ONE WHOLE STEP of VolumetricTriangulationNet -- train-mode forward, MAE + 0.01 CE loss, backward, Adam -- against the step the
+    REFERENCE ITSELF takes on CPU (tests/golden/train_step.npz, oracle/make_golden.py ``train``).
+Gate for gradients: max|d| <= tol * max|ref| per tensor (fp32 kernels)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import check, record, to_cl, from_cl
+from oracle import spec, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lib():
+    import lt_hip as H
+    return H, H.lib()
+
+
+def _st():
+    return torch.cuda.current_stream(DEV).cuda_stream
+
+
+@pytest.mark.parametrize("flags_name,with_res", [("none", False), ("relu", False), ("relu", True), ("relu_pre", True)])
+@pytest.mark.parametrize("rows,C", [(1000, 64), (37, 16), (70000, 32)])
+def test_bn_act_fwd_bwd(rows, C, flags_name, with_res):
+    H, lib = _lib()
+    g = torch.Generator().manual_seed(rows + C)
+    y = torch.randn(rows, C, generator=g) * 2 + 0.5
+    res = torch.randn(rows, C, generator=g) if with_res else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    dz = torch.randn(rows, C, generator=g)
+    flags = {"none": 0, "relu": H.EPI_RELU_POST, "relu_pre": H.EPI_RELU_PRE}[flags_name]
+    # reference (fp64 autograd)
+    yd = y.double().requires_grad_(True); gd = gamma.double().requires_grad_(True); bd = beta.double().requires_grad_(True)
+    rd = res.double().requires_grad_(True) if with_res else None
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    n = (yd - mean) / torch.sqrt(var + 1e-5) * gd + bd
+    if flags_name == "relu_pre":
+        dz = dz * (n.detach().abs() > 1e-4).float()      # no upstream gradient where fp32 rounding could flip the ReLU mask
+        n = F.relu(n)
+    if with_res:
+        n = n + rd
+    if flags_name == "relu":
+        dz = dz * (n.detach().abs() > 1e-4).float()
+        n = F.relu(n)
+    (n * dz.double()).sum().backward()
+    # ours
+    yg, dzg = y.to(DEV), dz.to(DEV)
+    resg = res.to(DEV) if with_res else None
+    mg, vg = mean.detach().float().to(DEV), var.detach().float().to(DEV)
+    gg, bg = gamma.to(DEV), beta.to(DEV)
+    z = torch.empty_like(yg)
+    H.check(lib.lt_bn_act_fwd(yg.data_ptr(), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), H.ptr(resg), z.data_ptr(), rows, C, 1e-5, flags, _st()), "fwd")
+    tag = "train/bn_act %dx%d %s%s" % (rows, C, flags_name, "+res" if with_res else "")
+    check(tag + " fwd", z.cpu(), n.detach(), 2e-6)
+    dy, dga, dbe = torch.empty_like(yg), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dres = torch.full_like(yg, 3.0) if with_res else None
+    ws = torch.empty(max(1, lib.lt_bn_act_bwd_workspace(rows, C)), dtype=torch.uint8, device=DEV)
+    H.check(lib.lt_bn_act_bwd(dzg.data_ptr(), yg.data_ptr(), H.ptr(resg), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), dy.data_ptr(), dga.data_ptr(),
+                              dbe.data_ptr(), H.ptr(dres), 1 if with_res else 0, rows, C, 1e-5, flags, ws.data_ptr(), _st()), "bwd")
+    check(tag + " dy", dy.cpu(), yd.grad, 2e-5)
+    check(tag + " dgamma", dga.cpu(), gd.grad, 2e-5)
+    check(tag + " dbeta", dbe.cpu(), bd.grad, 2e-5)
+    if with_res:
+        check(tag + " dres (accumulated onto 3)", dres.cpu(), rd.grad + 3.0, 2e-6)
+
+
+@pytest.mark.parametrize("flags_name", ["none", "relu", "relu_pre"])
+def test_act_bwd_and_channel_sum(flags_name):
+    H, lib = _lib()
+    g = torch.Generator().manual_seed(5)
+    rows, C = 4099, 17
+    pre = torch.randn(rows, C, generator=g); res = torch.randn(rows, C, generator=g); dz = torch.randn(rows, C, generator=g)
+    flags = {"none": 0, "relu": H.EPI_RELU_POST, "relu_pre": H.EPI_RELU_PRE}[flags_name]
+    pd, rd = pre.double().requires_grad_(True), res.double().requires_grad_(True)
+    n = pd
+    if flags_name == "relu_pre":
+        n = F.relu(n)
+    n = n + rd
+    if flags_name == "relu":
+        n = F.relu(n)
+    (n * dz.double()).sum().backward()
+    zg, dzg, resg = n.detach().float().to(DEV), dz.to(DEV), res.to(DEV)
+    dy, dres = torch.empty_like(zg), torch.empty_like(zg)
+    H.check(lib.lt_act_bwd(dzg.data_ptr(), zg.data_ptr(), resg.data_ptr(), dy.data_ptr(), dres.data_ptr(), 0, rows * C, flags, _st()), "lt_act_bwd")
+    check("train/act_bwd %s dy" % flags_name, dy.cpu(), pd.grad, 1e-6)
+    check("train/act_bwd %s dres" % flags_name, dres.cpu(), rd.grad, 1e-6)
+    out = torch.empty(C, device=DEV)
+    ws = torch.empty(max(1, lib.lt_channel_sum_workspace(rows, C)), dtype=torch.uint8, device=DEV)
+    H.check(lib.lt_channel_sum(dzg.data_ptr(), rows, C, out.data_ptr(), 0, ws.data_ptr(), _st()), "lt_channel_sum")
+    check("train/channel_sum", out.cpu(), dz.double().sum(0), 1e-6)
+
+
+@pytest.mark.parametrize("nd,k,s,p,shape", [(2, 3, 2, 1, (3, 16, 20, 24)), (3, 2, 2, 0, (2, 32, 8, 8, 8)), (2, 3, 2, 1, (2, 64, 15, 17))])
+def test_maxpool_bwd(nd, k, s, p, shape):
+    H, lib = _lib()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(shape, generator=g)
+    x = F.relu(x)        # ties at zero, as behind the stem's ReLU
+    xd = x.double().requires_grad_(True)
+    y = (F.max_pool2d if nd == 2 else F.max_pool3d)(xd, k, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    (y * dy.double()).sum().backward()
+    xg, dyg = to_cl(x), to_cl(dy)
+    dx = torch.zeros_like(xg)
+    N, D, Hh, W, C = xg.shape
+    kk, ss, pp = ((1, k, k), (1, s, s), (0, p, p)) if nd == 2 else ((k,) * 3, (s,) * 3, (p,) * 3)
+    H.check(lib.lt_maxpool_bwd(xg.data_ptr(), dyg.data_ptr(), dx.data_ptr(), N, D, Hh, W, C, H.i3(kk), H.i3(ss), H.i3(pp), _st()), "lt_maxpool_bwd")
+    ref = xd.grad
+    ours = from_cl(dx, nd)
+    # where the input is exactly zero the gradient dies in the ReLU backward that follows: compare only where it matters, and the total
+    m = (x > 0)
+    check("train/maxpool_bwd nd=%d k=%d %s (x > 0)" % (nd, k, "x".join(map(str, shape))), ours * m, ref * m, 1e-6)
+    assert abs(float(ours.double().sum()) - float(ref.sum())) <= 1e-3 * float(ref.abs().sum())
+
+
+CONV_CASES = [  # nd, Cin, Cout, k, stride, pad, transposed, spatial
+    (2, 16, 32, 3, 1, 1, False, (10, 12)),
+    (2, 64, 64, 1, 1, 0, False, (9, 7)),
+    (2, 32, 64, 3, 2, 1, False, (12, 16)),
+    (2, 32, 128, 1, 2, 0, False, (12, 16)),
+    (2, 64, 32, 4, 2, 1, True, (6, 8)),
+    (3, 32, 32, 3, 1, 1, False, (6, 6, 6)),
+    (3, 16, 32, 1, 1, 0, False, (4, 6, 8)),
+    (3, 64, 32, 2, 2, 0, True, (3, 4, 5)),
+    (3, 32, 17, 1, 1, 0, False, (4, 4, 4)),
+    (3, 32, 16, 7, 1, 3, False, (8, 8, 8)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "nd%d_%dto%d_k%ds%dp%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], "_T" if c[6] else ""))
+@pytest.mark.parametrize("mode", ["bn_relu_res", "bias_only"])
+def test_tape_layer_gradients(case, mode):
+    """One layer through TrainTape: z = act(BN_train(conv(x) + b) [+ res]); all gradients vs torch-CPU fp64 autograd."""
+    import lt_engine as E
+    import lt_train
+    nd, Cin, Cout, k, s, p, tr, sp = case
+    if mode == "bn_relu_res" and Cout % 4:
+        pytest.skip("BatchNorm layers have Cout % 4 == 0 in these networks (the 17-joint output layer has none)")
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + k)
+    N = 3
+    x = torch.randn(N, Cin, *sp, generator=g)
+    wshape = (Cin, Cout) if tr else (Cout, Cin)
+    w = torch.randn(*wshape, *([k] * nd), generator=g) * (1.0 / np.sqrt(Cin * k ** nd))
+    b = torch.randn(Cout, generator=g) * 0.1
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2
+    conv = {(2, False): F.conv2d, (3, False): F.conv3d, (2, True): F.conv_transpose2d, (3, True): F.conv_transpose3d}[(nd, tr)]
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    gd, btd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = conv(xd, wd, bd, stride=s, padding=p)
+    use_bn = mode == "bn_relu_res"
+    res = torch.randn(y.shape, generator=g) if use_bn else None
+    rd = res.double().requires_grad_(True) if use_bn else None
+    if use_bn:
+        dims = [0] + list(range(2, 2 + nd))
+        mean = y.mean(dims, keepdim=True); var = y.var(dims, unbiased=False, keepdim=True)
+        shape = [1, -1] + [1] * nd
+        y = (y - mean) / torch.sqrt(var + 1e-5) * gd.reshape(shape) + btd.reshape(shape)
+        pre = (y + rd).detach()
+        y = F.relu(y + rd)
+    dz = torch.randn(y.shape, generator=g)
+    if use_bn:
+        dz = dz * (pre.abs() > 1e-4).float()      # no upstream gradient where fp32 rounding could flip the ReLU mask
+    (y * dz.double()).sum().backward()
+
+    tape = lt_train.TrainTape(DEV)
+    wp, bp = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    gp, btp = torch.nn.Parameter(gamma.to(DEV)), torch.nn.Parameter(beta.to(DEV))
+    rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    xa = E.Act(to_cl(x))
+    ra = E.Act(to_cl(res)) if use_bn else None
+    z = tape.conv(xa, wp, bp, (gp, btp, rm, rv) if use_bn else None, stride=s, pad=p, transposed=tr, relu=use_bn, residual=ra)
+    tag = "train/layer nd%d %d->%d k%d s%d p%d%s %s" % (nd, Cin, Cout, k, s, p, " T" if tr else "", mode)
+    check(tag + " z", from_cl(z.t, nd), y.detach(), 2e-5)
+    tape.seed(z, to_cl(dz))
+    pg = tape.backward()
+    check(tag + " dx", from_cl(tape.grad_of(xa), nd), xd.grad, 5e-5)
+    check(tag + " dw", pg[wp].cpu(), wd.grad, 5e-5)
+    if use_bn:
+        check(tag + " dgamma", pg[gp].cpu(), gd.grad, 5e-5)
+        check(tag + " dbeta", pg[btp].cpu(), btd.grad, 5e-5)
+        check(tag + " dres", from_cl(tape.grad_of(ra), nd), rd.grad, 1e-6)
+        # the bias in front of a training-mode BatchNorm has an exactly zero gradient; ours is rounding noise of the channel sums
+        assert float(pg[bp].abs().max()) <= 1e-4 * float(dz.abs().sum() / Cout)
+        n_el = y.numel() // Cout
+        yb = conv(x.double(), w.double(), b.double(), stride=s, padding=p)
+        dims = [0] + list(range(2, 2 + nd))
+        check(tag + " running_mean", rm.cpu(), 0.1 * yb.mean(dims), 1e-5)
+        check(tag + " running_var", rv.cpu(), 0.9 + 0.1 * yb.var(dims, unbiased=True), 1e-5)
+    else:
+        check(tag + " db", pg[bp].cpu(), bd.grad, 5e-5)
+
+
+def test_adam_step_vs_torch():
+    import lt_train
+    g = torch.Generator().manual_seed(3)
+    p0 = [torch.randn(1000, generator=g), torch.randn(33, 7, generator=g)]
+    ref = [torch.nn.Parameter(t.clone()) for t in p0]
+    ours = [torch.nn.Parameter(t.clone().to(DEV)) for t in p0]
+    o_ref = torch.optim.Adam([{"params": ref[:1]}, {"params": ref[1:], "lr": 1e-2}], lr=1e-3)
+    o_our = lt_train.Adam([{"params": ours[:1]}, {"params": ours[1:], "lr": 1e-2}], lr=1e-3)
+    for step in range(5):
+        for r, o in zip(ref, ours):
+            gr = torch.randn(r.shape, generator=g) * (10.0 ** (step - 2))
+            r.grad = gr.clone(); o.grad = gr.clone().to(DEV)
+        o_ref.step(); o_our.step()
+    for i, (r, o) in enumerate(zip(ref, ours)):
+        check("train/adam 5 steps tensor %d (parameter delta)" % i, o.detach().cpu() - p0[i], r.detach() - p0[i], 1e-4)      # 1e-4 of the largest delta = 1-2 ulp of the parameters themselves
+
+
+ZERO_GRAD = re.compile(r"^volume_net\.(.*\.(block\.0|res_branch\.0|res_branch\.3|skip_con\.0)|output_layer)\.bias$")
+
+
+def _train_case():
+    c = dict(nl=18, B=2, NV=3, H=128, V=64, seed=12)
+    cfg = synth.vol_config(c["nl"], c["V"], "softmax", 1.0, "mpii")
+    sd = synth.make_state_dict(spec.vol_net_spec(c["nl"], 17, False), seed=c["seed"], sharpen=60.0, basic_block=True)
+    inp = synth.make_inputs(c["B"], c["NV"], c["H"], seed=c["seed"], inside=False)
+    return c, cfg, sd, inp
+
+
+def test_whole_training_step_vs_reference(golden_dir):
+    """model.train(); forward; MAE(kp * 0.1) + 0.01 * VolumetricCELoss; backward; Adam (train.py:148-243, :430-437) -- every parameter's
+    gradient, the BatchNorm running statistics and the parameters after the step against the reference's own step on CPU."""
+    import lt_train
+    from mvn.models import loss as L
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    from test_gpu_models import _cameras
+    G = np.load(os.path.join(golden_dir, "train_step.npz"))
+    c, cfg, sd, inp = _train_case()
+    m = VolumetricTriangulationNet(cfg, device=DEV)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    m.train()
+    lr, pf_lr, vn_lr = [float(v) for v in G["lrs"]]
+    opt = lt_train.Adam([{"params": list(m.backbone.parameters())}, {"params": list(m.process_features.parameters()), "lr": pf_lr},
+                         {"params": list(m.volume_net.parameters()), "lr": vn_lr}], lr=lr)
+    batch = {"cameras": _cameras(inp, c["B"]), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+    np.random.seed(c["seed"] + 100)
+    kp, feats, vols, conf, cuboids, cvs, bps = m(inp["images"].to(DEV), torch.zeros(c["B"], c["NV"], 3, 4, device=DEV), batch)
+    # the reference's own deviation between 1 and 8 threads / under a 1e-6 relative change of the images rides on every gate below
+    kp_noise, loss_noise = float(G["kp_noise"]), float(G["loss_noise"])
+    d = (kp.detach().cpu().double() - torch.from_numpy(G["kp"]).double()).abs() / torch.from_numpy(G["kp"]).double().abs().clamp(min=1.0)
+    record("train/step forward keypoints (train-mode BN), rel with 1 mm floor", {"err": float(d.max()), "tol": 1e-4 + 2 * kp_noise, "reference_self_noise": kp_noise})
+    assert float(d.max()) <= 1e-4 + 2 * kp_noise, float(d.max())
+    check("train/step forward volumes", vols.detach().cpu()[:, :, ::4, ::4, ::4], G["vol_sub"], 1e-3 + 10 * kp_noise)
+    check("train/step forward features", feats.detach().cpu().reshape(c["B"] * c["NV"], *feats.shape[2:])[:, :, ::2, ::2], G["feat_sub"], 1e-4)
+    gt, val = torch.from_numpy(G["gt"]).to(DEV), torch.from_numpy(G["val"]).to(DEV)
+    mae = L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val)
+    ce = L.VolumetricCELoss()(cvs, vols, gt, val)
+    assert abs(float(mae.detach()) - float(G["mae"])) <= (1e-4 + 2 * loss_noise) * float(G["mae"]), (float(mae.detach()), float(G["mae"]))
+    assert abs(float(ce.detach()) - float(G["ce"])) <= 1e-3 * float(G["ce"]), (float(ce.detach()), float(G["ce"]))
+    opt.zero_grad()
+    (mae + 0.01 * ce).backward()
+    named = dict(m.named_parameters())
+    gn2, table = 0.0, []
+    gnorm_ref = float(G["grad_norm"])
+    n_zero = 0
+    for n in G["names"]:
+        n = str(n)
+        p = named[n]
+        assert p.grad is not None, "no gradient for " + n
+        gr = p.grad.detach().double().cpu()
+        ref_norm, ref_max, ref_sum = [float(v) for v in G["gn/" + n]]
+        noise = float(G["noise/" + n])
+        gn2 += float(gr.pow(2).sum())
+        if ZERO_GRAD.search(n) or noise > 0.05:
+            # a convolution bias in front of a training-mode BatchNorm (V2V's Conv3d / ConvTranspose3d layers, v2v.py:10-16, :57-61) or
+            # the output layer's bias under the softmax: the exact gradient is 0, both sides hold rounding noise of their channel sums
+            assert float(gr.abs().max()) <= 10 * ref_max + 1e-6 * gnorm_ref, (n, float(gr.abs().max()), ref_max)
+            n_zero += 1
+            continue
+        f = gr.reshape(-1)
+        sub = f[::max(1, f.numel() // 129)][:129]
+        e = float((sub - torch.from_numpy(G["g/" + n]).double()).abs().max()) / ref_max
+        en = abs(float(gr.norm()) - ref_norm) / ref_norm
+        table.append((max(e, en) / (1e-3 + 4 * noise), max(e, en), noise, n))
+    table.sort(reverse=True)
+    print("worst parameter gradients (err / gate, err, reference self-noise):", *["%.2f %.2e %.2e %s" % t for t in table[:8]], sep="\n  ")
+    errs = sorted(t[1] for t in table)
+    record("train/step parameter gradients vs the reference's step (max|d|/max|ref| on samples, and norm; gate 1e-3 + 4 x reference self-noise)",
+           {"worst_err_over_gate": table[0][0], "worst_err": errs[-1], "median_err": errs[len(errs) // 2], "parameters_compared": len(table),
+            "zero_gradient_parameters": n_zero, "median_reference_self_noise": sorted(t[2] for t in table)[len(table) // 2]})
+    assert table[0][0] <= 1.0, table[:8]
+    for n in G["no_grad"]:
+        assert named[str(n)].grad is None
+    gn = float(np.sqrt(gn2))
+    assert abs(gn - float(G["grad_norm"])) <= 2e-3 * float(G["grad_norm"]), (gn, float(G["grad_norm"]))
+    record("train/step global gradient norm", {"ours": gn, "reference": float(G["grad_norm"])})
+    # running statistics (momentum 0.1, unbiased variance)
+    bufs = dict(m.named_buffers())
+    w_rs = 0.0
+    for key in G.files:
+        if key.startswith("rs/"):
+            b = bufs[key[3:]].detach().double().cpu().reshape(-1)
+            sub = b[::max(1, b.numel() // 129)][:129]
+            ref = torch.from_numpy(G[key]).double()
+            w_rs = max(w_rs, float((sub - ref).abs().max() / ref.abs().max().clamp(min=1e-30)))
+    record("train/step BatchNorm running statistics", {"err": w_rs, "tol": 1e-4})
+    assert w_rs <= 1e-4, w_rs
+    # the Adam step: parameter deltas (the first step moves every element by ~lr * sign(g); compare the moved parameters)
+    opt.step()
+    torch.cuda.synchronize()
+    # Adam's first step is lr * g / (|g| + 1e-8), a sign function of the gradient: elements whose reference gradient is below the
+    # reference's own noise (exact zeros of dead channels on our side, 1e-12 on the reference's) can differ by 2 lr -- only the elements
+    # the reference knows the sign of are compared (lt_adam_step itself: test_adam_step_vs_torch)
+    w_p, w_name, n_known = 0.0, None, 0
+    for n in G["names"]:
+        n = str(n)
+        if ZERO_GRAD.search(n):
+            continue
+        f = named[n].detach().double().cpu().reshape(-1)
+        sub = f[::max(1, f.numel() // 129)][:129]
+        ref = torch.from_numpy(G["p1/" + n]).double()
+        gs = torch.from_numpy(G["g/" + n]).double().abs()
+        known = gs > 100 * (float(G["noise/" + n]) + 1e-3) * float(G["gn/" + n][1])
+        n_known += int(known.sum())
+        lr_n = lr if n.startswith("backbone.") else pf_lr if n.startswith("process_features.") else vn_lr
+        e = float(((sub - ref).abs() * known).max()) / lr_n      # in units of one full Adam step
+        if e > w_p:
+            w_p, w_name = e, n
+    record("train/step parameters after Adam, worst |d| in units of lr", {"err": w_p, "tol": 2e-2, "name": w_name, "elements_compared": n_known})
+    assert w_p <= 2e-2, (w_p, w_name)
+    assert n_known > 1000, n_known
+    # and the next inference forward uses the UPDATED weights (plan cache fingerprint)
+    m.eval()
+    with torch.no_grad():
+        kp2 = m(inp["images"].to(DEV), None, batch)[0]
+    assert torch.isfinite(kp2).all()
+
+
+def test_training_loss_decreases_over_steps():
+    """Ten Adam steps on one fixed batch: the loss of the reference's objective goes down (sanity of the whole loop)."""
+    import lt_train
+    from mvn.models import loss as L
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    from test_gpu_models import _cameras
+    c, cfg, sd, inp = _train_case()
+    m = VolumetricTriangulationNet(cfg, device=DEV)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    m.train()
+    opt = lt_train.Adam(list(m.parameters()), lr=1e-4)
+    batch = {"cameras": _cameras(inp, c["B"]), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+    gt = torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float().to(DEV)
+    val = torch.ones(c["B"], 17, 1, device=DEV)
+    losses = []
+    for it in range(10):
+        np.random.seed(0)
+        kp, _, vols, _, _, cvs, _ = m(inp["images"].to(DEV), None, batch)
+        loss = L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val) + 0.01 * L.VolumetricCELoss()(cvs, vols, gt, val)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    record("train/loss over 10 Adam steps", losses)
+    assert losses[-1] < losses[0], losses
