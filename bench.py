@@ -183,6 +183,62 @@ def family_table(ops):
     return fam, conv
 
 
+def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
+    """--train: BASELINE config 5's step in its present form -- train-mode forward (batch-statistics BatchNorm), MAE + 0.01 x
+    VolumetricCELoss (train.py:217-230), backward, gradient all-reduce over RCCL for N > 1 (overlapped with the backward,
+    lt_dist.GradReducer), the reference's three-group Adam (train.py:430-437).  fp32 throughout (the reference trains in fp32);
+    every kernel is liblt_hip's.  Not the headline metric: its own JSON line."""
+    import lt_dist
+    import lt_train
+    from mvn.models import loss as L
+    B = args.batch
+    model.to(dev)
+    model.train()
+    model.grad_reducer = lt_dist.GradReducer() if world > 1 else None
+    opt = lt_train.Adam([{"params": list(model.backbone.parameters())}, {"params": list(model.process_features.parameters()), "lr": 1e-3},
+                         {"params": list(model.volume_net.parameters()), "lr": 1e-3}], lr=1e-4)
+    g = torch.Generator().manual_seed(5 + rank)
+    gt = (torch.as_tensor(np.asarray(batch["pred_keypoints_3d"]))[:, :, :3].float() + torch.randn(B, 17, 3, generator=g) * 30).to(dev)
+    val = torch.ones(B, 17, 1, device=dev)
+    mae, ce = L.KeypointsMAELoss(), L.VolumetricCELoss()
+    losses = []
+
+    def step():
+        kp, _, vols, _, _, cvs, _ = model(images, None, batch)
+        loss = mae(kp * 0.1, gt * 0.1, val) + 0.01 * ce(cvs, vols, gt, val)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    for _ in range(max(2, args.warmup)):
+        losses.append(step())
+    dt_local, _ = time_steps(lambda: losses.append(step()), args.steps, barrier)
+    value, total, dt = lt_dist.job_throughput(B * args.steps, dt_local, dev)
+    per_rank = lt_dist.gather_floats(B * args.steps / dt_local, dev)
+    lv = [float(l) for l in losses]
+    assert all(np.isfinite(lv)), lv
+    if rank == 0:
+        # algorithmic flops: forward 2*MAC of every convolution, backward twice that (input + weight gradients)
+        P = model._build_plan(1, args.views, args.image, args.image, dev, dry_run=True)
+        fwd_flops = P["plan"].flops * B if hasattr(P["plan"], "flops") else None
+        res = {"metric": "multi-view samples/sec (%d-view vol-softmax training step: fwd + bwd + Adam)" % args.views, "value": value, "unit": "samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup), "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "training step of: " + workload, "per_gpu_batch": B, "global_batch": B * world,
+                          "parallelism": "data parallel x%d, bucketed gradient all-reduce (RCCL) overlapped with the backward" % world if world > 1 else "1 GPU",
+                          "loss": "KeypointsMAELoss(scale 0.1) + 0.01 * VolumetricCELoss", "optimizer": "Adam lr 1e-4 / 1e-3 / 1e-3 (3 groups)"},
+               "per_rank_samples_per_s": per_rank, "loss_first_last": [lv[0], lv[-1]],
+               "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
+        if fwd_flops:
+            ach = 3 * fwd_flops / (1e-3 * res["ms_per_step"]) / 1e12
+            res["roofline"] = {"kernel": "whole step (convolutions: forward + input gradient + weight gradient = 3 x forward MACs)", "bound": "mfma",
+                               "achieved": ach, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS["fp32"], "traffic": None}
+        print(json.dumps(res))
+    barrier()
+    lt_dist.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,10 +258,11 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32, help="host threads for the CPU baseline leg")
     ap.add_argument("--tile", type=int, default=0, help="force a conv tile id (LT_TILE_*), 0 = auto")
     ap.add_argument("--preroll-s", type=float, default=1.0, help="untimed steady-state run before the W warm-up steps (clocks settle)")
+    ap.add_argument("--train", action="store_true", help="time the training step (fwd + bwd + Adam, fp32) instead of the forward; its own JSON line")
     ap.add_argument("--stub-cpu", action="store_true", help="TEST ONLY: gloo backend, no GPU, step() is a sleep (exercises launcher + timing plumbing)")
     args = ap.parse_args()
     if not args.batch:
-        args.batch = 16 if args.volume >= 128 else 32
+        args.batch = 8 if args.train else 16 if args.volume >= 128 else 32
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)       # does not return
@@ -263,9 +320,11 @@ def main():
     # ---- CPU leg first (rank 0, N = 1): the reported baseline AND the parity references; the GPU is idle meanwhile, so the timed
     # region below is not a blip at the start of a CPU-dominated run
     cpu_base, refs = None, None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and not args.train:
         cpu_base, refs = cpu_leg(model.state_dict(), args, images_cpu, batch, geom)
     images = images_cpu.to(dev)
+    if args.train:
+        return train_leg(args, model, dev, world, rank, barrier, images, batch, workload)
 
     def step():
         return model(images, None, batch)

@@ -242,8 +242,10 @@ int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32_t C, float
  * lt_channel_sum: out[c] (+)= sum over rows of x[row][c] (bias gradients), fp64 accumulation.
  * lt_maxpool_bwd: dx (pre-zeroed / accumulated) += dy at the first maximal element of every window (atomics).
  * lt_conv_wgrad : dw[co][tap * Cin + ci] (=|+=) sum_m dy[m][co] * x[m @ tap][ci] over the GEMM rows m = (n, od, oh, ow) of the forward
- *   convolution described by (N, D, H, W, Cin, Do, Ho, Wo, stride, pad, taps); exact-fp32 MFMA, no atomics.  For a transposed convolution
- *   swap the roles (dy := the layer's INPUT at its own resolution, x := the output gradient, stride 2): dw[ci][tap * Cout + co].
+ *   convolution described by (N, D, H, W, Cin, Do, Ho, Wo, stride, pad, taps); exact-fp32 MFMA, no atomics (the pixel range is cut into
+ *   slabs whose partial sums are added in a fixed order: workspace of lt_conv_wgrad_workspace(rows = N*Do*Ho*Wo, cout_pad, k_pad) bytes,
+ *   may be 0).  For a transposed convolution swap the roles (dy := the layer's INPUT at its own resolution, x := the output gradient,
+ *   stride 2): dw[ci][tap * Cout + co].
  * lt_adam_step  : torch.optim.Adam's single-tensor update (bias-corrected, eps outside the sqrt).
  * -------------------------------------------------------------------------------------------*/
 int lt_bn_act_fwd(const float* y, const float* mean, const float* var, const float* gamma, const float* beta, const float* residual, float* z,
@@ -258,9 +260,18 @@ size_t lt_channel_sum_workspace(int64_t rows, int32_t C);
 int lt_channel_sum(const float* x, int64_t rows, int32_t C, float* out, int32_t accumulate, void* workspace, void* stream);
 int lt_maxpool_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, const int32_t k[3],
                    const int32_t s[3], const int32_t p[3], void* stream);
+size_t lt_conv_wgrad_workspace(int64_t rows, int32_t cout_pad, int32_t k_pad);
 int lt_conv_wgrad(const float* dy, const float* x, const int32_t* taps, float* dw, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin, int32_t Do,
                   int32_t Ho, int32_t Wo, const int32_t stride[3], const int32_t pad[3], int32_t Cout, int32_t ldy, int32_t cout_pad, int32_t k_pad,
-                  int32_t ntaps, int32_t accumulate, void* stream);
+                  int32_t ntaps, int32_t accumulate, void* workspace, void* stream);
+/* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- the layout changes between a Parameter's own layout and the GEMM layouts of its layer
+ * (forward weights, input-gradient weights, weight-gradient blocks), with index maps built once when a training plan is recorded */
+int lt_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, void* stream);
+/* the same update for MANY tensors in one launch.  jobs (device memory): njobs records of
+ *   { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t n; float lr; int32_t first_block; }   (48 bytes)
+ * with first_block = running sum of ceil(n / 1024) over the preceding jobs; total_blocks = that sum over all jobs. */
+int lt_adam_step_multi(const void* jobs, int32_t njobs, int32_t total_blocks, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                       void* stream);
 int lt_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int32_t step, void* stream);
 

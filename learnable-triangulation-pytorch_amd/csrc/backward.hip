@@ -12,7 +12,7 @@
 // softmax aggregation out = sum_v w_v x_v, w = softmax_v(x):  d out / d x_v = w_v (1 + x_v - out).
 // The scatter is HBM/L2-atomic bound: NV x 4 taps x C fp32 atomics per voxel into maps that stay L2-resident
 // (4.7 MB per sample at config 2); one lane per (voxel, 4-channel vector), bricked voxel order like the forward.
-#include "lt_common.h"
+#include "colsum.h"
 
 using namespace lt;
 
@@ -306,6 +306,39 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, long long ro
     }
 }
 
+struct BnStatLoad {
+    const float* x; int C;
+    __device__ __forceinline__ void operator()(long long row, int c, float (&q)[2][4]) const {
+        const float4 v = *(const float4*)(x + (size_t)row * C + c);
+        q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w;
+        q[1][0] = v.x * v.x; q[1][1] = v.y * v.y; q[1][2] = v.z * v.z; q[1][3] = v.w * v.w;
+    }
+};
+
+__global__ __launch_bounds__(256) void bn_partial_vec_kernel(const float* __restrict__ x, long long rows, int C, int nslab, int cw4, int rl, double* __restrict__ part) {
+    colsum_partial<2>(rows, C, nslab, cw4, rl, part, BnStatLoad{x, C});
+}
+
+struct BnStatFin {
+    long long rows; float* mean; float* var; float* running_mean; float* running_var; float momentum;
+    __device__ __forceinline__ void operator()(int c, const double (&t)[2]) const {
+        const double m = t[0] / (double)rows;
+        double v = t[1] / (double)rows - m * m;
+        if (v < 0.0) v = 0.0;
+        mean[c] = (float)m;
+        var[c] = (float)v;
+        if (running_mean) {   // torch: running = (1 - momentum) * running + momentum * stat, the variance UNBIASED (n / (n - 1))
+            const double unb = rows > 1 ? v * (double)rows / (double)(rows - 1) : v;
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+        }
+    }
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_vec_kernel(const double* __restrict__ part, int C, int nslab, BnStatFin fin) {
+    colsum_finalize<2>(part, C, nslab, fin);
+}
+
 }  // namespace
 
 extern "C" int lt_unproject_bwd(int32_t dtype, const void* feats, const float* proj, const float* coords, const float* conf, const float* grad_out,
@@ -360,7 +393,8 @@ extern "C" int lt_volumetric_ce_fwd(const float* coords, const float* probs, con
 
 extern "C" size_t lt_bn_stats_workspace(int64_t rows, int32_t C) {
     const long long nslab = rows < 1024 ? 1 : (rows / 256 < 1024 ? rows / 256 : 1024);
-    return (size_t)nslab * C * 2 * sizeof(double);
+    const size_t generic = (size_t)nslab * C * 2 * sizeof(double), fast = colsum_workspace(rows, C, 2);
+    return generic > fast ? generic : fast;
 }
 
 extern "C" int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32_t C, float* mean, float* var, float* running_mean,
@@ -369,8 +403,17 @@ extern "C" int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32
     LT_REQUIRE(dtype == LT_F32 || dtype == LT_BF16, LT_ERR_INVALID, "lt_bn_stats_fwd: bad dtype %d", dtype);
     LT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), LT_ERR_INVALID, "lt_bn_stats_fwd: running_mean and running_var come together");
     LT_REQUIRE(rows >= 1 && C >= 1 && C <= 4096, LT_ERR_INVALID, "lt_bn_stats_fwd: bad shape rows=%lld C=%d", (long long)rows, C);
-    const int nslab = (int)(rows < 1024 ? 1 : (rows / 256 < 1024 ? rows / 256 : 1024));
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == LT_F32 && colsum_fast(C)) {       // the training path: float4 lanes, four rows in flight, parallel finalize (colsum.h)
+        const ColsumPlan p = colsum_plan(rows, C);
+        hipLaunchKernelGGL(bn_partial_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, (const float*)x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
+        LT_CHECK_LAUNCH("lt_bn_stats_fwd(partial)");
+        hipLaunchKernelGGL(bn_finalize_vec_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, C, p.nslab,
+                           BnStatFin{(long long)rows, mean, var, running_mean, running_var, momentum});
+        LT_CHECK_LAUNCH("lt_bn_stats_fwd(finalize)");
+        return LT_OK;
+    }
+    const int nslab = (int)(rows < 1024 ? 1 : (rows / 256 < 1024 ? rows / 256 : 1024));
     if (dtype == LT_F32) hipLaunchKernelGGL(bn_partial_kernel<float>, dim3(nslab), dim3(256), 0, st, (const float*)x, (long long)rows, C, nslab, (double*)workspace);
     else hipLaunchKernelGGL(bn_partial_kernel<bf16_t>, dim3(nslab), dim3(256), 0, st, (const bf16_t*)x, (long long)rows, C, nslab, (double*)workspace);
     LT_CHECK_LAUNCH("lt_bn_stats_fwd(partial)");

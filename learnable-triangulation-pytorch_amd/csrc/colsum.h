@@ -1,0 +1,121 @@
+// Column sums over a rows x C fp32 matrix (channels-last activations: BatchNorm statistics, BatchNorm backward sums, bias gradients).
+// Two deterministic stages:
+//   colsum_partial   grid (nslab, column blocks of 1024 channels): a workgroup owns a slab of rows; its 256 threads are RL row lanes x
+//                    CW4 float4 channel lanes (consecutive threads read consecutive 16-byte vectors of one row); every thread keeps
+//                    four rows in flight, accumulates in fp64, the row lanes are combined through LDS, one fp64 partial per
+//                    (slab, channel, quantity) goes to the workspace;
+//   colsum_finalize  16 slab lanes x 16 channels per workgroup add the partials in a fixed order and hand the NQ totals to a functor.
+// The slab count keeps >= 4 rows per thread, <= 1024 workgroups and <= 4 MB of partials.
+#pragma once
+#include "lt_common.h"
+
+namespace lt {
+
+struct ColsumPlan { int nslab, ncb, cw4, rl; };
+
+inline ColsumPlan colsum_plan(long long rows, int C) {
+    ColsumPlan p;
+    const int c4 = C / 4;
+    p.cw4 = c4 < 256 ? c4 : 256;
+    p.rl = 256 / p.cw4;
+    p.ncb = (c4 + 255) / 256;
+    long long n = rows / ((long long)p.rl * 4);
+    const long long cap_blocks = 1024 / p.ncb, cap_part = (256ll << 10) / C;
+    if (n > cap_blocks) n = cap_blocks;
+    if (n > cap_part) n = cap_part;
+    if (n < 1) n = 1;
+    p.nslab = (int)n;
+    return p;
+}
+
+// the vector path: C a multiple of 4 with C/4 a power of two up to 256, or a multiple of 1024
+inline bool colsum_fast(int C) {
+    if (C < 4 || C % 4) return false;
+    const int c4 = C / 4;
+    return c4 <= 256 ? (c4 & (c4 - 1)) == 0 : c4 % 256 == 0;
+}
+
+inline size_t colsum_workspace(long long rows, int C, int nq) {
+    return colsum_fast(C) ? (size_t)colsum_plan(rows, C).nslab * C * nq * sizeof(double) : 0;
+}
+
+// Load: void operator()(long long row, int c /* multiple of 4 */, float (&q)[NQ][4]) -- the NQ quantities of four consecutive channels
+template <int NQ, class Load>
+__device__ __forceinline__ void colsum_partial(long long rows, int C, int nslab, int cw4, int rl_n, double* __restrict__ part, const Load& load) {
+    __shared__ double red[256][NQ * 4 + 1];
+    const int slab = blockIdx.x;
+    const long long r0 = rows * slab / nslab, r1 = rows * (slab + 1) / nslab;
+    const int rl = threadIdx.x / cw4, cv = threadIdx.x - rl * cw4;
+    const int c = (blockIdx.y * 256 + cv) * 4;
+    double acc[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q][e] = 0.0;
+    if (c < C) {
+        long long r = r0 + rl;
+        for (; r + 3ll * rl_n < r1; r += 4ll * rl_n) {          // four rows in flight
+            float v[4][NQ][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load(r + (long long)u * rl_n, c, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[q][e] += (double)v[u][q][e];
+        }
+        for (; r < r1; r += rl_n) {
+            float v[NQ][4];
+            load(r, c, v);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[q][e] += (double)v[q][e];
+        }
+    }
+    if (rl_n > 1) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[threadIdx.x][q * 4 + e] = acc[q][e];
+        __syncthreads();
+        if (rl == 0)
+            for (int k = 1; k < rl_n; ++k)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[q][e] += red[k * cw4 + cv][q * 4 + e];
+    }
+    if (rl == 0 && c < C)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) part[((long long)slab * C + c + e) * NQ + q] = acc[q][e];
+}
+
+// Fin: void operator()(int c, const double (&tot)[NQ])
+template <int NQ, class Fin>
+__device__ __forceinline__ void colsum_finalize(const double* __restrict__ part, int C, int nslab, const Fin& fin) {
+    __shared__ double red[16][16][NQ];
+    const int kl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const int c = blockIdx.x * 16 + cl;
+    double tot[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) tot[q] = 0.0;
+    if (c < C)
+        for (int k = kl; k < nslab; k += 16)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) tot[q] += part[((long long)k * C + c) * NQ + q];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) red[kl][cl][q] = tot[q];
+    __syncthreads();
+    if (kl == 0 && c < C) {
+        for (int k = 1; k < 16; ++k)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) tot[q] += red[k][cl][q];
+        fin(c, tot);
+    }
+}
+
+}  // namespace lt

@@ -13,6 +13,7 @@
 //   lt_adam_step       torch.optim.Adam's update (train.py:430-437), one launch per parameter tensor
 // The convolution dgrad needs no kernel of its own: it is lt_conv_fwd over dY with the weights transposed / flipped (stride 1), as a
 // parity-phase transposed convolution (stride-2 layers) or as a strided convolution (the transposed layers) -- see lt_train.py.
+#include "colsum.h"
 #include "conv_common.h"
 
 using namespace lt;
@@ -131,6 +132,84 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     }
 }
 
+// the same three stages on float4 lanes (colsum.h); every BatchNorm layer of these networks takes this path
+struct BnBwdLoad {
+    BnBwdArgs a;
+    __device__ __forceinline__ void operator()(long long row, int c, float (&q)[2][4]) const {
+        const size_t off = (size_t)row * a.C + c;
+        const float4 dz4 = *(const float4*)(a.dz + off), y4 = *(const float4*)(a.y + off);
+        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.res) r4 = *(const float4*)(a.res + off);
+        const float dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float xh;
+            const float g = bn_g(a, dzv[e], yv[e], rv[e], c + e, xh);
+            q[0][e] = g; q[1][e] = g * xh;
+        }
+    }
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BnBwdArgs a, int cw4, int rl) {
+    colsum_partial<2>(a.rows, a.C, a.nslab, cw4, rl, a.part, BnBwdLoad{a});
+}
+
+struct BnBwdFin {
+    float* dgamma; float* dbeta;
+    __device__ __forceinline__ void operator()(int c, const double (&t)[2]) const { dbeta[c] = (float)t[0]; dgamma[c] = (float)t[1]; }
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_vec_kernel(const BnBwdArgs a) { colsum_finalize<2>(a.part, a.C, a.nslab, BnBwdFin{a.dgamma, a.dbeta}); }
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdArgs a) {
+    const int c4n = a.C >> 2;
+    const long long total = a.rows * c4n;
+    const float inv_n = 1.0f / (float)a.rows;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % c4n) * 4;
+        const size_t off = (size_t)i * 4;
+        const float4 dz4 = *(const float4*)(a.dz + off), y4 = *(const float4*)(a.y + off);
+        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.res) r4 = *(const float4*)(a.res + off);
+        const float dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+        float o[4], dr[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float xh;
+            const float g = bn_g(a, dzv[e], yv[e], rv[e], c + e, xh);
+            const float invstd = 1.0f / sqrtf(a.var[c + e] + a.eps);
+            o[e] = a.gamma[c + e] * invstd * (g - a.dbeta[c + e] * inv_n - xh * a.dgamma[c + e] * inv_n);
+            dr[e] = (a.flags & LT_EPI_RELU_POST) ? g : dzv[e];     // RELU_PRE / none: the residual is added after the activation
+        }
+        *(float4*)(a.dy + off) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.dres) {
+            if (a.accumulate_res) {
+                const float4 d0 = *(const float4*)(a.dres + off);
+                dr[0] += d0.x; dr[1] += d0.y; dr[2] += d0.z; dr[3] += d0.w;
+            }
+            *(float4*)(a.dres + off) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+        }
+    }
+}
+
+struct ChanSumLoad {
+    const float* x; int C;
+    __device__ __forceinline__ void operator()(long long row, int c, float (&q)[1][4]) const {
+        const float4 v = *(const float4*)(x + (size_t)row * C + c);
+        q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w;
+    }
+};
+__global__ __launch_bounds__(256) void channel_sum_vec_kernel(const float* __restrict__ x, long long rows, int C, int nslab, int cw4, int rl, double* __restrict__ part) {
+    colsum_partial<1>(rows, C, nslab, cw4, rl, part, ChanSumLoad{x, C});
+}
+struct ChanSumFin {
+    float* out; int accumulate;
+    __device__ __forceinline__ void operator()(int c, const double (&t)[1]) const { out[c] = accumulate ? out[c] + (float)t[0] : (float)t[0]; }
+};
+__global__ __launch_bounds__(256) void channel_sum_finalize_vec_kernel(const double* __restrict__ part, int C, int nslab, ChanSumFin fin) {
+    colsum_finalize<1>(part, C, nslab, fin);
+}
+
 // layers without BatchNorm: z = act(y, res) with y = conv + bias: dy = dz * mask, dres likewise
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ res,
                                                       float* __restrict__ dy, float* __restrict__ dres, int flags, int accumulate_res, long long total) {
@@ -216,77 +295,146 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
 struct WgradArgs {
     const float* dy;         // [M][ldy]: gradient of the convolution output, GEMM row m = (n, od, oh, ow)
     const float* x;          // channels-last input [N][D][H][W][Cin]
-    const int4* taps;        // [ntaps] = (dd, dh, dw, element offset) as in lt_conv_fwd
-    float* dw;               // [cout_pad][k_pad] fp32 (rows >= Cout / columns >= ntaps * Cin are written as 0)
+    const int4* taps;        // [ntaps] = (dd, dh, dw, unused)
+    float* out;              // S == 1: dw [cout_pad][k_pad];  S > 1: workspace [S][cout_pad][k_pad] of per-slab partial sums
     int N, D, H, W, Cin, log2Cin, Do, Ho, Wo, sd, sh, sw, pd, ph, pw;
     int Cout, ldy, k_pad, ntaps, M, accumulate, cout_pad;
+    int n_k_t, n_tiles, rows_per_slab;
 };
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
-    __shared__ float red[3][4][16][64];                   // waves 1-3: [k block][acc element][lane]
+// dW = dY^T x im2col(X): a GEMM whose reduction runs over the M = N*Do*Ho*Wo output pixels (1e4 .. 1e6) while the result is small
+// (Cout x taps*Cin).  One WAVE owns a (32 CT) x (32 KT) block of dW in 128 accumulator registers (exact-fp32 32x32x2 MFMA: one
+// value per lane and operand, so the operands go from global memory straight into the MFMA -- each lane's loads are 128-byte
+// coalesced rows of dY / of one tap's channels -- with no LDS stage and no barrier); the four waves of a workgroup take neighbouring
+// blocks (same dY columns: their dY loads hit L1), and the pixel range is cut into S slabs across blockIdx.y so that the launch
+// fills the chip whatever the layer's shape; slab partial sums are reduced by wgrad_reduce_kernel in a fixed order (deterministic).
+// Operands of the next pixel pair are loaded before the MFMAs of the current one (software pipeline, two register sets).
+template <int CT, int KT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int co0 = blockIdx.x * 32, k0 = blockIdx.y * 128;
-    const int col = lane & 31, half = lane >> 5;          // A: co = co0 + col, row m + half;  B: k = k0 + 32 j + col, row m + half
-    const bool co_ok = co0 + col < a.Cout;
-    int tap_dd[4], tap_dh[4], tap_dw[4], ci[4];
-    bool k_ok[4];
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= a.n_tiles) return;
+    const int co0 = (t / a.n_k_t) * (32 * CT), k0 = (t % a.n_k_t) * (32 * KT);
+    const int col = lane & 31, half = lane >> 5;          // A: co = co0 + 32 c + col, row m + half;  B: k = k0 + 32 j + col, row m + half
+    int tdelta[KT], toff[KT];                             // per GEMM column: packed (dd, dh, dw) of its tap (bit 31: no such column), element offset
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < KT; ++j) {
         const int k = k0 + 32 * j + col;
         const int tap = k >> a.log2Cin;
-        k_ok[j] = tap < a.ntaps;
-        const int4 tp = k_ok[j] ? a.taps[tap] : make_int4(0, 0, 0, 0);
-        tap_dd[j] = tp.x; tap_dh[j] = tp.y; tap_dw[j] = tp.z;
-        ci[j] = k & (a.Cin - 1);
-    }
-    f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    const int hw = a.Ho * a.Wo, dhw = a.Do * hw;
-    for (int m2 = wave * 2; m2 < a.M; m2 += 8) {
-        const int m = m2 + half;
-        const bool m_ok = m < a.M;
-        float av = 0.f, bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (m_ok) {
-            if (co_ok) av = a.dy[(size_t)m * a.ldy + co0 + col];
-            const int n = m / dhw;
-            int r = m - n * dhw;
-            const int od = r / hw; r -= od * hw;
-            const int oh = r / a.Wo, ow = r - oh * a.Wo;
-            const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int id = id0 + tap_dd[j], ih = ih0 + tap_dh[j], iw = iw0 + tap_dw[j];
-                if (k_ok[j] && (unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-                    bv[j] = a.x[((((size_t)n * a.D + id) * a.H + ih) * a.W + iw) * a.Cin + ci[j]];
-            }
+        if (tap < a.ntaps) {
+            const int4 tp = a.taps[tap];
+            tdelta[j] = (tp.x & 0xff) | ((tp.y & 0xff) << 8) | ((tp.z & 0xff) << 16);
+            toff[j] = ((tp.x * a.H + tp.y) * a.W + tp.z) * a.Cin + (k & (a.Cin - 1));
+        } else {
+            tdelta[j] = (int)0x80000000; toff[j] = 0;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
     }
-    if (wave > 0) {
+    bool co_ok[CT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+    for (int c = 0; c < CT; ++c) co_ok[c] = co0 + 32 * c + col < a.Cout;
+    f32x16 acc[CT][KT];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) red[wave - 1][j][e][lane] = acc[j][e];
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[c][j][e] = 0.f;
+    const int m_begin = blockIdx.y * a.rows_per_slab;
+    const int m_end = min(a.M, m_begin + a.rows_per_slab);
+    // this lane's row walks m_begin + half, + 2, + 4, ...: (n, od, oh, ow) advance incrementally
+    int m = m_begin + half;
+    const int hw = a.Ho * a.Wo, dhw = a.Do * hw;
+    int n = m / dhw, r = m - n * dhw;
+    int od = r / hw; r -= od * hw;
+    int oh = r / a.Wo, ow = r - oh * a.Wo;
+    const float* dyp = a.dy + co0 + col;
+
+    auto load = [&](float (&av)[CT], float (&bv)[KT]) {
+        const bool m_ok = m < m_end;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) av[c] = (m_ok && co_ok[c]) ? dyp[(long long)m * a.ldy + 32 * c] : 0.f;
+        const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+        const int pix = (((n * a.D + id0) * a.H + ih0) * a.W + iw0) * a.Cin;          // may point in front of the tensor (padding): only in-bounds taps are read
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const int td = tdelta[j];
+            const int id = id0 + (int)(signed char)(td & 0xff), ih = ih0 + (int)(signed char)((td >> 8) & 0xff), iw = iw0 + (int)(signed char)((td >> 16) & 0xff);
+            const bool ok = m_ok && td >= 0 && (unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            bv[j] = ok ? a.x[pix + toff[j]] : 0.f;
+        }
+        m += 2; ow += 2;
+        while (ow >= a.Wo) {
+            ow -= a.Wo;
+            if (++oh == a.Ho) { oh = 0; if (++od == a.Do) { od = 0; ++n; } }
+        }
+    };
+    auto mma = [&](const float (&av)[CT], const float (&bv)[KT]) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int j = 0; j < KT; ++j) acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[j], acc[c][j], 0, 0, 0);
+    };
+    // three pixel pairs in flight ahead of the one in the MFMAs (rows past m_end load zeros: the extra MFMAs add nothing)
+    float av0[CT], bv0[KT], av1[CT], bv1[KT], av2[CT], bv2[KT], av3[CT], bv3[KT];
+    const int nit = (m_end - m_begin + 1) >> 1;
+    load(av0, bv0); load(av1, bv1); load(av2, bv2);
+    for (int it = 0; it < nit; it += 4) {
+        load(av3, bv3); mma(av0, bv0);
+        load(av0, bv0); mma(av1, bv1);
+        load(av1, bv1); mma(av2, bv2);
+        load(av2, bv2); mma(av3, bv3);
     }
-    __syncthreads();
-    if (wave == 0) {
+    float* out = a.out + (size_t)blockIdx.y * a.cout_pad * a.k_pad;
+    const bool direct_acc = a.accumulate && gridDim.y == 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float v = acc[j][e] + red[0][j][e][lane] + red[1][j][e][lane] + red[2][j][e][lane];
-                const int row = co0 + 8 * (e >> 2) + 4 * half + (e & 3);       // C layout of the 32x32 MFMA: row = co, column = k
+                const int row = co0 + 32 * c + 8 * (e >> 2) + 4 * half + (e & 3);       // C layout of the 32x32 MFMA: row = co, column = k
                 const int k = k0 + 32 * j + col;
                 if (k < a.k_pad && row < a.cout_pad) {
-                    float* dst = a.dw + (size_t)row * a.k_pad + k;
-                    *dst = a.accumulate ? *dst + v : v;
+                    float* dst = out + (size_t)row * a.k_pad + k;
+                    *dst = direct_acc ? *dst + acc[c][j][e] : acc[c][j][e];
                 }
             }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n, int S, int accumulate) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
+        float s = accumulate ? dw[i] : 0.f;
+        for (int z = 0; z < S; ++z) s += ws[(size_t)z * n + i];
+        dw[i] = s;
     }
+}
+
+__global__ void gather_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
+        const int j = idx[i];
+        dst[i] = j >= 0 ? src[j] : 0.f;
+    }
+}
+
+struct WgradPlan { int variant, n_co_t, n_k_t, S, rows_per_slab; };
+
+// tile shape by layer shape, slab count so that ~1024 workgroups are in flight (two per CU at two waves per SIMD), partial sums capped at 48 MiB
+WgradPlan wgrad_plan(long long M, int cout_pad, int k_pad) {
+    WgradPlan p;
+    p.variant = k_pad <= 64 ? 0 : cout_pad <= 32 ? 2 : 1;
+    const int ct = p.variant == 0 ? 4 : p.variant == 1 ? 2 : 1, kt = 8 / ct;
+    p.n_co_t = (int)cdiv(cout_pad, 32 * ct); p.n_k_t = (int)cdiv(k_pad, 32 * kt);
+    const long long wgs = cdiv((long long)p.n_co_t * p.n_k_t, 4);
+    long long S = cdiv(1024, wgs);
+    const long long cap = (48ll << 20) / ((long long)cout_pad * k_pad * 4);
+    if (S > cap) S = cap;
+    if (S > M / 64) S = M / 64;
+    if (S < 1) S = 1;
+    long long rps = cdiv(M, S);
+    rps += rps & 1;
+    p.rows_per_slab = (int)rps;
+    p.S = (int)cdiv(M, rps);
+    return p;
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n, float lr,
@@ -300,6 +448,33 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         // torch.optim.Adam (single tensor): denom = sqrt(v) / sqrt(bias_correction2) + eps; p -= lr / bias_correction1 * m / denom
         const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
         p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
+struct AdamJob { float* p; const float* g; float* m; float* v; long long n; float lr; int first_block; };
+
+// every parameter tensor of the model in ONE launch: a workgroup updates 1024 consecutive elements of the job its index falls into
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamJob* __restrict__ jobs, int njobs, float beta1, float beta2, float eps, float weight_decay,
+                                                         float bc1, float bc2) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {          // last job whose first_block <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const AdamJob j = jobs[lo];
+    const long long base = (long long)(blockIdx.x - j.first_block) * 1024;
+    const float sq2 = sqrtf(bc2);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long i = base + u * 256 + threadIdx.x;
+        if (i >= j.n) break;
+        float grad = j.g[i];
+        if (weight_decay != 0.f) grad += weight_decay * j.p[i];
+        const float mi = beta1 * j.m[i] + (1.f - beta1) * grad;
+        const float vi = beta2 * j.v[i] + (1.f - beta2) * grad * grad;
+        j.m[i] = mi; j.v[i] = vi;
+        const float denom = sqrtf(vi) / sq2 + eps;
+        j.p[i] -= (j.lr / bc1) * (mi / denom);
     }
 }
 
@@ -319,7 +494,10 @@ extern "C" int lt_bn_act_fwd(const float* y, const float* mean, const float* var
     return LT_OK;
 }
 
-extern "C" size_t lt_bn_act_bwd_workspace(int64_t rows, int32_t C) { return (size_t)slabs_for(rows) * C * 2 * sizeof(double); }
+extern "C" size_t lt_bn_act_bwd_workspace(int64_t rows, int32_t C) {
+    const size_t generic = (size_t)slabs_for(rows) * C * 2 * sizeof(double), fast = colsum_workspace(rows, C, 2);
+    return generic > fast ? generic : fast;
+}
 
 extern "C" int lt_bn_act_bwd(const float* dz, const float* y, const float* residual, const float* mean, const float* var, const float* gamma,
                              const float* beta, float* dy, float* dgamma, float* dbeta, float* dres, int32_t accumulate_res, int64_t rows, int32_t C,
@@ -332,6 +510,18 @@ extern "C" int lt_bn_act_bwd(const float* dz, const float* y, const float* resid
     a.dgamma = dgamma; a.dbeta = dbeta; a.dy = dy; a.dres = dres; a.eps = eps; a.flags = flags; a.C = C; a.nslab = slabs_for(rows);
     a.accumulate_res = accumulate_res; a.rows = rows;
     hipStream_t st = (hipStream_t)stream;
+    if (colsum_fast(C)) {
+        const ColsumPlan p = colsum_plan(rows, C);
+        a.nslab = p.nslab;
+        hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, a, p.cw4, p.rl);
+        LT_CHECK_LAUNCH("lt_bn_act_bwd(reduce)");
+        hipLaunchKernelGGL(bn_bwd_finalize_vec_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, st, a);
+        LT_CHECK_LAUNCH("lt_bn_act_bwd(finalize)");
+        const long long vb = cdiv(rows * (C / 4), 256);
+        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3((unsigned)(vb < 16384 ? vb : 16384)), dim3(256), 0, st, a);
+        LT_CHECK_LAUNCH("lt_bn_act_bwd(apply)");
+        return LT_OK;
+    }
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(a.nslab), dim3(256), 0, st, a);
     LT_CHECK_LAUNCH("lt_bn_act_bwd(reduce)");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, a);
@@ -352,12 +542,23 @@ extern "C" int lt_act_bwd(const float* dz, const float* z, const float* residual
     return LT_OK;
 }
 
-extern "C" size_t lt_channel_sum_workspace(int64_t rows, int32_t C) { return (size_t)slabs_for(rows) * C * sizeof(double); }
+extern "C" size_t lt_channel_sum_workspace(int64_t rows, int32_t C) {
+    const size_t generic = (size_t)slabs_for(rows) * C * sizeof(double), fast = colsum_workspace(rows, C, 1);
+    return generic > fast ? generic : fast;
+}
 
 extern "C" int lt_channel_sum(const float* x, int64_t rows, int32_t C, float* out, int32_t accumulate, void* workspace, void* stream) {
     LT_REQUIRE(x && out && workspace && rows >= 1 && C >= 1, LT_ERR_INVALID, "lt_channel_sum: bad argument");
-    const int ns = slabs_for(rows);
     hipStream_t st = (hipStream_t)stream;
+    if (colsum_fast(C)) {
+        const ColsumPlan p = colsum_plan(rows, C);
+        hipLaunchKernelGGL(channel_sum_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
+        LT_CHECK_LAUNCH("lt_channel_sum(partial)");
+        hipLaunchKernelGGL(channel_sum_finalize_vec_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, C, p.nslab, ChanSumFin{out, accumulate});
+        LT_CHECK_LAUNCH("lt_channel_sum(finalize)");
+        return LT_OK;
+    }
+    const int ns = slabs_for(rows);
     hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(ns), dim3(256), 0, st, x, (long long)rows, C, ns, (double*)workspace);
     LT_CHECK_LAUNCH("lt_channel_sum(partial)");
     hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, C, ns, out, accumulate);
@@ -378,22 +579,60 @@ extern "C" int lt_maxpool_bwd(const float* x, const float* dy, float* dx, int32_
     return LT_OK;
 }
 
+extern "C" size_t lt_conv_wgrad_workspace(int64_t rows, int32_t cout_pad, int32_t k_pad) {
+    if (rows < 1 || cout_pad < 1 || k_pad < 1) return 0;
+    const WgradPlan p = wgrad_plan(rows, cout_pad, k_pad);
+    return p.S > 1 ? (size_t)p.S * cout_pad * k_pad * sizeof(float) : 0;
+}
+
 extern "C" int lt_conv_wgrad(const float* dy, const float* x, const int32_t* taps, float* dw, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
                              int32_t Do, int32_t Ho, int32_t Wo, const int32_t stride[3], const int32_t pad[3], int32_t Cout, int32_t ldy,
-                             int32_t cout_pad, int32_t k_pad, int32_t ntaps, int32_t accumulate, void* stream) {
+                             int32_t cout_pad, int32_t k_pad, int32_t ntaps, int32_t accumulate, void* workspace, void* stream) {
     LT_REQUIRE(dy && x && taps && dw && stride && pad, LT_ERR_INVALID, "lt_conv_wgrad: null argument");
     const int l2 = ilog2_exact(Cin);
     LT_REQUIRE(l2 >= 0, LT_ERR_UNSUPPORTED, "lt_conv_wgrad: Cin=%d must be a power of two", Cin);
     LT_REQUIRE(Cout >= 1 && ldy >= Cout && cout_pad >= Cout && k_pad >= ntaps * Cin && ntaps >= 1, LT_ERR_INVALID, "lt_conv_wgrad: bad sizes");
     const long long M = (long long)N * Do * Ho * Wo;
-    LT_REQUIRE(M >= 1 && M < (1ll << 31), LT_ERR_UNSUPPORTED, "lt_conv_wgrad: too many rows");
+    LT_REQUIRE(M >= 1 && M < (1ll << 31) && (long long)N * D * H * W * Cin < (1ll << 31) && M * ldy < (1ll << 40), LT_ERR_UNSUPPORTED,
+               "lt_conv_wgrad: too many rows / elements for 32-bit offsets");
+    const WgradPlan p = wgrad_plan(M, cout_pad, k_pad);
+    LT_REQUIRE(p.S == 1 || workspace, LT_ERR_INVALID, "lt_conv_wgrad: this shape needs a workspace of lt_conv_wgrad_workspace() bytes");
     WgradArgs a;
-    a.dy = dy; a.x = x; a.taps = (const int4*)taps; a.dw = dw;
+    a.dy = dy; a.x = x; a.taps = (const int4*)taps; a.out = p.S > 1 ? (float*)workspace : dw;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.log2Cin = l2; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
     a.sd = stride[0]; a.sh = stride[1]; a.sw = stride[2]; a.pd = pad[0]; a.ph = pad[1]; a.pw = pad[2];
     a.Cout = Cout; a.ldy = ldy; a.k_pad = k_pad; a.ntaps = ntaps; a.M = (int)M; a.accumulate = accumulate; a.cout_pad = cout_pad;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)cdiv(cout_pad, 32), (unsigned)cdiv(k_pad, 128)), dim3(256), 0, (hipStream_t)stream, a);
+    a.n_k_t = p.n_k_t; a.n_tiles = p.n_co_t * p.n_k_t; a.rows_per_slab = p.rows_per_slab;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)cdiv(a.n_tiles, 4), (unsigned)p.S);
+    if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad_kernel<4, 2>), grid, dim3(256), 0, st, a);
+    else if (p.variant == 1) hipLaunchKernelGGL((conv_wgrad_kernel<2, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<1, 8>), grid, dim3(256), 0, st, a);
     LT_CHECK_LAUNCH("lt_conv_wgrad");
+    if (p.S > 1) {
+        const long long n = (long long)cout_pad * k_pad;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096)), dim3(256), 0, st, (const float*)workspace, dw, n, p.S,
+                           accumulate);
+        LT_CHECK_LAUNCH("lt_conv_wgrad(reduce)");
+    }
+    return LT_OK;
+}
+
+extern "C" int lt_adam_step_multi(const void* jobs, int32_t njobs, int32_t total_blocks, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                                  void* stream) {
+    LT_REQUIRE(jobs && njobs >= 1 && total_blocks >= 1 && step >= 1, LT_ERR_INVALID, "lt_adam_step_multi: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const AdamJob*)jobs, njobs, beta1, beta2, eps, weight_decay,
+                       bc1, bc2);
+    LT_CHECK_LAUNCH("lt_adam_step_multi");
+    return LT_OK;
+}
+
+extern "C" int lt_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, void* stream) {
+    LT_REQUIRE(src && idx && dst && n >= 1, LT_ERR_INVALID, "lt_gather_f32: bad argument");
+    const long long blocks = cdiv(n, 256);
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, src, (const int*)idx, dst, (long long)n);
+    LT_CHECK_LAUNCH("lt_gather_f32");
     return LT_OK;
 }
 

@@ -244,6 +244,7 @@ class PlanBuilder:
         meta = {"kind": kind, "label": label, "flops": flops, "bytes": nbytes}
         if self.dry_run:
             meta["info"] = info or {}
+        self.last_info = info or {}        # lt_train.TrainTape reads the device buffers of the op it has just recorded
         self.ops.append((fn, meta))
 
     def conv(self, x, weight, bias=None, bn=None, stride=1, pad=0, transposed=False, relu=False, relu_pre=False,
@@ -267,8 +268,10 @@ class PlanBuilder:
         d.out_stride = H.i3(spec.out_stride)
         d.Cout, d.ldc, d.cout_pad, d.k_pad = spec.Cout, spec.Cout, spec.cout_pad, spec.k_pad
         d.nphase, d.flags, d.tile, d.stages = len(spec.phases), spec.flags, self.tile_override, self.stages
+        wdevs = []
         for i, ph in enumerate(spec.phases):
             wdev = self.const(ph.weight, self.dtype)
+            wdevs.append(wdev)
             tdev = self.const(ph.taps)
             d.phase[i].weight = wdev.data_ptr(); d.phase[i].taps = tdev.data_ptr()
             d.phase[i].ntaps = ph.taps.shape[0]; d.phase[i].out_off = H.i3(ph.out_off)
@@ -326,7 +329,7 @@ class PlanBuilder:
         self._add(lambda s, d=d, xp=x.t.data_ptr(), bip=bi.data_ptr(), scp=sc.data_ptr(), shp=sh.data_ptr(),
                   rp=H.ptr(residual.t) if residual is not None else None, yp=y.t.data_ptr():
                   H.check(lib.lt_conv_fwd(C.byref(d), xp, bip, scp, shp, rp, yp, s), "lt_conv_fwd"),
-                  "conv", label, 2 * macs, nbytes, {"spec": spec, "x": x, "y": y, "res": residual})
+                  "conv", label, 2 * macs, nbytes, {"spec": spec, "x": x, "y": y, "res": residual, "wdev": wdevs, "bias_dev": bi})
         return y
 
     def can_chain_pointwise(self, x, layers):

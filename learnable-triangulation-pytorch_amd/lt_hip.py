@@ -85,7 +85,10 @@ SIGNATURES = {
     "lt_channel_sum_workspace": (C.c_size_t, [i64, i32]),
     "lt_channel_sum": (C.c_int, [vp, i64, i32, vp, i32, vp, vp]),
     "lt_maxpool_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32 * 3, vp]),
-    "lt_conv_wgrad": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32, i32, i32, i32, i32, i32, vp]),
+    "lt_adam_step_multi": (C.c_int, [vp, i32, i32, f32, f32, f32, f32, i32, vp]),
+    "lt_gather_f32": (C.c_int, [vp, vp, vp, i64, vp]),
+    "lt_conv_wgrad_workspace": (C.c_size_t, [i64, i32, i32]),
+    "lt_conv_wgrad": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32, i32, i32, i32, i32, i32, vp, vp]),
     "lt_adam_step": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "lt_unproject_bwd": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, vp]),
     "lt_softargmax3d_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, i32, i32, i64, vp]),

@@ -28,22 +28,38 @@ BN_EPS = 1e-5
 
 
 class TrainTape:
-    """PlanBuilder-shaped object for ``record()``: conv / maxpool / alloc / release; executes eagerly on ``stream``."""
+    """PlanBuilder-shaped object for ``record()`` (conv / maxpool / alloc / release).  RECORD ONCE, REPLAY EVERY STEP: while the
+    modules' ``record()`` methods run, every launch is executed AND appended to ``fwd_ops``; the first backward walks the layers in
+    reverse the same way into ``bwd_ops``.  Every buffer (activations, gradients, GEMM-layout weights, workspaces, the flat arena of
+    parameter gradients) is allocated during recording and lives as long as the tape, so a later step is two loops over closures of
+    raw pointers -- no allocation, no host-side weight handling, no synchronisation.  The weights are LIVE: each layer's first op is
+    an ``lt_gather_f32`` from the Parameter (wherever the optimiser has left it) into the layer's GEMM layout, with an index map built
+    at record time by pushing a tensor of indices through the very host code that lays out inference weights."""
 
-    def __init__(self, device, momentum=0.1):
+    def __init__(self, device, params=(), momentum=0.1, reducer=None, bucket_bytes=64 << 20):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("training runs on the GPU only (device=%s); there is no CPU fallback" % device)
         self.dtype, self.code, self.dry_run = torch.float32, H.LT_F32, False
-        self.pb = E.PlanBuilder(device, torch.float32)          # builds the lt_conv_fwd descriptors; every op is run as it is recorded
-        self.tape = []                                          # backward closures, run in reverse
+        self.pb = E.PlanBuilder(device, torch.float32)          # builds the lt_conv_fwd descriptors
+        self.fwd_ops, self.bwd_ops = [], []                     # fn(stream) closures, in launch order
+        self._cur = self.fwd_ops
+        self.recorders = []                                     # one per layer: records (= runs once) that layer's backward
         self.grads = {}                                         # id(Act) -> (Act, gradient tensor of act.t's shape)
-        self.param_grads = {}                                   # Parameter -> gradient in the Parameter's own layout
         self.momentum = momentum
         self.no_grad_ids = set()                                # id(Act) of inputs that need no gradient (the images)
         self.npre = 0
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._ws = None
+        self._ws = torch.empty(1 << 16, dtype=torch.uint8, device=self.device)
+        self.keep = []
+        # parameter gradients: ONE flat fp32 arena, slices handed out in the order the backward produces them (so a bucket of the
+        # data-parallel all-reduce is a contiguous range that is complete early), 16-byte aligned
+        total = sum((p.numel() + 3) // 4 * 4 for p in params if p.requires_grad)
+        self.arena = torch.zeros(max(total, 4), dtype=torch.float32, device=self.device)
+        self.arena_off, self.bucket_start = 0, 0
+        self.param_grads = {}                                   # Parameter -> view of the arena
+        self.reducer, self.bucket_elems = reducer, max(1, int(bucket_bytes) // 4)
+        self.bwd_recorded = False
 
     # ---- PlanBuilder surface -------------------------------------------------------------------------------------------------
     def alloc(self, shape, dtype=None):
@@ -64,22 +80,46 @@ class TrainTape:
     def global_avgpool(self, x):
         raise NotImplementedError("training with the confidence heads (volume_aggregation_method conf*) is not built")
 
-    def _run_last(self):
-        fn, _ = self.pb.ops[-1]
+    def do(self, fn):
+        """Run fn(stream) now and keep it for every later step (forward list while record() runs, backward list afterwards)."""
         fn(self.stream)
+        self._cur.append(fn)
 
-    def _workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=self.device)
-        return self._ws
+    def _ws_need(self, nbytes):
+        if self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)       # closures read self._ws at call time
 
     def _add_grad(self, act, g):
-        """Registers g as (part of) the gradient of ``act``; returns the tensor a later producer should ADD to (or None)."""
         self.grads[id(act)] = (act, g)
 
     def grad_of(self, act):
         e = self.grads.get(id(act))
         return None if e is None else e[1]
+
+    def _gather(self, src, imap, dst):
+        """dst <- src[imap] every step; src is read where it lives AT CALL TIME (a Parameter the optimiser updates in place)."""
+        self.keep += [imap, dst]
+        n = dst.numel()
+        self.do(lambda st: H.check(H.lib().lt_gather_f32(src.data_ptr(), imap.data_ptr(), dst.data_ptr(), n, st), "lt_gather_f32"))
+
+    def _live_conv(self, x, wparam, wt=None, bias=None, **kw):
+        """lt_conv_fwd over the CURRENT values of ``wparam`` (optionally seen through the view transform ``wt``: the transposed / flipped
+        filter of an input gradient) and of ``bias``."""
+        assert wparam.numel() < (1 << 24)
+        idx = torch.arange(1, wparam.numel() + 1, dtype=torch.float32).reshape(wparam.shape)      # 1 + flat index; 0 = padding
+        if wt is not None:
+            idx = wt(idx).contiguous()
+        y = self.pb.conv(x, idx, bias, None, **kw)
+        fn, info = self.pb.ops[-1][0], self.pb.last_info
+        for wdev in info["wdev"]:
+            self._gather(wparam, (wdev.round().to(torch.int32) - 1).contiguous(), wdev)
+        if bias is not None:
+            bi = info["bias_dev"]
+            bmap = torch.full((bi.numel(),), -1, dtype=torch.int32)
+            bmap[:bias.numel()] = torch.arange(bias.numel(), dtype=torch.int32)
+            self._gather(bias, bmap.to(self.device), bi)
+        self.do(fn)
+        return y
 
     # ---- layers --------------------------------------------------------------------------------------------------------------
     def conv(self, x, weight, bias=None, bn=None, stride=1, pad=0, transposed=False, relu=False, relu_pre=False, residual=None, out_f32=False,
@@ -89,30 +129,30 @@ class TrainTape:
         lib = H.lib()
         flags = (H.EPI_RELU_POST if relu else 0) | (H.EPI_RELU_PRE if relu_pre else 0)
         if bn is None:          # convolution (+ bias) -> activation in the conv epilogue, as in inference
-            z = self.pb.conv(x, weight, bias, None, stride=stride, pad=pad, transposed=transposed, relu=relu, relu_pre=relu_pre, residual=residual)
-            self._run_last()
+            z = self._live_conv(x, weight, None, bias, stride=stride, pad=pad, transposed=transposed, relu=relu, relu_pre=relu_pre, residual=residual)
             y_raw = stats = None
         else:
-            y_raw = self.pb.conv(x, weight, bias, None, stride=stride, pad=pad, transposed=transposed)
-            self._run_last()
+            y_raw = self._live_conv(x, weight, None, bias, stride=stride, pad=pad, transposed=transposed)
             gamma, beta, rmean, rvar = bn
             Cc = y_raw.shape[-1]
             rows = y_raw.t.numel() // Cc
             mean = torch.empty(Cc, dtype=torch.float32, device=self.device)
             var = torch.empty(Cc, dtype=torch.float32, device=self.device)
-            ws = self._workspace(lib.lt_bn_stats_workspace(rows, Cc))
-            H.check(lib.lt_bn_stats_fwd(H.LT_F32, y_raw.t.data_ptr(), rows, Cc, mean.data_ptr(), var.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
-                                        float(self.momentum), ws.data_ptr(), self.stream), "lt_bn_stats_fwd")
+            self._ws_need(lib.lt_bn_stats_workspace(rows, Cc))
+            mom = float(self.momentum)
+            self.do(lambda st: H.check(lib.lt_bn_stats_fwd(H.LT_F32, y_raw.t.data_ptr(), rows, Cc, mean.data_ptr(), var.data_ptr(), rmean.data_ptr(),
+                                                           rvar.data_ptr(), mom, self._ws.data_ptr(), st), "lt_bn_stats_fwd"))
             z = self.alloc(y_raw.shape)
-            H.check(lib.lt_bn_act_fwd(y_raw.t.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), H.ptr(residual.t) if residual is not None else None,
-                                      z.t.data_ptr(), rows, Cc, BN_EPS, flags, self.stream), "lt_bn_act_fwd")
+            rp = residual.t if residual is not None else None
+            self.do(lambda st: H.check(lib.lt_bn_act_fwd(y_raw.t.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), H.ptr(rp),
+                                                         z.t.data_ptr(), rows, Cc, BN_EPS, flags, st), "lt_bn_act_fwd"))
             stats = (mean, var)
-        self.tape.append(lambda: self._conv_bwd(x, weight, bias, bn, stride, pad, transposed, flags, residual, y_raw, stats, z))
+        self.recorders.append(lambda: self._conv_bwd(x, weight, bias, bn, stride, pad, transposed, flags, residual, y_raw, stats, z))
         return z
 
     def maxpool(self, x, k, s, p, nd):
         y = self.pb.maxpool(x, k, s, p, nd)
-        self._run_last()
+        self.do(self.pb.ops[-1][0])
         kk = (1, k, k) if nd == 2 else (k, k, k)
         ss = (1, s, s) if nd == 2 else (s, s, s)
         pp = (0, p, p) if nd == 2 else (p, p, p)
@@ -123,13 +163,37 @@ class TrainTape:
                 return
             dx = self.grad_of(x)
             if dx is None:
-                dx = torch.zeros_like(x.t)
+                dx = torch.empty_like(x.t)
                 self._add_grad(x, dx)
+                self.do(lambda st: dx.zero_())
             N, D, Hh, W, Cc = x.shape
-            H.check(H.lib().lt_maxpool_bwd(x.t.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, D, Hh, W, Cc, H.i3(kk), H.i3(ss), H.i3(pp), self.stream),
-                    "lt_maxpool_bwd")
-        self.tape.append(bwd)
+            self.do(lambda st: H.check(H.lib().lt_maxpool_bwd(x.t.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, D, Hh, W, Cc, H.i3(kk), H.i3(ss), H.i3(pp), st),
+                                       "lt_maxpool_bwd"))
+        self.recorders.append(bwd)
         return y
+
+    # ---- parameter gradients -----------------------------------------------------------------------------------------------------
+    def _grad_view(self, p):
+        if p in self.param_grads:
+            raise NotImplementedError("a parameter shared by two layers (not the case in these networks)")
+        n, off = p.numel(), self.arena_off
+        if off + n > self.arena.numel():
+            raise RuntimeError("parameter-gradient arena too small: pass every trainable parameter to TrainTape(params=...)")
+        self.arena_off += (n + 3) // 4 * 4
+        v = self.arena[off:off + n].view(p.shape)
+        self.param_grads[p] = v
+        return v
+
+    def _grads_ready(self, final=False):
+        """Called after the op that completes a parameter gradient has been recorded: a full bucket starts its all-reduce here, behind
+        the kernels that produced it and in front of the rest of the backward (lt_dist.GradReducer)."""
+        if self.reducer is None:
+            return
+        a, b = self.bucket_start, self.arena_off
+        if b > a and (final or b - a >= self.bucket_elems):
+            chunk = self.arena[a:b]
+            self.do(lambda st: self.reducer.reduce_inplace(chunk))
+            self.bucket_start = b
 
     # ---- backward of one convolution layer ---------------------------------------------------------------------------------------
     def _conv_bwd(self, x, weight, bias, bn, stride, pad, transposed, flags, residual, y_raw, stats, z):
@@ -141,6 +205,7 @@ class TrainTape:
         rows = z.t.numel() // Cout
         dy = torch.empty_like(z.t)
         dres, acc_res = None, 0
+        rp = residual.t if residual is not None else None
         if residual is not None:
             dres = self.grad_of(residual)
             acc_res = 1 if dres is not None else 0
@@ -150,21 +215,18 @@ class TrainTape:
         if bn is not None:
             gamma, beta, _, _ = bn
             mean, var = stats
-            dgamma, dbeta = torch.empty_like(mean), torch.empty_like(mean)
-            ws = self._workspace(lib.lt_bn_act_bwd_workspace(rows, Cout))
-            H.check(lib.lt_bn_act_bwd(dz.data_ptr(), y_raw.t.data_ptr(), H.ptr(residual.t) if residual is not None else None, mean.data_ptr(), var.data_ptr(),
-                                      gamma.data_ptr(), beta.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), H.ptr(dres), acc_res, rows, Cout,
-                                      BN_EPS, flags, ws.data_ptr(), self.stream), "lt_bn_act_bwd")
-            self._param_grad(gamma, dgamma)
-            self._param_grad(beta, dbeta)
+            dgamma, dbeta = self._grad_view(gamma), self._grad_view(beta)
+            self._ws_need(lib.lt_bn_act_bwd_workspace(rows, Cout))
+            self.do(lambda st: H.check(lib.lt_bn_act_bwd(dz.data_ptr(), y_raw.t.data_ptr(), H.ptr(rp), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
+                                                         beta.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), H.ptr(dres), acc_res, rows, Cout,
+                                                         BN_EPS, flags, self._ws.data_ptr(), st), "lt_bn_act_bwd"))
         else:
-            H.check(lib.lt_act_bwd(dz.data_ptr(), z.t.data_ptr(), H.ptr(residual.t) if residual is not None else None, dy.data_ptr(), H.ptr(dres), acc_res,
-                                   z.t.numel(), flags, self.stream), "lt_act_bwd")
+            total = z.t.numel()
+            self.do(lambda st: H.check(lib.lt_act_bwd(dz.data_ptr(), z.t.data_ptr(), H.ptr(rp), dy.data_ptr(), H.ptr(dres), acc_res, total, flags, st), "lt_act_bwd"))
         if bias is not None and bias.requires_grad:
-            db = torch.empty(Cout, dtype=torch.float32, device=self.device)
-            ws = self._workspace(lib.lt_channel_sum_workspace(rows, Cout))
-            H.check(lib.lt_channel_sum(dy.data_ptr(), rows, Cout, db.data_ptr(), 0, ws.data_ptr(), self.stream), "lt_channel_sum")
-            self._param_grad(bias, db)
+            db = self._grad_view(bias)
+            self._ws_need(lib.lt_channel_sum_workspace(rows, Cout))
+            self.do(lambda st: H.check(lib.lt_channel_sum(dy.data_ptr(), rows, Cout, db.data_ptr(), 0, self._ws.data_ptr(), st), "lt_channel_sum"))
         nd = weight.dim() - 2
         st3 = ((1,) + (stride,) * 2) if nd == 2 else (stride,) * 3
         pd3 = ((0,) + (pad,) * 2) if nd == 2 else (pad,) * 3
@@ -174,71 +236,95 @@ class TrainTape:
         ntaps = taps_all.shape[0]
         N, D, Hh, W, cin_buf = x.shape
         if weight.requires_grad:
-            # ---- weight gradient: dw[co][tap * Cin + ci] over the GEMM rows of the forward convolution
+            # ---- weight gradient: dw[co][tap * Cin + ci] over the GEMM rows of the forward convolution, then into the Parameter's layout
             if not transposed:
-                cop = E.cout_pad_of(Cout)
-                kp = ntaps * cin_buf
-                dw = torch.empty(cop, kp, dtype=torch.float32, device=self.device)
-                H.check(lib.lt_conv_wgrad(dy.data_ptr(), x.t.data_ptr(), taps_all.data_ptr(), dw.data_ptr(), N, D, Hh, W, cin_buf, z.shape[1], z.shape[2], z.shape[3],
-                                          H.i3(st3), H.i3(pd3), Cout, Cout, cop, kp, ntaps, 0, self.stream), "lt_conv_wgrad")
-                g = dw[:Cout].reshape(Cout, *ks3, cin_buf)[..., :weight.shape[1]].permute(0, 4, 1, 2, 3)
-                self._param_grad(weight, (g[:, :, 0] if nd == 2 else g).contiguous())
+                cop, kp = E.cout_pad_of(Cout), ntaps * cin_buf
+                a_ptr, b_ptr = dy, x.t
+                geo = (N, D, Hh, W, cin_buf, z.shape[1], z.shape[2], z.shape[3], Cout, Cout)
+                wrows = rows
+                ar = torch.arange(cop * kp, dtype=torch.int32).reshape(cop, kp)
+                imap = ar[:Cout].reshape(Cout, *ks3, cin_buf)[..., :weight.shape[1]].permute(0, 4, 1, 2, 3)
             else:
                 # ConvTranspose: out[2 q - p + a] += x[q][ci] W[ci][co][a]  ->  dW[ci][a][co] = sum_q x[q][ci] dY[2 q - p + a][co]: the same
                 # kernel with the layer's INPUT in the role of "dy" (rows = input pixels) and the output gradient in the role of "x"
                 cin_t = weight.shape[0]
-                cop = E.cout_pad_of(cin_t)
-                kp = ntaps * Cout
-                dw = torch.empty(cop, kp, dtype=torch.float32, device=self.device)
+                cop, kp = E.cout_pad_of(cin_t), ntaps * Cout
+                a_ptr, b_ptr = x.t, dy
                 oN, oD, oH, oW, _ = z.shape
-                H.check(lib.lt_conv_wgrad(x.t.data_ptr(), dy.data_ptr(), taps_all.data_ptr(), dw.data_ptr(), oN, oD, oH, oW, Cout, D, Hh, W,
-                                          H.i3(st3), H.i3(pd3), cin_t, cin_buf, cop, kp, ntaps, 0, self.stream), "lt_conv_wgrad(transposed)")
-                g = dw[:cin_t].reshape(cin_t, *ks3, Cout).permute(0, 4, 1, 2, 3)
-                self._param_grad(weight, (g[:, :, 0] if nd == 2 else g).contiguous())
+                geo = (oN, oD, oH, oW, Cout, D, Hh, W, cin_t, cin_buf)
+                wrows = N * D * Hh * W
+                ar = torch.arange(cop * kp, dtype=torch.int32).reshape(cop, kp)
+                imap = ar[:cin_t].reshape(cin_t, *ks3, Cout).permute(0, 4, 1, 2, 3)
+            imap = (imap[:, :, 0] if nd == 2 else imap).contiguous().reshape(-1).to(self.device)
+            dw = torch.empty(cop, kp, dtype=torch.float32, device=self.device)
+            self._ws_need(lib.lt_conv_wgrad_workspace(wrows, cop, kp))
+            self.keep += [taps_all, a_ptr, b_ptr]
+            self.do(lambda st: H.check(lib.lt_conv_wgrad(a_ptr.data_ptr(), b_ptr.data_ptr(), taps_all.data_ptr(), dw.data_ptr(), geo[0], geo[1], geo[2], geo[3], geo[4],
+                                                         geo[5], geo[6], geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, self._ws.data_ptr(), st),
+                                       "lt_conv_wgrad"))
+            self._gather(dw, imap, self._grad_view(weight))
+        self._grads_ready()
         # ---- input gradient (skipped for the network input)
         if id(x) in self.no_grad_ids:
             return
         prev = self.grad_of(x)
-        w = weight.detach()
         if Cout & (Cout - 1) or Cout < 4:       # lt_conv_fwd wants a power-of-two channel count on its input: pad dY with zero channels (17 joints -> 32)
             cpad = max(4, 1 << (Cout - 1).bit_length())
             dyp = torch.zeros(*dy.shape[:-1], cpad, dtype=torch.float32, device=self.device)
-            dyp[..., :Cout] = dy
-            dy = dyp
-        dya = E.Act(dy)
+            dyv = dyp[..., :Cout]
+            self.do(lambda st: dyv.copy_(dy))
+            dy_in = dyp                     # (dy itself must keep its name: the closures above read it when they are replayed)
+        else:
+            dy_in = dy
+        dya = E.Act(dy_in)
+        res = E.Act(prev) if prev is not None else None
         if not transposed and stride == 1:
-            wt = w.transpose(0, 1).flip(*range(2, 2 + nd)).contiguous()           # [Cin, Cout, k..]: correlation with the flipped, transposed filter
-            dx = self.pb.conv(dya, wt, None, None, stride=1, pad=ks[0] - 1 - pad, residual=E.Act(prev) if prev is not None else None)
+            # correlation with the flipped, transposed filter [Cin, Cout, k..]
+            dx = self._live_conv(dya, weight, lambda t: t.transpose(0, 1).flip(*range(2, 2 + nd)), None, stride=1, pad=ks[0] - 1 - pad, residual=res)
         elif not transposed:
             assert stride == 2 and all(d % 2 == 0 for d in ((Hh, W) if nd == 2 else (D, Hh, W))), "stride-2 layers need even input sizes"
             # the adjoint of a strided convolution is the transposed convolution with the SAME weight tensor read as [in = Cout, out = Cin]
-            dx = self.pb.conv(dya, w, None, None, stride=2, pad=pad, transposed=True, output_padding=1, residual=E.Act(prev) if prev is not None else None)
+            dx = self._live_conv(dya, weight, None, None, stride=2, pad=pad, transposed=True, output_padding=1, residual=res)
         else:
             # the adjoint of ConvTranspose(weight [Cin, Cout, k..], stride 2) is Conv(stride 2) with that tensor read as [out = Cin, in = Cout]
-            dx = self.pb.conv(dya, w, None, None, stride=2, pad=pad, residual=E.Act(prev) if prev is not None else None)
-        self._run_last()
+            dx = self._live_conv(dya, weight, None, None, stride=2, pad=pad, residual=res)
         g = dx.t
         if g.shape[-1] != cin_buf:
             raise RuntimeError("input gradient has %d channels, the activation %d" % (g.shape[-1], cin_buf))
         self._add_grad(x, g)
 
-    def _param_grad(self, p, g):
-        old = self.param_grads.get(p)
-        self.param_grads[p] = g if old is None else old + g          # a parameter used twice (not the case in these nets)
-
     # ---- driver ---------------------------------------------------------------------------------------------------------------------
     def seed(self, act, grad):
-        """Gradient of the loss with respect to an output Act of the recorded forward."""
-        self._add_grad(act, grad.contiguous())
+        """Gradient buffer of the loss with respect to an output Act of the recorded forward (written before every backward)."""
+        assert grad.is_contiguous()
+        self._add_grad(act, grad)
 
     def add_backward(self, fn):
-        """A custom op's backward (unprojection): fn() reads grad_of(output) and registers the inputs' gradients."""
-        self.tape.append(fn)
+        """A custom op's backward (unprojection): fn() reads grad_of(output), registers the inputs' gradients and records its launches
+        with ``do``."""
+        self.recorders.append(fn)
 
-    def backward(self):
-        for fn in reversed(self.tape):
-            fn()
-        self.tape = []
+    def run_forward(self):
+        """Replay of the recorded forward on the current stream (the first forward IS the recording)."""
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        for fn in self.fwd_ops:
+            fn(self.stream)
+
+    def run_backward(self):
+        """First call: records (= runs) the backward; later calls replay it.  Returns {Parameter: gradient view of the arena} (averaged
+        over the ranks when a reducer is attached)."""
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        if not self.bwd_recorded:
+            self._cur = self.bwd_ops
+            for rec in reversed(self.recorders):
+                rec()
+            self._grads_ready(final=True)
+            self.recorders, self.bwd_recorded = [], True
+        else:
+            for fn in self.bwd_ops:
+                fn(self.stream)
+        if self.reducer is not None:
+            self.reducer.wait_all()
         return self.param_grads
 
 
@@ -252,13 +338,18 @@ def adam_groups(model, config_opt):
 
 
 class Adam:
-    """torch.optim.Adam's update through lt_adam_step (one launch per tensor), same hyper-parameter surface for what the reference uses
-    (train.py:430-437: lr per group, default betas / eps, no weight decay)."""
+    """torch.optim.Adam's update through liblt_hip, same hyper-parameter surface for what the reference uses (train.py:430-437: lr per
+    group, default betas / eps, no weight decay).  All tensors of a group with the same betas / eps / weight decay are updated by ONE
+    launch (lt_adam_step_multi) driven by a small job table that is rebuilt and uploaded every step (the gradients are new tensors)."""
+    JOB = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8"), ("lr", "f4"), ("fb", "i4")])
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        groups = params if params and isinstance(params[0], dict) else [{"params": list(params)}]
-        self.param_groups = [dict({"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}, **g) for g in groups]
+        params = list(params)
+        groups = params if params and isinstance(params[0], dict) else [{"params": params}]
+        self.param_groups = [dict({"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}, **dict(g, params=list(g["params"]))) for g in groups]
         self.state = {}
+        self.steps = 0
+        self._tables = {}
 
     def zero_grad(self):
         for g in self.param_groups:
@@ -267,15 +358,39 @@ class Adam:
 
     def step(self):
         lib = H.lib()
+        self.steps += 1
+        batches = {}          # (betas, eps, weight decay, device) -> jobs
+        touched = []
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None or not p.requires_grad:
                     continue
-                st = self.state.setdefault(p, {"step": 0, "m": torch.zeros_like(p), "v": torch.zeros_like(p)})
-                st["step"] += 1
-                grad = p.grad.contiguous()
-                with torch.no_grad():
-                    H.check(lib.lt_adam_step(p.data_ptr(), grad.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(), float(g["lr"]),
-                                             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), st["step"],
-                                             torch.cuda.current_stream(p.device).cuda_stream), "lt_adam_step")
-                    p.add_(0)      # bumps the version counter: cached inference plans are rebuilt from the new weights
+                if p.device.type != "cuda" or p.dtype != torch.float32:
+                    raise RuntimeError("lt_train.Adam updates fp32 parameters on the GPU")
+                st = self.state.get(p)
+                if st is None:
+                    st = self.state[p] = {"m": torch.zeros_like(p, memory_format=torch.contiguous_format), "v": torch.zeros_like(p, memory_format=torch.contiguous_format)}
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                key = (float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), p.device)
+                batches.setdefault(key, []).append((p, grad, st, float(g["lr"])))
+                touched.append(p)
+        for (b1, b2, eps, wd, dev), items in batches.items():
+            tab = np.zeros(len(items), dtype=self.JOB)
+            fb = 0
+            for i, (p, grad, st, lr_) in enumerate(items):
+                tab[i] = (p.data_ptr(), grad.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(), lr_, fb)
+                fb += (p.numel() + 1023) // 1024
+            slot = self._tables.get((dev, len(items)))
+            if slot is None:
+                slot = self._tables[(dev, len(items))] = (torch.empty(tab.nbytes, dtype=torch.uint8).pin_memory(), torch.empty(tab.nbytes, dtype=torch.uint8, device=dev),
+                                                          torch.cuda.Event())
+            host, devt, ev = slot
+            ev.synchronize()                       # the previous step's upload of this table has been consumed
+            host.numpy()[:] = tab.view(np.uint8)
+            with torch.cuda.device(dev):
+                devt.copy_(host, non_blocking=True)
+                ev.record()
+                H.check(lib.lt_adam_step_multi(devt.data_ptr(), len(items), fb, b1, b2, eps, wd, self.steps, torch.cuda.current_stream(dev).cuda_stream),
+                        "lt_adam_step_multi")
+        for p in touched:          # version counters: cached inference plans see that the weights have changed
+            torch.autograd.graph.increment_version(p)

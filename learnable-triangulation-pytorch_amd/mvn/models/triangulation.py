@@ -14,6 +14,8 @@ deep-copies B*NV Camera objects) and one small H2D copy of the geometry block.
 """
 import ctypes as C
 
+from collections import OrderedDict
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -39,95 +41,142 @@ def _no_training(m):
                                   "(SURVEY.md section 8f row 1); call model.eval()")
 
 
-class _VolTrainFn(torch.autograd.Function):
-    """The whole training-mode forward of VolumetricTriangulationNet as ONE autograd node: forward runs the layers through an
-    lt_train.TrainTape (liblt_hip, fp32, BatchNorm on batch statistics), backward walks the tape and hands the parameter gradients
-    back to autograd -- so ``loss.backward()``, ``torch.optim`` / ``lt_train.Adam`` and DistributedDataParallel's gradient hooks work
-    as with the reference (train.py:233-243, :452-453).  Inputs: (model, images, batch, *parameters)."""
-    @staticmethod
-    def forward(ctx, model, images, batch, *params):
+class _VolTrainPlan:
+    """The training step of VolumetricTriangulationNet for one input shape, recorded once and replayed (lt_train.TrainTape): the first
+    forward / backward run the layers while recording them; later steps re-launch the recorded closures over the same buffers.  What
+    changes from step to step enters through fixed buffers: the images (layout change into ``x_in``), the geometry block (one pinned
+    H2D copy, as in inference), the parameters (gathered live into the GEMM layouts), the loss gradient (``lt_softargmax3d_bwd`` into
+    ``gl``)."""
+
+    def __init__(self, model, B, NV, Hh, W, device):
+        self.model, self.B, self.NV, self.Hh, self.W, self.device = model, B, NV, Hh, W, device
+        self.tape = None
+        self.step_id = 0
+
+    def forward(self, images, batch):
         import lt_train
-        ctx.set_materialize_grads(False)              # an unused output arrives as None in backward, not as a dense zero tensor
-        ctx._lt_accepts_sparse_prob_grads = True      # VolumetricCELoss's one-voxel gradients are applied inside lt_softargmax3d_bwd
-        device = images.device
-        B, NV = images.shape[:2]
-        Hh, W = images.shape[3:]
+        model, B, NV, Hh, W, device = self.model, self.B, self.NV, self.Hh, self.W, self.device
         V, J = model.volume_size, model.num_joints
         lib = H.lib()
-        with torch.cuda.device(device):
-            tape = lt_train.TrainTape(device)
-            st = tape.stream
-            x = images.reshape(B * NV, 3, Hh, W).float().contiguous()
-            x_in = tape.alloc((B * NV, 1, Hh, W, E.min_cin_of(torch.float32)))
-            H.check(lib.lt_nchw_to_nhwc(H.LT_F32, x.data_ptr(), x_in.t.data_ptr(), B * NV, 3, Hh * W, x_in.t.shape[-1], st), "lt_nchw_to_nhwc")
-            tape.no_grad_ids.add(id(x_in))
-            _, feats256, _, volc = model.backbone.record(tape, x_in, want_heatmaps=False)
+        st = torch.cuda.current_stream(device).cuda_stream
+        x = images.reshape(B * NV, 3, Hh, W)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        first = self.tape is None
+        if first:
+            self.tape = tape = lt_train.TrainTape(device, params=list(model.parameters()), reducer=getattr(model, "grad_reducer", None))
+            self.x_in = tape.alloc((B * NV, 1, Hh, W, E.min_cin_of(torch.float32)))
+            tape.no_grad_ids.add(id(self.x_in))
+        tape = self.tape
+        H.check(lib.lt_nchw_to_nhwc(H.LT_F32, x.data_ptr(), self.x_in.t.data_ptr(), B * NV, 3, Hh * W, self.x_in.t.shape[-1], st), "lt_nchw_to_nhwc")
+        if first:
+            # layers in front of the unprojection (its launch needs the map size, the geometry block the launch reads needs the maps' size too)
+            _, feats256, _, volc = model.backbone.record(tape, self.x_in, want_heatmaps=False)
             if volc is not None:
                 raise NotImplementedError("training with volume_aggregation_method conf* is not built")
             pf = model.process_features[0]
-            feats = tape.conv(feats256, pf.weight, pf.bias, None)
+            self.feats = feats = tape.conv(feats256, pf.weight, pf.bias, None)
             h, w = feats.shape[2], feats.shape[3]
-            # host geometry exactly as in inference (numpy fp64; theta ~ U(0, 2 pi) because self.training), one H2D copy
             n_geo = B * NV * 12 + B * 15
-            o_pos, o_cen, o_rot = B * NV * 12, B * NV * 12 + 3 * B, B * NV * 12 + 6 * B
-            G = {"hw": (h, w), "offs": (o_pos, o_cen, o_rot), "geo_ring": [torch.zeros(n_geo, dtype=torch.float32).pin_memory()],
-                 "geo_events": [None], "geo_slot": 0}
-            position, base, sides = model._host_geometry(batch, B, (Hh, W), G)
-            geo = G["geo_host"].to(device, non_blocking=False)
-            gp = geo.data_ptr()
-            coords = torch.empty(B, V, V, V, 3, dtype=torch.float32, device=device)
+            self.G = {"hw": (h, w), "offs": (B * NV * 12, B * NV * 12 + 3 * B, B * NV * 12 + 6 * B),
+                      "geo_ring": [torch.zeros(n_geo, dtype=torch.float32).pin_memory() for _ in range(GEO_RING)],
+                      "geo_events": [None] * GEO_RING, "geo_slot": 0}
+            self.geo = torch.zeros(n_geo, dtype=torch.float32, device=device)
+            self.n_front = len(tape.fwd_ops)
+        else:
+            for fn in tape.fwd_ops[:self.n_front]:
+                fn(st)
+        G = self.G
+        h, w = G["hw"]
+        o_pos, o_cen, o_rot = G["offs"]
+        # host geometry exactly as in inference (numpy fp64; theta ~ U(0, 2 pi) because self.training), one pinned H2D copy
+        position, base, sides = model._host_geometry(batch, B, (Hh, W), G)
+        self.geo.copy_(G["geo_host"], non_blocking=True)
+        ev = G["geo_events"][G["geo_slot"]] = G["geo_events"][G["geo_slot"]] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        if first:
+            feats, gp = self.feats, self.geo.data_ptr()
+            self.coords = coords = torch.empty(B, V, V, V, 3, dtype=torch.float32, device=device)
             vol = tape.alloc((B, V, V, V, 32))
             step = float(np.float32(model.cuboid_side / (V - 1)))
             agg = H.AGG[model.volume_aggregation_method]
-            H.check(lib.lt_unproject_grid_fwd(H.LT_F32, feats.t.data_ptr(), gp, gp + 4 * o_pos, gp + 4 * o_cen, gp + 4 * o_rot, step,
-                                              int(bool(model.transfer_cmu_to_human36m)), coords.data_ptr(), None, vol.t.data_ptr(), B, NV, 32, h, w, V, agg, st),
-                    "lt_unproject_grid_fwd")
+            cmu = int(bool(model.transfer_cmu_to_human36m))
+            tape.do(lambda s_: H.check(lib.lt_unproject_grid_fwd(H.LT_F32, feats.t.data_ptr(), gp, gp + 4 * o_pos, gp + 4 * o_cen, gp + 4 * o_rot, step, cmu,
+                                                                 coords.data_ptr(), None, vol.t.data_ptr(), B, NV, 32, h, w, V, agg, s_), "lt_unproject_grid_fwd"))
 
             def unproject_bwd():
                 dvol = tape.grad_of(vol)
                 if dvol is None:
                     return
-                gfe = torch.zeros_like(feats.t)
-                H.check(lib.lt_unproject_bwd(H.LT_F32, feats.t.data_ptr(), gp, coords.data_ptr(), None, dvol.data_ptr(), gfe.data_ptr(), None, B, NV, 32, h, w,
-                                             V ** 3, agg, st), "lt_unproject_bwd")
+                gfe = torch.empty_like(feats.t)
+                tape.do(lambda s_: gfe.zero_())
+                tape.do(lambda s_: H.check(lib.lt_unproject_bwd(H.LT_F32, feats.t.data_ptr(), gp, coords.data_ptr(), None, dvol.data_ptr(), gfe.data_ptr(), None,
+                                                                B, NV, 32, h, w, V ** 3, agg, s_), "lt_unproject_bwd"))
                 tape.seed(feats, gfe)
             tape.add_backward(unproject_bwd)
-            logits = model.volume_net.record(tape, vol)          # channels-last (B,V,V,V,J) fp32
-            kp = torch.empty(B, J, 3, dtype=torch.float32, device=device)
-            probs = torch.empty(B, J, V, V, V, dtype=torch.float32, device=device)
+            self.logits = logits = model.volume_net.record(tape, vol)          # channels-last (B,V,V,V,J) fp32
+            self.kp = kp = torch.empty(B, J, 3, dtype=torch.float32, device=device)
+            self.probs = probs = torch.empty(B, J, V, V, V, dtype=torch.float32, device=device)
             ws = torch.empty(max(1, lib.lt_softargmax3d_workspace(B, J, V ** 3)), dtype=torch.uint8, device=device)
-            mult, sm = float(model.volume_multiplier), int(bool(model.volume_softmax))
-            H.check(lib.lt_softargmax3d_fwd(logits.t.data_ptr(), coords.data_ptr(), mult, sm, 1, J, kp.data_ptr(), probs.data_ptr(), B, J, V ** 3,
-                                            ws.data_ptr(), st), "lt_softargmax3d_fwd")
-        ctx.tape, ctx.logits, ctx.coords, ctx.kp, ctx.probs, ctx.params = tape, logits, coords, kp, probs, params
-        ctx.mult, ctx.sm, ctx.geo_keep = mult, sm, geo
-        feats_out = feats.t.reshape(B, NV, h, w, 32).permute(0, 1, 4, 2, 3).clone()
-        base_points = torch.from_numpy(base.astype(np.float32)).to(device)
+            self.mult, self.sm = float(model.volume_multiplier), int(bool(model.volume_softmax))
+            mult, sm = self.mult, self.sm
+            tape.do(lambda s_: H.check(lib.lt_softargmax3d_fwd(logits.t.data_ptr(), coords.data_ptr(), mult, sm, 1, J, kp.data_ptr(), probs.data_ptr(), B, J, V ** 3,
+                                                               ws.data_ptr(), s_), "lt_softargmax3d_fwd"))
+            self.gl = torch.empty(B, V ** 3, J, dtype=torch.float32, device=device)         # d loss / d logits, channels-last like the logits
+            tape.seed(logits, self.gl.view(logits.t.shape))
+        else:
+            for fn in tape.fwd_ops[self.n_front:]:
+                fn(st)
+        self.step_id += 1
+        feats_out = self.feats.t.reshape(B, NV, h, w, 32).permute(0, 1, 4, 2, 3).clone()
+        base_points = self.geo[o_cen:o_rot].reshape(B, 3).clone()
+        return self.kp.clone(), self.probs.clone(), feats_out, self.coords.clone(), base_points, position, sides
+
+    def backward(self, g_kp, idx, val):
+        B, J = self.probs.shape[:2]
+        nvox = self.probs[0, 0].numel()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        H.check(H.lib().lt_softargmax3d_bwd(self.probs.data_ptr(), self.coords.data_ptr(), self.kp.data_ptr(), g_kp.data_ptr(), H.ptr(idx), H.ptr(val), self.mult, self.sm, 1,
+                                            self.gl.data_ptr(), B, J, nvox, st), "lt_softargmax3d_bwd")
+        pg = self.tape.run_backward()
+        flat = self.tape.arena.clone()          # autograd gets its own copy: the arena is overwritten by the next step
+        off = self.tape.arena.data_ptr()
+        return {p: flat[(v.data_ptr() - off) // 4:(v.data_ptr() - off) // 4 + v.numel()].view(v.shape) for p, v in pg.items()}
+
+
+class _VolTrainFn(torch.autograd.Function):
+    """The whole training-mode forward of VolumetricTriangulationNet as ONE autograd node: forward runs (the first time: records) the
+    layers through the plan's lt_train.TrainTape (liblt_hip, fp32, BatchNorm on batch statistics), backward replays the tape's backward
+    and hands the parameter gradients back to autograd -- so ``loss.backward()``, ``torch.optim`` / ``lt_train.Adam`` work as with the
+    reference (train.py:233-243).  Inputs: (plan, images, batch, *parameters)."""
+
+    @staticmethod
+    def forward(ctx, plan, images, batch, *params):
+        ctx.set_materialize_grads(False)              # an unused output arrives as None in backward, not as a dense zero tensor
+        ctx._lt_accepts_sparse_prob_grads = True      # VolumetricCELoss's one-voxel gradients are applied inside lt_softargmax3d_bwd
+        with torch.cuda.device(images.device):
+            kp, probs, feats_out, coords, base_points, position, sides = plan.forward(images, batch)
+        ctx.plan, ctx.step_id, ctx.params = plan, plan.step_id, params
         ctx.mark_non_differentiable(feats_out, coords, base_points)
-        model._train_extra = (position, sides)
+        plan.model._train_extra = (position, sides)
         return kp, probs, feats_out, coords, base_points
 
     @staticmethod
     def backward(ctx, g_kp, g_probs, *unused):
-        tape, logits, coords, kp, probs = ctx.tape, ctx.logits, ctx.coords, ctx.kp, ctx.probs
-        B, J = probs.shape[:2]
-        nvox = probs[0, 0].numel()
-        dev = probs.device
-        with torch.cuda.device(dev):
-            g_kp = torch.zeros_like(kp) if g_kp is None else g_kp.float().contiguous()
+        plan = ctx.plan
+        if ctx.step_id != plan.step_id:
+            raise RuntimeError("only the LATEST training forward of a shape can be backpropagated (its activations live in the plan's buffers, "
+                               "which a newer forward has overwritten)")
+        with torch.cuda.device(plan.device):
+            g_kp = torch.zeros_like(plan.kp) if g_kp is None else g_kp.float().contiguous()
             sparse = getattr(ctx, "_lt_sparse_prob_grads", [])
             idx = val = None
             if len(sparse) == 1:
                 idx, val = sparse[0]
             elif len(sparse) > 1 or (g_probs is not None and g_probs.stride() != (0,) * g_probs.dim()):
                 raise NotImplementedError("a dense gradient on the returned volumes in training (only VolumetricCELoss's sparse one is built)")
-            gl = torch.empty(B, nvox, J, dtype=torch.float32, device=dev)         # channels-last like the logits
-            H.check(H.lib().lt_softargmax3d_bwd(probs.data_ptr(), coords.data_ptr(), kp.data_ptr(), g_kp.data_ptr(), H.ptr(idx), H.ptr(val), ctx.mult, ctx.sm, 1,
-                                                gl.data_ptr(), B, J, nvox, tape.stream), "lt_softargmax3d_bwd")
-            tape.seed(logits, gl.reshape(logits.t.shape))
-            pg = tape.backward()
+            pg = plan.backward(g_kp, idx, val)
         grads = tuple(pg.get(p) if p.requires_grad else None for p in ctx.params)
-        ctx.tape = None
         return (None, None, None) + grads
 
 
@@ -321,12 +370,32 @@ class VolumetricTriangulationNet(_PlannedNet):
     def _forward_train(self, images, batch):
         """Training mode (any BatchNorm in train()): fp32, batch statistics, running statistics updated, random cuboid rotation; the
         result carries the autograd node whose backward is liblt_hip's (lt_train.py).  Same 7-tuple as the inference forward."""
+        bns = [c for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm)]
+        if not all(c.training for c in bns):
+            raise NotImplementedError("a mix of training-mode and eval-mode BatchNorm layers (frozen statistics) is not built: "
+                                      "model.train() or model.eval() as a whole (train.py:163-166)")
+        if any(c.momentum is None or abs(c.momentum - 0.1) > 1e-12 or not c.track_running_stats or not c.affine for c in bns):
+            raise NotImplementedError("BatchNorm with a momentum other than 0.1, without running statistics or without affine parameters")
         params = tuple(self.parameters())
         off = [n for n, t in list(self.named_parameters()) + list(self.named_buffers()) if t.device != images.device]
         if off:
             raise RuntimeError("training updates the parameters where they live: move the model to %s first (model.to(device), as "
                                "train.py:424 does); %d tensors are elsewhere, e.g. %s" % (images.device, len(off), off[0]))
-        kp, probs, feats, coords, base_points = _VolTrainFn.apply(self, images, batch, *params)
+        B, NV = images.shape[:2]
+        key = (B, NV, images.shape[3], images.shape[4], images.device, self.volume_size, float(self.cuboid_side), float(self.volume_multiplier),
+               bool(self.volume_softmax), self.volume_aggregation_method, bool(self.transfer_cmu_to_human36m), self.num_joints,
+               tuple(p.requires_grad for p in params), id(getattr(self, "grad_reducer", None)))
+        plans = self.__dict__.setdefault("_train_plans", OrderedDict())
+        plan = plans.get(key)
+        if plan is None:
+            while len(plans) >= 2:
+                plans.popitem(last=False)          # frees its activations and gradient buffers
+            plan = plans[key] = _VolTrainPlan(self, B, NV, images.shape[3], images.shape[4], images.device)
+        plans.move_to_end(key)
+        kp, probs, feats, coords, base_points = _VolTrainFn.apply(plan, images, batch, *params)
+        with torch.no_grad():
+            for c in bns:
+                c.num_batches_tracked += 1
         position, sides = self.__dict__.pop("_train_extra")
         cuboids = [volumetric.Cuboid3D(position[i], sides) for i in range(images.shape[0])]
         return kp, feats, probs, None, cuboids, coords, base_points

@@ -104,3 +104,54 @@ def test_bench_under_torchrun_env_does_not_relaunch():
     assert len(lines) == 1
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["self_launched"] is False and res["total_samples"] == 12
+
+
+def _reducer_worker(rank, world, port, q):
+    sys.path.insert(0, PKG)
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import lt_dist
+    lt_dist.init("gloo")
+    shapes = [(64, 3, 7, 7), (64,), (128, 64, 3, 3), (5,), (1000, 33), (17, 32, 1, 1, 1)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    red = lt_dist.GradReducer(bucket_bytes=100_000)           # several buckets, the last one partly filled
+    grads = [torch.randn(s, generator=torch.Generator().manual_seed(7 * i + rank)) for i, s in enumerate(shapes)]
+    for p, g in zip(reversed(params), reversed(grads)):           # the tape pushes in backward order
+        red.push(p, g.clone())
+    out = red.finish()
+    q.put((rank, [out[p].detach().numpy().copy() for p in params], red.buckets_sent))     # by value: the worker may exit first
+    lt_dist.barrier()
+    lt_dist.shutdown()
+
+
+def test_grad_reducer_two_ranks_mean_of_bucketed_gradients():
+    """Data-parallel training's one exchange (train.py:450-453's DistributedDataParallel): bucketed async all-reduce -> the mean."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shapes = [(64, 3, 7, 7), (64,), (128, 64, 3, 3), (5,), (1000, 33), (17, 32, 1, 1, 1)]
+    want = [(torch.randn(s, generator=torch.Generator().manual_seed(7 * i)) + torch.randn(s, generator=torch.Generator().manual_seed(7 * i + 1))) / 2
+            for i, s in enumerate(shapes)]
+    for rank, outs, nb in got:
+        assert nb >= 3
+        for o, w in zip(outs, want):
+            o = torch.from_numpy(o)
+            assert o.shape == w.shape and torch.allclose(o, w, atol=1e-7)
+
+
+def test_grad_reducer_single_process_returns_the_gradients():
+    sys.path.insert(0, PKG)
+    import lt_dist
+    red = lt_dist.GradReducer(bucket_bytes=1000)
+    ps = [torch.nn.Parameter(torch.zeros(10, 10)), torch.nn.Parameter(torch.zeros(3))]
+    gs = [torch.randn(10, 10), torch.randn(3)]
+    for p, g in zip(ps, gs):
+        red.push(p, g)
+    out = red.finish()
+    assert all(torch.equal(out[p], g) for p, g in zip(ps, gs))

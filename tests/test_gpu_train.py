@@ -171,17 +171,35 @@ def test_tape_layer_gradients(case, mode):
         dz = dz * (pre.abs() > 1e-4).float()      # no upstream gradient where fp32 rounding could flip the ReLU mask
     (y * dz.double()).sum().backward()
 
-    tape = lt_train.TrainTape(DEV)
     wp, bp = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
     gp, btp = torch.nn.Parameter(gamma.to(DEV)), torch.nn.Parameter(beta.to(DEV))
+    tape = lt_train.TrainTape(DEV, params=[wp, bp, gp, btp])
     rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
     xa = E.Act(to_cl(x))
     ra = E.Act(to_cl(res)) if use_bn else None
     z = tape.conv(xa, wp, bp, (gp, btp, rm, rv) if use_bn else None, stride=s, pad=p, transposed=tr, relu=use_bn, residual=ra)
     tag = "train/layer nd%d %d->%d k%d s%d p%d%s %s" % (nd, Cin, Cout, k, s, p, " T" if tr else "", mode)
     check(tag + " z", from_cl(z.t, nd), y.detach(), 2e-5)
-    tape.seed(z, to_cl(dz))
-    pg = tape.backward()
+    dzb = to_cl(dz)
+    tape.seed(z, dzb)
+    pg = tape.run_backward()          # records the backward while running it
+    first = {k: v.clone() for k, v in pg.items()}
+    # REPLAY with other weights and another upstream gradient, then with the original ones again: the recorded closures read the live values
+    with torch.no_grad():
+        saved = [t.clone() for t in (wp, bp, gp, btp)]
+        for t in (wp, bp, gp, btp):
+            t.mul_(1.5).add_(0.01)
+        dzb.mul_(-2.0)
+    tape.run_forward(); tape.run_backward()
+    assert not torch.allclose(pg[wp], first[wp])
+    with torch.no_grad():
+        for t, s0 in zip((wp, bp, gp, btp), saved):
+            t.copy_(s0)
+        dzb.copy_(to_cl(dz))
+        rm.zero_(); rv.fill_(1.0)
+    tape.run_forward(); pg = tape.run_backward()
+    for k in first:
+        assert torch.allclose(pg[k], first[k], rtol=1e-5, atol=1e-6 * float(first[k].abs().max())), "replay differs from the recording"
     check(tag + " dx", from_cl(tape.grad_of(xa), nd), xd.grad, 5e-5)
     check(tag + " dw", pg[wp].cpu(), wd.grad, 5e-5)
     if use_bn:
@@ -330,6 +348,18 @@ def test_whole_training_step_vs_reference(golden_dir):
     record("train/step parameters after Adam, worst |d| in units of lr", {"err": w_p, "tol": 2e-2, "name": w_name, "elements_compared": n_known})
     assert w_p <= 2e-2, (w_p, w_name)
     assert n_known > 1000, n_known
+    # the REPLAYED training forward reads the updated parameters: same result as a fresh model (fresh recording) with the new state dict
+    np.random.seed(c["seed"] + 100)
+    kp_replay = m(inp["images"].to(DEV), None, batch)[0].detach().clone()
+    m2 = VolumetricTriangulationNet(cfg, device=DEV)
+    m2.load_state_dict(m.state_dict(), strict=True)
+    m2.to(DEV)
+    m2.train()
+    sd_before = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+    np.random.seed(c["seed"] + 100)
+    kp_fresh = m2(inp["images"].to(DEV), None, batch)[0].detach()
+    check("train/step replayed forward after Adam vs a fresh recording with the updated weights", kp_replay.cpu(), kp_fresh.cpu(), 1e-6)
+    assert float((kp_replay.cpu() - torch.from_numpy(G["kp"])).abs().max()) > 1e-3      # and the step did move the prediction
     # and the next inference forward uses the UPDATED weights (plan cache fingerprint)
     m.eval()
     with torch.no_grad():

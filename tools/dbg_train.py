@@ -1,17 +1,28 @@
-import os, sys, numpy as np, torch
-sys.path.insert(0, "/root/repo/learnable-triangulation-pytorch_amd"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
-from oracle import spec, synth
-import lt_train, lt_engine as E
-orig = lt_train.TrainTape._run_last
-def run_last(self):
-    orig(self); torch.cuda.synchronize(); print("ok", self.pb.ops[-1][1]["label"], flush=True)
-lt_train.TrainTape._run_last = run_last
-from test_gpu_train import _train_case
-from test_gpu_models import _cameras
+"""Scratch: memory / time checkpoints of one training step (GPU box)."""
+import os, sys, time, numpy as np, torch
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(R, "learnable-triangulation-pytorch_amd")); sys.path.insert(0, R)
+import bench
 from mvn.models.triangulation import VolumetricTriangulationNet
-c, cfg, sd, inp = _train_case()
-m = VolumetricTriangulationNet(cfg, device="cuda:0"); m.load_state_dict(sd); m.to("cuda:0"); m.train()
-batch = {"cameras": _cameras(inp, c["B"]), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
-out = m(inp["images"].to("cuda:0"), None, batch)
-torch.cuda.synchronize(); print("forward ok", out[0][0, :2])
-out[0].sum().backward(); torch.cuda.synchronize(); print("backward ok")
+import lt_train
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+dev = torch.device("cuda:0")
+m = VolumetricTriangulationNet(bench.vol_config(152, 64, "fp32"), device=dev); m.to(dev); m.train()
+images, batch, geom = bench.synthetic_batch(B, 4, 384, 1000)
+images = images.to(dev)
+gb = lambda: torch.cuda.memory_allocated() / 1e9
+print("model", gb())
+orig_conv = lt_train.TrainTape.conv
+stats = {"n": 0}
+def conv(self, x, *a, **k):
+    z = orig_conv(self, x, *a, **k); stats["n"] += 1
+    if stats["n"] % 40 == 0: print("  fwd layer", stats["n"], tuple(z.shape), round(gb(), 2), flush=True)
+    return z
+lt_train.TrainTape.conv = conv
+for it in range(2):
+    torch.cuda.synchronize(); t0 = time.time()
+    out = m(images, None, batch)
+    torch.cuda.synchronize(); t1 = time.time(); print("forward", round(t1 - t0, 3), "s", gb(), "GB")
+    out[0].sum().backward()
+    torch.cuda.synchronize(); t2 = time.time(); print("backward", round(t2 - t1, 3), "s", gb(), "GB, peak", torch.cuda.max_memory_allocated() / 1e9)
+    del out
