@@ -161,13 +161,23 @@ struct BnBwdFin {
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_vec_kernel(const BnBwdArgs a) { colsum_finalize<2>(a.part, a.C, a.nslab, BnBwdFin{a.dgamma, a.dbeta}); }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdArgs a) {
-    const int c4n = a.C >> 2;
-    const long long total = a.rows * c4n;
+// dy (and the residual's gradient): a thread keeps ONE float4 of channels -- its per-channel constants live in registers -- and walks rows
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdArgs a, int nslab, int cw4, int rl_n) {
+    const long long r0 = a.rows * blockIdx.x / nslab, r1 = a.rows * (blockIdx.x + 1) / nslab;
+    const int rl = threadIdx.x / cw4, cv = threadIdx.x - rl * cw4;
+    const int c = (blockIdx.y * 256 + cv) * 4;
+    if (c >= a.C) return;
     const float inv_n = 1.0f / (float)a.rows;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % c4n) * 4;
-        const size_t off = (size_t)i * 4;
+    float invstd[4], mean[4], gam[4], bet[4], k1[4], kb[4], kg[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        invstd[e] = 1.0f / sqrtf(a.var[c + e] + a.eps);
+        mean[e] = a.mean[c + e]; gam[e] = a.gamma[c + e]; bet[e] = a.beta[c + e];
+        k1[e] = gam[e] * invstd[e]; kb[e] = a.dbeta[c + e] * inv_n; kg[e] = a.dgamma[c + e] * inv_n;
+    }
+    const bool post = a.flags & LT_EPI_RELU_POST, pre = a.flags & LT_EPI_RELU_PRE;
+    for (long long r = r0 + rl; r < r1; r += rl_n) {
+        const size_t off = (size_t)r * a.C + c;
         const float4 dz4 = *(const float4*)(a.dz + off), y4 = *(const float4*)(a.y + off);
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.res) r4 = *(const float4*)(a.res + off);
@@ -175,11 +185,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdArgs a
         float o[4], dr[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float xh;
-            const float g = bn_g(a, dzv[e], yv[e], rv[e], c + e, xh);
-            const float invstd = 1.0f / sqrtf(a.var[c + e] + a.eps);
-            o[e] = a.gamma[c + e] * invstd * (g - a.dbeta[c + e] * inv_n - xh * a.dgamma[c + e] * inv_n);
-            dr[e] = (a.flags & LT_EPI_RELU_POST) ? g : dzv[e];     // RELU_PRE / none: the residual is added after the activation
+            const float xh = (yv[e] - mean[e]) * invstd[e];          // the same expressions as bn_g: the mask must match the reduction's
+            const float v = xh * gam[e] + bet[e];
+            float mk = 1.f;
+            if (post) mk = (v + rv[e]) > 0.f ? 1.f : 0.f;
+            else if (pre) mk = v > 0.f ? 1.f : 0.f;
+            const float g = dzv[e] * mk;
+            o[e] = k1[e] * (g - kb[e] - xh * kg[e]);
+            dr[e] = post ? g : dzv[e];     // RELU_PRE / none: the residual is added after the activation
         }
         *(float4*)(a.dy + off) = make_float4(o[0], o[1], o[2], o[3]);
         if (a.dres) {
@@ -309,24 +322,37 @@ struct WgradArgs {
 // blocks (same dY columns: their dY loads hit L1), and the pixel range is cut into S slabs across blockIdx.y so that the launch
 // fills the chip whatever the layer's shape; slab partial sums are reduced by wgrad_reduce_kernel in a fixed order (deterministic).
 // Operands of the next pixel pair are loaded before the MFMAs of the current one (software pipeline, two register sets).
+// bits t = 0 .. 7 with 0 <= i0 + t < size
+__device__ __forceinline__ int range_mask(int i0, int size) {
+    const int lo = max(0, -i0), hi = min(7, size - 1 - i0);          // hi < lo: empty
+    return hi >= lo ? ((2 << hi) - 1) & ~((1 << lo) - 1) : 0;
+}
+
 template <int CT, int KT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = blockIdx.x * 4 + wave;
+    // workgroups are dealt round-robin to the 8 XCDs: give every XCD a CONTIGUOUS range of (slab, tile group) pairs, slab-major, so that
+    // the tiles of one slab (same dY / X rows) and neighbouring slabs (shared halo rows / planes) meet in the same L2
+    const int total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int lin2 = (total & 7) ? lin : (lin & 7) * (total >> 3) + (lin >> 3);
+    const int slab = lin2 / (int)gridDim.x, tgroup = lin2 - slab * (int)gridDim.x;
+    const int t = tgroup * 4 + wave;
     if (t >= a.n_tiles) return;
     const int co0 = (t / a.n_k_t) * (32 * CT), k0 = (t % a.n_k_t) * (32 * KT);
     const int col = lane & 31, half = lane >> 5;          // A: co = co0 + 32 c + col, row m + half;  B: k = k0 + 32 j + col, row m + half
-    int tdelta[KT], toff[KT];                             // per GEMM column: packed (dd, dh, dw) of its tap (bit 31: no such column), element offset
+    // per GEMM column: element offset of its tap and channel, and a selector with one bit per dimension (bit dd, bit 8 + dh, bit 16 + dw;
+    // bit 31 alone for a column past K): a pixel's taps are valid where its per-dimension range masks contain the selector
+    int tsel[KT], toff[KT];
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
         const int k = k0 + 32 * j + col;
         const int tap = k >> a.log2Cin;
         if (tap < a.ntaps) {
             const int4 tp = a.taps[tap];
-            tdelta[j] = (tp.x & 0xff) | ((tp.y & 0xff) << 8) | ((tp.z & 0xff) << 16);
+            tsel[j] = (1 << tp.x) | (1 << (8 + tp.y)) | (1 << (16 + tp.z));
             toff[j] = ((tp.x * a.H + tp.y) * a.W + tp.z) * a.Cin + (k & (a.Cin - 1));
         } else {
-            tdelta[j] = (int)0x80000000; toff[j] = 0;
+            tsel[j] = (int)0x80000000; toff[j] = 0;
         }
     }
     bool co_ok[CT];
@@ -339,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         for (int j = 0; j < KT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[c][j][e] = 0.f;
-    const int m_begin = blockIdx.y * a.rows_per_slab;
+    const int m_begin = slab * a.rows_per_slab;
     const int m_end = min(a.M, m_begin + a.rows_per_slab);
     // this lane's row walks m_begin + half, + 2, + 4, ...: (n, od, oh, ow) advance incrementally
     int m = m_begin + half;
@@ -349,42 +375,62 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     int oh = r / a.Wo, ow = r - oh * a.Wo;
     const float* dyp = a.dy + co0 + col;
 
-    auto load = [&](float (&av)[CT], float (&bv)[KT]) {
+    // BRANCH-FREE loads with NOTHING behind them: an absent element (padding, a row past the slab, a column past K) is read from
+    // offset 0 and its validity bit is cleared; the bits are applied in mma(), i.e. in program order BEHIND the loads of the next
+    // pipeline stages.  (Loads inside divergent branches cannot be counted by the compiler, and a select directly behind a load makes it
+    // wait there: either way every MFMA group would sit behind vmcnt(0) and the software pipeline below would be serialised.)
+    auto load = [&](float (&av)[CT], float (&bv)[KT], unsigned& okbits) {
         const bool m_ok = m < m_end;
+        unsigned bits = 0;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) av[c] = (m_ok && co_ok[c]) ? dyp[(long long)m * a.ldy + 32 * c] : 0.f;
+        for (int c = 0; c < CT; ++c) {
+            const bool ok = m_ok & co_ok[c];
+            av[c] = dyp[ok ? (long long)m * a.ldy + 32 * c : 0ll];
+            bits |= ok ? 1u << (KT + c) : 0u;
+        }
         const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
         const int pix = (((n * a.D + id0) * a.H + ih0) * a.W + iw0) * a.Cin;          // may point in front of the tensor (padding): only in-bounds taps are read
+        // per dimension the tap offsets t with 0 <= i0 + t < size, as a bit range [max(0, -i0), min(7, size - 1 - i0)] (taps are 0 .. 7)
+        const int rmask = m_ok ? (range_mask(id0, a.D) | (range_mask(ih0, a.H) << 8) | (range_mask(iw0, a.W) << 16)) : 0;
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
-            const int td = tdelta[j];
-            const int id = id0 + (int)(signed char)(td & 0xff), ih = ih0 + (int)(signed char)((td >> 8) & 0xff), iw = iw0 + (int)(signed char)((td >> 16) & 0xff);
-            const bool ok = m_ok && td >= 0 && (unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            bv[j] = ok ? a.x[pix + toff[j]] : 0.f;
+            const bool ok = (rmask & tsel[j]) == tsel[j];
+            bv[j] = *(const float*)((const char*)a.x + ((size_t)(ok ? (unsigned)(pix + toff[j]) : 0u) << 2));
+            bits |= ok ? 1u << j : 0u;
         }
+        okbits = bits;
+        // next pixel pair, branch-free: a coordinate moves by at most 2, so two conditional wraps per level always suffice
         m += 2; ow += 2;
-        while (ow >= a.Wo) {
-            ow -= a.Wo;
-            if (++oh == a.Ho) { oh = 0; if (++od == a.Do) { od = 0; ++n; } }
-        }
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) { const int w = ow >= a.Wo; ow -= w ? a.Wo : 0; oh += w; }
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) { const int w = oh >= a.Ho; oh -= w ? a.Ho : 0; od += w; }
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) { const int w = od >= a.Do; od -= w ? a.Do : 0; n += w; }
     };
-    auto mma = [&](const float (&av)[CT], const float (&bv)[KT]) {
+    auto mma = [&](const float (&av)[CT], const float (&bv)[KT], unsigned bits) {
+        float af[CT], bf[KT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) af[c] = (bits >> (KT + c)) & 1u ? av[c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) bf[j] = (bits >> j) & 1u ? bv[j] : 0.f;
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int j = 0; j < KT; ++j) acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[j], acc[c][j], 0, 0, 0);
+            for (int j = 0; j < KT; ++j) acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c], bf[j], acc[c][j], 0, 0, 0);
     };
-    // three pixel pairs in flight ahead of the one in the MFMAs (rows past m_end load zeros: the extra MFMAs add nothing)
+    // three pixel pairs in flight ahead of the one in the MFMAs (rows past m_end load nothing: the extra MFMAs add zeros)
     float av0[CT], bv0[KT], av1[CT], bv1[KT], av2[CT], bv2[KT], av3[CT], bv3[KT];
+    unsigned ok0, ok1, ok2, ok3;
     const int nit = (m_end - m_begin + 1) >> 1;
-    load(av0, bv0); load(av1, bv1); load(av2, bv2);
+    load(av0, bv0, ok0); load(av1, bv1, ok1); load(av2, bv2, ok2);
     for (int it = 0; it < nit; it += 4) {
-        load(av3, bv3); mma(av0, bv0);
-        load(av0, bv0); mma(av1, bv1);
-        load(av1, bv1); mma(av2, bv2);
-        load(av2, bv2); mma(av3, bv3);
+        load(av3, bv3, ok3); mma(av0, bv0, ok0);
+        load(av0, bv0, ok0); mma(av1, bv1, ok1);
+        load(av1, bv1, ok1); mma(av2, bv2, ok2);
+        load(av2, bv2, ok2); mma(av3, bv3, ok3);
     }
-    float* out = a.out + (size_t)blockIdx.y * a.cout_pad * a.k_pad;
+    float* out = a.out + (size_t)slab * a.cout_pad * a.k_pad;
     const bool direct_acc = a.accumulate && gridDim.y == 1;
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -430,10 +476,11 @@ WgradPlan wgrad_plan(long long M, int cout_pad, int k_pad) {
     if (S > cap) S = cap;
     if (S > M / 64) S = M / 64;
     if (S < 1) S = 1;
+    if (S >= 8) S &= ~7ll;          // a multiple of 8: the kernel gives each XCD a contiguous range of slabs
     long long rps = cdiv(M, S);
     rps += rps & 1;
     p.rows_per_slab = (int)rps;
-    p.S = (int)cdiv(M, rps);
+    p.S = (int)S;                   // trailing slabs may be empty (they write zeros)
     return p;
 }
 
@@ -517,8 +564,9 @@ extern "C" int lt_bn_act_bwd(const float* dz, const float* y, const float* resid
         LT_CHECK_LAUNCH("lt_bn_act_bwd(reduce)");
         hipLaunchKernelGGL(bn_bwd_finalize_vec_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, st, a);
         LT_CHECK_LAUNCH("lt_bn_act_bwd(finalize)");
-        const long long vb = cdiv(rows * (C / 4), 256);
-        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3((unsigned)(vb < 16384 ? vb : 16384)), dim3(256), 0, st, a);
+        long long ns = rows / ((long long)p.rl * 2);          // >= 2 rows per thread, <= 4096 workgroups
+        ns = ns < 1 ? 1 : ns > 4096 / p.ncb ? 4096 / p.ncb : ns;
+        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3((unsigned)ns, p.ncb), dim3(256), 0, st, a, (int)ns, p.cw4, p.rl);
         LT_CHECK_LAUNCH("lt_bn_act_bwd(apply)");
         return LT_OK;
     }
@@ -603,6 +651,7 @@ extern "C" int lt_conv_wgrad(const float* dy, const float* x, const int32_t* tap
     a.sd = stride[0]; a.sh = stride[1]; a.sw = stride[2]; a.pd = pad[0]; a.ph = pad[1]; a.pw = pad[2];
     a.Cout = Cout; a.ldy = ldy; a.k_pad = k_pad; a.ntaps = ntaps; a.M = (int)M; a.accumulate = accumulate; a.cout_pad = cout_pad;
     a.n_k_t = p.n_k_t; a.n_tiles = p.n_co_t * p.n_k_t; a.rows_per_slab = p.rows_per_slab;
+
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)cdiv(a.n_tiles, 4), (unsigned)p.S);
     if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad_kernel<4, 2>), grid, dim3(256), 0, st, a);
