@@ -370,6 +370,8 @@ class VolumetricTriangulationNet(_PlannedNet):
     def _forward_train(self, images, batch):
         """Training mode (any BatchNorm in train()): fp32, batch statistics, running statistics updated, random cuboid rotation; the
         result carries the autograd node whose backward is liblt_hip's (lt_train.py).  Same 7-tuple as the inference forward."""
+        if self.volume_aggregation_method.startswith("conf"):
+            raise NotImplementedError("training with volume_aggregation_method conf* (the confidence heads) is not built")
         bns = [c for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm)]
         if not all(c.training for c in bns):
             raise NotImplementedError("a mix of training-mode and eval-mode BatchNorm layers (frozen statistics) is not built: "

@@ -393,3 +393,82 @@ def test_training_loss_decreases_over_steps():
         losses.append(float(loss.detach()))
     record("train/loss over 10 Adam steps", losses)
     assert losses[-1] < losses[0], losses
+
+
+def _dp_grads(rank, reducer):
+    """One training forward / backward of the small case on shard ``rank`` (its own samples); returns {name: gradient (cpu)}."""
+    from mvn.models import loss as L
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    from test_gpu_models import _cameras
+    cfg = synth.vol_config(18, 32, "softmax", 1.0, "mpii")
+    sd = synth.make_state_dict(spec.vol_net_spec(18, 17, False), seed=12, sharpen=60.0, basic_block=True)
+    inp = synth.make_inputs(2, 3, 128, seed=30 + rank, inside=False)
+    m = VolumetricTriangulationNet(cfg, device=DEV)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    m.train()
+    m.grad_reducer = reducer
+    batch = {"cameras": _cameras(inp, 2), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+    gt = torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float().to(DEV)
+    val = torch.ones(2, 17, 1, device=DEV)
+    out = {}
+    for it in range(2):          # the second pass is the REPLAY of the recorded step (with the all-reduce ops inside the backward)
+        np.random.seed(77)
+        kp, _, vols, _, _, cvs, _ = m(inp["images"].to(DEV), None, batch)
+        loss = L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val) + 0.01 * L.VolumetricCELoss()(cvs, vols, gt, val)
+        for p in m.parameters():
+            p.grad = None
+        loss.backward()
+        torch.cuda.synchronize()
+        out[it] = {n: p.grad.detach().float().cpu().numpy().copy() for n, p in m.named_parameters() if p.grad is not None}
+    return out
+
+
+def _dp_worker(rank, world, port, q):
+    import sys
+    for p in (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "learnable-triangulation-pytorch_amd"),
+              os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import lt_dist
+    lt_dist.init("gloo")           # one GPU on the box: both ranks share cuda:0, the exchange goes through gloo (RCCL needs a GPU per rank)
+    torch.cuda.set_device(0)
+    red = lt_dist.GradReducer(bucket_bytes=4 << 20)
+    g = _dp_grads(rank, red)
+    q.put((rank, {it: {n: (float(np.linalg.norm(v.astype(np.float64))), v.reshape(-1)[::max(1, v.size // 64)][:64].copy()) for n, v in gi.items()} for it, gi in g.items()},
+           red.buckets_sent))
+    lt_dist.barrier()
+    lt_dist.shutdown()
+
+
+def test_data_parallel_two_ranks_gradient_mean():
+    """Data-parallel training (train.py:450-453): two ranks, each with its own samples, gradients averaged by lt_dist.GradReducer from
+    inside the recorded backward (bucket by bucket) -- equal to the mean of the two shards' single-process gradients, in the recording
+    step and in the replayed one."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single = [_dp_grads(r, None)[0] for r in range(2)]
+    worst = 0.0
+    for rank, res, nb in got:
+        assert nb >= 4, nb          # several buckets per backward, two backwards
+        for it in (0, 1):
+            for n, (norm, sample) in res[it].items():
+                want = 0.5 * (single[0][n].astype(np.float64) + single[1][n].astype(np.float64))
+                ws = want.reshape(-1)[::max(1, want.size // 64)][:64]
+                scale = max(float(np.abs(want).max()), 1e-6 * float(np.linalg.norm(want)) + 1e-12)
+                if ZERO_GRAD.search(n):
+                    continue
+                worst = max(worst, float(np.abs(sample - ws).max()) / scale, abs(norm - float(np.linalg.norm(want))) / max(float(np.linalg.norm(want)), 1e-12))
+    record("train/data parallel 2 ranks: averaged gradients vs mean of the shards' gradients", {"err": worst, "tol": 2e-3})
+    assert worst <= 2e-3, worst

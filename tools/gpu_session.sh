@@ -19,6 +19,19 @@ tests)
   echo "kernels rc=$?" | tee -a $OUT/session.log; tail -5 $OUT/test_kernels.log | tee -a $OUT/session.log
   timeout 1200 python -m pytest tests/test_gpu_models.py -m gpu -q --tb=short -p no:cacheprovider > $OUT/test_models.log 2>&1
   echo "models rc=$?" | tee -a $OUT/session.log; tail -5 $OUT/test_models.log | tee -a $OUT/session.log
+  timeout 900 python -m pytest tests/test_gpu_backward.py tests/test_gpu_train.py -m gpu -q --tb=short -p no:cacheprovider > $OUT/test_train.log 2>&1
+  echo "backward+train rc=$?" | tee -a $OUT/session.log; tail -5 $OUT/test_train.log | tee -a $OUT/session.log
+  ;;
+train)
+  # BASELINE config 5 in its present form: fp32 training step (fwd + bwd + Adam) at 4 and 8 samples per step, and its kernel profile
+  for B in 4 8; do
+    timeout 600 python bench.py --train --steps 10 --warmup 3 --batch $B > $OUT/bench_train_b$B.json 2> $OUT/bench_train_b$B.err
+    echo "bench train B=$B rc=$?" | tee -a $OUT/session.log; cat $OUT/bench_train_b$B.json | tee -a $OUT/session.log
+  done
+  rm -rf $OUT/prof_train
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python $R/bench.py --train --steps 5 --warmup 3 --batch 8 > $OUT/prof_train.json 2> $OUT/prof_train.err
+  echo "prof train rc=$?" | tee -a $OUT/session.log
+  find $OUT/prof_train -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/train_kernel_stats.csv
   ;;
 smoke)
   timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/session.log; tail -3 $OUT/smoke.log | tee -a $OUT/session.log
