@@ -52,6 +52,7 @@ class TrainTape:
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         self._ws = torch.empty(1 << 16, dtype=torch.uint8, device=self.device)
         self.keep = []
+        self.labels, self._label = {}, "op"              # id(closure) -> label, for profile()
         # parameter gradients: ONE flat fp32 arena, slices handed out in the order the backward produces them (so a bucket of the
         # data-parallel all-reduce is a contiguous range that is complete early), 16-byte aligned
         total = sum((p.numel() + 3) // 4 * 4 for p in params if p.requires_grad)
@@ -80,10 +81,30 @@ class TrainTape:
     def global_avgpool(self, x):
         raise NotImplementedError("training with the confidence heads (volume_aggregation_method conf*) is not built")
 
-    def do(self, fn):
+    def do(self, fn, label=None):
         """Run fn(stream) now and keep it for every later step (forward list while record() runs, backward list afterwards)."""
         fn(self.stream)
         self._cur.append(fn)
+        self.labels[id(fn)] = label or self._label
+
+    def profile(self, ops, reps=3):
+        """[(label, ms)] of every recorded op in ``ops`` (fwd_ops / bwd_ops), each launch between its own pair of events on the stream
+        (after a replay of the whole list, so that every buffer holds sane values); collective ops are skipped."""
+        st = torch.cuda.current_stream(self.device)
+        out = []
+        for fn in ops:
+            lab = self.labels.get(id(fn)) or "op"
+            if lab == "allreduce":
+                continue
+            best = None
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st); fn(st.cuda_stream); e1.record(st)
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                best = t if best is None else min(best, t)
+            out.append((lab, best))
+        return out
 
     def _ws_need(self, nbytes):
         if self._ws.numel() < nbytes:
@@ -100,7 +121,7 @@ class TrainTape:
         """dst <- src[imap] every step; src is read where it lives AT CALL TIME (a Parameter the optimiser updates in place)."""
         self.keep += [imap, dst]
         n = dst.numel()
-        self.do(lambda st: H.check(H.lib().lt_gather_f32(src.data_ptr(), imap.data_ptr(), dst.data_ptr(), n, st), "lt_gather_f32"))
+        self.do(lambda st: H.check(H.lib().lt_gather_f32(src.data_ptr(), imap.data_ptr(), dst.data_ptr(), n, st), "lt_gather_f32"), "gather")
 
     def _live_conv(self, x, wparam, wt=None, bias=None, **kw):
         """lt_conv_fwd over the CURRENT values of ``wparam`` (optionally seen through the view transform ``wt``: the transposed / flipped
@@ -118,7 +139,7 @@ class TrainTape:
             bmap = torch.full((bi.numel(),), -1, dtype=torch.int32)
             bmap[:bias.numel()] = torch.arange(bias.numel(), dtype=torch.int32)
             self._gather(bias, bmap.to(self.device), bi)
-        self.do(fn)
+        self.do(fn, ("dgrad " if self._cur is self.bwd_ops else "conv ") + self.pb.ops[-1][1]["label"])
         return y
 
     # ---- layers --------------------------------------------------------------------------------------------------------------
@@ -141,11 +162,11 @@ class TrainTape:
             self._ws_need(lib.lt_bn_stats_workspace(rows, Cc))
             mom = float(self.momentum)
             self.do(lambda st: H.check(lib.lt_bn_stats_fwd(H.LT_F32, y_raw.t.data_ptr(), rows, Cc, mean.data_ptr(), var.data_ptr(), rmean.data_ptr(),
-                                                           rvar.data_ptr(), mom, self._ws.data_ptr(), st), "lt_bn_stats_fwd"))
+                                                           rvar.data_ptr(), mom, self._ws.data_ptr(), st), "lt_bn_stats_fwd"), "bn_stats %dx%d" % (rows, Cc))
             z = self.alloc(y_raw.shape)
             rp = residual.t if residual is not None else None
             self.do(lambda st: H.check(lib.lt_bn_act_fwd(y_raw.t.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), H.ptr(rp),
-                                                         z.t.data_ptr(), rows, Cc, BN_EPS, flags, st), "lt_bn_act_fwd"))
+                                                         z.t.data_ptr(), rows, Cc, BN_EPS, flags, st), "lt_bn_act_fwd"), "bn_act %dx%d" % (rows, Cc))
             stats = (mean, var)
         self.recorders.append(lambda: self._conv_bwd(x, weight, bias, bn, stride, pad, transposed, flags, residual, y_raw, stats, z))
         return z
@@ -192,7 +213,7 @@ class TrainTape:
         a, b = self.bucket_start, self.arena_off
         if b > a and (final or b - a >= self.bucket_elems):
             chunk = self.arena[a:b]
-            self.do(lambda st: self.reducer.reduce_inplace(chunk))
+            self.do(lambda st: self.reducer.reduce_inplace(chunk), "allreduce")
             self.bucket_start = b
 
     # ---- backward of one convolution layer ---------------------------------------------------------------------------------------
@@ -219,7 +240,7 @@ class TrainTape:
             self._ws_need(lib.lt_bn_act_bwd_workspace(rows, Cout))
             self.do(lambda st: H.check(lib.lt_bn_act_bwd(dz.data_ptr(), y_raw.t.data_ptr(), H.ptr(rp), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
                                                          beta.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), H.ptr(dres), acc_res, rows, Cout,
-                                                         BN_EPS, flags, self._ws.data_ptr(), st), "lt_bn_act_bwd"))
+                                                         BN_EPS, flags, self._ws.data_ptr(), st), "lt_bn_act_bwd"), "bn_bwd %dx%d" % (rows, Cout))
         else:
             total = z.t.numel()
             self.do(lambda st: H.check(lib.lt_act_bwd(dz.data_ptr(), z.t.data_ptr(), H.ptr(rp), dy.data_ptr(), H.ptr(dres), acc_res, total, flags, st), "lt_act_bwd"))
@@ -261,7 +282,7 @@ class TrainTape:
             self.keep += [taps_all, a_ptr, b_ptr]
             self.do(lambda st: H.check(lib.lt_conv_wgrad(a_ptr.data_ptr(), b_ptr.data_ptr(), taps_all.data_ptr(), dw.data_ptr(), geo[0], geo[1], geo[2], geo[3], geo[4],
                                                          geo[5], geo[6], geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, self._ws.data_ptr(), st),
-                                       "lt_conv_wgrad"))
+                                       "lt_conv_wgrad"), "wgrad %s %s rows %d cout_pad %d K %d" % ("x".join(map(str, weight.shape)), "T" if transposed else "", wrows, cop, kp))
             self._gather(dw, imap, self._grad_view(weight))
         self._grads_ready()
         # ---- input gradient (skipped for the network input)
