@@ -542,6 +542,81 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_brick_kernel(const BrickA
     }
 }
 
+// ---- weight gradient of V2V's 7x7x7 front convolution (32 -> 16 channels, stride 1, pad 3) ----------------------------------------------
+// 343 taps x (16 x 32) = 686 KB of accumulators: one workgroup owns ONE kd plane of the filter (49 taps x 16 co x 32 ci = 98 blocks of
+// the 16x16x4 fp32 MFMA -- no padding of the 16 output channels to a 32-row tile -- 24-25 blocks of 4 registers per wave).  Bricks of
+// 2 x 4 x 16 voxels: dY brick (8 KB) and the two X planes the kd needs with a 3-voxel (h, w) halo (2 x 10 x 22 voxels x 32 ch = 55 KB) in
+// LDS.  Taps must be in (kd, kh, kw) order (the kernel traps otherwise).  13.5 ms -> see DESIGN.md.
+constexpr int K7_HD = 2, K7_HH = BRK_H + 6, K7_HW = BRK_W + 6, K7_HVOX = K7_HD * K7_HH * K7_HW;
+
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_k7_kernel(const BrickArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[K7_HVOX * 32];
+    __shared__ __attribute__((aligned(16))) float ds[BRK_VOX * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;            // MFMA 16x16x4: A row / B column = lane % 16, k (voxel of the quad) = lane / 16
+    const int kd = blockIdx.x;
+    // this wave's blocks: b = wave, wave + 4, ... < 98; block b = (tap of the plane, ci half)
+    int boff[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+        const int b = wave + 4 * i;
+        const int t = b < 98 ? b >> 1 : 0;
+        const int4 tp = a.taps[kd * 49 + t];
+        if (tp.x != kd) __builtin_trap();
+        boff[i] = (tp.y * K7_HW + tp.z) * 32 + (b & 1) * 16;
+    }
+    f32x4 acc[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int b_begin = blockIdx.z * a.bricks_per_slab, b_end = min(a.nbricks, b_begin + a.bricks_per_slab);
+    for (int br = b_begin; br < b_end; ++br) {
+        int r = br;
+        const int bw = r % a.nbw; r /= a.nbw;
+        const int bh = r % a.nbh; r /= a.nbh;
+        const int bd = r % a.nbd;
+        const int n = r / a.nbd;
+        const int d0 = bd * BRK_D, h0 = bh * BRK_H, w0 = bw * BRK_W;
+        __syncthreads();
+        for (int i = threadIdx.x; i < K7_HVOX * 8; i += 256) {
+            const int v = i >> 3, q = i & 7;
+            const int hw_ = v % K7_HW, t2 = v / K7_HW;
+            const int hh_ = t2 % K7_HH, hd_ = t2 / K7_HH;
+            const int d = d0 + hd_ + kd - 3, h = h0 + hh_ - 3, w = w0 + hw_ - 3;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+                val = *(const float4*)(a.x + ((((size_t)n * a.D + d) * a.H + h) * a.W + w) * 32 + q * 4);
+            *(float4*)(xs + v * 32 + q * 4) = val;
+        }
+        for (int i = threadIdx.x; i < BRK_VOX * 4; i += 256) {          // 128 voxels x 4 float4 (16 co)
+            const int v = i >> 2, q = i & 3;
+            const int w = v % BRK_W, t2 = v / BRK_W;
+            const int h = t2 % BRK_H, d = t2 / BRK_H;
+            const size_t row = (((size_t)n * a.D + d0 + d) * a.H + h0 + h) * a.W + w0 + w;
+            *(float4*)(ds + v * 16 + q * 4) = *(const float4*)(a.dy + row * a.ldy + q * 4);
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int s4 = 0; s4 < BRK_VOX / 4; ++s4) {
+            const int v = 4 * s4 + kq;                        // four voxels along w per MFMA (16 wide: a quad never straddles a row)
+            const int w = v % BRK_W, t2 = v / BRK_W;
+            const int h = t2 % BRK_H, d = t2 / BRK_H;
+            const float av = ds[v * 16 + col];
+            const float* xb = xs + ((d * K7_HH + h) * K7_HW + w) * 32 + col;
+#pragma unroll
+            for (int i = 0; i < 25; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[boff[i]], acc[i], 0, 0, 0);
+        }
+    }
+    float* out = a.out + (size_t)blockIdx.z * a.cout_pad * a.k_pad;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+        const int b = wave + 4 * i;
+        if (b >= 98) break;
+        const int k = (kd * 49 + (b >> 1)) * 32 + (b & 1) * 16 + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[(size_t)(4 * kq + e) * a.k_pad + k] = acc[i][e];       // C: row = 4 (lane / 16) + e = co, column = lane % 16 = ci
+    }
+}
+
 // ---- weight gradient of the 1x1 / stride 1 convolutions: dW[co][ci] = sum_m dY[m][co] X[m][ci], an LDS-tiled GEMM ----------------------
 // Workgroup tile 128 (co) x 128 (ci), 2 x 2 waves of 64 x 64 (four 32x32 accumulator blocks each); the reduction index m (pixels) is
 // walked in chunks of 32 rows staged in LDS (row stride 160 floats: the two half-waves of a ds_read_b32 land in different bank halves);
@@ -972,6 +1047,24 @@ extern "C" int lt_conv_wgrad(const float* dy, const float* x, const int32_t* tap
             LT_REQUIRE(hipMemsetAsync(workspace, 0, (size_t)S * cout_pad * k_pad * sizeof(float), st) == hipSuccess, LT_ERR_LAUNCH, "lt_conv_wgrad: memset failed");
         hipLaunchKernelGGL(conv2d_wgrad_brick_kernel, dim3(Cout / 32, (unsigned)cdiv(Cin, 128), (unsigned)S), dim3(256), 0, st, b);
         LT_CHECK_LAUNCH("lt_conv_wgrad(brick2d)");
+        const long long n = (long long)cout_pad * k_pad;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096)), dim3(256), 0, st, (const float*)workspace, dw, n, (int)S, accumulate);
+        LT_CHECK_LAUNCH("lt_conv_wgrad(reduce)");
+        return LT_OK;
+    }
+    if (unit && ntaps == 343 && pad[0] == 3 && pad[1] == 3 && pad[2] == 3 && Cin == 32 && Cout == 16 && cout_pad == 16 && k_pad == 343 * 32 && ldy >= 16 && ldy % 4 == 0 &&
+        D % BRK_D == 0 && H % BRK_H == 0 && W % BRK_W == 0 && workspace) {
+        BrickArgs b;
+        b.dy = dy; b.x = x; b.taps = (const int4*)taps; b.out = (float*)workspace;
+        b.N = N; b.D = D; b.H = H; b.W = W; b.Cin = Cin; b.ldy = ldy; b.cout_pad = cout_pad; b.k_pad = k_pad;
+        b.nbd = D / BRK_D; b.nbh = H / BRK_H; b.nbw = W / BRK_W; b.nbricks = N * b.nbd * b.nbh * b.nbw;
+        long long S = 73;                              // 7 kd planes x 73 slabs = 511 workgroups, two per CU
+        S = S > cap_slabs ? cap_slabs : S;
+        S = S > b.nbricks ? b.nbricks : S;
+        b.bricks_per_slab = (int)cdiv(b.nbricks, S);
+        S = cdiv(b.nbricks, b.bricks_per_slab);
+        hipLaunchKernelGGL(conv3d_wgrad_k7_kernel, dim3(7, 1, (unsigned)S), dim3(256), 0, st, b);
+        LT_CHECK_LAUNCH("lt_conv_wgrad(7^3)");
         const long long n = (long long)cout_pad * k_pad;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096)), dim3(256), 0, st, (const float*)workspace, dw, n, (int)S, accumulate);
         LT_CHECK_LAUNCH("lt_conv_wgrad(reduce)");

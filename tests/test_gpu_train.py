@@ -135,6 +135,7 @@ CONV_CASES = [  # nd, Cin, Cout, k, stride, pad, transposed, spatial
     (3, 32, 16, 7, 1, 3, False, (8, 8, 8)),
     (3, 32, 64, 3, 1, 1, False, (4, 8, 16)),       # whole bricks of 2 x 4 x 16 voxels: the LDS-brick weight-gradient kernel
     (3, 64, 32, 3, 1, 1, False, (2, 4, 32)),
+    (3, 32, 16, 7, 1, 3, False, (4, 4, 16)),       # V2V's 7^3 front layer: one kd plane of the filter per workgroup, 16x16x4 MFMA
     (2, 32, 64, 3, 1, 1, False, (16, 8)),          # 8 x 8 pixel bricks: the 2D LDS-brick weight-gradient kernel (one partly filled ci block)
     (2, 256, 32, 3, 1, 1, False, (8, 8)),          # two ci blocks of 128
     (2, 256, 128, 1, 1, 0, False, (5, 7)),         # the LDS-tiled pointwise weight-gradient GEMM (ragged last chunk of rows)
