@@ -1113,6 +1113,30 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
+    // The four-wave pointwise variant (the 1x1 expand layers: 8 K steps, then a tile of residual + output traffic) is HBM-bound and its
+    // epilogue used to request each 48-row pass's residual vectors at the top of that pass, one exposed round trip per pass.  Now the
+    // first pass's vectors are requested HERE, before the first DMA piece (oldest in the in-order vmcnt queue: every counted wait of
+    // the K loop still holds), and inside the epilogue pass p + 1's are requested before pass p touches LDS.
+    constexpr bool RES_EARLY = PW && NWM == 1;
+    constexpr int E_LPR = WN / 8, E_RPP = 64 / E_LPR, E_ITP = 48 / E_RPP;
+    const uint4 neg0 = make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
+    uint4 rv_next[RES_EARLY ? E_ITP : 1];
+    auto res_load = [&](int p, uint4* rv) {
+        const int colv_ = n0 + wn * WN + (lane % E_LPR) * 8;
+        if (a.res != nullptr) {
+#pragma unroll
+            for (int k = 0; k < E_ITP; ++k) {          // unconditional loads (a lane outside the tensor reads element 0 and never uses it): a select
+                const int m = m0 + wm * WM + p * 48 + k * E_RPP + lane / E_LPR;          // behind a load would make the compiler wait at the load
+                const bool ok = (m < a.M) & (colv_ < a.Cout);
+                rv[k] = *(const uint4*)((const T*)a.res + (ok ? (long long)m * a.ldc + colv_ : 0ll));       // PW: the output pixel IS the GEMM row
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < E_ITP; ++k) rv[k] = neg0;
+        }
+    };
+    if constexpr (RES_EARLY) res_load(0, rv_next);
+
     // B fragments in BPF + 1 register sets: set ks % (BPF + 1) holds step ks, requested BPF steps ahead.  BPF = 2 (-DLT6_BPF=2) was
     // built to test whether the in-order return of vector-memory loads (a B load is only seen once every older LDS-DMA piece of the
     // wave has landed) explains the wait in front of the barrier: per layer 110 / 104 us (BPF 1) vs 112 / 109 and 104 / 107 us (BPF 2,
@@ -1292,6 +1316,7 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
         sc[j] = a.scale ? a.scale[colj] : 1.f;
         sf[j] = a.shift ? a.shift[colj] : 0.f;
     }
+    static_assert(ITP == E_ITP && EP_ROWS == 48, "residual prefetch geometry");
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         long long off[ITP];
@@ -1299,7 +1324,15 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
 #pragma unroll
         for (int k = 0; k < ITP; ++k) {                  // this pass's residual vectors first: independent round trips
             off[k] = out_off(p, k);
-            rv[k] = (has_res && off[k] >= 0) ? *(const uint4*)((const T*)a.res + off[k]) : make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
+            if constexpr (RES_EARLY) rv[k] = rv_next[k];
+            else rv[k] = (has_res && off[k] >= 0) ? *(const uint4*)((const T*)a.res + off[k]) : make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
+        }
+        if constexpr (RES_EARLY) {
+            if (p == 0) {          // the compiler cannot see the asm vmcnt(0) behind the K loop: let it place its wait for the early loads HERE, not
+#pragma unroll                     // behind the next pass's requests (where it would wait for those too)
+                for (int k = 0; k < ITP; ++k) asm volatile("" ::"v"(rv[k].x));
+            }
+            if (p + 1 < NPASS) res_load(p + 1, rv_next);          // the next pass's round trip runs under this pass's LDS staging and stores
         }
 #pragma unroll
         for (int ii = 0; ii < 3; ++ii)

@@ -478,3 +478,38 @@ def test_data_parallel_two_ranks_gradient_mean():
                 worst = max(worst, float(np.abs(sample - ws).max()) / scale, abs(norm - float(np.linalg.norm(want))) / max(float(np.linalg.norm(want)), 1e-12))
     record("train/data parallel 2 ranks: averaged gradients vs mean of the shards' gradients", {"err": worst, "tol": 2e-3})
     assert worst <= 2e-3, worst
+
+
+def test_rccl_single_rank_process_group_comes_up():
+    """The boxes these tests run on have ONE GPU, and RCCL refuses two ranks on one device -- but a world of one rank still loads
+    librccl, builds a communicator and launches its kernels: backend "nccl" all-reduce / barrier on device tensors, and the
+    GradReducer path driven through it (what bench.py --gpus N / --train use with N ranks)."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(os.environ["LT_ROOT"], "learnable-triangulation-pytorch_amd"))
+import lt_dist
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["LT_PORT"])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="env://", world_size=1, rank=0)
+t = torch.arange(1024, dtype=torch.float32, device="cuda:0")
+dist.all_reduce(t)
+dist.barrier()
+red = lt_dist.GradReducer(bucket_bytes=1 << 12)
+red.world = 2                      # force the collective path (sum over the one rank, then / 2)
+flat = torch.ones(4096, device="cuda:0")
+red.reduce_inplace(flat[:2048]); red.reduce_inplace(flat[2048:]); red.wait_all()
+torch.cuda.synchronize()
+assert float(t[5]) == 5.0 and float(flat.sum()) == 2048.0, (float(t[5]), float(flat.sum()))
+print("RCCL_OK", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else "")
+dist.destroy_process_group()
+'''
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LT_ROOT=root, LT_PORT=str(port))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    record("dist/RCCL single-rank process group (backend nccl) on the GPU box", r.stdout.strip().splitlines()[-1])
