@@ -513,3 +513,83 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
     record("dist/RCCL single-rank process group (backend nccl) on the GPU box", r.stdout.strip().splitlines()[-1])
+
+
+def test_training_api_semantics_accumulation_stale_backward_torch_optimizer():
+    """What a training loop may do around the step: gradient accumulation over two forward/backward cycles (autograd owns the returned
+    gradients, the plan's arena is overwritten), backpropagating a STALE forward (refused loudly), torch.optim.Adam on the same .grad
+    tensors (same update as lt_train.Adam), a no_grad forward in training mode, a second batch size (second plan)."""
+    import lt_train
+    from mvn.models import loss as L
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    from test_gpu_models import _cameras
+    cfg = synth.vol_config(18, 32, "softmax", 1.0, "mpii")
+    sd = synth.make_state_dict(spec.vol_net_spec(18, 17, False), seed=12, sharpen=60.0, basic_block=True)
+    inp = synth.make_inputs(2, 3, 128, seed=31, inside=False)
+    batch = {"cameras": _cameras(inp, 2), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+    gt = torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float().to(DEV)
+    val = torch.ones(2, 17, 1, device=DEV)
+    images = inp["images"].to(DEV)
+
+    def make():
+        m = VolumetricTriangulationNet(cfg, device=DEV)
+        m.load_state_dict(sd, strict=True)
+        m.to(DEV)
+        m.train()
+        return m
+
+    def loss_of(m):
+        np.random.seed(3)
+        kp, _, vols, _, _, cvs, _ = m(images, None, batch)
+        return L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val) + 0.01 * L.VolumetricCELoss()(cvs, vols, gt, val)
+
+    m = make()
+    loss_of(m).backward()
+    g1 = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    # running statistics moved with the first forward: the second cycle sees the same weights, so the same gradients (up to atomics)
+    loss_of(m).backward()                              # no zero_grad: accumulation
+    worst = 0.0
+    for n, p in m.named_parameters():
+        if p.grad is None or ZERO_GRAD.search(n):
+            continue
+        worst = max(worst, float((p.grad - 2 * g1[n]).abs().max() / g1[n].abs().max().clamp(min=1e-20)))
+    record("train/api gradient accumulation (2 cycles vs 2 x 1 cycle)", {"err": worst, "tol": 2e-3})
+    assert worst <= 2e-3, worst
+    # a stale forward cannot be backpropagated
+    l_old = loss_of(m)
+    l_new = loss_of(m)
+    with pytest.raises(RuntimeError, match="LATEST"):
+        l_old.backward()
+    l_new.backward()
+    # torch.optim.Adam vs lt_train.Adam from the same gradients
+    ma, mb = make(), make()
+    oa = torch.optim.Adam([{"params": ma.backbone.parameters()}, {"params": ma.process_features.parameters(), "lr": 1e-3},
+                           {"params": ma.volume_net.parameters(), "lr": 1e-3}], lr=1e-4)
+    ob = lt_train.Adam([{"params": list(mb.backbone.parameters())}, {"params": list(mb.process_features.parameters()), "lr": 1e-3},
+                        {"params": list(mb.volume_net.parameters()), "lr": 1e-3}], lr=1e-4)
+    for mm, oo in ((ma, oa), (mb, ob)):
+        oo.zero_grad()
+        loss_of(mm).backward()
+    with torch.no_grad():          # identical gradients for both optimisers (the two backwards differ by atomics noise, and Adam's first step is a sign)
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            if pa.grad is not None:
+                pb.grad.copy_(pa.grad)
+    before = [p.detach().clone() for p in ma.parameters()]
+    oa.step(); ob.step()
+    torch.cuda.synchronize()
+    wd = 0.0
+    for p0, pa, pb in zip(before, ma.parameters(), mb.parameters()):
+        if pa.grad is not None:
+            wd = max(wd, float(((pa - pb).abs().max() / (pa - p0).abs().max().clamp(min=1e-12)).detach()))
+    record("train/api torch.optim.Adam vs lt_train.Adam, one step from equal gradients (difference / step size)", {"err": wd, "tol": 1e-3})
+    assert wd <= 1e-3, wd
+    # no_grad forward in training mode (validation without eval()): runs, returns no graph
+    with torch.no_grad():
+        kp = m(images, None, batch)[0]
+    assert not kp.requires_grad and torch.isfinite(kp).all()
+    # another batch size: a second recorded plan beside the first
+    inp1 = synth.make_inputs(1, 3, 128, seed=32, inside=False)
+    b1 = {"cameras": _cameras(inp1, 1), "pred_keypoints_3d": inp1["pred_keypoints_3d"]}
+    kp1 = m(inp1["images"].to(DEV), None, b1)[0]
+    kp1.sum().backward()
+    assert len(m._train_plans) == 2 and torch.isfinite(kp1).all()
