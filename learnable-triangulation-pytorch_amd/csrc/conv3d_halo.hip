@@ -18,13 +18,12 @@
 //   weights: per tap a [cout_pad][CINB] slab, slot lv ^ ((-(col/VPR)) % NVV) (conflict free for both MFMA shapes).
 // Weight ring: NBUF chunk buffers, NBUF-1 chunks of DMA in flight (counted vmcnt), one barrier per chunk.
 //
-// Kernels in this file (dispatch: conv3d_halo_try / conv2d_band_try at the end):
+// Kernels in this file (dispatch: conv3d_halo_try at the end):
 //   conv3d_halo_kernel          one tile per workgroup, weight ring in LDS, optional loader waves: fp32, and the bf16 shapes below miss
 //   conv3d_halo_persist_kernel  3^3 32->32: persistent, weights resident, double-buffered halo (small grids)
 //   conv3d_halo_col_kernel      3^3 32->32: column walk, ring of 4-plane halo groups, epilogue under the next tile's MFMAs
-//   conv3d_halo7_kernel / 7b    7^3 32->16: loader waves; tap-major / kd-register-blocked (default)
+//   conv3d_halo7b_kernel        7^3 32->16: loader waves, kd-register-blocked
 //   conv3d_halo_wreg_kernel     3^3 64->64, 32->64, 128->128: halo-only LDS, weights as fragments from global memory
-//   conv2d_band_kernel          2D 3x3 256->256 on 24-wide maps (opt-in): row bands in LDS, weights from global memory
 #include <stdlib.h>
 
 #include <type_traits>
@@ -1463,187 +1462,6 @@ __global__ __launch_bounds__(256, (CIN == 128 ? 1 : 2)) void conv3d_halo_wreg_ke
     }
 }
 
-// ---- 2D 3x3, 256 -> 256 on 24-wide maps (the 36 bottleneck convs of ResNet-152 layer3): row bands in LDS, weights from global ----
-// The implicit GEMM gathers its A operand nine times (once per tap) through LDS-DMA and runs this layer at ~53 % of the MFMA rate
-// the chip sustains.  Here a workgroup owns a BAND of 12 rows x 24 columns = 288 pixels of one image and half of the output
-// channels (128 = one 32-channel block per compute wave): the band's halo (14 x 26 pixels) is staged ONCE per 64-channel K chunk
-// (46 KB; two buffers: loader waves request chunk q+1 while the compute waves multiply chunk q), every tap reads its voxel
-// fragments from that image with immediates, and the weights come from global memory as fragments of the transposed product
-// (lt_conv_pack_weights_t32), one coalesced 1 KB load per nine MFMAs.  256 bands x 2 channel halves = two workgroups per CU
-// in sequence, the two halves of a band on the same XCD.  OPT-IN (the plan packs the weights for it only with LT_CONV_BAND=1):
-// per layer it measures 83 us against 90 us for conv_igemm6, but inside the replayed forward the step is 1 % slower (two rounds
-// of workgroups, each with an exposed first-chunk load and epilogue, against one round).  Slot swizzle of the 128-byte pixel chunks: (column / 2 + 4 row) & 7 --
-// 16 consecutive pixels of a fragment read (also across the row wrap at column 24) then hit 16 different (bank half, slot) pairs;
-// a tap moves it by XOR constants, the K block by (g << 5), so a read is one v_xor + ds_read with an immediate.
-struct BandArgs {
-    const void* x;
-    const void* wfrag;
-    void* y;
-    const void* res;
-    const float* bias;
-    const float* scale;
-    const float* shift;
-    int N, H, W, ldc, flags, bands;   // bands per image
-};
-
-template <typename T>
-__global__ __launch_bounds__(512) void conv2d_band_kernel(const BandArgs a) {
-    constexpr int CIN = 256, KC = 64, NQ = CIN / KC, W_ = 24, RB = 12, PWID = W_ + 2, HROWS = RB + 2;
-    constexpr int HV = HROWS * PWID;                      // 364 halo pixels
-    constexpr int CHUNK_B = ((HV * KC * 2 + 1023) / 1024) * 1024;   // 47104
-    constexpr int NI = CHUNK_B / 1024;                    // 46 DMA pieces per chunk
-    constexpr int NF = RB * W_ / 32;                      // 9 pixel fragments
-    constexpr int G = KC / 16;                            // 4 K blocks per chunk
-    static_assert(sizeof(T) == 2 && RB * W_ == 288 && 2 * CHUNK_B <= 160 * 1024, "bf16, 288-pixel band, two chunk buffers");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page_h;
-    asm volatile("" : "+s"(zp_bits));
-    const void* const zero_page = (const void*)(size_t)zp_bits;
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // workgroup -> (band tile, channel half): b and b + 8 (same XCD) are the two halves of one band
-    const int lin = blockIdx.x;
-    const int chalf = (lin >> 3) & 1;
-    const int tile = (lin & 7) + 8 * (lin >> 4);
-    const int n = tile / a.bands, r0 = (tile % a.bands) * RB;
-    const T* __restrict__ x = (const T*)a.x + (size_t)n * a.H * a.W * CIN;
-    auto sw = [](int hrow, int hcol) -> int { return ((hcol >> 1) + 4 * hrow) & 7; };
-
-    if (wave >= 4) {
-        // ================================= loader waves =================================
-        const int wl = wave & 3;
-        constexpr int MAXP = (NI + 3) / 4;
-        int poff[MAXP];                                   // element offset of this lane's 16 bytes of piece m inside chunk 0, or -1
-#pragma unroll
-        for (int m = 0; m < MAXP; ++m) {
-            const int q = (wl + 4 * m) * 64 + lane;
-            const int hv = q >> 3, pv = q & 7;
-            const int hrow = hv / PWID, hcol = hv - hrow * PWID;
-            const int lv = pv ^ sw(hrow, hcol);
-            const int gy = r0 - 1 + hrow, gx = hcol - 1;
-            const bool ok = hv < HV && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            poff[m] = ok ? (gy * a.W + gx) * CIN + lv * 8 : -1;
-        }
-        auto issue = [&](int q) {
-#pragma unroll
-            for (int m = 0; m < MAXP; ++m)
-                if (wl + 4 * m < NI) {
-                    const void* src = poff[m] >= 0 ? (const void*)(x + poff[m] + q * KC) : zero_page;
-                    dma16h(src, lds0 + (q & 1) * CHUNK_B + (wl + 4 * m) * 1024);
-                }
-        };
-        issue(0);
-        for (int q = 0; q < NQ; ++q) {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // chunk q landed; the compute waves are done with chunk q-1
-            if (q + 1 < NQ) issue(q + 1);
-        }
-        return;
-    }
-
-    // ================================= compute waves =================================
-    const int cb = 4 * chalf + wave;                      // 32-channel output block
-    const int vl = lane & 31, hh = lane >> 5;
-    // pixel fragment f: pixel m = 32 f + vl = (row m / 24, column m % 24).  Read address of tap (kh, kw), K block g, buffer b:
-    //   (A[f][kw] ^ ((g << 5) ^ ((kh & 1) << 6))) + kh * PWID * 128 + b * CHUNK_B, the last two as the immediate
-    unsigned A[NF][3];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const int m = 32 * f + vl;
-        const int row = m / W_, col = m - row * W_;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) A[f][kw] = lds0 + (row * PWID + col + kw) * (KC * 2) + ((hh ^ sw(row, col + kw)) << 4);
-    }
-    // weight fragments: (tap, 16-channel K block kb of 16, Cout block of 8) -> 1 KB at (((tap * 16 + kb) * 8 + cb) * 64 + lane) * 16 B
-    // (wave-uniform base + 32-bit lane offset: the loads take the SGPR-base form, no 64-bit address per unit in VGPRs)
-    const T* wb = (const T*)a.wfrag + (size_t)cb * 64 * 8;
-    const unsigned wlane = lane * 8;
-    constexpr size_t WKB = (size_t)8 * 64 * 8;            // elements per K block
-    constexpr int UPC = 9 * G, WD = 2;                    // units per chunk (tap-major, then K block); weight prefetch distance
-                                                          // (2 x 288 MFMA cycles; 3 already spills at the 256-register limit)
-    auto wptr = [&](int q, int u) -> const T* {           // unit u of chunk q
-        const int tap = u / G, gl = u % G;
-        return wb + ((size_t)tap * 16 + 4 * q + gl) * WKB + wlane;
-    };
-
-    f32x16 acc[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
-
-    V16 wf[WD + 1];
-    V16 xa[NF];
-    auto read_x = [&](auto bc, auto uc, auto fc) {
-        constexpr int b = decltype(bc)::value, u = decltype(uc)::value, f = decltype(fc)::value;
-        constexpr int tap = u / G, g = u % G, kh = tap / 3, kw = tap % 3;
-        constexpr unsigned XC = (unsigned)((g << 5) ^ ((kh & 1) << 6));
-        // the XOR as volatile asm: left to the compiler, all 216 distinct (fragment, kw, constant) addresses are computed up
-        // front and live in (spilled) registers
-        unsigned ad = A[f][kw];
-        if constexpr (XC != 0) asm volatile("v_xor_b32 %0, %2, %1" : "=v"(ad) : "v"(A[f][kw]), "n"(XC));
-        xa[f].u = *(const uint4*)((lptr_t)(size_t)(ad + kh * PWID * (KC * 2) + b * CHUNK_B));
-    };
-    // one K chunk out of buffer B: 36 units of (1 weight fragment, 9 pixel fragments, 9 MFMAs); the pixel fragments of unit u+1 are
-    // read into the registers unit u has just multiplied with, the weight fragments WD units ahead
-    auto chunk = [&](auto bc, int q) {
-        constexpr int b = decltype(bc)::value;
-#pragma unroll
-        for (int u = 0; u < WD; ++u) wf[u] = *(const V16*)wptr(q, u);
-        static_for<0, NF>([&](auto fc) { read_x(bc, std::integral_constant<int, 0>{}, fc); });
-        static_for<0, UPC>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            if constexpr (u + WD < UPC) wf[(u + WD) % (WD + 1)] = *(const V16*)wptr(q, u + WD);
-            static_for<0, NF>([&](auto fc) {
-                constexpr int f = decltype(fc)::value;
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % (WD + 1)].h, xa[f].h, acc[f], 0, 0, 0);
-                if constexpr (u + 1 < UPC) read_x(bc, std::integral_constant<int, u + 1>{}, fc);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-#pragma unroll 1
-    for (int q = 0; q < NQ; q += 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // chunk q is in buffer 0
-        chunk(std::integral_constant<int, 0>{}, q);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // chunk q + 1 is in buffer 1
-        chunk(std::integral_constant<int, 1>{}, q + 1);
-    }
-
-    // ---- epilogue from the accumulators: lane (pixel, h) holds channels 32 cb + 8 h + e (e < 8) and 32 cb + 16 + 8 h + (e - 8) ----
-    float esc[16], esf[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int c = 32 * cb + 16 * (e >> 3) + 8 * hh + (e & 7);
-        const float bi = a.bias ? a.bias[c] : 0.f, sc = a.scale ? a.scale[c] : 1.f, sf = a.shift ? a.shift[c] : 0.f;
-        esc[e] = sc; esf[e] = bi * sc + sf;
-    }
-    const EpiFloors fl = epi_floors(a.flags);
-    const bool has_res = a.res != nullptr;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const int m = 32 * f + vl;
-        const int row = m / W_, col = m - row * W_;
-        const size_t oo = (((size_t)n * a.H + r0 + row) * a.W + col) * (size_t)a.ldc + 32 * cb + 8 * hh;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const uint4 rv = has_res ? *(const uint4*)((const T*)a.res + oo + 16 * q) : make_uint4(0, 0, 0, 0);
-            const unsigned rr[4] = {rv.x, rv.y, rv.z, rv.w};
-            unsigned o[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int e = 8 * q + 2 * d;
-                const float v0 = epi_apply(fmaf(acc[f][e], esc[e], esf[e]), fl, __uint_as_float(rr[d] << 16));
-                const float v1 = epi_apply(fmaf(acc[f][e + 1], esc[e + 1], esf[e + 1]), fl, __uint_as_float(rr[d] & 0xffff0000u));
-                o[d] = pack_bf16x2(v0, v1);
-            }
-            *(uint4*)((T*)a.y + oo + 16 * q) = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-    }
-}
-
 // lt_conv_fwd packing [cout_pad][k_pad] (k = tap * cin + ci) -> fragments of the transposed product:
 // [tap][cin / 16][cout_pad / 32][64 lanes][8]; lane (r = l & 31, h = l >> 5) holds row chan(r) + 32 block, K elements 16 g + 8 h .. + 7
 __global__ void conv_pack_t32_kernel(const bf16_t* __restrict__ w, int cout_pad, int k_pad, int cin, int ntaps, bf16_t* __restrict__ out) {
@@ -1675,206 +1493,8 @@ __global__ void conv_pack_t32_kernel(const bf16_t* __restrict__ w, int cout_pad,
 // workgroup with the next tile's first halo planes prefetched into the planes the tap loop has passed, and separate halo /
 // weight loader waves (both ~10 % slower: the plane bursts delay the weight pieces queued behind them).  The next lever is
 // LDS traffic: keeping the 7 kd-taps of one (kh, kw) in registers and sweeping the 10 input planes (17 reads per 28 MFMAs).
-template <typename T>
-__global__ __launch_bounds__(512) void conv3d_halo7_kernel(const HaloArgs a) {
-    constexpr int KS = 7, CIN = 32, CP = 16, TD = 4, TH = 8, TW = 8, TPC = 7, NBUF = 5, PD = 2;
-    typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, 4> C;
-    static_assert(sizeof(T) == 2, "bf16 only");
-    constexpr int MF = C::MF, SM = C::SM, SN = C::SN, G = C::G, NACC = C::NACC, NVV = C::NVV, VPR = C::VPR, CINB = C::CINB;
-    static_assert(MF == 16 && SM == 4 && SN == 1 && G == 1 && NVV == 4 && C::SW::FSH == 0 && C::SW::FA == 0 && C::SW::FC == 0, "7^3 32->16 layout");
-    static_assert(C::SLAB == 1024 && C::WCH == TPC * 1024, "one DMA piece per tap of a chunk");
-    static_assert(C::HALO_BYTES + NBUF * C::WCH <= 160 * 1024, "halo + weight ring must fit LDS");
-    typedef typename Mma<T, MF>::acc_t acc_t;
-    constexpr int NCH = KS * KS;                         // 49 chunks: c = kd*7 + kh
-    constexpr int KDSTEP = C::HH * C::PW * CINB;         // bytes per d-plane of the halo image
-    constexpr int NI_H = C::HALO_BYTES / 1024;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-    const unsigned lds_w = lds0 + C::HALO_BYTES;
-
-    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page_h;
-    asm volatile("" : "+s"(zp_bits));
-    const void* const zero_page = (const void*)(size_t)zp_bits;
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const bool loader = wave >= 4;
-    const int wl = wave & 3;
-    constexpr int P = KS / 2;
-
-    const int tps = a.tiles_d * a.tiles_h * a.tiles_w;
-    int n, tix;
-    if (a.xcd_pin) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        n = xcd + 8 * (j / tps);
-        tix = j % tps;
-    } else {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-        n = lin / tps;
-        tix = lin % tps;
-    }
-    const int w0 = (tix % a.tiles_w) * TW;
-    const int h0 = ((tix / a.tiles_w) % a.tiles_h) * TH;
-    const int d0 = (tix / (a.tiles_w * a.tiles_h)) * TD;
-
-    if (loader) {
-        // ================================= loader waves =================================
-        const T* __restrict__ x = (const T*)a.x + (size_t)n * a.D * a.H * a.W * CIN;
-        const T* __restrict__ w = (const T*)a.w;
-#ifndef LT_ABL_NO_A
-        for (int i = wl; i < NI_H; i += 4) {
-            const int q = i * 64 + lane;
-            const int hv = q / NVV, pv = q % NVV;
-            const int hw_ = hv % C::PW, hh_ = (hv / C::PW) % C::HH, hd_ = hv / (C::PW * C::HH);
-            const int lv = pv ^ C::fswz(hd_, hh_, hw_);
-            const int id = d0 - P + hd_, ih = h0 - P + hh_, iw = w0 - P + hw_;
-            const bool ok = hv < C::HV && hw_ < C::HW && ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-            const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : zero_page;
-            dma16h(src, lds0 + i * 1024);
-        }
-#endif
-        // weight pieces of this loader: tap wl (and wl + 4 when < 7) of every chunk; chunk c, tap tj -> weight column block
-        // (c*7 + tj)*CIN: the source advances by 7*CIN elements per chunk
-        const int pv = lane % NVV, col = lane / NVV;     // 64 lanes = 16 columns x 4 vectors = one tap slab
-        const int lv = pv ^ ((-(col / VPR)) & (NVV - 1));
-        const T* wsrc0 = w + (size_t)col * a.k_pad + (size_t)wl * CIN + lv * C::VEC;
-        const T* wsrc1 = wsrc0 + 4 * CIN;
-        const bool two = wl + 4 < TPC;
-#ifdef LT_ABL_NO_B
-        const int dpc = 0;
-#else
-        const int dpc = two ? 2 : 1;
-#endif
-        auto stage_w = [&](int c) {
-#ifdef LT_ABL_NO_B
-            return;
-#endif
-            const unsigned dst = lds_w + (c % NBUF) * C::WCH;
-            dma16h(wsrc0 + (size_t)c * TPC * CIN, dst + wl * 1024);
-            if (two) dma16h(wsrc1 + (size_t)c * TPC * CIN, dst + (wl + 4) * 1024);
-        };
-#pragma unroll
-        for (int c = 0; c < NBUF - 1; ++c) stage_w(c);
-        for (int c = 0; c < NCH; ++c) {
-            // chunks <= c+1 (and, before them, the halo) must have landed; at most NBUF-3 younger chunks stay in flight
-            int younger = NCH - 2 - c;
-            if (younger > NBUF - 3) younger = NBUF - 3;
-            if (younger < 0) younger = 0;
-            wait_vmcnt_h(younger * dpc);
-            asm volatile("s_barrier" ::: "memory");
-            if (c + NBUF - 1 < NCH) stage_w(c + NBUF - 1);
-        }
-        asm volatile("s_barrier" ::: "memory");          // the consumers' "done with the LDS images" barrier
-        return;
-    }
-
-    // ================================= consumer waves =================================
-    HaloCst<SN> cst;
-    cst.load(a, lane, MF);
-    constexpr int E_VECO = C::VEC, E_LPR = CP / E_VECO, E_RPP = 64 / E_LPR, E_NIT = 64 / E_RPP;
-    static_assert(E_NIT <= 4, "epilogue rows per lane");
-    const bool vec_epi = (a.Cout % E_VECO == 0) && (a.ldc % E_VECO == 0);
-    const bool pre_res = vec_epi && a.res != nullptr && !(a.flags & LT_EPI_NO_RES_PREFETCH);
-    uint4 rp0, rp1, rp2, rp3, rp4, rp5, rp6, rp7;
-    rp0 = rp1 = rp2 = rp3 = rp4 = rp5 = rp6 = rp7 = make_uint4(0, 0, 0, 0);
-    if (pre_res) {
-        const int cqp = (lane % E_LPR) * E_VECO;
-        auto pf = [&](int k) -> uint4 {
-            const int r = 64 * wave + lane / E_LPR + k * E_RPP;
-            const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
-            const size_t pixv = (((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw;
-            const void* src = cqp < a.Cout ? (const void*)((const T*)a.res + pixv * a.ldc + cqp) : zero_page;
-            return *(const uint4*)src;
-        };
-        if (E_NIT > 0) rp0 = pf(0);
-        if (E_NIT > 1) rp1 = pf(1);
-        if (E_NIT > 2) rp2 = pf(2);
-        if (E_NIT > 3) rp3 = pf(3);
-    }
-
-    // fragment bases: row r = 64 wave + 16 i + (lane & 15) = voxel (td = wave, th = 2 i + (r15 >> 3), tw = r15 & 7); the lane's K
-    // vector lane >> 4; swizzle f = (tw + kw) & 3 -> four variants by kw & 3
-    const int r15 = lane & 15, lvb = lane >> 4;
-    int abase[4][SM];
-#pragma unroll
-    for (int i = 0; i < SM; ++i) {
-        const int tw = r15 & 7, th = 2 * i + (r15 >> 3);
-        const int own = ((wave * C::HH + th) * C::PW + tw) * CINB;
-#pragma unroll
-        for (int vv = 0; vv < 4; ++vv) abase[vv][i] = (int)lds0 + own + ((lvb ^ ((tw + vv) & 3)) << 4);
-    }
-    const int bsw = (-(r15 / VPR)) & (NVV - 1);
-    const unsigned bbase = lds_w + r15 * CINB + ((lvb ^ bsw) << 4);
-
-    acc_t acc[SM][SN];
-    double dacc[1][1][1];
-#pragma unroll
-    for (int i = 0; i < SM; ++i)
-#pragma unroll
-        for (int e = 0; e < NACC; ++e) acc[i][0][e] = 0.f;
-
-    constexpr int RPT = SM + SN;                         // 5 reads per tap
-    static_assert((PD + 1) * RPT <= 15, "lookahead exceeds the lgkmcnt counter");
-    V16 fa[TPC][SM], fb[TPC];
-    unsigned cur[4][SM];                                 // abase + kd * KDSTEP
-    // tap (KH, KW) of the chunk whose weight buffer starts at wb, relative to the kd plane in `cur` (+ DKD planes)
-    auto load_tap = [&](unsigned wb, auto khc, auto kwc, auto dkdc) {
-        constexpr int KH = decltype(khc)::value, KW = decltype(kwc)::value, DKD = decltype(dkdc)::value;
-        constexpr int imm = DKD * KDSTEP + (KH * C::PW + KW) * CINB;
-        static_for<0, SM>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            lds_read16<imm>(fa[KW][i], cur[KW & 3][i]);
-        });
-        lds_read16<KW * C::SLAB>(fb[KW], wb);
-    };
-    auto do_kd = [&](int kd, auto lastc) {
-        constexpr bool LAST_KD = decltype(lastc)::value;
-#pragma unroll
-        for (int vv = 0; vv < 4; ++vv)
-#pragma unroll
-            for (int i = 0; i < SM; ++i) cur[vv][i] = (unsigned)abase[vv][i] + kd * KDSTEP;
-        const int rb = (kd * KS) % NBUF;                  // ring slot of this kd's first chunk
-        static_for<0, KS>([&](auto khc) {
-            constexpr int KH = decltype(khc)::value;
-            constexpr bool LAST = LAST_KD && KH == KS - 1;
-            asm volatile("s_barrier" ::: "memory");      // the loaders have chunks <= c+1 (and, the first time, the halo) in LDS
-            const unsigned wb = bbase + ((rb + KH) % NBUF) * C::WCH, wb_n = bbase + ((rb + KH + 1) % NBUF) * C::WCH;
-            if constexpr (KH == 0) {
-                if (kd == 0) {                           // pipeline prologue: the first PD taps
-                    static_for<0, PD>([&](auto kwc) { load_tap(wb, std::integral_constant<int, 0>{}, kwc, std::integral_constant<int, 0>{}); });
-                }
-            }
-            static_for<0, TPC>([&](auto kwc) {
-                constexpr int KW = decltype(kwc)::value;
-                constexpr int ahead = (KW + PD < TPC) ? PD : (LAST ? TPC - 1 - KW : PD);   // taps in flight behind this one
-                if constexpr (KW + PD < TPC) load_tap(wb, khc, std::integral_constant<int, KW + PD>{}, std::integral_constant<int, 0>{});
-                else if constexpr (!LAST) {
-                    if constexpr (KH + 1 < KS) load_tap(wb_n, std::integral_constant<int, KH + 1>{}, std::integral_constant<int, KW + PD - TPC>{},
-                                                        std::integral_constant<int, 0>{});
-                    else load_tap(wb_n, std::integral_constant<int, 0>{}, std::integral_constant<int, KW + PD - TPC>{}, std::integral_constant<int, 1>{});
-                }
-                lgkm_wait<ahead * RPT>();
-#pragma unroll
-                for (int i = 0; i < SM; ++i) frag_ready(fa[KW][i]);
-                frag_ready(fb[KW]);
-#pragma unroll
-                for (int i = 0; i < SM; ++i) LT_HMMA(acc[i][0], fa[KW][i], fb[KW]);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-    };
-    for (int kd = 0; kd < KS - 1; ++kd) do_kd(kd, std::false_type{});
-    do_kd(KS - 1, std::true_type{});
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the halo / weight images
-
-#ifdef LT_ABL_NO_EPI
-    if (a.N < 0)
-#endif
-    halo_epilogue<T, CP, MF, SM, SN, NACC, TH, TW, false>(smem, a, wave, lane, n, d0, h0, w0, acc, dacc, pre_res, rp0, rp1, rp2, rp3, rp4, rp5,
-                                                         rp6, rp7, cst);
-}
+// (conv3d_halo7_kernel, the tap-major kernel these notes describe, was superseded by the kd-register-blocked variant below and removed
+// in round 2; its measurements stay because they motivate that variant.)
 
 // ---- 7^3 kernel, kd-register-blocked variant ------------------------------------------------------------------------------------
 // conv3d_halo7_kernel reads five fragments from LDS per four MFMAs (one voxel fragment per output plane + the tap's weights) and
@@ -2101,19 +1721,11 @@ __global__ __launch_bounds__(512) void conv3d_halo7b_kernel(const HaloArgs a) {
 int launch_halo7(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<bf16_t, 7, 32, 16, 4, 8, 8, 7, 4> C;
     constexpr int LDS = C::HALO_BYTES + 5 * C::WCH;
-    auto kern = conv3d_halo7_kernel<bf16_t>;
-    LT_OPT_IN_LDS(kern, 160 * 1024);
     const long long nblk = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
-    const char* kdb = getenv("LT_HALO_7B");              // kd-register-blocked variant: default; LT_HALO_7B=0 selects the tap-major kernel
-    if (!kdb || kdb[0] != '0') {                         // (read per call: the tests run both)
-        auto kern_b = conv3d_halo7b_kernel<bf16_t>;
-        LT_OPT_IN_LDS(kern_b, 160 * 1024);
-        hipLaunchKernelGGL(kern_b, dim3((unsigned)nblk), dim3(512), LDS, s, a);
-        LT_CHECK_LAUNCH("lt_conv_fwd(halo 7^3, kd-blocked)");
-        return LT_OK;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), LDS, s, a);
-    LT_CHECK_LAUNCH("lt_conv_fwd(halo 7^3)");
+    auto kern_b = conv3d_halo7b_kernel<bf16_t>;
+    LT_OPT_IN_LDS(kern_b, 160 * 1024);
+    hipLaunchKernelGGL(kern_b, dim3((unsigned)nblk), dim3(512), LDS, s, a);
+    LT_CHECK_LAUNCH("lt_conv_fwd(halo 7^3, kd-blocked)");
     return LT_OK;
 }
 
@@ -2175,28 +1787,6 @@ int launch_halo(const HaloArgs& a, hipStream_t s) {
 }  // namespace
 
 namespace lt {
-
-// 2D 3x3 / stride 1 / pad 1, 256 -> 256 on 24-wide maps, weights available in the transposed fragment order: row-band kernel.
-// 1 = launched, 0 = not applicable, < 0 = error.
-int conv2d_band_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, hipStream_t s) {
-    if (dtype != LT_BF16 || nphase != 1 || getenv("LT_CONV_NO_BAND")) return 0;
-    const PhaseArg& p0 = c.phase[0];
-    if (!p0.wfrag_t || p0.ntaps != 9 || c.D != 1 || c.Do != 1 || c.OD != 1 || c.pd != 0 || c.ph != 1 || c.pw != 1) return 0;
-    if (c.sd != 1 || c.sh != 1 || c.sw != 1 || c.osd != 1 || c.osh != 1 || c.osw != 1 || p0.ood || p0.ooh || p0.oow) return 0;
-    if (c.H != c.Ho || c.W != c.Wo || c.OH != c.Ho || c.OW != c.Wo) return 0;
-    if (c.Cin != 256 || c.Cout != 256 || cout_pad != 256 || c.ldc % 8 || c.W != 24 || c.H % 12) return 0;
-    if (c.flags & (LT_EPI_STORE_F32 | LT_EPI_SIGMOID)) return 0;
-    const long long tiles = (long long)c.N * (c.H / 12);
-    if (tiles % 8 || tiles < 128) return 0;               // the two channel halves of a band are dealt to one XCD; fill the chip
-    BandArgs a;
-    a.x = c.x; a.wfrag = p0.wfrag_t; a.y = c.y; a.res = c.res; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
-    a.N = c.N; a.H = c.H; a.W = c.W; a.ldc = c.ldc; a.flags = c.flags; a.bands = c.H / 12;
-    auto kern = conv2d_band_kernel<bf16_t>;
-    LT_OPT_IN_LDS(kern, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * 2)), dim3(512), 2 * 47104, s, a);
-    LT_CHECK_LAUNCH("lt_conv_fwd(2D band)");
-    return 1;
-}
 
 // Returns 1 and launches when the problem matches one of the instantiated halo configurations, 0 when the caller should
 // fall back to the implicit-GEMM path, negative on error.

@@ -97,7 +97,5 @@ int conv7_try(const ConvArgs& a, int cout_pad, int max_taps, bool pw, hipStream_
 int conv_pw_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, hipStream_t s);
 // conv3d_halo.hip: 1 = launched, 0 = not applicable (fall back), < 0 = error
 int conv3d_halo_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, bool forced, hipStream_t s);
-// conv3d_halo.hip, 2D row-band kernel (3x3 256->256 on 24-wide maps, weights in the transposed fragment order): 1 / 0 / < 0
-int conv2d_band_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, hipStream_t s);
 
 }  // namespace lt

@@ -274,11 +274,6 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
             return LT_ERR_UNSUPPORTED;
         }
     }
-    if (tile == LT_TILE_AUTO && !force_v1) {             // 2D 3x3 256 -> 256 on 24-wide maps: row bands in LDS, weights from global memory
-        const int rc = conv2d_band_try(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, s);
-        if (rc < 0) return rc;
-        if (rc == 1) return LT_OK;
-    }
     if (tile == LT_TILE_AUTO && !force_v1) {             // narrow single-tap layers (V2V skip convs, 2x2x2 deconvs): streaming kernel
         const int rc = conv_pw_try(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, s);
         if (rc < 0) return rc;

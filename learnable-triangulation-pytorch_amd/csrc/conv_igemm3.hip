@@ -16,8 +16,8 @@
 //   * fragments: hand-issued ds_read_b128 with counted lgkmcnt (hipcc falls back to lgkmcnt(0) beyond one group in flight).
 // bf16 only (the fp32 parity mode stays on conv_igemm2), one phase, pointwise or uniform-tap addressing, vector epilogue.
 //
-// Kernels in this file (dispatch: conv3_try at the end): conv_igemm3_kernel (288 x 128 / 64, 8 or 12 waves), conv_igemm4_kernel
-// (opt-in: four compute + four loader waves), conv_igemm5_kernel (288 x 256, 32-element K steps, both operands staged),
+// Kernels in this file (dispatch: conv3_try at the end): conv_igemm3_kernel (288 x 128 / 64, 8 or 12 waves),
+// conv_igemm5_kernel (288 x 256, 32-element K steps, both operands staged),
 // conv_igemm6_kernel (288 x 256 or 144 x 256, weights from global memory in fragment order: the default for Cout % 256 == 0).
 #include <stdlib.h>
 
@@ -433,279 +433,6 @@ __global__ __launch_bounds__(256 * NWM) void conv_igemm3_kernel(const ConvArgs a
         if (NPASS > 2) LT3_PASS(2, rp4, rp5, rp5)
     }
 #undef LT3_PASS
-}
-
-// ---- role-specialised variant: four compute waves with 144 x 64 tiles + four loader waves --------------------------------------
-// In the 12-wave kernel above every wave both issues DMA pieces and feeds the matrix pipe, and all of them re-read the A
-// panel from LDS (192 KB of fragment reads + 52 KB of DMA writes per K step on one LDS: ~1500 cycles against 1152 cycles of
-// MFMA; measured 2480 per K step).  Here waves 0-3 compute 2 (M) x 2 (N) tiles of 144 x 64 (9 x 4 accumulator tiles of the
-// 16x16x32 MFMA, 104 KB of fragment reads per K step) and never touch a memory instruction inside the K loop; waves 4-7 issue
-// the 52 DMA pieces of a stage (13 each), wait for them and meet the compute waves at the one barrier per K step.
-template <int MODE>
-__global__ __launch_bounds__(512) void conv_igemm4_kernel(const ConvArgs a) {
-    typedef bf16_t T;
-    constexpr bool PW = MODE == 1;
-    constexpr int BM = BM3, BN = 128, WM = 144, WN = 64, MF = 16, SM = WM / MF, SN = WN / MF, G = 2, NST = 3, VEC = 8, BK = 64;
-    constexpr int NPA = BM / 8, NPB = BN / 8, NLD = 4;   // 36 + 16 pieces per stage, four loader waves
-    constexpr int A_IT = NPA / NLD, B_IT = NPB / NLD;    // 9 + 4 pieces per loader and stage
-    static_assert(NPA % NLD == 0 && NPB % NLD == 0, "pieces divide evenly over the loaders");
-    constexpr int STAGE = (BM + BN) * ROW_BYTES;
-    constexpr int REGION = NST * STAGE;
-    constexpr int EP_ROWS = 48, EP_LD = WN + 4, EP_WAVE = EP_ROWS * EP_LD * 4, NPASS = WM / EP_ROWS;
-    static_assert(4 * EP_WAVE <= REGION && NPASS == 3, "epilogue staging");
-    typedef typename Mma<T, MF>::acc_t acc_t;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int4* s_taps = (int4*)(smem + REGION);               // [ntaps] (unused when PW)
-    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
-
-    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page3;
-    asm volatile("" : "+s"(zp_bits));
-    const void* const zero_page = (const void*)(size_t)zp_bits;
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const bool loader = wave >= 4;
-    int lin = blockIdx.x;
-    if (!(a.flags & LT_EPI_NO_XCD_REMAP)) {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = lin & 7, j = lin >> 3;
-        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int tile_n = lin % a.tiles_n;
-    const int tile_m = lin / a.tiles_n;
-    const PhaseArg ph = a.phase[0];
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int nk = a.k_pad / BK;
-    if (!PW) {
-        for (int i = t; i < ph.ntaps; i += 512) s_taps[i] = ph.taps[i];
-    }
-    __syncthreads();
-
-    if (loader) {
-        // ================================= loader waves =================================
-        const T* __restrict__ x = (const T*)a.x;
-        const T* __restrict__ w = (const T*)ph.w;
-        const int wl = wave - 4, tl = t - 256;           // thread index among the 256 loader threads
-        // thread tl fills physical slot tl&7 of rows (tl>>3) + 32 i; logical K vector v = (tl&7) ^ ((row>>1)&7), the same for all its rows
-        const int v = (tl & 7) ^ ((tl >> 4) & 7);
-        int id0[PW ? 1 : A_IT], ih0[PW ? 1 : A_IT], iw0[PW ? 1 : A_IT], baseC[A_IT], cur[PW ? 1 : A_IT];
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int m = m0 + (tl >> 3) + 32 * i;
-            if (PW) baseC[i] = m < a.M ? m * a.Cin + v * VEC : -1;
-            else if (m < a.M) {
-                int n, od, oh, ow;
-                decode_row(a, m, n, od, oh, ow);
-                id0[i] = od * a.sd - a.pd;
-                ih0[i] = oh * a.sh - a.ph;
-                iw0[i] = ow * a.sw - a.pw;
-                baseC[i] = (((n * a.D + id0[i]) * a.H + ih0[i]) * a.W + iw0[i]) * a.Cin;
-            } else {
-                id0[i] = -(1 << 24);
-                ih0[i] = iw0[i] = baseC[i] = 0;
-            }
-        }
-        const T* wrow[B_IT];
-#pragma unroll
-        for (int j = 0; j < B_IT; ++j) wrow[j] = w + (size_t)(n0 + (tl >> 3) + 32 * j) * a.k_pad + v * VEC;
-        auto stage = [&](int ks, int buf) {
-            const unsigned sA = lds0 + buf * STAGE, sB = sA + BM * ROW_BYTES;
-            if (PW) {
-#pragma unroll
-                for (int i = 0; i < A_IT; ++i) {
-                    const void* src = baseC[i] >= 0 ? (const void*)(x + (baseC[i] + ks * BK)) : zero_page;
-                    dma16(src, sA + (wl + NLD * i) * 1024);
-                }
-            } else {
-                const int k0 = ks * BK;
-                const int c0 = k0 & (a.Cin - 1);
-                if (c0 == 0) {
-                    const int tap = k0 >> a.log2Cin;
-                    int4 tp = make_int4(-(1 << 24), 0, 0, 0);
-                    if (tap < ph.ntaps) tp = s_taps[tap];
-#pragma unroll
-                    for (int i = 0; i < A_IT; ++i) {
-                        const int id = id0[i] + tp.x, ih = ih0[i] + tp.y, iw = iw0[i] + tp.z;
-                        const bool ok = ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-                        cur[i] = ok ? baseC[i] + tp.w + v * VEC : -1;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < A_IT; ++i) {
-                    const void* src = cur[i] >= 0 ? (const void*)(x + (cur[i] + c0)) : zero_page;
-                    dma16(src, sA + (wl + NLD * i) * 1024);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < B_IT; ++j) dma16(wrow[j] + ks * BK, sB + (wl + NLD * j) * 1024);
-        };
-        constexpr int DPS = A_IT + B_IT;                 // 13 pieces per loader and stage
-        if (0 < nk) stage(0, 0);
-        if (1 < nk) stage(1, 1);
-        for (int ks = 0; ks < nk; ++ks) {
-            // stage ks must have landed; stage ks+1 may stay in flight
-            if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            static_assert(DPS == 13, "the literal in the s_waitcnt above");
-            asm volatile("s_barrier" ::: "memory");      // stage ks landed (all loaders); the compute waves are done with stage ks-1
-            if (ks + 2 < nk) stage(ks + 2, (ks + 2) % NST);
-        }
-        asm volatile("s_barrier" ::: "memory");          // the compute waves' "ring becomes staging" barrier
-        return;
-    }
-
-    // ================================= compute waves =================================
-    const int wm = wave >> 1, wn = wave & 1;
-    constexpr int LPR = WN / 8, RPP = 64 / LPR, ITP = EP_ROWS / RPP;   // 8 lanes per row, 8 rows per iteration, 6 iterations per pass
-    static_assert(EP_ROWS % RPP == 0, "whole iterations");
-    const int colv = n0 + wn * WN + (lane % LPR) * 8;
-    auto out_off = [&](int p, int k) -> long long {   // element offset of the lane's 8-channel vector, or -1
-        const int m = m0 + wm * WM + p * EP_ROWS + k * RPP + lane / LPR;
-        if (m >= a.M || colv >= a.Cout) return -1;
-        long long pix = m;
-        if (!PW) {
-            int n, od, oh, ow;
-            decode_row(a, m, n, od, oh, ow);
-            pix = ((long long)(n * a.OD + od * a.osd + ph.ood) * a.OH + oh * a.osh + ph.ooh) * a.OW + ow * a.osw + ph.oow;
-        }
-        return pix * a.ldc + colv;
-    };
-    const int r15 = lane & 15;
-    const int fsw = (r15 >> 1) & 7;
-    unsigned aoff[G], boff[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const unsigned fo = r15 * ROW_BYTES + ((((lane >> 4) + 4 * g) ^ fsw) << 4);
-        aoff[g] = lds0 + wm * WM * ROW_BYTES + fo;
-        boff[g] = lds0 + BM * ROW_BYTES + wn * WN * ROW_BYTES + fo;
-    }
-    acc_t acc[SM][SN];
-#pragma unroll
-    for (int i = 0; i < SM; ++i)
-#pragma unroll
-        for (int j = 0; j < SN; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-
-    // read stream of one K step: per group g the SN B fragments, then the SM A fragments; LOOK entries of lookahead
-    constexpr int RPG = SN + SM, TOTAL = G * RPG, LOOK = 7, RA = LOOK + 1;
-    static_assert(LOOK + 1 <= 15, "lgkmcnt range");
-#ifdef LT_TRACE
-    long long tr_bar = 0, tr_cmp = 0;
-    const long long tr_begin = LT_CLK3();
-    const long long tr_rt0 = (long long)__builtin_amdgcn_s_memrealtime();
-    long long tr_prev = tr_begin;
-#endif
-    for (int ks = 0; ks < nk; ++ks) {
-#ifdef LT_TRACE
-        const long long tr0 = LT_CLK3();
-        tr_cmp += tr0 - tr_prev;
-#endif
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // stage ks is in LDS; every compute wave is done with stage ks-1
-#ifdef LT_TRACE
-        tr_prev = LT_CLK3();
-        tr_bar += tr_prev - tr0;
-#endif
-        const unsigned sbase = (ks % NST) * STAGE;
-        const unsigned abase[G] = {aoff[0] + sbase, aoff[1] + sbase};
-        const unsigned bbase[G] = {boff[0] + sbase, boff[1] + sbase};
-        V16 fa[RA], fb[G][SN];
-        auto issue = [&](auto kc) {
-            constexpr int K = decltype(kc)::value;
-            constexpr int g = K / RPG, r = K % RPG;
-            if constexpr (r < SN) lds_read16<r * 16 * ROW_BYTES>(fb[g][r], bbase[g]);
-            else lds_read16<(r - SN) * 16 * ROW_BYTES>(fa[(g * SM + r - SN) % RA], abase[g]);
-        };
-        static_for<0, G * SM>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            constexpr int g = u / SM, i = u % SM;
-            constexpr int pos = s3_pos(u, SM, SN);
-            constexpr int prev_target = s3_target(u - 1, SM, SN, LOOK, TOTAL);
-            constexpr int target = s3_target(u, SM, SN, LOOK, TOTAL);
-            static_for<prev_target, target>([&](auto kc) { issue(kc); });
-            lgkm_wait<target - pos - 1>();
-            if constexpr (i == 0) {
-#pragma unroll
-                for (int j = 0; j < SN; ++j) frag_ready(fb[g][j]);
-            }
-            frag_ready(fa[u % RA]);
-#pragma unroll
-            for (int j = 0; j < SN; ++j) LT3_MMA(acc[i][j], fa[u % RA], fb[g][j]);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    }
-#ifdef LT_TRACE
-    {
-        const long long tr_end = LT_CLK3();
-        tr_cmp += tr_end - tr_prev;
-        const long long tr_rt1 = (long long)__builtin_amdgcn_s_memrealtime();
-        if (wave == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 1024 && lane == 0) {
-            long long* o = g_trace3 + (blockIdx.x >> 3) * 8;
-            o[0] = tr_end - tr_begin; o[1] = 0; o[2] = tr_bar; o[3] = 0; o[4] = tr_cmp; o[5] = nk; o[6] = tr_rt1 - tr_rt0; o[7] = blockIdx.x;
-        }
-    }
-#endif
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring becomes the epilogue staging area
-#ifdef LT_ABL_NO_EPI
-    if (a.M >= 0) return;
-#endif
-    // ---- epilogue: three passes of 48 rows through this wave's private fp32 LDS tile -> 16-byte vectors ----
-    const EpiFloors fl = epi_floors(a.flags);
-    const bool has_res = a.res != nullptr;
-    float* ep = (float*)(smem + wave * EP_WAVE);
-    float bi[SN], sc[SN], sf[SN];
-#pragma unroll
-    for (int j = 0; j < SN; ++j) {
-        const int colj = n0 + wn * WN + j * MF + r15;    // < cout_pad: the constant arrays are padded
-        bi[j] = a.bias ? a.bias[colj] : 0.f;
-        sc[j] = a.scale ? a.scale[colj] : 1.f;
-        sf[j] = a.shift ? a.shift[colj] : 0.f;
-    }
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        long long off[ITP];
-        uint4 rv[ITP];
-#pragma unroll
-        for (int k = 0; k < ITP; ++k) {                  // this pass's residual vectors first: independent round trips
-            off[k] = out_off(p, k);
-            rv[k] = (has_res && off[k] >= 0) ? *(const uint4*)((const T*)a.res + off[k]) : make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
-        }
-#pragma unroll
-        for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-            for (int j = 0; j < SN; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    ep[(ii * MF + (lane >> 4) * 4 + e) * EP_LD + j * MF + r15] = (acc[3 * p + ii][j][e] + bi[j]) * sc[j] + sf[j];
-#pragma unroll
-        for (int k = 0; k < ITP; ++k) {
-            if (off[k] < 0) continue;
-            const float* src = ep + (k * RPP + lane / LPR) * EP_LD + (lane % LPR) * 8;
-            const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
-            const float vv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-            const unsigned ru[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
-            unsigned ou[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                ou[e] = pack_bf16x2(epi_apply(vv[2 * e], fl, __uint_as_float(ru[e] << 16)), epi_apply(vv[2 * e + 1], fl, __uint_as_float(ru[e] & 0xffff0000u)));
-            *(uint4*)((T*)a.y + off[k]) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
-        }
-    }
-}
-
-template <int MODE>
-int launch4(ConvArgs a, int cout_pad, int max_taps, hipStream_t s) {
-    a.tiles_n = cout_pad / 128;
-    const long long nblk = cdiv(a.M, BM3) * a.tiles_n;
-    LT_REQUIRE(nblk < (1ll << 31), LT_ERR_INVALID, "lt_conv_fwd: grid too large");
-    const size_t lds = 3 * (size_t)(BM3 + 128) * ROW_BYTES + (size_t)max_taps * sizeof(int4);
-    LT_REQUIRE(lds <= 160 * 1024, LT_ERR_UNSUPPORTED, "lt_conv_fwd: 288-row tile needs %zu B of LDS", lds);
-    auto kern = conv_igemm4_kernel<MODE>;
-    LT_OPT_IN_LDS(kern, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(512), lds, s, a);
-    LT_CHECK_LAUNCH("lt_conv_fwd(v4)");
-    return LT_OK;
 }
 
 // ---- 288 x 256 tile, 32-element K steps, four stages (Cout % 256 == 0) ---------------------------------------------------------
@@ -1486,16 +1213,10 @@ int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_ta
         if (a.k_pad < 512) return 0;
     }
     static const bool w8 = getenv("LT_CONV_V3_W8") != nullptr;   // A/B: eight waves (2 per SIMD) instead of twelve
-    // role-specialised variant: opt-in (LT_CONV_V4=1, read per call so that the tests reach it).  In the per-layer microbench it is
-    // 10-15 % faster (3x3 256->256 at 128 images: 100 vs 116 us), inside the full forward it is a wash (93 vs 96 us; 1x1
-    // 1024->256 56 vs 52 us): its four loader waves need ~1900 cycles per K step for their 13 DMA pieces each and the compute
-    // waves (1540 cycles per step for 1152 cycles of MFMA) wait for them at the barrier.
-    const char* v4e = getenv("LT_CONV_V4");
-    const bool use_v4 = v4e && v4e[0] == '1';
+    // (a role-specialised variant -- four compute waves + four loader waves, conv_igemm4 -- was 10-15 % faster per layer on dense data
+    // and a wash inside the forward: removed in round 2)
     int rc;
-    if (BN == 128 && use_v4 && !w8) {
-        rc = pw ? launch4<1>(a, cout_pad, max_taps, s) : launch4<2>(a, cout_pad, max_taps, s);
-    } else if (w8) {
+    if (w8) {
         if (BN == 128) rc = pw ? launch3<128, 1, 2>(a, cout_pad, max_taps, s) : launch3<128, 2, 2>(a, cout_pad, max_taps, s);
         else rc = pw ? launch3<64, 1, 2>(a, cout_pad, max_taps, s) : launch3<64, 2, 2>(a, cout_pad, max_taps, s);
     } else {

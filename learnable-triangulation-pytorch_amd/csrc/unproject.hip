@@ -267,177 +267,9 @@ __global__ __launch_bounds__(256) void unproject_kernel(const UnprojArgs a) {
     }
 }
 
-// ---- LDS-staged variant (bf16, C = 32, NV <= 4, bricked volumes; opt-in, see lt_unproject_fwd) ---------------------------------
-// The kernel above gathers every bilinear corner from L1/L2: 4 views x 4 corners x 64 B per voxel = 4.3 GB of cache traffic per
-// step at 16 samples, which is what bounds it (0.6 ms, 6 % of the HBM roofline).  A 4x4x16 voxel brick projects onto a
-// ~10x10-pixel patch of each view, so here the 1024 threads of a workgroup (256 voxels x 4 channel vectors) first agree on the
-// bounding boxes of the corners they need in every view (wave min/max, then LDS atomics), copy those patches of the
-// channels-last feature maps into LDS with coalesced 16-byte loads (at most UP_PATCH_PX pixels per view; a view whose patch
-// is larger falls back to global gathers), and then sample the four corners from LDS: three passes, two barriers.  The
-// arithmetic and the zero-padding rules are those of sample_view.
-constexpr int UP_PATCH_PX = 256;
-constexpr int UP_NV = 4;                                // views staged per workgroup (4 x 16 KB of LDS)
-
-struct UpProj {                                         // projection of one voxel into one view (as in sample_view)
-    float we, ww, ws, wn;
-    int x0, y0;
-    bool xw_ok, xe_ok, yn_ok, ys_ok, active;
-};
-__device__ __forceinline__ UpProj up_project(const float* __restrict__ P, float X0, float X1, float X2, int h, int w) {
-    constexpr bool FAST = true;
-    UpProj r;
-    const float px = __fadd_rn(fmaf(X2, P[2], fmaf(X1, P[1], __fmul_rn(X0, P[0]))), P[3]);
-    const float py = __fadd_rn(fmaf(X2, P[6], fmaf(X1, P[5], __fmul_rn(X0, P[4]))), P[7]);
-    float pz = __fadd_rn(fmaf(X2, P[10], fmaf(X1, P[9], __fmul_rn(X0, P[8]))), P[11]);
-    const bool invalid = pz <= 0.0f;
-    if (pz == 0.0f) pz = 1.0f;
-    const float u = div_<FAST>(px, pz), vv = div_<FAST>(py, pz);
-    const float gx = __fmul_rn(2.0f, __fsub_rn(div_<FAST>(u, (float)h), 0.5f));
-    const float gy = __fmul_rn(2.0f, __fsub_rn(div_<FAST>(vv, (float)w), 0.5f));
-    const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), 0.5f * (float)(w - 1));
-    const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), 0.5f * (float)(h - 1));
-    const float xw = floorf(ix), yn = floorf(iy);
-    r.we = __fsub_rn(ix, xw); r.ww = __fsub_rn(1.0f, r.we);
-    r.ws = __fsub_rn(iy, yn); r.wn = __fsub_rn(1.0f, r.ws);
-    r.xw_ok = xw >= 0.f && xw <= (float)(w - 1); r.xe_ok = xw >= -1.f && xw <= (float)(w - 2);
-    r.yn_ok = yn >= 0.f && yn <= (float)(h - 1); r.ys_ok = yn >= -1.f && yn <= (float)(h - 2);
-    r.active = !invalid && (r.xw_ok || r.xe_ok) && (r.yn_ok || r.ys_ok);
-    r.x0 = r.active ? (int)xw : 0; r.y0 = r.active ? (int)yn : 0;
-    return r;
-}
-
-__global__ __launch_bounds__(1024) void unproject_lds_kernel(const UnprojArgs a) {
-    typedef bf16_t T;
-    constexpr int CH = 8, C = 32;
-    constexpr bool FAST = true;
-    __shared__ uint4 patch[UP_NV][UP_PATCH_PX * 4];     // [view][pixel][4 vectors of 8 channels]
-    __shared__ int bbox[UP_NV][4];                      // xlo, xhi, ylo, yhi
-    int b, chunk;
-    if (a.xcd_pin) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        b = xcd + 8 * (j / a.chunks);
-        chunk = j % a.chunks;
-    } else {
-        b = blockIdx.x / a.chunks;
-        chunk = blockIdx.x % a.chunks;
-    }
-    const long long nvox = (long long)a.v0 * a.v1 * a.v2;
-    const T* feats = (const T*)a.feats + (long long)b * a.NV * a.h * a.w * C;
-    const float* Pm = a.proj + (long long)b * a.NV * 12;
-    const float* coords = a.coords + (long long)b * nvox * 3;
-    T* out = (T*)a.out + (long long)b * nvox * C;
-    const int nk = a.v2 >> 4, nj = a.v1 >> 2;
-    const int bk = (chunk % nk) << 4, bj = ((chunk / nk) % nj) << 2, bi = (chunk / (nk * nj)) << 2;
-    const int t = threadIdx.x, lane = t & 63;
-    const int vb = t >> 2, c0 = (t & 3) * CH;
-    const long long vox = ((long long)(bi + (vb >> 6)) * a.v1 + bj + ((vb >> 4) & 3)) * a.v2 + bk + (vb & 15);
-    const float X0 = coords[vox * 3], X1 = coords[vox * 3 + 1], X2 = coords[vox * 3 + 2];
-    const int h = a.h, w = a.w;
-    if (t < UP_NV * 4) bbox[t >> 2][t & 3] = (t & 1) ? -(1 << 30) : (1 << 30);
-    __syncthreads();
-    // ---- pass 1: bounding boxes of the corners this workgroup reads, all views ----
-#pragma unroll
-    for (int v = 0; v < UP_NV; ++v) {
-        if (v < a.NV) {
-            const UpProj q = up_project(Pm + v * 12, X0, X1, X2, h, w);
-            int xl = q.active ? (q.xw_ok ? q.x0 : q.x0 + 1) : (1 << 30), xh = q.active ? (q.xe_ok ? q.x0 + 1 : q.x0) : -(1 << 30);
-            int yl = q.active ? (q.yn_ok ? q.y0 : q.y0 + 1) : (1 << 30), yh = q.active ? (q.ys_ok ? q.y0 + 1 : q.y0) : -(1 << 30);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                xl = min(xl, __shfl_xor(xl, off)); xh = max(xh, __shfl_xor(xh, off));
-                yl = min(yl, __shfl_xor(yl, off)); yh = max(yh, __shfl_xor(yh, off));
-            }
-            if (lane == 0) { atomicMin(&bbox[v][0], xl); atomicMax(&bbox[v][1], xh); atomicMin(&bbox[v][2], yl); atomicMax(&bbox[v][3], yh); }
-        }
-    }
-    __syncthreads();
-    // ---- pass 2: copy the patches (coalesced 16-byte loads) ----
-#pragma unroll
-    for (int v = 0; v < UP_NV; ++v) {
-        if (v < a.NV) {
-            const int pxl = bbox[v][0], pxh = bbox[v][1], pyl = bbox[v][2], pyh = bbox[v][3];
-            const int pw = pxh - pxl + 1, ph = pyh - pyl + 1;
-            if (pxh >= pxl && pyh >= pyl && pw * ph <= UP_PATCH_PX) {
-                const T* fmap = feats + (long long)v * h * w * C;
-                const int nvec = pw * ph * 4;
-                for (int idx = t; idx < nvec; idx += 1024) {
-                    const int pix = idx >> 2, ry = pix / pw, rx = pix - ry * pw;
-                    patch[v][idx] = *(const uint4*)(fmap + ((long long)(pyl + ry) * w + pxl + rx) * C + (idx & 3) * 8);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- pass 3: bilinear samples from LDS (or from global memory for a view whose patch did not fit) ----
-    float vals[UP_NV][CH];
-#pragma unroll
-    for (int v = 0; v < UP_NV; ++v) {
-#pragma unroll
-        for (int e = 0; e < CH; ++e) vals[v][e] = 0.f;
-        if (v < a.NV) {
-            const UpProj q = up_project(Pm + v * 12, X0, X1, X2, h, w);
-            if (q.active) {
-                const int pxl = bbox[v][0], pxh = bbox[v][1], pyl = bbox[v][2], pyh = bbox[v][3];
-                const int pw = pxh - pxl + 1, ph = pyh - pyl + 1;
-                const bool fits = pw * ph <= UP_PATCH_PX;
-                float t00[CH], t01[CH], t10[CH], t11[CH];
-#pragma unroll
-                for (int e = 0; e < CH; ++e) t00[e] = t01[e] = t10[e] = t11[e] = 0.f;
-                if (fits) {
-                    const T* lp = (const T*)patch[v] + (((q.y0 - pyl) * pw + (q.x0 - pxl)) * 4) * 8 + c0;
-                    if (q.yn_ok && q.xw_ok) ChVec<T, CH>::ld(lp, t00);
-                    if (q.yn_ok && q.xe_ok) ChVec<T, CH>::ld(lp + C, t01);
-                    if (q.ys_ok && q.xw_ok) ChVec<T, CH>::ld(lp + pw * C, t10);
-                    if (q.ys_ok && q.xe_ok) ChVec<T, CH>::ld(lp + pw * C + C, t11);
-                } else {
-                    const T* base = feats + (long long)v * h * w * C + ((long long)q.y0 * w + q.x0) * C + c0;
-                    if (q.yn_ok && q.xw_ok) ChVec<T, CH>::ld(base, t00);
-                    if (q.yn_ok && q.xe_ok) ChVec<T, CH>::ld(base + C, t01);
-                    if (q.ys_ok && q.xw_ok) ChVec<T, CH>::ld(base + (long long)w * C, t10);
-                    if (q.ys_ok && q.xe_ok) ChVec<T, CH>::ld(base + (long long)w * C + C, t11);
-                }
-                const float nw = __fmul_rn(q.wn, q.ww), ne = __fmul_rn(q.wn, q.we), sw = __fmul_rn(q.ws, q.ww), se = __fmul_rn(q.ws, q.we);
-#pragma unroll
-                for (int e = 0; e < CH; ++e) vals[v][e] = t00[e] * nw + t01[e] * ne + t10[e] * sw + t11[e] * se;
-            }
-        }
-    }
-    // ---- view aggregation (same arithmetic as the SMALL_NV branch above) ----
-    float res[CH];
-#pragma unroll
-    for (int e = 0; e < CH; ++e) {
-        float r;
-        if (a.agg == LT_AGG_SOFTMAX) {
-            float m = vals[0][e];
-#pragma unroll
-            for (int v = 1; v < UP_NV; ++v) if (v < a.NV) m = fmaxf(m, vals[v][e]);
-            float s = 0.f, tt = 0.f;
-#pragma unroll
-            for (int v = 0; v < UP_NV; ++v) if (v < a.NV) { const float ex = exp_<FAST>(vals[v][e] - m); s += ex; tt += vals[v][e] * ex; }
-            r = div_<FAST>(tt, s);
-        } else if (a.agg == LT_AGG_MAX) {
-            r = vals[0][e];
-#pragma unroll
-            for (int v = 1; v < UP_NV; ++v) if (v < a.NV) r = fmaxf(r, vals[v][e]);
-        } else if (a.agg == LT_AGG_CONF || a.agg == LT_AGG_CONF_NORM) {
-            float cs = 1.f;
-            if (a.agg == LT_AGG_CONF_NORM) {
-                cs = 0.f;
-#pragma unroll
-                for (int v = 0; v < UP_NV; ++v) if (v < a.NV) cs += a.conf[((long long)b * a.NV + v) * C + c0 + e];
-            }
-            r = 0.f;
-#pragma unroll
-            for (int v = 0; v < UP_NV; ++v) if (v < a.NV) r += vals[v][e] * __fdiv_rn(a.conf[((long long)b * a.NV + v) * C + c0 + e], cs);
-        } else {
-            r = 0.f;
-#pragma unroll
-            for (int v = 0; v < UP_NV; ++v) if (v < a.NV) r += vals[v][e];
-        }
-        res[e] = r;
-    }
-    ChVec<T, CH>::st(out + vox * C + c0, res);
-}
+// (unproject_lds_kernel, an LDS-staged variant of the gather -- opt-in with LT_UNPROJ_LDS=1 -- measured 0.90 ms against 0.57 ms for the
+// gathering kernel at the BASELINE shape and was removed in round 2: the 37 MB of feature maps are L2-resident and the gather keeps 16
+// independent loads in flight per lane, while the staged copy exposes one load round trip per workgroup between its two barriers.)
 
 // ---- quad kernel: bf16, C = 32, 4 or 8 views, softmax aggregation, bricked volumes (BASELINE configurations 2 and 4) ------------------
 // The generic kernel above is VALU-bound (~700 instructions per lane-item at 4 views; PMC: 40 % of the cycles waiting on instruction
@@ -641,16 +473,6 @@ int unproject_dispatch(UnprojArgs& a, int dtype, bool grid, hipStream_t st) {
     if (dtype == LT_F32) {
         if (a.C % 4 == 0) return launch_unproject<float, 4>(a, st);
         return launch_unproject<float, 1>(a, st);
-    }
-    // LDS-staged variant: opt-in (LT_UNPROJ_LDS=1, read per call so that the tests can exercise both).  Measured at the BASELINE
-    // shape (16 samples, 4 views, 96x96x32 maps, 64^3 voxels): 0.90 ms staged vs 0.57 ms gathering -- the 37 MB of feature maps
-    // are L2-resident and the gather keeps 16 independent loads in flight per lane, while the staged copy exposes one load
-    // round trip per workgroup between its two barriers.
-    const char* use_lds = getenv("LT_UNPROJ_LDS");
-    if (a.C == 32 && a.NV <= UP_NV && a.bricked && use_lds && use_lds[0] == '1') {
-        hipLaunchKernelGGL(unproject_lds_kernel, dim3(nblk), dim3(1024), 0, st, a);
-        LT_CHECK_LAUNCH("lt_unproject_fwd(lds)");
-        return LT_OK;
     }
     if (a.C % 8 == 0) return launch_unproject<bf16_t, 8>(a, st);
     return launch_unproject<bf16_t, 1>(a, st);

@@ -277,18 +277,7 @@ class PlanBuilder:
             d.phase[i].ntaps = ph.taps.shape[0]; d.phase[i].out_off = H.i3(ph.out_off)
             # wide bf16 layers also get their weights in MFMA fragment order (B operand read straight from global memory by
             # the 288 x 256 kernel); packed once, here
-            # opt-in (LT_CONV_BAND=1 when the plan is built): per layer 90 -> 83 us, but 1 % slower inside the replayed forward
-            band = (os.environ.get("LT_CONV_BAND") == "1"
-                    and self.dtype == torch.bfloat16 and not self.dry_run and not transposed and tuple(weight.shape) == (256, 256, 3, 3)
-                    and spec.stride == (1, 1, 1) and spec.pad == (0, 1, 1) and x.shape[-1] == 256 and x.shape[3] == 24 and x.shape[2] % 12 == 0
-                    and (x.shape[0] * (x.shape[2] // 12)) % 8 == 0 and x.shape[0] * (x.shape[2] // 12) >= 128)
-            if band:   # 3x3 256 -> 256 on 24-wide maps: fragments of the transposed product for conv2d_band_kernel
-                wfr = torch.empty_like(wdev)
-                H.check(H.lib().lt_conv_pack_weights_t32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, 256, 9, wfr.data_ptr(), H.cur_stream()),
-                        "lt_conv_pack_weights_t32")
-                self.keep.append(wfr)
-                d.phase[i].weight_frag, d.phase[i].weight_frag_layout = wfr.data_ptr(), 2
-            elif self.dtype == torch.bfloat16 and not self.dry_run and spec.cout_pad % 256 == 0 and spec.k_pad % 64 == 0:
+            if self.dtype == torch.bfloat16 and not self.dry_run and spec.cout_pad % 256 == 0 and spec.k_pad % 64 == 0:
                 wfr = torch.empty_like(wdev)
                 # the 288-row layers get their weights in the fragment order of the 32x32x16 MFMA (conv_igemm7: +1 % end to end over
                 # conv_igemm6, 3x3 256->256 90.8 -> 87.4 us, 1x1 1024->256 50.9 -> 48.2 us inside the forward; LT_CONV_NO_V7=1 when the

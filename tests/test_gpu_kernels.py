@@ -105,12 +105,11 @@ V3_CASES = {  # name: (nd, N, cin, cout, k, stride, pad, spatial, residual)
 }
 
 
-@pytest.mark.parametrize("v4", ["0", "1"])
 @pytest.mark.parametrize("case", list(V3_CASES))
-def test_conv_v3_288(case, v4, monkeypatch):
-    """288-row / 3-stage kernels vs torch (bf16), forced with LT_TILE3_288, and AUTO agrees: the 12-wave kernel and (LT_CONV_V4=1,
-    Cout % 128 == 0) the role-specialised one with four compute and four loader waves."""
-    monkeypatch.setenv("LT_CONV_V4", v4)
+def test_conv_v3_288(case):
+    """288-row / 3-stage kernels vs torch (bf16), forced with LT_TILE3_288, and AUTO agrees (the 12-wave kernel; the role-specialised
+    conv_igemm4 that LT_CONV_V4=1 used to select lost its A/B inside the forward and was removed in round 2)."""
+    v4 = "0"
     nd, N, cin, cout, k, s, p, sp, with_res = V3_CASES[case]
     g = torch.Generator().manual_seed(len(case) * 7 + cin)
     x = torch.randn(N, cin, *sp, generator=g)
@@ -525,13 +524,12 @@ def test_pwchain(nlayers, J, planar):
     check("pwchain/L%d_J%d%s" % (nlayers, J, "/planar" if planar else ""), y.t.cpu(), ref, 1e-2)
 
 
-@pytest.mark.parametrize("staged", ["0", "1"])
-def test_unproject_bf16_lds_staged(staged, monkeypatch):
-    """bf16 / C = 32 / bricked volumes: the default gather kernel and the opt-in LDS-staged kernel (LT_UNPROJ_LDS=1): patches that
-    fit (V = 32, 24x24 maps) and the per-view fallback to global gathers (V = 16 bricks spanning the whole cube side on 96x96
-    maps), every aggregation, vs the oracle."""
+def test_unproject_bf16_bricked_volumes(monkeypatch):
+    """bf16 / C = 32 / bricked volumes through the default dispatch (quad kernel for 4 / 8 views + softmax, generic gather otherwise),
+    every aggregation, vs the oracle.  (An LDS-staged variant, opt-in with LT_UNPROJ_LDS=1, measured 0.90 vs 0.57 ms and was removed
+    in round 2.)"""
     from mvn.utils import op
-    monkeypatch.setenv("LT_UNPROJ_LDS", staged)
+    staged = "0"
     synth = __import__("oracle.synth", fromlist=["x"])
     g = torch.Generator().manual_seed(21)
     # (B, views, volume, map size, a camera inside the cube): NV == 4 + softmax takes the quad kernel (unproject_q4_kernel)
@@ -621,15 +619,11 @@ def test_deconv4x4_phases_288x256(bsrc, monkeypatch):
     check("deconv4x4_288x256/%s vs igemm2" % bsrc, out, gen, 1.5e-2)
 
 
-@pytest.mark.parametrize("band", ["1", "0"], ids=["band", "igemm"])
 @pytest.mark.parametrize("N,H_", [(64, 24), (128, 24), (32, 48)])
-def test_conv2d_band_256_256(N, H_, band, monkeypatch):
-    """3x3 / stride 1 / pad 1, 256 -> 256 on 24-wide maps (ResNet-152 layer3 at 384^2 inputs): conv2d_band_kernel (row bands in LDS,
-    weights as fragments from global memory; opt-in with LT_CONV_BAND=1) and the implicit GEMM (default) vs torch: ReLU, residual + ReLU."""
-    if band == "1":
-        monkeypatch.setenv("LT_CONV_BAND", "1")      # opt-in: read when the plan packs the layer's weights
-    else:
-        monkeypatch.delenv("LT_CONV_BAND", raising=False)
+def test_conv2d_3x3_256_256_layer3(N, H_):
+    """3x3 / stride 1 / pad 1, 256 -> 256 on 24-wide maps (ResNet-152 layer3 at 384^2 inputs) through the default dispatch vs torch:
+    ReLU, residual + ReLU.  (A dedicated row-band kernel for this layer, opt-in with LT_CONV_BAND=1, was 8 % faster per layer on dense
+    data and 1 % slower inside the forward: removed in round 2.)"""
     g = torch.Generator().manual_seed(N + H_)
     x = torch.randn(N, 256, H_, 24, generator=g)
     w = torch.randn(256, 256, 3, 3, generator=g) * (1.0 / (256 * 9) ** 0.5)
@@ -638,9 +632,9 @@ def test_conv2d_band_256_256(N, H_, band, monkeypatch):
     rd = bf16_round
     conv = _bn_ref(F.conv2d(rd(x), rd(w), None, 1, 1), bn)
     out = run_conv(x, w, None, bn, 1, 1, torch.bfloat16, 0, relu=True)
-    check("conv2d_band=%s/N%d_H%d/relu" % (band, N, H_), out, torch.relu(conv), 1.5e-2)
+    check("conv2d_3x3_256/N%d_H%d/relu" % (N, H_), out, torch.relu(conv), 1.5e-2)
     out2 = run_conv(x, w, None, bn, 1, 1, torch.bfloat16, 0, relu=True, residual=res)
-    check("conv2d_band=%s/N%d_H%d/res" % (band, N, H_), out2, torch.relu(conv + rd(res)), 1.5e-2)
+    check("conv2d_3x3_256/N%d_H%d/res" % (N, H_), out2, torch.relu(conv + rd(res)), 1.5e-2)
 
 
 @pytest.mark.parametrize("wsrc", ["registers", "lds"])
@@ -669,11 +663,11 @@ def test_conv3d_halo_64_64_weight_source(N, sp, cin, cout, wsrc, monkeypatch):
     check("conv3d_halo_%d_%d/%s/N%d/plain" % (cin, cout, wsrc, N), out2, _bn_ref(conv, bn), 1.5e-2)
 
 
-@pytest.mark.parametrize("kdb", ["1", "0"])
 @pytest.mark.parametrize("case", ["halo_7x7_32_16", "halo_7x7_32_16_big"])
-def test_conv3d_halo7_variants(case, kdb, monkeypatch):
-    """Both 7^3 loader-wave kernels: kd-register-blocked (default, LT_HALO_7B=1) and tap-major (LT_HALO_7B=0)."""
-    monkeypatch.setenv("LT_HALO_7B", kdb)
+def test_conv3d_halo7_variants(case):
+    """The 7^3 loader-wave kernel (kd-register-blocked; the tap-major kernel it superseded was removed in round 2): residual + ReLU,
+    affine only."""
+    kdb = "1"
     N, cin, cout, k, sp, dts = HALO_CASES[case]
     g = torch.Generator().manual_seed(len(case) + 3)
     x = torch.randn(N, cin, *sp, generator=g)
