@@ -81,8 +81,9 @@ typedef struct lt_conv_phase {
     int32_t out_off[3];  /* ood, ooh, oow                                                            */
     const void* weight_frag; /* optional (NULL = none): the same bf16 weights in an MFMA fragment order, so that a kernel can read
                                 its weight operand with coalesced loads instead of staging it through LDS */
-    int32_t weight_frag_layout; /* 0 = none; 1 = lt_conv_pack_weights (Cout % 256 == 0 layers, 288 x 256 kernel);
-                                   2 = lt_conv_pack_weights_t32 (3x3x3 64->64 / 32->64 / 128->128 halo kernel, 3x3 256->256 band kernel) */
+    int32_t weight_frag_layout; /* 0 = none; 1 = lt_conv_pack_weights (Cout % 256 == 0 layers, 288 x 256 / 144 x 256 kernels on the 16x16x32 MFMA);
+                                   2 = lt_conv_pack_weights_t32 (3x3x3 64->64 / 32->64 / 128->128 halo kernel);
+                                   3 = lt_conv_pack_weights32 (288 x 256 kernel on the 32x32x16 MFMA) */
 } lt_conv_phase;
 
 typedef struct lt_conv_desc {
@@ -107,7 +108,7 @@ int lt_conv_pack_weights(const void* weight, int32_t cout_pad, int32_t k_pad, vo
 /* The fragment order of the TRANSPOSED product (weights as the first MFMA operand), used by the 3x3x3 64 -> 64 halo kernel:
  * [tap][cin / 16][cout_pad / 32][64 lanes][8]; lane (r = l & 31, h = l >> 5) holds output channel
  * 32 b + 16 (r >> 4) + 8 ((r >> 2) & 1) + 4 ((r >> 3) & 1) + (r & 3), K elements 16 g + 8 h .. + 7 of the tap.
- * lt_conv_phase.weight_frag_layout says which of the two orders weight_frag holds; a kernel only uses the one it was written for. */
+ * lt_conv_phase.weight_frag_layout says which of the orders weight_frag holds; a kernel only uses the one it was written for. */
 int lt_conv_pack_weights_t32(const void* weight, int32_t cout_pad, int32_t k_pad, int32_t cin, int32_t ntaps, void* packed,
                              void* stream);
 /* B-fragment order of the 32x32x16 MFMA (layout 3, conv_igemm7): [k_pad / 32][cout_pad / 32][2 K halves][64 lanes][8]; lane l of
