@@ -768,6 +768,27 @@ __global__ void gather_kernel(const float* __restrict__ src, const int* __restri
     }
 }
 
+struct GatherJob { const float* src; const int* idx; float* dst; long long n; int first_block; int pad_; };
+
+// many gathers in ONE launch (a layer's gather is a few-microsecond kernel: 750 of them per training step were launch-bound);
+// a workgroup serves 1024 consecutive elements of the job its index falls into
+__global__ __launch_bounds__(256) void gather_multi_kernel(const GatherJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const GatherJob j = jobs[lo];
+    const long long base = (long long)(blockIdx.x - j.first_block) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long long i = base + u * 256 + threadIdx.x;
+        if (i >= j.n) break;
+        const int k = j.idx[i];
+        j.dst[i] = k >= 0 ? j.src[k] : 0.f;
+    }
+}
+
 struct WgradPlan { int variant, n_co_t, n_k_t, S, rows_per_slab; };
 
 // tile shape by layer shape, slab count so that ~1024 workgroups are in flight (two per CU at two waves per SIMD), partial sums capped at 48 MiB
@@ -1100,6 +1121,13 @@ extern "C" int lt_adam_step_multi(const void* jobs, int32_t njobs, int32_t total
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const AdamJob*)jobs, njobs, beta1, beta2, eps, weight_decay,
                        bc1, bc2);
     LT_CHECK_LAUNCH("lt_adam_step_multi");
+    return LT_OK;
+}
+
+extern "C" int lt_gather_f32_multi(const void* jobs, int32_t njobs, int32_t total_blocks, void* stream) {
+    LT_REQUIRE(jobs && njobs >= 1 && total_blocks >= 1, LT_ERR_INVALID, "lt_gather_f32_multi: bad argument");
+    hipLaunchKernelGGL(gather_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const GatherJob*)jobs, njobs);
+    LT_CHECK_LAUNCH("lt_gather_f32_multi");
     return LT_OK;
 }
 

@@ -53,6 +53,7 @@ class TrainTape:
         self._ws = torch.empty(1 << 16, dtype=torch.uint8, device=self.device)
         self.keep = []
         self.labels, self._label = {}, "op"              # id(closure) -> label, for profile()
+        self.batched, self.fwd_jobs, self.bwd_jobs, self._job_tabs = {}, [], [], {}      # parameter gathers: one launch per replay
         # parameter gradients: ONE flat fp32 arena, slices handed out in the order the backward produces them (so a bucket of the
         # data-parallel all-reduce is a contiguous range that is complete early), 16-byte aligned
         total = sum((p.numel() + 3) // 4 * 4 for p in params if p.requires_grad)
@@ -117,11 +118,18 @@ class TrainTape:
         e = self.grads.get(id(act))
         return None if e is None else e[1]
 
-    def _gather(self, src, imap, dst):
-        """dst <- src[imap] every step; src is read where it lives AT CALL TIME (a Parameter the optimiser updates in place)."""
+    def _gather(self, src, imap, dst, group=None):
+        """dst <- src[imap] every step; src is read where it lives AT CALL TIME (a Parameter the optimiser updates in place).  Gathers of
+        parameters (``group`` = "w": the GEMM layouts of the forward and of the input gradients) run one by one while the tape is
+        recorded and as ONE launch per replay (lt_gather_f32_multi at the head of the forward / of the backward: the weights do not
+        change in between) -- 750 few-microsecond kernels per step were launch-bound."""
         self.keep += [imap, dst]
         n = dst.numel()
-        self.do(lambda st: H.check(H.lib().lt_gather_f32(src.data_ptr(), imap.data_ptr(), dst.data_ptr(), n, st), "lt_gather_f32"), "gather")
+        fn = lambda st: H.check(H.lib().lt_gather_f32(src.data_ptr(), imap.data_ptr(), dst.data_ptr(), n, st), "lt_gather_f32")
+        self.do(fn, "gather")
+        if group is not None:
+            self.batched[id(fn)] = True
+            (self.fwd_jobs if self._cur is self.fwd_ops else self.bwd_jobs).append((src, imap, dst, n))
 
     def _live_conv(self, x, wparam, wt=None, bias=None, **kw):
         """lt_conv_fwd over the CURRENT values of ``wparam`` (optionally seen through the view transform ``wt``: the transposed / flipped
@@ -133,12 +141,12 @@ class TrainTape:
         y = self.pb.conv(x, idx, bias, None, **kw)
         fn, info = self.pb.ops[-1][0], self.pb.last_info
         for wdev in info["wdev"]:
-            self._gather(wparam, (wdev.round().to(torch.int32) - 1).contiguous(), wdev)
+            self._gather(wparam, (wdev.round().to(torch.int32) - 1).contiguous(), wdev, "w")
         if bias is not None:
             bi = info["bias_dev"]
             bmap = torch.full((bi.numel(),), -1, dtype=torch.int32)
             bmap[:bias.numel()] = torch.arange(bias.numel(), dtype=torch.int32)
-            self._gather(bias, bmap.to(self.device), bi)
+            self._gather(bias, bmap.to(self.device), bi, "w")
         self.do(fn, ("dgrad " if self._cur is self.bwd_ops else "conv ") + self.pb.ops[-1][1]["label"])
         return y
 
@@ -325,11 +333,34 @@ class TrainTape:
         with ``do``."""
         self.recorders.append(fn)
 
+    JOB = np.dtype([("src", "u8"), ("idx", "u8"), ("dst", "u8"), ("n", "i8"), ("fb", "i4"), ("pad", "i4")])
+
+    def _gather_all(self, which, jobs):
+        """One lt_gather_f32_multi launch for ``jobs``; the table is rebuilt only when a Parameter's storage has moved."""
+        if not jobs:
+            return
+        key = tuple(j[0].data_ptr() for j in jobs)
+        tab = self._job_tabs.get(which)
+        if tab is None or tab[0] != key:
+            arr = np.zeros(len(jobs), dtype=self.JOB)
+            fb = 0
+            for i, (src, imap, dst, n) in enumerate(jobs):
+                arr[i] = (src.data_ptr(), imap.data_ptr(), dst.data_ptr(), n, fb, 0)
+                fb += (n + 1023) // 1024
+            dev = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+            tab = self._job_tabs[which] = (key, dev, len(jobs), fb)
+        H.check(H.lib().lt_gather_f32_multi(tab[1].data_ptr(), tab[2], tab[3], self.stream), "lt_gather_f32_multi")
+
+    def replay(self, ops, start=0, stop=None):
+        for fn in ops[start:stop]:
+            if id(fn) not in self.batched:
+                fn(self.stream)
+
     def run_forward(self):
         """Replay of the recorded forward on the current stream (the first forward IS the recording)."""
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
-        for fn in self.fwd_ops:
-            fn(self.stream)
+        self._gather_all("fwd", self.fwd_jobs)
+        self.replay(self.fwd_ops)
 
     def run_backward(self):
         """First call: records (= runs) the backward; later calls replay it.  Returns {Parameter: gradient view of the arena} (averaged
@@ -342,8 +373,8 @@ class TrainTape:
             self._grads_ready(final=True)
             self.recorders, self.bwd_recorded = [], True
         else:
-            for fn in self.bwd_ops:
-                fn(self.stream)
+            self._gather_all("bwd", self.bwd_jobs)
+            self.replay(self.bwd_ops)
         if self.reducer is not None:
             self.reducer.wait_all()
         return self.param_grads

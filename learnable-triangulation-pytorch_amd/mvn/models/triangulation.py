@@ -84,8 +84,9 @@ class _VolTrainPlan:
             self.geo = torch.zeros(n_geo, dtype=torch.float32, device=device)
             self.n_front = len(tape.fwd_ops)
         else:
-            for fn in tape.fwd_ops[:self.n_front]:
-                fn(st)
+            tape.stream = st
+            tape._gather_all("fwd", tape.fwd_jobs)          # every layer's weights into its GEMM layout, one launch
+            tape.replay(tape.fwd_ops, 0, self.n_front)
         G = self.G
         h, w = G["hw"]
         o_pos, o_cen, o_rot = G["offs"]
@@ -125,8 +126,7 @@ class _VolTrainPlan:
             self.gl = torch.empty(B, V ** 3, J, dtype=torch.float32, device=device)         # d loss / d logits, channels-last like the logits
             tape.seed(logits, self.gl.view(logits.t.shape))
         else:
-            for fn in tape.fwd_ops[self.n_front:]:
-                fn(st)
+            tape.replay(tape.fwd_ops, self.n_front)
         self.step_id += 1
         feats_out = self.feats.t.reshape(B, NV, h, w, 32).permute(0, 1, 4, 2, 3).clone()
         base_points = self.geo[o_cen:o_rot].reshape(B, 3).clone()
