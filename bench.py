@@ -194,6 +194,8 @@ def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
     B = args.batch
     model.to(dev)
     model.train()
+    model.train_precision = args.train_dtype
+    np.random.seed(1234 + rank)          # the cuboid rotations of the steps (triangulation.py:318-319): the same sequence every run
     model.grad_reducer = lt_dist.GradReducer() if world > 1 else None
     opt = lt_train.Adam([{"params": list(model.backbone.parameters())}, {"params": list(model.process_features.parameters()), "lr": 1e-3},
                          {"params": list(model.volume_net.parameters()), "lr": 1e-3}], lr=1e-4)
@@ -224,11 +226,14 @@ def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
         fwd_flops = P["plan"].flops * B if hasattr(P["plan"], "flops") else None
         res = {"metric": "multi-view samples/sec (%d-view vol-softmax training step: fwd + bwd + Adam)" % args.views, "value": value, "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup), "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.train_dtype == "fp32" else "bf16 MFMA for the convolutions and their input gradients (fp32 accumulation and storage); f32 activations, "
+                                                                  "BatchNorm, weight gradients, optimiser",
+               "data": "synthetic",
                "config": {"workload": "training step of: " + workload, "per_gpu_batch": B, "global_batch": B * world,
                           "parallelism": "data parallel x%d, bucketed gradient all-reduce (RCCL) overlapped with the backward" % world if world > 1 else "1 GPU",
                           "loss": "KeypointsMAELoss(scale 0.1) + 0.01 * VolumetricCELoss", "optimizer": "Adam lr 1e-4 / 1e-3 / 1e-3 (3 groups)"},
-               "per_rank_samples_per_s": per_rank, "loss_first_last": [lv[0], lv[-1]],
+               "per_rank_samples_per_s": per_rank, "loss_first_last": [lv[0], lv[-1]], "losses": [round(v, 4) for v in lv],
                "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
         if fwd_flops:
             ach = 3 * fwd_flops / (1e-3 * res["ms_per_step"]) / 1e12
@@ -258,6 +263,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32, help="host threads for the CPU baseline leg")
     ap.add_argument("--tile", type=int, default=0, help="force a conv tile id (LT_TILE_*), 0 = auto")
     ap.add_argument("--preroll-s", type=float, default=1.0, help="untimed steady-state run before the W warm-up steps (clocks settle)")
+    ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="--train: fp32 (the reference's precision, default) or bf16 = the "
+                    "convolutions and their input gradients on the bf16 MFMA (bf16 copies of the operands, fp32 accumulation / storage), everything else fp32")
     ap.add_argument("--train", action="store_true", help="time the training step (fwd + bwd + Adam, fp32) instead of the forward; its own JSON line")
     ap.add_argument("--stub-cpu", action="store_true", help="TEST ONLY: gloo backend, no GPU, step() is a sleep (exercises launcher + timing plumbing)")
     args = ap.parse_args()

@@ -268,6 +268,8 @@ int lt_conv_wgrad(const float* dy, const float* x, const int32_t* taps, float* d
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- the layout changes between a Parameter's own layout and the GEMM layouts of its layer
  * (forward weights, input-gradient weights, weight-gradient blocks), with index maps built once when a training plan is recorded */
 int lt_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, void* stream);
+/* fp32 -> bf16, round to nearest even (operands of the mixed-precision training convolutions); 16-byte aligned pointers */
+int lt_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* many gathers in one launch.  jobs (device memory): njobs records of
  *   { const float* src; const int32_t* idx; float* dst; int64_t n; int32_t first_block; int32_t pad; }   (40 bytes)
  * with first_block = running sum of ceil(n / 1024) over the preceding jobs; total_blocks = that sum over all jobs. */

@@ -768,6 +768,17 @@ __global__ void gather_kernel(const float* __restrict__ src, const int* __restri
     }
 }
 
+// fp32 -> bf16 (round to nearest even), eight elements per thread: the operands of the mixed-precision training convolutions
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n) {
+    const long long n8 = n >> 3;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += 256ll * gridDim.x) {
+        const float4 a = ((const float4*)src)[2 * i], b = ((const float4*)src)[2 * i + 1];
+        ((uint4*)dst)[i] = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (n8 << 3) + threadIdx.x; i < n; i += 256) dst[i] = f32_to_bf16(src[i]);
+}
+
 struct GatherJob { const float* src; const int* idx; float* dst; long long n; int first_block; int pad_; };
 
 // many gathers in ONE launch (a layer's gather is a few-microsecond kernel: 750 of them per training step were launch-bound);
@@ -1121,6 +1132,14 @@ extern "C" int lt_adam_step_multi(const void* jobs, int32_t njobs, int32_t total
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const AdamJob*)jobs, njobs, beta1, beta2, eps, weight_decay,
                        bc1, bc2);
     LT_CHECK_LAUNCH("lt_adam_step_multi");
+    return LT_OK;
+}
+
+extern "C" int lt_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    LT_REQUIRE(src && dst && n >= 1 && ((size_t)src % 16 == 0) && ((size_t)dst % 16 == 0), LT_ERR_INVALID, "lt_cast_f32_bf16: bad argument (16-byte aligned pointers)");
+    const long long blocks = cdiv(n >> 3, 256);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long long)n);
+    LT_CHECK_LAUNCH("lt_cast_f32_bf16");
     return LT_OK;
 }
 

@@ -36,12 +36,17 @@ class TrainTape:
     an ``lt_gather_f32`` from the Parameter (wherever the optimiser has left it) into the layer's GEMM layout, with an index map built
     at record time by pushing a tensor of indices through the very host code that lays out inference weights."""
 
-    def __init__(self, device, params=(), momentum=0.1, reducer=None, bucket_bytes=64 << 20):
+    def __init__(self, device, params=(), momentum=0.1, reducer=None, bucket_bytes=64 << 20, mixed=False):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("training runs on the GPU only (device=%s); there is no CPU fallback" % device)
         self.dtype, self.code, self.dry_run = torch.float32, H.LT_F32, False
         self.pb = E.PlanBuilder(device, torch.float32)          # builds the lt_conv_fwd descriptors
+        # mixed precision: the convolutions (forward and input gradients) take bf16 COPIES of their operands to the bf16 MFMA and store
+        # fp32 (LT_EPI_STORE_F32); activations, BatchNorm, weight gradients, optimiser stay fp32 (the master weights are the Parameters)
+        self.mixed = bool(mixed)
+        self.pbh = E.PlanBuilder(device, torch.bfloat16) if self.mixed else None
+        self._bf16 = {}                                         # id(Act) -> (Act, bf16 copy); cast op recorded with the first consumer
         self.fwd_ops, self.bwd_ops = [], []                     # fn(stream) closures, in launch order
         self._cur = self.fwd_ops
         self.recorders = []                                     # one per layer: records (= runs once) that layer's backward
@@ -131,6 +136,20 @@ class TrainTape:
             self.batched[id(fn)] = True
             (self.fwd_jobs if self._cur is self.fwd_ops else self.bwd_jobs).append((src, imap, dst, n))
 
+    def _cast(self, src, dst):
+        n = src.numel()
+        self.keep += [src, dst]
+        self.do(lambda st: H.check(H.lib().lt_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), n, st), "lt_cast_f32_bf16"), "cast")
+
+    def _bf16_of(self, act):
+        e = self._bf16.get(id(act))
+        if e is None:
+            t16 = torch.empty(act.t.shape, dtype=torch.bfloat16, device=self.device)
+            self._bf16[id(act)] = (act, t16)
+            self._cast(act.t, t16)
+            return E.Act(t16)
+        return E.Act(e[1])
+
     def _live_conv(self, x, wparam, wt=None, bias=None, **kw):
         """lt_conv_fwd over the CURRENT values of ``wparam`` (optionally seen through the view transform ``wt``: the transposed / flipped
         filter of an input gradient) and of ``bias``."""
@@ -138,6 +157,29 @@ class TrainTape:
         idx = torch.arange(1, wparam.numel() + 1, dtype=torch.float32).reshape(wparam.shape)      # 1 + flat index; 0 = padding
         if wt is not None:
             idx = wt(idx).contiguous()
+        if self.mixed:
+            residual = kw.pop("residual", None)
+            x16 = self._bf16_of(x)
+            spec_idx = E.make_conv_spec(idx, None, None, x16.shape, kw.get("stride", 1), kw.get("pad", 0), torch.bfloat16, kw.get("transposed", False), 0,
+                                        kw.get("output_padding", 0))
+            y = self.pbh.conv(x16, torch.zeros(idx.shape), bias, None, out_f32=True, **kw)
+            fn, info = self.pbh.ops[-1][0], self.pbh.last_info
+            assert len(spec_idx.phases) == len(info["wdev"])
+            for ph, wdev in zip(spec_idx.phases, info["wdev"]):
+                assert tuple(ph.weight.shape) == tuple(wdev.shape)
+                stage = torch.empty(wdev.shape, dtype=torch.float32, device=self.device)          # fp32 GEMM layout, then the bf16 copy the kernel reads
+                self._gather(wparam, (ph.weight.round().to(torch.int32) - 1).contiguous().to(self.device), stage, "w")
+                self._cast(stage, wdev)
+            if bias is not None:
+                bi = info["bias_dev"]
+                bmap = torch.full((bi.numel(),), -1, dtype=torch.int32)
+                bmap[:bias.numel()] = torch.arange(bias.numel(), dtype=torch.int32)
+                self._gather(bias, bmap.to(self.device), bi, "w")
+            self.do(fn, ("dgrad " if self._cur is self.bwd_ops else "conv ") + self.pbh.ops[-1][1]["label"])
+            if residual is not None:          # the fp32 gradient that is already there cannot ride in a bf16 kernel's epilogue
+                yt, rt = y.t, residual.t
+                self.do(lambda st: yt.add_(rt), "add")
+            return y
         y = self.pb.conv(x, idx, bias, None, **kw)
         fn, info = self.pb.ops[-1][0], self.pb.last_info
         for wdev in info["wdev"]:

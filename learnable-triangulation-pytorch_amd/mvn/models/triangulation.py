@@ -64,8 +64,9 @@ class _VolTrainPlan:
             x = x.float().contiguous()
         first = self.tape is None
         if first:
-            self.tape = tape = lt_train.TrainTape(device, params=list(model.parameters()), reducer=getattr(model, "grad_reducer", None))
-            self.x_in = tape.alloc((B * NV, 1, Hh, W, E.min_cin_of(torch.float32)))
+            mixed = getattr(model, "train_precision", "fp32") == "bf16"
+            self.tape = tape = lt_train.TrainTape(device, params=list(model.parameters()), reducer=getattr(model, "grad_reducer", None), mixed=mixed)
+            self.x_in = tape.alloc((B * NV, 1, Hh, W, E.min_cin_of(torch.bfloat16 if mixed else torch.float32)))
             tape.no_grad_ids.add(id(self.x_in))
         tape = self.tape
         H.check(lib.lt_nchw_to_nhwc(H.LT_F32, x.data_ptr(), self.x_in.t.data_ptr(), B * NV, 3, Hh * W, self.x_in.t.shape[-1], st), "lt_nchw_to_nhwc")
@@ -386,7 +387,9 @@ class VolumetricTriangulationNet(_PlannedNet):
         B, NV = images.shape[:2]
         key = (B, NV, images.shape[3], images.shape[4], images.device, self.volume_size, float(self.cuboid_side), float(self.volume_multiplier),
                bool(self.volume_softmax), self.volume_aggregation_method, bool(self.transfer_cmu_to_human36m), self.num_joints,
-               tuple(p.requires_grad for p in params), id(getattr(self, "grad_reducer", None)))
+               tuple(p.requires_grad for p in params), id(getattr(self, "grad_reducer", None)), getattr(self, "train_precision", "fp32"))
+        if getattr(self, "train_precision", "fp32") not in ("fp32", "bf16"):
+            raise ValueError("train_precision must be 'fp32' (the reference's precision) or 'bf16' (bf16 MFMA convolutions, fp32 everything else)")
         plans = self.__dict__.setdefault("_train_plans", OrderedDict())
         plan = plans.get(key)
         if plan is None:

@@ -144,8 +144,11 @@ CONV_CASES = [  # nd, Cin, Cout, k, stride, pad, transposed, spatial
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "nd%d_%dto%d_k%ds%dp%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], "_T" if c[6] else ""))
 @pytest.mark.parametrize("mode", ["bn_relu_res", "bias_only"])
-def test_tape_layer_gradients(case, mode):
-    """One layer through TrainTape: z = act(BN_train(conv(x) + b) [+ res]); all gradients vs torch-CPU fp64 autograd."""
+@pytest.mark.parametrize("mixed", [False, True], ids=["fp32", "bf16mma"])
+def test_tape_layer_gradients(case, mode, mixed):
+    """One layer through TrainTape: z = act(BN_train(conv(x) + b) [+ res]); all gradients vs torch-CPU fp64 autograd.  ``mixed``: the
+    convolution and its input gradient on the bf16 MFMA (bf16 copies of the operands, fp32 accumulation and storage), everything else
+    fp32 -- compared with the same fp64 reference at bf16-operand tolerances."""
     import lt_engine as E
     import lt_train
     nd, Cin, Cout, k, s, p, tr, sp = case
@@ -174,18 +177,19 @@ def test_tape_layer_gradients(case, mode):
         y = F.relu(y + rd)
     dz = torch.randn(y.shape, generator=g)
     if use_bn:
-        dz = dz * (pre.abs() > 1e-4).float()      # no upstream gradient where fp32 rounding could flip the ReLU mask
+        dz = dz * (pre.abs() > (1e-4 if not mixed else 5e-2)).float()      # no upstream gradient where rounding (fp32 / bf16 operands) could flip the ReLU mask
     (y * dz.double()).sum().backward()
 
     wp, bp = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
     gp, btp = torch.nn.Parameter(gamma.to(DEV)), torch.nn.Parameter(beta.to(DEV))
-    tape = lt_train.TrainTape(DEV, params=[wp, bp, gp, btp])
+    tape = lt_train.TrainTape(DEV, params=[wp, bp, gp, btp], mixed=mixed)
+    T1, T2, T3 = (2e-5, 5e-5, 1e-6) if not mixed else (2e-2, 2e-2, 2e-2)
     rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
     xa = E.Act(to_cl(x))
     ra = E.Act(to_cl(res)) if use_bn else None
     z = tape.conv(xa, wp, bp, (gp, btp, rm, rv) if use_bn else None, stride=s, pad=p, transposed=tr, relu=use_bn, residual=ra)
-    tag = "train/layer nd%d %d->%d k%d s%d p%d%s %s" % (nd, Cin, Cout, k, s, p, " T" if tr else "", mode)
-    check(tag + " z", from_cl(z.t, nd), y.detach(), 2e-5)
+    tag = "train/layer%s nd%d %d->%d k%d s%d p%d%s %s" % (" bf16mma" if mixed else "", nd, Cin, Cout, k, s, p, " T" if tr else "", mode)
+    check(tag + " z", from_cl(z.t, nd), y.detach(), T1)
     dzb = to_cl(dz)
     tape.seed(z, dzb)
     pg = tape.run_backward()          # records the backward while running it
@@ -206,21 +210,21 @@ def test_tape_layer_gradients(case, mode):
     tape.run_forward(); pg = tape.run_backward()
     for k in first:
         assert torch.allclose(pg[k], first[k], rtol=1e-5, atol=1e-6 * float(first[k].abs().max())), "replay differs from the recording"
-    check(tag + " dx", from_cl(tape.grad_of(xa), nd), xd.grad, 5e-5)
-    check(tag + " dw", pg[wp].cpu(), wd.grad, 5e-5)
+    check(tag + " dx", from_cl(tape.grad_of(xa), nd), xd.grad, T2)
+    check(tag + " dw", pg[wp].cpu(), wd.grad, T2)
     if use_bn:
-        check(tag + " dgamma", pg[gp].cpu(), gd.grad, 5e-5)
-        check(tag + " dbeta", pg[btp].cpu(), btd.grad, 5e-5)
-        check(tag + " dres", from_cl(tape.grad_of(ra), nd), rd.grad, 1e-6)
+        check(tag + " dgamma", pg[gp].cpu(), gd.grad, T2)
+        check(tag + " dbeta", pg[btp].cpu(), btd.grad, T2)
+        check(tag + " dres", from_cl(tape.grad_of(ra), nd), rd.grad, T3)
         # the bias in front of a training-mode BatchNorm has an exactly zero gradient; ours is rounding noise of the channel sums
         assert float(pg[bp].abs().max()) <= 1e-4 * float(dz.abs().sum() / Cout)
         n_el = y.numel() // Cout
         yb = conv(x.double(), w.double(), b.double(), stride=s, padding=p)
         dims = [0] + list(range(2, 2 + nd))
-        check(tag + " running_mean", rm.cpu(), 0.1 * yb.mean(dims), 1e-5)
-        check(tag + " running_var", rv.cpu(), 0.9 + 0.1 * yb.var(dims, unbiased=True), 1e-5)
+        check(tag + " running_mean", rm.cpu(), 0.1 * yb.mean(dims), 1e-5 if not mixed else 1e-2)
+        check(tag + " running_var", rv.cpu(), 0.9 + 0.1 * yb.var(dims, unbiased=True), 1e-5 if not mixed else 1e-2)
     else:
-        check(tag + " db", pg[bp].cpu(), bd.grad, 5e-5)
+        check(tag + " db", pg[bp].cpu(), bd.grad, T2)
 
 
 def test_adam_step_vs_torch():
@@ -593,3 +597,57 @@ def test_training_api_semantics_accumulation_stale_backward_torch_optimizer():
     kp1 = m(inp1["images"].to(DEV), None, b1)[0]
     kp1.sum().backward()
     assert len(m._train_plans) == 2 and torch.isfinite(kp1).all()
+
+
+def test_mixed_precision_training_step_deviation_and_descent(golden_dir):
+    """train_precision = "bf16": the convolutions and their input gradients on the bf16 MFMA, everything else fp32.  Outside the fp32
+    tolerance by construction (like the bf16 inference mode): the deviation of one whole step from the reference's step is RECORDED
+    (joints, loss, parameter gradients), loosely bounded, and ten Adam steps must lower the loss."""
+    import lt_train
+    from mvn.models import loss as L
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    from test_gpu_models import _cameras
+    G = np.load(os.path.join(golden_dir, "train_step.npz"))
+    c, cfg, sd, inp = _train_case()
+    m = VolumetricTriangulationNet(cfg, device=DEV)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    m.train()
+    m.train_precision = "bf16"
+    batch = {"cameras": _cameras(inp, c["B"]), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+    np.random.seed(c["seed"] + 100)
+    kp, feats, vols, conf, cuboids, cvs, bps = m(inp["images"].to(DEV), None, batch)
+    d = (kp.detach().cpu().double() - torch.from_numpy(G["kp"]).double()).abs() / torch.from_numpy(G["kp"]).double().abs().clamp(min=1.0)
+    gt, val = torch.from_numpy(G["gt"]).to(DEV), torch.from_numpy(G["val"]).to(DEV)
+    mae = L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val)
+    ce = L.VolumetricCELoss()(cvs, vols, gt, val)
+    (mae + 0.01 * ce).backward()
+    named = dict(m.named_parameters())
+    errs = []
+    for n in G["names"]:
+        n = str(n)
+        if ZERO_GRAD.search(n):
+            continue
+        f = named[n].grad.detach().double().cpu().reshape(-1)
+        sub = f[::max(1, f.numel() // 129)][:129]
+        errs.append(float((sub - torch.from_numpy(G["g/" + n]).double()).abs().max()) / float(G["gn/" + n][1]))
+    errs.sort()
+    record("train/mixed precision (bf16 MFMA convolutions) one step vs the reference's fp32 step -- deviation, not gated",
+           {"joints_max_rel": float(d.max()), "mae": float(mae.detach()), "mae_reference": float(G["mae"]), "ce": float(ce.detach()), "ce_reference": float(G["ce"]),
+            "parameter_gradient_err_median": errs[len(errs) // 2], "parameter_gradient_err_p90": errs[int(len(errs) * 0.9)], "parameter_gradient_err_max": errs[-1]})
+    assert float(d.max()) < 5e-2 and errs[len(errs) // 2] < 0.2, (float(d.max()), errs[len(errs) // 2])
+    # descent
+    opt = lt_train.Adam(list(m.parameters()), lr=1e-4)
+    gt2 = torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float().to(DEV)
+    val2 = torch.ones(c["B"], 17, 1, device=DEV)
+    losses = []
+    for it in range(10):
+        np.random.seed(0)
+        kp, _, vols, _, _, cvs, _ = m(inp["images"].to(DEV), None, batch)
+        loss = L.KeypointsMAELoss()(kp * 0.1, gt2 * 0.1, val2) + 0.01 * L.VolumetricCELoss()(cvs, vols, gt2, val2)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    record("train/mixed precision loss over 10 Adam steps", losses)
+    assert losses[-1] < losses[0], losses

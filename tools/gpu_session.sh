@@ -28,6 +28,10 @@ train)
     timeout 600 python bench.py --train --steps 10 --warmup 3 --batch $B > $OUT/bench_train_b$B.json 2> $OUT/bench_train_b$B.err
     echo "bench train B=$B rc=$?" | tee -a $OUT/session.log; cat $OUT/bench_train_b$B.json | tee -a $OUT/session.log
   done
+  for B in 4 8; do
+    timeout 600 python bench.py --train --train-dtype bf16 --steps 10 --warmup 3 --batch $B > $OUT/bench_train_bf16mma_b$B.json 2> $OUT/bench_train_bf16mma_b$B.err
+    echo "bench train bf16-MFMA B=$B rc=$?" | tee -a $OUT/session.log; cat $OUT/bench_train_bf16mma_b$B.json | tee -a $OUT/session.log
+  done
   rm -rf $OUT/prof_train
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python $R/bench.py --train --steps 5 --warmup 3 --batch 8 > $OUT/prof_train.json 2> $OUT/prof_train.err
   echo "prof train rc=$?" | tee -a $OUT/session.log
