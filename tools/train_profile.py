@@ -1,4 +1,4 @@
-"""Per-op timing of the recorded training step (GPU box): python tools/train_profile.py [B]  -> table grouped by op kind and the
+"""Per-op timing of the recorded training step (GPU box): python tools/train_profile.py [B] [fp32|bf16]  -> table grouped by op kind and the
 most expensive weight-gradient / convolution launches."""
 import os, sys, json, collections, numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,8 +6,10 @@ sys.path.insert(0, os.path.join(R, "learnable-triangulation-pytorch_amd")); sys.
 import bench
 from mvn.models.triangulation import VolumetricTriangulationNet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+PREC = sys.argv[2] if len(sys.argv) > 2 else "fp32"
 dev = torch.device("cuda:0")
 m = VolumetricTriangulationNet(bench.vol_config(152, 64, "fp32"), device=dev); m.to(dev); m.train()
+m.train_precision = PREC
 images, batch, geom = bench.synthetic_batch(B, 4, 384, 1000)
 images = images.to(dev)
 for _ in range(2):
@@ -30,4 +32,4 @@ for name, ops in (("fwd", tape.fwd_ops), ("bwd", tape.bwd_ops)):
         print("   %8.3f ms  x%-3d %s" % (ms, n, lab))
     res[name] = [(lab, n, ms) for lab, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])]
 os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(R, "gpurun_out", "train_ops_b%d.json" % B), "w"), indent=0)
+json.dump(res, open(os.path.join(R, "gpurun_out", "train_ops_b%d%s.json" % (B, "" if PREC == "fp32" else "_" + PREC)), "w"), indent=0)
