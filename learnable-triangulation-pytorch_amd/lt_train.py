@@ -17,6 +17,7 @@ does with ``total_loss.backward()`` (train.py:233-236) arrives here through the 
 forward (mvn/models/triangulation.py), so ``torch.optim`` / DDP hooks see ordinary ``.grad`` tensors.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -56,6 +57,12 @@ class TrainTape:
         self.npre = 0
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         self._ws = torch.empty(1 << 16, dtype=torch.uint8, device=self.device)
+        # weight gradients are off the backward's critical path (only the optimiser reads them): they run on a SIDE stream behind an event
+        # that marks "this layer's dY is complete", next to the input-gradient convolutions and the (memory-bound) BatchNorm backward of the
+        # layers in front -- their own workspace, their own unpack gather, the gradient all-reduce behind them.  LT_TRAIN_NO_OVERLAP=1: one stream.
+        self.overlap = os.environ.get("LT_TRAIN_NO_OVERLAP") is None
+        self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
+        self._ws2 = torch.empty(1 << 16, dtype=torch.uint8, device=self.device)
         self.keep = []
         self.labels, self._label = {}, "op"              # id(closure) -> label, for profile()
         self.batched, self.fwd_jobs, self.bwd_jobs, self._job_tabs = {}, [], [], {}      # parameter gathers: one launch per replay
@@ -263,7 +270,14 @@ class TrainTape:
         a, b = self.bucket_start, self.arena_off
         if b > a and (final or b - a >= self.bucket_elems):
             chunk = self.arena[a:b]
-            self.do(lambda st: self.reducer.reduce_inplace(chunk), "allreduce")
+
+            def reduce(st):
+                if self.side is not None:          # behind the weight-gradient kernels that complete the bucket
+                    with torch.cuda.stream(self.side):
+                        self.reducer.reduce_inplace(chunk)
+                else:
+                    self.reducer.reduce_inplace(chunk)
+            self.do(reduce, "allreduce")
             self.bucket_start = b
 
     # ---- backward of one convolution layer ---------------------------------------------------------------------------------------
@@ -328,12 +342,24 @@ class TrainTape:
                 imap = ar[:cin_t].reshape(cin_t, *ks3, Cout).permute(0, 4, 1, 2, 3)
             imap = (imap[:, :, 0] if nd == 2 else imap).contiguous().reshape(-1).to(self.device)
             dw = torch.empty(cop, kp, dtype=torch.float32, device=self.device)
-            self._ws_need(lib.lt_conv_wgrad_workspace(wrows, cop, kp))
-            self.keep += [taps_all, a_ptr, b_ptr]
-            self.do(lambda st: H.check(lib.lt_conv_wgrad(a_ptr.data_ptr(), b_ptr.data_ptr(), taps_all.data_ptr(), dw.data_ptr(), geo[0], geo[1], geo[2], geo[3], geo[4],
-                                                         geo[5], geo[6], geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, self._ws.data_ptr(), st),
-                                       "lt_conv_wgrad"), "wgrad %s %s rows %d cout_pad %d K %d" % ("x".join(map(str, weight.shape)), "T" if transposed else "", wrows, cop, kp))
-            self._gather(dw, imap, self._grad_view(weight))
+            need = lib.lt_conv_wgrad_workspace(wrows, cop, kp)
+            if self._ws2.numel() < need:
+                self._ws2 = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            self.keep += [taps_all, a_ptr, b_ptr, imap, dw]
+            gview = self._grad_view(weight)
+            ng = gview.numel()
+            label = "wgrad %s %s rows %d cout_pad %d K %d" % ("x".join(map(str, weight.shape)), "T" if transposed else "", wrows, cop, kp)
+            ev = torch.cuda.Event() if self.overlap else None
+
+            def wgrad(st):
+                if ev is not None:          # dY (and this layer's BatchNorm / bias gradients) are complete on the main stream: the side stream may go
+                    ev.record(torch.cuda.current_stream(self.device))
+                    self.side.wait_event(ev)
+                    st = self.side.cuda_stream
+                H.check(lib.lt_conv_wgrad(a_ptr.data_ptr(), b_ptr.data_ptr(), taps_all.data_ptr(), dw.data_ptr(), geo[0], geo[1], geo[2], geo[3], geo[4], geo[5], geo[6],
+                                          geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, self._ws2.data_ptr(), st), "lt_conv_wgrad")
+                H.check(lib.lt_gather_f32(dw.data_ptr(), imap.data_ptr(), gview.data_ptr(), ng, st), "lt_gather_f32")      # into the Parameter's layout
+            self.do(wgrad, label)
         self._grads_ready()
         # ---- input gradient (skipped for the network input)
         if id(x) in self.no_grad_ids:
@@ -417,7 +443,12 @@ class TrainTape:
         else:
             self._gather_all("bwd", self.bwd_jobs)
             self.replay(self.bwd_ops)
-        if self.reducer is not None:
+        if self.side is not None:
+            if self.reducer is not None:
+                with torch.cuda.stream(self.side):
+                    self.reducer.wait_all()
+            torch.cuda.current_stream(self.device).wait_stream(self.side)          # the gradients are complete for whoever reads them next
+        elif self.reducer is not None:
             self.reducer.wait_all()
         return self.param_grads
 
