@@ -250,11 +250,12 @@ int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32_t C, float
  * lt_adam_step  : torch.optim.Adam's single-tensor update (bias-corrected, eps outside the sqrt).
  * -------------------------------------------------------------------------------------------*/
 int lt_bn_act_fwd(const float* y, const float* mean, const float* var, const float* gamma, const float* beta, const float* residual, float* z,
-                  int64_t rows, int32_t C, float eps, int32_t flags, void* stream);
+                  void* z_bf16 /* optional: a bf16 copy of z on the way (mixed-precision training), or NULL */, int64_t rows, int32_t C, float eps,
+                  int32_t flags, void* stream);
 size_t lt_bn_act_bwd_workspace(int64_t rows, int32_t C);
 int lt_bn_act_bwd(const float* dz, const float* y, const float* residual, const float* mean, const float* var, const float* gamma, const float* beta,
-                  float* dy, float* dgamma, float* dbeta, float* dres, int32_t accumulate_res, int64_t rows, int32_t C, float eps, int32_t flags,
-                  void* workspace, void* stream);
+                  float* dy, void* dy_bf16 /* optional bf16 copy of dy, or NULL */, float* dgamma, float* dbeta, float* dres, int32_t accumulate_res,
+                  int64_t rows, int32_t C, float eps, int32_t flags, void* workspace, void* stream);
 int lt_act_bwd(const float* dz, const float* z, const float* residual, float* dy, float* dres, int32_t accumulate_res, int64_t total, int32_t flags,
                void* stream);
 size_t lt_channel_sum_workspace(int64_t rows, int32_t C);

@@ -27,6 +27,7 @@ struct BnActArgs {
     const float* mean; const float* var; const float* gamma; const float* beta;
     const float* res;      // rows x C or null
     float* z;
+    bf16_t* z16;           // optional bf16 copy of z (mixed-precision training: the next convolution's operand), or null
     float eps;
     int flags, C;
     long long rows;
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActArgs a) {
             o[e] = epi_apply(v, fl, rr[e]);
         }
         *(float4*)(a.z + off) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.z16) *(uint2*)(a.z16 + off) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
     }
 }
 
@@ -61,6 +63,7 @@ struct BnBwdArgs {
     double* part;            // [nslab][C][2]: sum g, sum g x^
     float* dgamma; float* dbeta;
     float* dy;               // rows x C
+    bf16_t* dy16;            // optional bf16 copy of dy (mixed-precision training: the input-gradient convolution's operand), or null
     float* dres;             // rows x C or null: gradient of the residual input (accumulated when accumulate_res)
     float eps;
     int flags, C, nslab, accumulate_res;
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdArgs a
             dr[e] = post ? g : dzv[e];     // RELU_PRE / none: the residual is added after the activation
         }
         *(float4*)(a.dy + off) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.dy16) *(uint2*)(a.dy16 + off) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
         if (a.dres) {
             if (a.accumulate_res) {
                 const float4 d0 = *(const float4*)(a.dres + off);
@@ -868,11 +872,11 @@ int slabs_for(long long rows) { return (int)(rows < 1024 ? 1 : (rows / 256 < 102
 }  // namespace
 
 extern "C" int lt_bn_act_fwd(const float* y, const float* mean, const float* var, const float* gamma, const float* beta, const float* residual,
-                             float* z, int64_t rows, int32_t C, float eps, int32_t flags, void* stream) {
+                             float* z, void* z_bf16, int64_t rows, int32_t C, float eps, int32_t flags, void* stream) {
     LT_REQUIRE(y && mean && var && gamma && beta && z, LT_ERR_INVALID, "lt_bn_act_fwd: null argument");
     LT_REQUIRE(rows >= 1 && C >= 4 && C % 4 == 0, LT_ERR_UNSUPPORTED, "lt_bn_act_fwd: C %% 4 == 0 required (C=%d)", C);
     BnActArgs a;
-    a.y = y; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.res = residual; a.z = z; a.eps = eps; a.flags = flags; a.C = C; a.rows = rows;
+    a.y = y; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.res = residual; a.z = z; a.z16 = (bf16_t*)z_bf16; a.eps = eps; a.flags = flags; a.C = C; a.rows = rows;
     const long long blocks = cdiv(rows * (C / 4), 256);
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, a);
     LT_CHECK_LAUNCH("lt_bn_act_fwd");
@@ -885,14 +889,14 @@ extern "C" size_t lt_bn_act_bwd_workspace(int64_t rows, int32_t C) {
 }
 
 extern "C" int lt_bn_act_bwd(const float* dz, const float* y, const float* residual, const float* mean, const float* var, const float* gamma,
-                             const float* beta, float* dy, float* dgamma, float* dbeta, float* dres, int32_t accumulate_res, int64_t rows, int32_t C,
-                             float eps, int32_t flags, void* workspace, void* stream) {
+                             const float* beta, float* dy, void* dy_bf16, float* dgamma, float* dbeta, float* dres, int32_t accumulate_res, int64_t rows,
+                             int32_t C, float eps, int32_t flags, void* workspace, void* stream) {
     LT_REQUIRE(dz && y && mean && var && gamma && beta && dy && dgamma && dbeta && workspace, LT_ERR_INVALID, "lt_bn_act_bwd: null argument");
     LT_REQUIRE(rows >= 1 && C >= 1 && C <= 4096, LT_ERR_INVALID, "lt_bn_act_bwd: bad shape");
     LT_REQUIRE(!dres || residual, LT_ERR_INVALID, "lt_bn_act_bwd: a residual gradient needs the residual");
     BnBwdArgs a;
     a.dz = dz; a.y = y; a.res = residual; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.part = (double*)workspace;
-    a.dgamma = dgamma; a.dbeta = dbeta; a.dy = dy; a.dres = dres; a.eps = eps; a.flags = flags; a.C = C; a.nslab = slabs_for(rows);
+    a.dgamma = dgamma; a.dbeta = dbeta; a.dy = dy; a.dy16 = (bf16_t*)dy_bf16; a.dres = dres; a.eps = eps; a.flags = flags; a.C = C; a.nslab = slabs_for(rows);
     a.accumulate_res = accumulate_res; a.rows = rows;
     hipStream_t st = (hipStream_t)stream;
     if (colsum_fast(C)) {
@@ -908,6 +912,7 @@ extern "C" int lt_bn_act_bwd(const float* dz, const float* y, const float* resid
         LT_CHECK_LAUNCH("lt_bn_act_bwd(apply)");
         return LT_OK;
     }
+    LT_REQUIRE(!dy_bf16, LT_ERR_UNSUPPORTED, "lt_bn_act_bwd: the bf16 copy of dy needs a channel count of the vector path (C=%d)", C);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(a.nslab), dim3(256), 0, st, a);
     LT_CHECK_LAUNCH("lt_bn_act_bwd(reduce)");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, a);

@@ -78,9 +78,9 @@ SIGNATURES = {
     "lt_softargmax3d_fwd": (C.c_int, [vp, vp, f32, i32, i32, i32, vp, vp, i32, i32, i64, vp, vp]),
     "lt_softargmax2d_fwd": (C.c_int, [vp, f32, i32, vp, vp, i32, i32, i32, vp]),
     "lt_triangulate_dlt": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
-    "lt_bn_act_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),
+    "lt_bn_act_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp]),
     "lt_bn_act_bwd_workspace": (C.c_size_t, [i64, i32]),
-    "lt_bn_act_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, f32, i32, vp, vp]),
+    "lt_bn_act_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, f32, i32, vp, vp]),
     "lt_act_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i64, i32, vp]),
     "lt_channel_sum_workspace": (C.c_size_t, [i64, i32]),
     "lt_channel_sum": (C.c_int, [vp, i64, i32, vp, i32, vp, vp]),

@@ -222,8 +222,12 @@ class TrainTape:
                                                            rvar.data_ptr(), mom, self._ws.data_ptr(), st), "lt_bn_stats_fwd"), "bn_stats %dx%d" % (rows, Cc))
             z = self.alloc(y_raw.shape)
             rp = residual.t if residual is not None else None
+            z16 = None
+            if self.mixed and Cc % 4 == 0:          # the next convolution's bf16 operand is written on the way (no separate cast pass)
+                z16 = torch.empty(z.t.shape, dtype=torch.bfloat16, device=self.device)
+                self._bf16[id(z)] = (z, z16)
             self.do(lambda st: H.check(lib.lt_bn_act_fwd(y_raw.t.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), H.ptr(rp),
-                                                         z.t.data_ptr(), rows, Cc, BN_EPS, flags, st), "lt_bn_act_fwd"), "bn_act %dx%d" % (rows, Cc))
+                                                         z.t.data_ptr(), H.ptr(z16), rows, Cc, BN_EPS, flags, st), "lt_bn_act_fwd"), "bn_act %dx%d" % (rows, Cc))
             stats = (mean, var)
         self.recorders.append(lambda: self._conv_bwd(x, weight, bias, bn, stride, pad, transposed, flags, residual, y_raw, stats, z))
         return z
@@ -302,9 +306,12 @@ class TrainTape:
             mean, var = stats
             dgamma, dbeta = self._grad_view(gamma), self._grad_view(beta)
             self._ws_need(lib.lt_bn_act_bwd_workspace(rows, Cout))
+            dy16 = None
+            if self.mixed and id(x) not in self.no_grad_ids and Cout >= 4 and Cout & (Cout - 1) == 0:      # the input gradient's bf16 operand on the way
+                dy16 = torch.empty(dy.shape, dtype=torch.bfloat16, device=self.device)
             self.do(lambda st: H.check(lib.lt_bn_act_bwd(dz.data_ptr(), y_raw.t.data_ptr(), H.ptr(rp), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
-                                                         beta.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), H.ptr(dres), acc_res, rows, Cout,
-                                                         BN_EPS, flags, self._ws.data_ptr(), st), "lt_bn_act_bwd"), "bn_bwd %dx%d" % (rows, Cout))
+                                                         beta.data_ptr(), dy.data_ptr(), H.ptr(dy16), dgamma.data_ptr(), dbeta.data_ptr(), H.ptr(dres), acc_res, rows,
+                                                         Cout, BN_EPS, flags, self._ws.data_ptr(), st), "lt_bn_act_bwd"), "bn_bwd %dx%d" % (rows, Cout))
         else:
             total = z.t.numel()
             self.do(lambda st: H.check(lib.lt_act_bwd(dz.data_ptr(), z.t.data_ptr(), H.ptr(rp), dy.data_ptr(), H.ptr(dres), acc_res, total, flags, st), "lt_act_bwd"))
@@ -374,6 +381,8 @@ class TrainTape:
         else:
             dy_in = dy
         dya = E.Act(dy_in)
+        if bn is not None and dy16 is not None:
+            self._bf16[id(dya)] = (dya, dy16)
         res = E.Act(prev) if prev is not None else None
         if not transposed and stride == 1:
             # correlation with the flipped, transposed filter [Cin, Cout, k..]

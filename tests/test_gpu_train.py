@@ -58,14 +58,18 @@ def test_bn_act_fwd_bwd(rows, C, flags_name, with_res):
     mg, vg = mean.detach().float().to(DEV), var.detach().float().to(DEV)
     gg, bg = gamma.to(DEV), beta.to(DEV)
     z = torch.empty_like(yg)
-    H.check(lib.lt_bn_act_fwd(yg.data_ptr(), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), H.ptr(resg), z.data_ptr(), rows, C, 1e-5, flags, _st()), "fwd")
+    z16 = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    H.check(lib.lt_bn_act_fwd(yg.data_ptr(), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), H.ptr(resg), z.data_ptr(), z16.data_ptr(), rows, C, 1e-5, flags, _st()), "fwd")
+    assert torch.equal(z16, z.bfloat16()), "the bf16 copy is the rounded fp32 result"
     tag = "train/bn_act %dx%d %s%s" % (rows, C, flags_name, "+res" if with_res else "")
     check(tag + " fwd", z.cpu(), n.detach(), 2e-6)
     dy, dga, dbe = torch.empty_like(yg), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     dres = torch.full_like(yg, 3.0) if with_res else None
     ws = torch.empty(max(1, lib.lt_bn_act_bwd_workspace(rows, C)), dtype=torch.uint8, device=DEV)
-    H.check(lib.lt_bn_act_bwd(dzg.data_ptr(), yg.data_ptr(), H.ptr(resg), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), dy.data_ptr(), dga.data_ptr(),
-                              dbe.data_ptr(), H.ptr(dres), 1 if with_res else 0, rows, C, 1e-5, flags, ws.data_ptr(), _st()), "bwd")
+    dy16 = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    H.check(lib.lt_bn_act_bwd(dzg.data_ptr(), yg.data_ptr(), H.ptr(resg), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), dy.data_ptr(), dy16.data_ptr(),
+                              dga.data_ptr(), dbe.data_ptr(), H.ptr(dres), 1 if with_res else 0, rows, C, 1e-5, flags, ws.data_ptr(), _st()), "bwd")
+    assert torch.equal(dy16, dy.bfloat16())
     check(tag + " dy", dy.cpu(), yd.grad, 2e-5)
     check(tag + " dgamma", dga.cpu(), gd.grad, 2e-5)
     check(tag + " dbeta", dbe.cpu(), bd.grad, 2e-5)
