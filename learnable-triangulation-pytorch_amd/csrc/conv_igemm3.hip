@@ -855,7 +855,13 @@ __global__ __launch_bounds__(256 * NWM, 2) void conv_igemm6_kernel(const ConvArg
             for (int k = 0; k < E_ITP; ++k) {          // unconditional loads (a lane outside the tensor reads element 0 and never uses it): a select
                 const int m = m0 + wm * WM + p * 48 + k * E_RPP + lane / E_LPR;          // behind a load would make the compiler wait at the load
                 const bool ok = (m < a.M) & (colv_ < a.Cout);
-                rv[k] = *(const uint4*)((const T*)a.res + (ok ? (long long)m * a.ldc + colv_ : 0ll));       // PW: the output pixel IS the GEMM row
+                {          // non-temporal: the residual (the previous block's output) is dead after this read -- it should not push the A panel and the
+                    // weights out of L2 / the memory-side cache (+1.2 % end to end, in-session A/B with the plain load; a non-temporal
+                    // STORE of the output gave half of that back: the next layer reads it)
+                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                    const u32x4_ t_ = __builtin_nontemporal_load((const u32x4_*)((const T*)a.res + (ok ? (long long)m * a.ldc + colv_ : 0ll)));
+                    rv[k] = make_uint4(t_[0], t_[1], t_[2], t_[3]);
+                }
             }
         } else {
 #pragma unroll
