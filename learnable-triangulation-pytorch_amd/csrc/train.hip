@@ -10,7 +10,13 @@
 //                      (v_mfma_f32_32x32x2_f32: its A/B operands are ONE value per lane with the lanes along the 32 output rows / columns,
 //                      so channels-last dY / X rows feed it with fully coalesced 128-byte loads and no transposition -- the 16-bit MFMAs
 //                      want 8 consecutive K = 8 consecutive PIXELS per lane, i.e. a transposed operand).  K here is the pixel index.
-//   lt_adam_step       torch.optim.Adam's update (train.py:430-437), one launch per parameter tensor
+//                      Kernels behind it, chosen by layer shape: conv_wgrad_kernel<CT, KT> (generic: operands straight from L2, branch-free
+//                      4-stage software pipeline, pixel slabs + deterministic reduce), conv3d_wgrad_brick_kernel (3^3 / stride 1: dY brick
+//                      and X halo brick in LDS, taps split over the waves), conv3d_wgrad_k7_kernel (7^3 32 -> 16: one filter plane per
+//                      workgroup on the 16x16x4 MFMA), conv2d_wgrad_brick_kernel (2D 3x3: 8 x 8 pixel bricks), wgrad_pw_kernel (1x1: LDS GEMM)
+//   lt_gather_f32(_multi)  dst[i] = src[idx[i]]: live Parameters -> GEMM layouts, weight-gradient blocks -> Parameter layout
+//   lt_cast_f32_bf16   bf16 copies of the convolution operands of the mixed-precision step (lt_bn_act_fwd / _bwd can write them on the way)
+//   lt_adam_step(_multi)  torch.optim.Adam's update (train.py:430-437): one launch per tensor / one launch per parameter group
 // The convolution dgrad needs no kernel of its own: it is lt_conv_fwd over dY with the weights transposed / flipped (stride 1), as a
 // parity-phase transposed convolution (stride-2 layers) or as a strided convolution (the transposed layers) -- see lt_train.py.
 #include "colsum.h"
