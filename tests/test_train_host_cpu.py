@@ -1,0 +1,156 @@
+"""CPU: the HOST logic of the training step (lt_train.TrainTape) without a GPU, against torch autograd:
+
+  * live weights -- the index maps that turn a Parameter into a layer's GEMM layouts (forward matrix, the transposed / flipped
+    matrix of the input gradient, the parity phases of the stride-2 adjoints) are built by pushing a tensor of indices through
+    lt_engine.make_conv_spec: gather(parameter, map) must equal make_conv_spec(parameter);
+  * the three input-gradient formulations (stride 1: correlation with the flipped / transposed filter; stride 2: transposed
+    convolution with output_padding 1; ConvTranspose: the strided convolution it is the adjoint of), executed by the CPU interpreter of
+    the lt_conv_fwd contract (tests/emul.py), against torch.autograd;
+  * the weight-gradient block layout dW[co][tap * Cin + ci] (and the transposed role) and the map that unpacks it into the
+    Parameter's own layout, against torch.autograd.
+What remains for the GPU suite (tests/test_gpu_train.py) is kernel == contract."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import lt_engine as E
+from emul import emulate_conv
+
+CASES = [  # nd, Cin, Cout, k, stride, pad, transposed, spatial
+    (2, 8, 16, 3, 1, 1, False, (6, 8)),
+    (2, 16, 8, 1, 1, 0, False, (5, 7)),
+    (2, 8, 16, 3, 2, 1, False, (8, 6)),
+    (2, 8, 32, 1, 2, 0, False, (6, 8)),
+    (2, 16, 8, 4, 2, 1, True, (3, 4)),
+    (3, 8, 8, 3, 1, 1, False, (4, 4, 6)),
+    (3, 16, 8, 2, 2, 0, True, (2, 3, 2)),
+    (3, 8, 17, 1, 1, 0, False, (2, 2, 3)),
+]
+IDS = ["nd%d_%dto%d_k%ds%dp%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], "_T" if c[6] else "") for c in CASES]
+
+
+def _cl(x):  # N,C,(D),H,W -> N,D,H,W,C
+    if x.dim() == 4:
+        x = x.unsqueeze(2)
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _from_cl(y, nd):
+    y = y.permute(0, 4, 1, 2, 3)
+    return y[:, :, 0] if nd == 2 else y
+
+
+def _index_like(w):
+    return torch.arange(1, w.numel() + 1, dtype=torch.float32).reshape(w.shape)
+
+
+def _gathered_spec(w, wt, in_shape, dtype=torch.float32, **kw):
+    """What TrainTape._live_conv leaves in the layer's weight buffers: the index map from make_conv_spec(indices), gathered from the
+    flat parameter."""
+    idx = _index_like(w)
+    if wt is not None:
+        idx = wt(idx).contiguous()
+    spec_i = E.make_conv_spec(idx, None, None, in_shape, kw.get("stride", 1), kw.get("pad", 0), dtype, kw.get("transposed", False), 0, kw.get("output_padding", 0))
+    flat = w.reshape(-1)
+    for ph in spec_i.phases:
+        imap = ph.weight.round().to(torch.int64) - 1
+        ph.weight = torch.where(imap >= 0, flat[imap.clamp(min=0)], torch.zeros(()))
+    return spec_i
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16_layout"])
+def test_live_weight_maps_equal_host_packing(case, dtype):
+    nd, Cin, Cout, k, s, p, tr, sp = case
+    g = torch.Generator().manual_seed(Cin + 3 * Cout + k)
+    w = torch.randn(*((Cin, Cout) if tr else (Cout, Cin)), *([k] * nd), generator=g)
+    N = 2
+    cin_buf = max(Cin, E.min_cin_of(dtype))
+    in_shape = (N, 1 if nd == 2 else sp[0], *(sp if nd == 2 else sp[1:]), cin_buf)
+    want = E.make_conv_spec(w, None, None, in_shape, s, p, dtype, tr, 0)
+    got = _gathered_spec(w, None, in_shape, dtype, stride=s, pad=p, transposed=tr)
+    assert len(want.phases) == len(got.phases)
+    for a, b in zip(want.phases, got.phases):
+        assert torch.equal(a.weight, b.weight) and torch.equal(a.taps, b.taps)
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_input_gradient_formulations(case):
+    """dx of every layer kind through the lt_conv_fwd contract (emulate_conv) with the weights TrainTape would gather."""
+    nd, Cin, Cout, k, s, p, tr, sp = case
+    if Cout & (Cout - 1):
+        pytest.skip("the tape pads dY to a power-of-two channel count first (covered on the GPU)")
+    g = torch.Generator().manual_seed(11 * Cin + Cout + k)
+    N = 2
+    x = torch.randn(N, Cin, *sp, generator=g, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(*((Cin, Cout) if tr else (Cout, Cin)), *([k] * nd), generator=g, dtype=torch.float64)
+    conv = {(2, False): F.conv2d, (3, False): F.conv3d, (2, True): F.conv_transpose2d, (3, True): F.conv_transpose3d}[(nd, tr)]
+    y = conv(x, w, None, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    (y * dy).sum().backward()
+    wf = w.float()
+    dyc = _cl(dy.float())
+    if not tr and s == 1:
+        spec = _gathered_spec(wf, lambda t: t.transpose(0, 1).flip(*range(2, 2 + nd)), tuple(dyc.shape), stride=1, pad=k - 1 - p)
+    elif not tr:
+        spec = _gathered_spec(wf, None, tuple(dyc.shape), stride=2, pad=p, transposed=True, output_padding=1)
+    else:
+        spec = _gathered_spec(wf, None, tuple(dyc.shape), stride=2, pad=p)
+    dx = _from_cl(emulate_conv(spec, dyc), nd)
+    assert dx.shape == x.grad.shape, (dx.shape, x.grad.shape)
+    assert float((dx.double() - x.grad).abs().max()) <= 2e-5 * float(x.grad.abs().max())
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_weight_gradient_block_layout_and_unpack_map(case):
+    """dW[co][tap * Cin + ci] = sum over output pixels of dY[pix][co] * X[pix * stride + tap - pad][ci] (ConvTranspose: the roles of the
+    layer's input and of dY swapped), then the unpack map of TrainTape._conv_bwd -> the Parameter's layout; vs torch.autograd."""
+    nd, Cin, Cout, k, s, p, tr, sp = case
+    g = torch.Generator().manual_seed(5 * Cin + Cout + 2 * k)
+    N = 2
+    x = torch.randn(N, Cin, *sp, generator=g, dtype=torch.float64)
+    w = torch.randn(*((Cin, Cout) if tr else (Cout, Cin)), *([k] * nd), generator=g, dtype=torch.float64).requires_grad_(True)
+    conv = {(2, False): F.conv2d, (3, False): F.conv3d, (2, True): F.conv_transpose2d, (3, True): F.conv_transpose3d}[(nd, tr)]
+    y = conv(x, w, None, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    (y * dy).sum().backward()
+    ks3 = (1,) + (k,) * 2 if nd == 2 else (k,) * 3
+    st3 = (1, s, s) if nd == 2 else (s, s, s)
+    pd3 = (0, p, p) if nd == 2 else (p, p, p)
+    xc, dyc = _cl(x), _cl(dy)                       # N, D, H, W, C
+    if not tr:
+        rows_t, gath_t, cr, cg = dyc, xc, Cout, Cin       # "dy" role: rows; "x" role: gathered at row * stride + tap - pad
+    else:
+        rows_t, gath_t, cr, cg = xc, dyc, Cin, Cout
+    cop = E.cout_pad_of(cr)
+    kp = ks3[0] * ks3[1] * ks3[2] * cg
+    dw = torch.zeros(cop, kp, dtype=torch.float64)
+    Nn, Dr, Hr, Wr, _ = rows_t.shape
+    _, Dg, Hg, Wg, _ = gath_t.shape
+    t = 0
+    for a in range(ks3[0]):
+        for b in range(ks3[1]):
+            for c in range(ks3[2]):
+                for od in range(Dr):
+                    i_d = od * st3[0] - pd3[0] + a
+                    if not 0 <= i_d < Dg:
+                        continue
+                    for oh in range(Hr):
+                        i_h = oh * st3[1] - pd3[1] + b
+                        if not 0 <= i_h < Hg:
+                            continue
+                        for ow in range(Wr):
+                            i_w = ow * st3[2] - pd3[2] + c
+                            if not 0 <= i_w < Wg:
+                                continue
+                            dw[:cr, t * cg:(t + 1) * cg] += rows_t[:, od, oh, ow, :].t() @ gath_t[:, i_d, i_h, i_w, :]
+                t += 1
+    ar = torch.arange(cop * kp).reshape(cop, kp)
+    if not tr:
+        imap = ar[:Cout].reshape(Cout, *ks3, Cin)[..., :Cin].permute(0, 4, 1, 2, 3)
+    else:
+        imap = ar[:Cin].reshape(Cin, *ks3, Cout).permute(0, 4, 1, 2, 3)
+    imap = (imap[:, :, 0] if nd == 2 else imap).contiguous().reshape(-1)
+    gw = dw.reshape(-1)[imap].reshape(w.shape)
+    assert float((gw - w.grad).abs().max()) <= 1e-10 * float(w.grad.abs().max())
