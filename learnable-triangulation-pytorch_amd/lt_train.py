@@ -63,6 +63,8 @@ class TrainTape:
         self.overlap = os.environ.get("LT_TRAIN_NO_OVERLAP") is None
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._ws2 = torch.empty(1 << 16, dtype=torch.uint8, device=self.device)
+        self._n_wgrad = 0
+        self.wgrad_main_every = int(os.environ.get("LT_TRAIN_WGRAD_MAIN_EVERY", "6" if mixed else "0"))
         self.keep = []
         self.labels, self._label = {}, "op"              # id(closure) -> label, for profile()
         self.batched, self.fwd_jobs, self.bwd_jobs, self._job_tabs = {}, [], [], {}      # parameter gathers: one launch per replay
@@ -356,7 +358,11 @@ class TrainTape:
             gview = self._grad_view(weight)
             ng = gview.numel()
             label = "wgrad %s %s rows %d cout_pad %d K %d" % ("x".join(map(str, weight.shape)), "T" if transposed else "", wrows, cop, kp)
-            ev = torch.cuda.Event() if self.overlap else None
+            # load balance of the two streams: with the convolutions on the bf16 MFMA the main stream's backward (input gradients + BatchNorm)
+            # is shorter than the side stream's fp32 weight gradients, so every k-th weight gradient stays on the main stream
+            self._n_wgrad += 1
+            on_main = self.wgrad_main_every > 0 and self._n_wgrad % self.wgrad_main_every == 0
+            ev = torch.cuda.Event() if (self.overlap and not on_main) else None
 
             def wgrad(st):
                 if ev is not None:          # dY (and this layer's BatchNorm / bias gradients) are complete on the main stream: the side stream may go
