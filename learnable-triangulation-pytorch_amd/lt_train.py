@@ -277,8 +277,12 @@ class TrainTape:
         if b > a and (final or b - a >= self.bucket_elems):
             chunk = self.arena[a:b]
 
+            rev = torch.cuda.Event() if self.side is not None else None
+
             def reduce(st):
-                if self.side is not None:          # behind the weight-gradient kernels that complete the bucket
+                if self.side is not None:          # behind the weight-gradient kernels that complete the bucket, on either stream
+                    rev.record(torch.cuda.current_stream(self.device))
+                    self.side.wait_event(rev)
                     with torch.cuda.stream(self.side):
                         self.reducer.reduce_inplace(chunk)
                 else:
@@ -352,8 +356,6 @@ class TrainTape:
             imap = (imap[:, :, 0] if nd == 2 else imap).contiguous().reshape(-1).to(self.device)
             dw = torch.empty(cop, kp, dtype=torch.float32, device=self.device)
             need = lib.lt_conv_wgrad_workspace(wrows, cop, kp)
-            if self._ws2.numel() < need:
-                self._ws2 = torch.empty(int(need), dtype=torch.uint8, device=self.device)
             self.keep += [taps_all, a_ptr, b_ptr, imap, dw]
             gview = self._grad_view(weight)
             ng = gview.numel()
@@ -363,6 +365,10 @@ class TrainTape:
             self._n_wgrad += 1
             on_main = self.wgrad_main_every > 0 and self._n_wgrad % self.wgrad_main_every == 0
             ev = torch.cuda.Event() if (self.overlap and not on_main) else None
+            if ev is None:          # on the main stream: the main stream's workspace (the side stream's may be in use by a concurrent weight gradient)
+                self._ws_need(need)
+            elif self._ws2.numel() < need:
+                self._ws2 = torch.empty(int(need), dtype=torch.uint8, device=self.device)
 
             def wgrad(st):
                 if ev is not None:          # dY (and this layer's BatchNorm / bias gradients) are complete on the main stream: the side stream may go
@@ -370,7 +376,8 @@ class TrainTape:
                     self.side.wait_event(ev)
                     st = self.side.cuda_stream
                 H.check(lib.lt_conv_wgrad(a_ptr.data_ptr(), b_ptr.data_ptr(), taps_all.data_ptr(), dw.data_ptr(), geo[0], geo[1], geo[2], geo[3], geo[4], geo[5], geo[6],
-                                          geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, self._ws2.data_ptr(), st), "lt_conv_wgrad")
+                                          geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, (self._ws if ev is None else self._ws2).data_ptr(), st),
+                        "lt_conv_wgrad")
                 H.check(lib.lt_gather_f32(dw.data_ptr(), imap.data_ptr(), gview.data_ptr(), ng, st), "lt_gather_f32")      # into the Parameter's layout
             self.do(wgrad, label)
         self._grads_ready()
