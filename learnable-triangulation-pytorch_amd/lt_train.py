@@ -62,7 +62,7 @@ class TrainTape:
         # layers in front -- their own workspace, their own unpack gather, the gradient all-reduce behind them.  LT_TRAIN_NO_OVERLAP=1: one stream.
         self.overlap = os.environ.get("LT_TRAIN_NO_OVERLAP") is None
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
-        self._ws2 = torch.empty(1 << 16, dtype=torch.uint8, device=self.device)
+        self._ws2 = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)         # >= the 48 MiB cap of lt_conv_wgrad's partial sums
         self._n_wgrad = 0
         self.wgrad_main_every = int(os.environ.get("LT_TRAIN_WGRAD_MAIN_EVERY", "6" if mixed else "0"))
         self.keep = []
@@ -368,6 +368,7 @@ class TrainTape:
             if ev is None:          # on the main stream: the main stream's workspace (the side stream's may be in use by a concurrent weight gradient)
                 self._ws_need(need)
             elif self._ws2.numel() < need:
+                self._ws2.record_stream(self.side)          # a side-stream kernel of the recording step may still be using it: not to be handed out before that
                 self._ws2 = torch.empty(int(need), dtype=torch.uint8, device=self.device)
 
             def wgrad(st):
