@@ -118,6 +118,13 @@ def _reducer_worker(rank, world, port, q):
     for p, g in zip(reversed(params), reversed(grads)):           # the tape pushes in backward order
         red.push(p, g.clone())
     out = red.finish()
+    # the in-place path the recorded backward uses: contiguous ranges of the gradient arena, summed asynchronously, meaned by wait_all()
+    arena = torch.cat([g.reshape(-1) for g in grads]).clone()
+    red.reduce_inplace(arena[:5000]); red.reduce_inplace(arena[5000:])
+    red.wait_all()
+    want_arena = torch.cat([((torch.randn(s, generator=torch.Generator().manual_seed(7 * i)) + torch.randn(s, generator=torch.Generator().manual_seed(7 * i + 1))) / 2).reshape(-1)
+                            for i, s in enumerate(shapes)])
+    assert torch.allclose(arena, want_arena, atol=1e-7), "reduce_inplace / wait_all"
     q.put((rank, [out[p].detach().numpy().copy() for p in params], red.buckets_sent))     # by value: the worker may exit first
     lt_dist.barrier()
     lt_dist.shutdown()
