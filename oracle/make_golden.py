@@ -374,6 +374,7 @@ def gen_train(mvn):
     scaled by (1 + 1e-6) -- and the fixture stores, per parameter, how far the reference's gradient moves between them
     (``noise/<name>``): the test gates ours against the reference within that measured self-noise."""
     import mvn.models.loss as L
+    torch.set_num_threads(8)          # the fixture's fp32 summation order (the 1-thread run below measures what another order changes)
     c = dict(nl=18, B=2, NV=3, H=128, V=64, seed=12)
     cfg = synth.vol_config(c["nl"], c["V"], "softmax", 1.0, "mpii")
     sp = spec.vol_net_spec(c["nl"], 17, False)
@@ -405,7 +406,7 @@ def gen_train(mvn):
     thetas = np.random.uniform(0.0, 2 * np.pi, size=c["B"])
     t0 = time.time()
     ref, opt, r = step()
-    nthr = torch.get_num_threads()
+    nthr = 8
     torch.set_num_threads(1)
     ref1, _, r1 = step(gt=r["gt"])
     torch.set_num_threads(nthr)
