@@ -173,7 +173,8 @@ class PoseResNet(E.PlanCache):
         """x: (N,3,H,W) fp32 on the GPU -> (heatmaps (N,J,h,w), features (N,256,h,w), alg_confidences, vol_confidences)."""
         H.require_gpu(x, "images")
         if self.training:
-            raise NotImplementedError("train-mode BatchNorm / backward are not built yet (SURVEY.md section 8f row 1); call .eval()")
+            raise NotImplementedError("training runs through VolumetricTriangulationNet, whose step is recorded as a whole (lt_train.py); "
+                                      "the stand-alone forward of this module is inference only: call .eval()")
         key = (tuple(x.shape), self.compute_dtype, x.device)
         N, Cc, Hh, W = x.shape
 

@@ -141,7 +141,8 @@ class V2VModel(E.PlanCache):
         """x: (N,Cin,V,V,V) on the GPU -> (N,Cout,V,V,V) fp32 logits (reference :164-169)."""
         H.require_gpu(x, "volumes")
         if self.training:
-            raise NotImplementedError("train-mode BatchNorm / backward are not built yet (SURVEY.md section 8f row 1); call .eval()")
+            raise NotImplementedError("training runs through VolumetricTriangulationNet, whose step is recorded as a whole (lt_train.py); "
+                                      "the stand-alone forward of this module is inference only: call .eval()")
         key = (tuple(x.shape), self.compute_dtype, x.device)
 
         def build():
