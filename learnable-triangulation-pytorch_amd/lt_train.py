@@ -1,20 +1,24 @@
 """Training-mode execution of the reference-shaped networks (BASELINE config 5): the modules'
-``record()`` methods -- the same code that records the inference plan -- run against a ``TrainTape`` that EXECUTES every layer at
-once in training mode (convolution without a folded BatchNorm -> batch statistics -> normalise + ReLU + residual) and remembers
-what the backward needs; ``TrainTape.backward()`` then walks the layers in reverse:
+``record()`` methods -- the same code that records the inference plan -- run against a ``TrainTape`` that EXECUTES every layer
+as it is recorded, in training mode (convolution without a folded BatchNorm -> batch statistics -> normalise + ReLU + residual),
+keeps every launch as a closure over fixed buffers, and records the backward the same way on the first ``run_backward()``; later steps
+REPLAY the two launch lists (DESIGN.md "Training step").  The backward of a layer:
 
     activation / BatchNorm backward   lt_bn_act_bwd / lt_act_bwd   (csrc/train.hip)
     bias gradient                     lt_channel_sum
-    weight gradient                   lt_conv_wgrad               (exact-fp32 MFMA, no atomics)
+    weight gradient                   lt_conv_wgrad               (exact-fp32 MFMA, no atomics) on a SIDE stream, behind an event
     input gradient                    lt_conv_fwd over dY with the weights transposed + flipped (stride 1), as a parity-phase transposed
                                       convolution (stride-2 layers: k=3/p=1 or k=1/p=0 with output_padding 1) or as the strided convolution a
                                       transposed layer is the adjoint of; an already existing gradient of the input rides in as the
                                       epilogue's residual, so sums over consumers cost no extra pass
     max pool                          lt_maxpool_bwd
 
-Everything is fp32 (the reference trains in fp32); all arithmetic is liblt_hip's, torch only owns the memory.  What the reference
-does with ``total_loss.backward()`` (train.py:233-236) arrives here through the autograd Function that wraps a network's training
-forward (mvn/models/triangulation.py), so ``torch.optim`` / DDP hooks see ordinary ``.grad`` tensors.
+The weights are live (lt_gather_f32 from the Parameters into each layer's GEMM layout, index maps built at record time), the
+parameter gradients land in one flat arena (contiguous buckets for lt_dist.GradReducer).  fp32 throughout by default (the reference
+trains in fp32); ``mixed=True`` takes the convolutions and their input gradients to the bf16 MFMA (bf16 operand copies, fp32
+accumulation and storage).  All arithmetic is liblt_hip's, torch only owns the memory.  What the reference does with
+``total_loss.backward()`` (train.py:233-236) arrives here through the autograd Function that wraps a network's training forward
+(mvn/models/triangulation.py), so ``torch.optim`` and hooks see ordinary ``.grad`` tensors.
 """
 import ctypes as C
 import os
