@@ -269,6 +269,11 @@ int lt_conv_wgrad(const float* dy, const float* x, const int32_t* taps, float* d
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- the layout changes between a Parameter's own layout and the GEMM layouts of its layer
  * (forward weights, input-gradient weights, weight-gradient blocks), with index maps built once when a training plan is recorded */
 int lt_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, void* stream);
+/* small helpers of the training tape, so that no torch op sits between the launches: y += x; dst[r][c] = c < C ? src[r][c] : 0 (dY of
+ * the 17-joint layer widened to the power-of-two channel count lt_conv_fwd wants on its input); zero fill (scatter targets) */
+int lt_add_f32(float* y, const float* x, int64_t n, void* stream);
+int lt_pad_channels_f32(const float* src, float* dst, int64_t rows, int32_t C, int32_t c_pad, void* stream);
+int lt_zero(void* p, int64_t nbytes, void* stream);
 /* fp32 -> bf16, round to nearest even (operands of the mixed-precision training convolutions); 16-byte aligned pointers */
 int lt_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* many gathers in one launch.  jobs (device memory): njobs records of

@@ -789,6 +789,29 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
         for (long long i = (n8 << 3) + threadIdx.x; i < n; i += 256) dst[i] = f32_to_bf16(src[i]);
 }
 
+// y += x (an input gradient that cannot ride in a bf16 kernel's epilogue), float4 lanes
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ y, const float* __restrict__ x, long long n) {
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += 256ll * gridDim.x) {
+        float4 a = ((float4*)y)[i];
+        const float4 b = ((const float4*)x)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        ((float4*)y)[i] = a;
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) y[i] += x[i];
+}
+
+// dst[r][c] = c < C ? src[r][c] : 0 -- dY of the 17-joint output layer widened to the 32 channels lt_conv_fwd wants on its input
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows, int C, int Cpad) {
+    const long long total = rows * Cpad;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+        const long long r = i / Cpad;
+        const int c = (int)(i - r * Cpad);
+        dst[i] = c < C ? src[r * C + c] : 0.f;
+    }
+}
+
 struct GatherJob { const float* src; const int* idx; float* dst; long long n; int first_block; int pad_; };
 
 // many gathers in ONE launch (a layer's gather is a few-microsecond kernel: 750 of them per training step were launch-bound);
@@ -1143,6 +1166,28 @@ extern "C" int lt_adam_step_multi(const void* jobs, int32_t njobs, int32_t total
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const AdamJob*)jobs, njobs, beta1, beta2, eps, weight_decay,
                        bc1, bc2);
     LT_CHECK_LAUNCH("lt_adam_step_multi");
+    return LT_OK;
+}
+
+extern "C" int lt_add_f32(float* y, const float* x, int64_t n, void* stream) {
+    LT_REQUIRE(y && x && n >= 1 && ((size_t)y % 16 == 0) && ((size_t)x % 16 == 0), LT_ERR_INVALID, "lt_add_f32: bad argument (16-byte aligned pointers)");
+    const long long blocks = cdiv(n >> 2, 256);
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, y, x, (long long)n);
+    LT_CHECK_LAUNCH("lt_add_f32");
+    return LT_OK;
+}
+
+extern "C" int lt_pad_channels_f32(const float* src, float* dst, int64_t rows, int32_t C, int32_t c_pad, void* stream) {
+    LT_REQUIRE(src && dst && rows >= 1 && C >= 1 && c_pad >= C, LT_ERR_INVALID, "lt_pad_channels_f32: bad argument");
+    const long long blocks = cdiv(rows * c_pad, 256);
+    hipLaunchKernelGGL(pad_channels_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)rows, C, c_pad);
+    LT_CHECK_LAUNCH("lt_pad_channels_f32");
+    return LT_OK;
+}
+
+extern "C" int lt_zero(void* p, int64_t nbytes, void* stream) {
+    LT_REQUIRE(p && nbytes >= 1, LT_ERR_INVALID, "lt_zero: bad argument");
+    LT_REQUIRE(hipMemsetAsync(p, 0, (size_t)nbytes, (hipStream_t)stream) == hipSuccess, LT_ERR_LAUNCH, "lt_zero: hipMemsetAsync failed");
     return LT_OK;
 }
 

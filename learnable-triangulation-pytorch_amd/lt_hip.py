@@ -86,6 +86,9 @@ SIGNATURES = {
     "lt_channel_sum": (C.c_int, [vp, i64, i32, vp, i32, vp, vp]),
     "lt_maxpool_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32 * 3, vp]),
     "lt_adam_step_multi": (C.c_int, [vp, i32, i32, f32, f32, f32, f32, i32, vp]),
+    "lt_add_f32": (C.c_int, [vp, vp, i64, vp]),
+    "lt_pad_channels_f32": (C.c_int, [vp, vp, i64, i32, i32, vp]),
+    "lt_zero": (C.c_int, [vp, i64, vp]),
     "lt_cast_f32_bf16": (C.c_int, [vp, vp, i64, vp]),
     "lt_gather_f32_multi": (C.c_int, [vp, i32, i32, vp]),
     "lt_gather_f32": (C.c_int, [vp, vp, vp, i64, vp]),

@@ -191,7 +191,8 @@ class TrainTape:
             self.do(fn, ("dgrad " if self._cur is self.bwd_ops else "conv ") + self.pbh.ops[-1][1]["label"])
             if residual is not None:          # the fp32 gradient that is already there cannot ride in a bf16 kernel's epilogue
                 yt, rt = y.t, residual.t
-                self.do(lambda st: yt.add_(rt), "add")
+                n_add = yt.numel()
+                self.do(lambda st: H.check(H.lib().lt_add_f32(yt.data_ptr(), rt.data_ptr(), n_add, st), "lt_add_f32"), "add")
             return y
         y = self.pb.conv(x, idx, bias, None, **kw)
         fn, info = self.pb.ops[-1][0], self.pb.last_info
@@ -253,7 +254,8 @@ class TrainTape:
             if dx is None:
                 dx = torch.empty_like(x.t)
                 self._add_grad(x, dx)
-                self.do(lambda st: dx.zero_())
+                nb = dx.numel() * 4
+                self.do(lambda st: H.check(H.lib().lt_zero(dx.data_ptr(), nb, st), "lt_zero"), "zero")
             N, D, Hh, W, Cc = x.shape
             self.do(lambda st: H.check(H.lib().lt_maxpool_bwd(x.t.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, D, Hh, W, Cc, H.i3(kk), H.i3(ss), H.i3(pp), st),
                                        "lt_maxpool_bwd"))
@@ -392,9 +394,8 @@ class TrainTape:
         prev = self.grad_of(x)
         if Cout & (Cout - 1) or Cout < 4:       # lt_conv_fwd wants a power-of-two channel count on its input: pad dY with zero channels (17 joints -> 32)
             cpad = max(4, 1 << (Cout - 1).bit_length())
-            dyp = torch.zeros(*dy.shape[:-1], cpad, dtype=torch.float32, device=self.device)
-            dyv = dyp[..., :Cout]
-            self.do(lambda st: dyv.copy_(dy))
+            dyp = torch.empty(*dy.shape[:-1], cpad, dtype=torch.float32, device=self.device)
+            self.do(lambda st: H.check(lib.lt_pad_channels_f32(dy.data_ptr(), dyp.data_ptr(), rows, Cout, cpad, st), "lt_pad_channels_f32"), "pad")
             dy_in = dyp                     # (dy itself must keep its name: the closures above read it when they are replayed)
         else:
             dy_in = dy

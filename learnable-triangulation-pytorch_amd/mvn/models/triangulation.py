@@ -111,7 +111,8 @@ class _VolTrainPlan:
                 if dvol is None:
                     return
                 gfe = torch.empty_like(feats.t)
-                tape.do(lambda s_: gfe.zero_())
+                nb = gfe.numel() * 4
+                tape.do(lambda s_: H.check(lib.lt_zero(gfe.data_ptr(), nb, s_), "lt_zero"))
                 tape.do(lambda s_: H.check(lib.lt_unproject_bwd(H.LT_F32, feats.t.data_ptr(), gp, coords.data_ptr(), None, dvol.data_ptr(), gfe.data_ptr(), None,
                                                                 B, NV, 32, h, w, V ** 3, agg, s_), "lt_unproject_bwd"))
                 tape.seed(feats, gfe)
