@@ -483,11 +483,11 @@ class TrainTape:
 
 def adam_groups(model, config_opt):
     """The reference's three parameter groups for the volumetric model (train.py:430-437): backbone at ``lr``, ``process_features`` and
-    ``volume_net`` at their own rates when the config names them."""
+    ``volume_net`` at their own rates when the config names them (``process_features_lr`` / ``volume_net_lr``), else at ``lr``."""
     lr = config_opt.lr
     return [{"params": list(model.backbone.parameters())},
-            {"params": list(model.process_features.parameters()), "lr": getattr(config_opt, "process_features_lr", lr) if hasattr(config_opt, "process_features_lr") else lr},
-            {"params": list(model.volume_net.parameters()), "lr": getattr(config_opt, "volume_net_lr", lr) if hasattr(config_opt, "volume_net_lr") else lr}]
+            {"params": list(model.process_features.parameters()), "lr": getattr(config_opt, "process_features_lr", lr)},
+            {"params": list(model.volume_net.parameters()), "lr": getattr(config_opt, "volume_net_lr", lr)}]
 
 
 class Adam:

@@ -154,3 +154,23 @@ def test_weight_gradient_block_layout_and_unpack_map(case):
     imap = (imap[:, :, 0] if nd == 2 else imap).contiguous().reshape(-1)
     gw = dw.reshape(-1)[imap].reshape(w.shape)
     assert float((gw - w.grad).abs().max()) <= 1e-10 * float(w.grad.abs().max())
+
+
+def test_adam_groups_follow_the_reference_config():
+    """train.py:430-437: backbone at opt.lr, process_features / volume_net at their own rates when the YAML names them."""
+    import lt_train
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    from oracle import synth
+    m = VolumetricTriangulationNet(synth.vol_config(18, 32), device="cpu")
+
+    class Opt:
+        lr = 1e-4
+    g = lt_train.adam_groups(m, Opt())
+    assert [x.get("lr", 1e-4) for x in g] == [1e-4, 1e-4, 1e-4]
+    Opt.process_features_lr, Opt.volume_net_lr = 1e-3, 2e-3
+    g = lt_train.adam_groups(m, Opt())
+    assert "lr" not in g[0] and g[1]["lr"] == 1e-3 and g[2]["lr"] == 2e-3
+    n = sum(len(x["params"]) for x in g)
+    assert n == len(list(m.parameters()))          # every parameter in exactly one group
+    opt = lt_train.Adam(g, lr=Opt.lr)
+    assert [pg["lr"] for pg in opt.param_groups] == [1e-4, 1e-3, 2e-3]
