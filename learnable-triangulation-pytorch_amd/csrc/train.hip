@@ -1058,7 +1058,7 @@ extern "C" int lt_conv_wgrad(const float* dy, const float* x, const int32_t* tap
     LT_REQUIRE(M >= 1 && M < (1ll << 31) && (long long)N * D * H * W * Cin < (1ll << 31) && M * ldy < (1ll << 40), LT_ERR_UNSUPPORTED,
                "lt_conv_wgrad: too many rows / elements for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
-    if (brick_ok(N, D, H, W, Cin, Do, Ho, Wo, stride, pad, Cout, cout_pad, k_pad, ntaps)) {
+    if (ldy % 4 == 0 && brick_ok(N, D, H, W, Cin, Do, Ho, Wo, stride, pad, Cout, cout_pad, k_pad, ntaps)) {          // (float4 rows of dY)
         const BrickPlan bp = brick_plan(N, D, H, W, Cin, Cout, cout_pad, k_pad);
         LT_REQUIRE(workspace, LT_ERR_INVALID, "lt_conv_wgrad: this shape needs a workspace of lt_conv_wgrad_workspace() bytes");
         BrickArgs b;
@@ -1075,7 +1075,8 @@ extern "C" int lt_conv_wgrad(const float* dy, const float* x, const int32_t* tap
     }
     const bool unit = stride[0] == 1 && stride[1] == 1 && stride[2] == 1 && D == Do && H == Ho && W == Wo;
     const long long cap_slabs = (48ll << 20) / ((long long)cout_pad * k_pad * 4);
-    if (unit && ntaps == 1 && pad[0] == 0 && pad[1] == 0 && pad[2] == 0 && Cout % 4 == 0 && Cin % 4 == 0 && k_pad == Cin && Cout >= 64 && Cin >= 64 && workspace) {
+    if (unit && ntaps == 1 && pad[0] == 0 && pad[1] == 0 && pad[2] == 0 && Cout % 4 == 0 && Cin % 4 == 0 && ldy % 4 == 0 && k_pad == Cin && Cout >= 64 && Cin >= 64 &&
+        workspace) {
         // the bottleneck 1x1 layers: LDS-tiled GEMM
         PwArgs b;
         b.dy = dy; b.x = x; b.out = (float*)workspace; b.M = (int)M; b.Cout = Cout; b.Cin = Cin; b.ldy = ldy; b.cout_pad = cout_pad; b.k_pad = k_pad;
@@ -1095,7 +1096,7 @@ extern "C" int lt_conv_wgrad(const float* dy, const float* x, const int32_t* tap
         LT_CHECK_LAUNCH("lt_conv_wgrad(reduce)");
         return LT_OK;
     }
-    if (unit && ntaps == 9 && D == 1 && pad[0] == 0 && pad[1] == 1 && pad[2] == 1 && H % B2_H == 0 && W % B2_W == 0 && Cout % 32 == 0 && Cin % 32 == 0 &&
+    if (unit && ntaps == 9 && D == 1 && pad[0] == 0 && pad[1] == 1 && pad[2] == 1 && H % B2_H == 0 && W % B2_W == 0 && Cout % 32 == 0 && Cin % 32 == 0 && ldy % 4 == 0 &&
         cout_pad >= Cout && k_pad == 9 * Cin && workspace) {
         // the backbone's 3x3 layers (taps in (kh, kw) order): LDS bricks
         Brick2Args b;
