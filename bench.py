@@ -95,7 +95,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_leg(state_dict, args, images, batch, geom, budget_s=20.0):
+def cpu_leg(state_dict, args, images, batch, geom):
     """The oracle (oracle/vol_oracle.py: the reference's forward restated on torch-CPU fp32 -- the same ATen conv / batch_norm /
     grid_sample / softmax calls the reference issues, pinned to the reference's own outputs by tests/golden) on the host cores
     of this box, same weights.  One forward of sample 1 (warm-up) and as many timed forwards of sample 0 as fit ~budget_s
@@ -112,7 +112,8 @@ def cpu_leg(state_dict, args, images, batch, geom, budget_s=20.0):
     cores = max(1, min(avail, args.cpu_threads))   # oneDNN on >64 threads thrashes on these small layers (measured: 256 threads -> 170 s/forward)
     torch.set_num_threads(cores)
     run = lambda i: vol_oracle.volumetric_forward(sd, cfg, images[i:i + 1], K, R, t, batch["pred_keypoints_3d"][i:i + 1], stages=True)
-    nref = min(2, images.shape[0])
+    budget_s = args.cpu_budget_s
+    nref = max(1, min(args.cpu_parity_samples, images.shape[0]))
     refs = [None] * nref
     if nref > 1:
         refs[1] = run(1)
@@ -128,7 +129,7 @@ def cpu_leg(state_dict, args, images, batch, geom, budget_s=20.0):
     return base, refs
 
 
-def parity_block(kp_gpu, refs, dtype):
+def parity_block(kp_gpu, refs, dtype, cuboid_side=2500.0):
     """Joints of the timed kernel set vs the oracle: SURVEY.md 8(d) gate formula (max |d| / max(|ref|, 1 mm)) and MPJPE."""
     kp = kp_gpu[:len(refs)].float().cpu().numpy()
     ref = np.concatenate([r["keypoints_3d"].numpy() for r in refs])
@@ -144,7 +145,11 @@ def parity_block(kp_gpu, refs, dtype):
     exact = np.concatenate(exact)
     rel_exact = np.abs(kp.astype(np.float64) - exact) / np.maximum(np.abs(exact), 1.0)
     ref_self = np.abs(ref.astype(np.float64) - exact) / np.maximum(np.abs(exact), 1.0)
+    dabs = np.abs(kp.astype(np.float64) - ref.astype(np.float64))
+    dabs_exact = np.abs(kp.astype(np.float64) - exact)
     return {"dtype": dtype, "samples": len(refs), "joints_max_rel": float(rel.max()),
+            "joints_max_abs_mm": float(dabs.max()), "joints_max_abs_mm_vs_exact": float(dabs_exact.max()),
+            "joints_max_abs_over_cuboid_side": float(dabs.max() / cuboid_side), "cuboid_side_mm": float(cuboid_side),
             "joints_max_rel_vs_exact_softargmax_of_ref_logits": float(rel_exact.max()), "reference_own_fp32_reduction_error": float(ref_self.max()),
             "mpjpe_mm": float(np.sqrt(((kp - ref) ** 2).sum(-1)).mean()), "gate": 1e-4, "meets_gate": bool(rel.max() <= 1e-4 + ref_self.max() and rel_exact.max() <= 1e-4),
             "against": "CPU oracle (fp32, pinned to the reference's outputs), same weights and inputs, samples 0..%d of the timed batch" % (len(refs) - 1),
@@ -160,6 +165,27 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     os.execvpe(cmd[0], cmd, env)
+
+
+def sub_leg(argv, timeout_s):
+    """One more configuration in the SAME driver-run line: bench.py re-run as a child process (fresh plan memory; a failing leg cannot
+    take the headline down), its one JSON line parsed and embedded.  Used for BASELINE config 4 and the training step."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LT_BENCH_SELF_LAUNCHED"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %d s" % timeout_s, "argv": argv}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        return {"error": "rc %d" % r.returncode, "stderr_tail": r.stderr[-600:], "argv": argv}
+    out = json.loads(lines[0])
+    out["leg_wall_s"] = time.perf_counter() - t0
+    out["argv"] = argv
+    return out
 
 
 def time_steps(step, n, barrier):
@@ -196,7 +222,9 @@ def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
     model.train()
     model.train_precision = args.train_dtype
     np.random.seed(1234 + rank)          # the cuboid rotations of the steps (triangulation.py:318-319): the same sequence every run
-    model.grad_reducer = lt_dist.GradReducer() if world > 1 else None
+    # DistributedDataParallel's semantics (train.py:453): rank 0's parameters and buffers on every rank before the first step (the ranks
+    # build their models from the same seed here, attach() makes it true whatever they did), buffers re-broadcast at every forward
+    model.grad_reducer = lt_dist.GradReducer().attach(model) if world > 1 else None
     opt = lt_train.Adam([{"params": list(model.backbone.parameters())}, {"params": list(model.process_features.parameters()), "lr": 1e-3},
                          {"params": list(model.volume_net.parameters()), "lr": 1e-3}], lr=1e-4)
     g = torch.Generator().manual_seed(5 + rank)
@@ -220,6 +248,10 @@ def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
     per_rank = lt_dist.gather_floats(B * args.steps / dt_local, dev)
     lv = [float(l) for l in losses]
     assert all(np.isfinite(lv)), lv
+    comm = lt_dist.comm_info(dev)          # from the communicator: ranks that took part in an all-reduce, backend, RCCL version, devices
+    if world > 1:
+        comm["replicas_identical_after_training"] = model.grad_reducer.replicas_identical(model, buffers=False)
+        comm["gradient_buckets_per_step"] = model.grad_reducer.buckets_sent // max(1, len(lv))
     if rank == 0:
         # algorithmic flops: forward 2*MAC of every convolution, backward twice that (input + weight gradients)
         P = model._build_plan(1, args.views, args.image, args.image, dev, dry_run=True)
@@ -234,6 +266,7 @@ def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
                           "parallelism": "data parallel x%d, bucketed gradient all-reduce (RCCL) overlapped with the backward" % world if world > 1 else "1 GPU",
                           "loss": "KeypointsMAELoss(scale 0.1) + 0.01 * VolumetricCELoss", "optimizer": "Adam lr 1e-4 / 1e-3 / 1e-3 (3 groups)"},
                "per_rank_samples_per_s": per_rank, "loss_first_last": [lv[0], lv[-1]], "losses": [round(v, 4) for v in lv],
+               "rccl": comm,
                "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
         if fwd_flops:
             ach = 3 * fwd_flops / (1e-3 * res["ms_per_step"]) / 1e12
@@ -266,6 +299,9 @@ def main():
     ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="--train: fp32 (the reference's precision, default) or bf16 = the "
                     "convolutions and their input gradients on the bf16 MFMA (bf16 copies of the operands, fp32 accumulation / storage), everything else fp32")
     ap.add_argument("--train", action="store_true", help="time the training step (fwd + bwd + Adam, fp32) instead of the forward; its own JSON line")
+    ap.add_argument("--no-legs", action="store_true", help="skip the config-4 and training legs of the default (config 2, N = 1) run")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="CPU baseline leg: timed forwards of sample 0 until this many seconds (at least one)")
+    ap.add_argument("--cpu-parity-samples", type=int, default=2, help="samples of the timed batch the CPU oracle evaluates as parity references")
     ap.add_argument("--stub-cpu", action="store_true", help="TEST ONLY: gloo backend, no GPU, step() is a sleep (exercises launcher + timing plumbing)")
     args = ap.parse_args()
     if not args.batch:
@@ -350,6 +386,7 @@ def main():
     value, total_samples, dt = lt_dist.job_throughput(B * args.steps, dt_local, dev)   # all ranks' samples / slowest rank
     per_rank = lt_dist.gather_floats(B * args.steps / dt_local, dev)
     assert torch.isfinite(out[0]).all()
+    comm = lt_dist.comm_info(dev)          # all ranks: an all-reduce of ones through the communicator (nranks), backend, RCCL version, devices
 
     result = None
     if rank == 0:
@@ -360,10 +397,10 @@ def main():
             "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": "batch-sharded replicas x%d, no data-path collective" % world,
                        "hip_graph": not args.no_graph, "self_launched": os.environ.get("LT_BENCH_SELF_LAUNCHED") == "1"},
-            "per_rank_samples_per_s": per_rank,
+            "per_rank_samples_per_s": per_rank, "rccl": comm,
         }
         if refs is not None:
-            result["parity"] = parity_block(out[0], refs, args.dtype)
+            result["parity"] = parity_block(out[0], refs, args.dtype, model.cuboid_side)
         if not args.no_profile:
             plan = list(model._plans.values())[-1]["plan"]
             side = model._side_stream(dev)
@@ -419,7 +456,7 @@ def main():
                     a32 = conv32["flops"] / (conv32["ms"] * 1e-3) / 1e12
                     leg["roofline"] = {"bound": "mfma", "achieved": a32, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": a32 / PEAK_TFLOPS["fp32"]}
                 if refs is not None:
-                    leg["parity"] = parity_block(o32[0], refs, "fp32")
+                    leg["parity"] = parity_block(o32[0], refs, "fp32", model.cuboid_side)
                 result["fp32_parity_mode"] = leg
                 model.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
                 model.invalidate_plans()
@@ -439,6 +476,15 @@ def main():
                 dtb, _ = time_steps(sb, nb, lambda: None)
                 sweep[str(bs)] = {"samples_per_s": bs * nb / dtb, "ms_per_step": 1e3 * dtb / nb}
             result["batch_sweep"] = sweep
+            if c2 and not args.no_legs:
+                # ---- the other BASELINE configurations in the same driver-run line (VERDICT r2 "next" 4): config 4 (8 views, 128^3) with its
+                # own roofline / roofline_hbm / parity, and the training step (config 5's step on one GPU, fp32 like the reference)
+                del out
+                model.invalidate_plans()
+                torch.cuda.empty_cache()
+                result["config4"] = sub_leg(["--views", "8", "--volume", "128", "--batch", "16", "--steps", "3", "--warmup", "1", "--no-extras",
+                                             "--cpu-budget-s", "1", "--cpu-parity-samples", "1", "--preroll-s", "0.3"], 600)
+                result["train"] = sub_leg(["--train", "--batch", "4", "--steps", "3", "--warmup", "2"], 600)
         if cpu_base is not None:
             result["cpu_baseline"] = cpu_base
     barrier()

@@ -274,6 +274,9 @@ int lt_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, v
 int lt_add_f32(float* y, const float* x, int64_t n, void* stream);
 int lt_pad_channels_f32(const float* src, float* dst, int64_t rows, int32_t C, int32_t c_pad, void* stream);
 int lt_zero(void* p, int64_t nbytes, void* stream);
+/* *ptrs[i] += delta for n int64 scalars in device memory (ptrs: device array of n pointers): BatchNorm's num_batches_tracked counters of a
+ * whole network in one launch (torch: one `num_batches_tracked += 1` kernel per layer, pose_resnet.py / v2v.py BatchNorm modules in train()) */
+int lt_add_i64_multi(const void* ptrs, int32_t n, int64_t delta, void* stream);
 /* fp32 -> bf16, round to nearest even (operands of the mixed-precision training convolutions); 16-byte aligned pointers */
 int lt_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* many gathers in one launch.  jobs (device memory): njobs records of

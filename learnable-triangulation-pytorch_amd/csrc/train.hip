@@ -1186,6 +1186,19 @@ extern "C" int lt_pad_channels_f32(const float* src, float* dst, int64_t rows, i
     return LT_OK;
 }
 
+// BatchNorm's num_batches_tracked counters (int64 scalars scattered over the module tree): ONE launch adds delta to all of them
+__global__ void add_i64_multi_kernel(long long* const* __restrict__ ptrs, int n, long long delta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) *ptrs[i] += delta;
+}
+
+extern "C" int lt_add_i64_multi(const void* ptrs, int32_t n, int64_t delta, void* stream) {
+    LT_REQUIRE(ptrs && n >= 1, LT_ERR_INVALID, "lt_add_i64_multi: bad argument");
+    hipLaunchKernelGGL(add_i64_multi_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (long long* const*)ptrs, n, (long long)delta);
+    LT_CHECK_LAUNCH("lt_add_i64_multi");
+    return LT_OK;
+}
+
 extern "C" int lt_zero(void* p, int64_t nbytes, void* stream) {
     LT_REQUIRE(p && nbytes >= 1, LT_ERR_INVALID, "lt_zero: bad argument");
     LT_REQUIRE(hipMemsetAsync(p, 0, (size_t)nbytes, (hipStream_t)stream) == hipSuccess, LT_ERR_LAUNCH, "lt_zero: hipMemsetAsync failed");

@@ -31,7 +31,7 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "lt_common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(HERE, "..", "include", "lt_hip.h")]
+    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "lt_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -39,7 +39,12 @@ def build(force=False, verbose=True):
     """Compile every csrc/*.hip for gfx950 and link lib/liblt_hip.so.  Returns the library path."""
     if not force and not is_stale():
         return LIB
-    return _build(LIB, "build", [], verbose)
+    if force:
+        os.environ["LT_BUILD_FORCE"] = "1"
+    try:
+        return _build(LIB, "build", [], verbose)
+    finally:
+        os.environ.pop("LT_BUILD_FORCE", None)
 
 
 def build_variant(name, defines, verbose=True, only=None):
@@ -57,6 +62,8 @@ def _build(LIB, objsub, extra, verbose, only=None):
     objdir = os.path.join(HERE, objsub)
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "lt_hip.h")]
+    force_all = bool(extra) and only is None and False or os.environ.get("LT_BUILD_FORCE") == "1"
 
     def compile_one(src):
         if only is not None and os.path.basename(src) not in only:
@@ -65,6 +72,9 @@ def _build(LIB, objsub, extra, verbose, only=None):
                 raise RuntimeError("variant build: default object of %s is missing or stale, run lt_build.build() first" % src)
             return base_obj
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        # incremental: an object newer than its source, every header and this script (the flags) is kept
+        if not force_all and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in [src, __file__] + headers):
+            return obj
         cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -81,19 +81,92 @@ def job_throughput(samples_this_rank, elapsed_this_rank, device="cpu"):
     return total / t, total, t
 
 
-class GradReducer:
-    """Bucketed, overlapped mean of parameter gradients over the ranks.
+def _flat_broadcast(tensors, src, group):
+    """Broadcast ``tensors`` from rank ``src`` in as few collectives as possible: one flat buffer per (dtype, device), copied back in
+    place.  What DistributedDataParallel does with ``_sync_module_states`` / ``_broadcast_coalesced`` (the reference: train.py:453)."""
+    by = {}
+    for t in tensors:
+        by.setdefault((t.dtype, t.device), []).append(t)
+    n = 0
+    for (dtype, device), ts in by.items():
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src, group=group)
+        o = 0
+        with torch.no_grad():
+            for t in ts:
+                k = t.numel()
+                t.copy_(flat[o:o + k].view(t.shape))          # in place: optimiser state, plan fingerprints (version counters) follow
+                o += k
+        n += 1
+    return n
 
-        reducer.push(param, grad)   as soon as a gradient has been launched (any order, the same on every rank)
-        reducer.finish()            -> {param: averaged gradient}; waits (stream-wise on GPUs) for the buckets in flight
+
+def _checksum(tensors):
+    """fp64 (sum, sum of squares, count) over ``tensors`` -- cheap fingerprint used to PROVE that replicas are identical."""
+    s = torch.zeros(3, dtype=torch.float64, device=tensors[0].device if tensors else "cpu")
+    for t in tensors:
+        d = t.detach().double()
+        s[0] += d.sum(); s[1] += (d * d).sum(); s[2] += d.numel()
+    return s
+
+
+class GradReducer:
+    """The data-parallel exchange of the training step, with DistributedDataParallel's semantics (reference: train.py:450-453) laid out for
+    the recorded backward:
+
+        reducer.attach(model)        construction-time broadcast of every parameter AND buffer from rank 0 (DDP's _sync_module_states): ranks
+                                     that built their model from different seeds start identical; remembers the buffers for sync_buffers()
+        reducer.sync_buffers()       DDP(broadcast_buffers=True): rank 0's buffers (BatchNorm running statistics, num_batches_tracked) to every
+                                     rank at the start of a training forward -- called by VolumetricTriangulationNet._forward_train
+        reducer.reduce_inplace(flat) asynchronous all-reduce of a contiguous range of the gradient arena, recorded by the tape right behind the
+                                     kernels that complete the bucket (the ring over xGMI overlaps the rest of the backward)
+        reducer.wait_all()           end of the backward: sums -> means.  On RCCL the mean is the collective's own (ReduceOp.AVG): no extra
+                                     kernel per bucket; gloo has no AVG, there the division is one in-place op per bucket
+        reducer.push / finish        the packed (non-arena) form, any gradient order that is the same on every rank
+        reducer.replicas_identical(model)   all-gathers a checksum of parameters + buffers: True iff every rank holds the same model
     """
 
-    def __init__(self, bucket_bytes=64 << 20, group=None):
+    def __init__(self, bucket_bytes=64 << 20, group=None, broadcast_buffers=True):
         self.bucket_bytes, self.group = int(bucket_bytes), group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.backend = dist.get_backend(group) if self.on else None
+        # RCCL / NCCL average inside the collective; gloo (CPU tests) sums and the division is ours
+        self.avg = self.backend == "nccl"
+        self.op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         self.items, self.size, self.pending, self.inplace = [], 0, [], []
         self.buckets_sent = 0
+        self.broadcast_buffers = bool(broadcast_buffers)
+        self._buffers, self.attached = [], False
+        self.n_broadcasts = 0
 
+    # ---- DistributedDataParallel's construction-time / per-forward synchronisation -------------------------------------------------------
+    def attach(self, model, src=0):
+        """Every parameter and buffer of ``model`` becomes rank ``src``'s (in place).  Returns self."""
+        params = [p for p in model.parameters()]
+        self._buffers = [b for b in model.buffers()]
+        if self.world > 1:
+            self.n_broadcasts += _flat_broadcast(params + self._buffers, src, self.group)
+            for p in params:          # cached inference plans / weight fingerprints see the new values
+                torch.autograd.graph.increment_version(p)
+        self.attached = True
+        return self
+
+    def sync_buffers(self, src=0):
+        if self.world > 1 and self.broadcast_buffers and self._buffers:
+            self.n_broadcasts += _flat_broadcast(self._buffers, src, self.group)
+
+    def replicas_identical(self, model, buffers=True):
+        """buffers=False: parameters only (BatchNorm statistics are per rank between two sync_buffers(), as under DDP)."""
+        ts = list(model.parameters()) + (list(model.buffers()) if buffers else [])
+        mine = _checksum(ts)
+        if self.world == 1:
+            return True
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine, group=self.group)
+        return all(bool(torch.equal(o, out[0])) for o in out[1:])
+
+    # ---- gradients ------------------------------------------------------------------------------------------------------------------
     def push(self, param, grad):
         self.items.append((param, grad))
         self.size += grad.numel() * grad.element_size()
@@ -105,13 +178,13 @@ class GradReducer:
             return
         items, self.items, self.size = self.items, [], 0
         flat = torch.cat([g.reshape(-1) for _, g in items]) if len(items) > 1 else items[0][1].reshape(-1).clone()
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
+        work = dist.all_reduce(flat, op=self.op, group=self.group, async_op=True) if self.world > 1 else None
         self.pending.append((work, flat, items))
         self.buckets_sent += 1
 
     def reduce_inplace(self, flat):
-        """Starts the (asynchronous) sum of a contiguous gradient range over the ranks, in place; ``wait_all`` turns sums into means."""
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
+        """Starts the (asynchronous) mean of a contiguous gradient range over the ranks, in place; complete after ``wait_all``."""
+        work = dist.all_reduce(flat, op=self.op, group=self.group, async_op=True) if self.world > 1 else None
         self.inplace.append((work, flat))
         self.buckets_sent += 1
 
@@ -119,7 +192,8 @@ class GradReducer:
         for work, flat in self.inplace:
             if work is not None:
                 work.wait()
-                flat.div_(self.world)
+                if not self.avg:
+                    flat.div_(self.world)
         self.inplace = []
 
     def finish(self):
@@ -128,13 +202,40 @@ class GradReducer:
         for work, flat, items in self.pending:
             if work is not None:
                 work.wait()
-                flat.div_(self.world)
+                if not self.avg:
+                    flat.div_(self.world)
             o = 0
             for p, g in items:
                 out[p] = flat[o:o + g.numel()].view(g.shape)
                 o += g.numel()
         self.pending = []
         return out
+
+
+def comm_info(device="cpu"):
+    """What the COMMUNICATOR says about the job (not the environment): the number of ranks that took part in an all-reduce of ones, the
+    backend, the RCCL version it was built against, and every rank's device -- bench.py prints it so that an N-GPU line proves N ranks."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"nranks": 1, "backend": None}
+    one = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    info = {"nranks": int(round(float(one.item()))), "backend": dist.get_backend(), "world_size": dist.get_world_size()}
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        try:
+            v = torch.cuda.nccl.version()
+            info["version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+        except Exception as e:          # noqa: BLE001 -- informational only
+            info["version"] = "unavailable (%s)" % type(e).__name__
+        pr = torch.cuda.get_device_properties(dev)
+        ident = "%s|%s" % (pr.name, getattr(pr, "pci_bus_id", getattr(pr, "uuid", dev.index)))
+        code = torch.zeros(64, dtype=torch.uint8, device=dev)
+        raw = ident.encode()[:64]
+        code[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+        out = [torch.zeros_like(code) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, code)
+        info["devices"] = [bytes(o.cpu().tolist()).rstrip(b"\0").decode(errors="replace") for o in out]
+    return info
 
 
 def shutdown():

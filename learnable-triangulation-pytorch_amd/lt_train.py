@@ -172,6 +172,10 @@ class TrainTape:
             idx = wt(idx).contiguous()
         if self.mixed:
             residual = kw.pop("residual", None)
+            if residual is not None and (kw.get("relu") or kw.get("relu_pre")):
+                # the bf16 kernel's epilogue would apply the activation BEFORE the separate fp32 residual add below: relu(v) + res, not
+                # relu(v + res).  No layer of these networks takes this path (the residual convolutions carry BatchNorm); refuse it loudly.
+                raise NotImplementedError("mixed precision: a BatchNorm-less convolution with both an activation and a residual")
             x16 = self._bf16_of(x)
             spec_idx = E.make_conv_spec(idx, None, None, x16.shape, kw.get("stride", 1), kw.get("pad", 0), torch.bfloat16, kw.get("transposed", False), 0,
                                         kw.get("output_padding", 0))
@@ -512,30 +516,51 @@ class Adam:
     def step(self):
         lib = H.lib()
         self.steps += 1
-        batches = {}          # (betas, eps, weight decay, device) -> jobs
+        batches = {}          # (betas, eps, weight decay, device, the parameters' own step count) -> jobs
         touched = []
+        fresh = []            # parameters seen for the first time: their moments come out of ONE zero-filled allocation
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None or not p.requires_grad:
                     continue
                 if p.device.type != "cuda" or p.dtype != torch.float32:
                     raise RuntimeError("lt_train.Adam updates fp32 parameters on the GPU")
-                st = self.state.get(p)
-                if st is None:
-                    st = self.state[p] = {"m": torch.zeros_like(p, memory_format=torch.contiguous_format), "v": torch.zeros_like(p, memory_format=torch.contiguous_format)}
+                if not p.is_contiguous():
+                    raise RuntimeError("lt_train.Adam updates parameters in place through their data pointer: a non-contiguous parameter "
+                                       "(shape %s, strides %s) is not supported" % (tuple(p.shape), p.stride()))
+                if p not in self.state:
+                    fresh.append(p)
+        for dev in {p.device for p in fresh}:
+            ps = [p for p in fresh if p.device == dev]
+            flat = torch.zeros(2 * sum((p.numel() + 3) // 4 * 4 for p in ps), dtype=torch.float32, device=dev)
+            o = 0
+            for p in ps:
+                n, npad = p.numel(), (p.numel() + 3) // 4 * 4
+                self.state[p] = {"m": flat[o:o + n].view(p.shape), "v": flat[o + npad:o + npad + n].view(p.shape), "step": 0}
+                o += 2 * npad
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None or not p.requires_grad:
+                    continue
+                st = self.state[p]
+                st["step"] += 1           # torch.optim.Adam's bias correction uses the PARAMETER's own step count (a parameter whose first
+                                          # gradient arrives later -- an unfrozen layer -- starts its correction there)
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                key = (float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), p.device)
+                key = (float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), p.device, st["step"])
                 batches.setdefault(key, []).append((p, grad, st, float(g["lr"])))
                 touched.append(p)
-        for (b1, b2, eps, wd, dev), items in batches.items():
+        self._tables_used = []
+        for (b1, b2, eps, wd, dev, pstep), items in batches.items():
             tab = np.zeros(len(items), dtype=self.JOB)
             fb = 0
             for i, (p, grad, st, lr_) in enumerate(items):
                 tab[i] = (p.data_ptr(), grad.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(), lr_, fb)
                 fb += (p.numel() + 1023) // 1024
-            slot = self._tables.get((dev, len(items)))
+            tkey = (dev, len(items), len(self._tables_used))          # one staging slot per launch of this step() (several step-count groups may share a size)
+            self._tables_used.append(tkey)
+            slot = self._tables.get(tkey)
             if slot is None:
-                slot = self._tables[(dev, len(items))] = (torch.empty(tab.nbytes, dtype=torch.uint8).pin_memory(), torch.empty(tab.nbytes, dtype=torch.uint8, device=dev),
+                slot = self._tables[tkey] = (torch.empty(tab.nbytes, dtype=torch.uint8).pin_memory(), torch.empty(tab.nbytes, dtype=torch.uint8, device=dev),
                                                           torch.cuda.Event())
             host, devt, ev = slot
             ev.synchronize()                       # the previous step's upload of this table has been consumed
@@ -543,7 +568,7 @@ class Adam:
             with torch.cuda.device(dev):
                 devt.copy_(host, non_blocking=True)
                 ev.record()
-                H.check(lib.lt_adam_step_multi(devt.data_ptr(), len(items), fb, b1, b2, eps, wd, self.steps, torch.cuda.current_stream(dev).cuda_stream),
+                H.check(lib.lt_adam_step_multi(devt.data_ptr(), len(items), fb, b1, b2, eps, wd, pstep, torch.cuda.current_stream(dev).cuda_stream),
                         "lt_adam_step_multi")
         for p in touched:          # version counters: cached inference plans see that the weights have changed
             torch.autograd.graph.increment_version(p)

@@ -42,20 +42,26 @@ def worker_init_fn(worker_id):
     np.random.seed(np.random.get_state()[1][0] + worker_id)
 
 
+STAGE_RING = 3          # pinned staging blocks per shape: prepare_batch of batch i+1, i+2 may fill while batch i's H2D copy is still queued
 _staging = {}
 
 
 def _pinned(shape, dtype):
+    """Next slot of the pinned staging ring for this shape: [tensor, event of the last H2D copy that read it].  The caller waits for that
+    event before overwriting the block (a loop that never synchronises -- inference without a loss.item() -- would otherwise hand batch
+    i+1's pixels to batch i's queued copy) and records a new one behind its own copy.  Same hazard handling as the geometry ring of
+    VolumetricTriangulationNet (GEO_RING) and the job table of lt_train.Adam."""
     key = (tuple(shape), dtype)
-    buf = _staging.get(key)
-    if buf is None:
+    ring = _staging.get(key)
+    if ring is None:
         if len(_staging) > 4:
             _staging.clear()
-        buf = torch.empty(shape, dtype=dtype)
-        if torch.cuda.is_available():
-            buf = buf.pin_memory()
-        _staging[key] = buf
-    return buf
+        pin = torch.cuda.is_available()
+        ring = _staging[key] = {"slots": [[torch.empty(shape, dtype=dtype).pin_memory() if pin else torch.empty(shape, dtype=dtype), None]
+                                          for _ in range(STAGE_RING)], "next": 0}
+    slot = ring["slots"][ring["next"]]
+    ring["next"] = (ring["next"] + 1) % STAGE_RING
+    return slot
 
 
 def prepare_batch(batch, device, config=None, is_train=True):
@@ -64,9 +70,14 @@ def prepare_batch(batch, device, config=None, is_train=True):
     device = torch.device(device)
     images = np.asarray(batch["images"])                     # (B, NV, H, W, 3), any real dtype
     if device.type == "cuda":
-        stage = _pinned(images.shape, torch.float32)
+        slot = _pinned(images.shape, torch.float32)
+        stage, ev = slot
+        if ev is not None:
+            ev.synchronize()                                          # the H2D copy that last read this block (STAGE_RING batches ago) has completed
         stage.copy_(torch.from_numpy(np.ascontiguousarray(images)))   # dtype conversion on the way into the pinned block
         dev = stage.to(device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(device))
     else:
         dev = torch.from_numpy(np.ascontiguousarray(images)).float()
     images_batch = dev.permute(0, 1, 4, 2, 3).contiguous()   # BxNVxHxWxC -> BxNVxCxHxW (reference img.py:95-98 per view)

@@ -16,7 +16,7 @@ class KeypointsMSELoss(nn.Module):
     def forward(self, keypoints_pred, keypoints_gt, keypoints_binary_validity):
         dimension = keypoints_pred.shape[-1]
         loss = torch.sum((keypoints_gt - keypoints_pred) ** 2 * keypoints_binary_validity)
-        return loss / (dimension * max(1, torch.sum(keypoints_binary_validity).item()))
+        return loss / (dimension * torch.clamp(torch.sum(keypoints_binary_validity), min=1))
 
 
 class KeypointsMSESmoothLoss(nn.Module):
@@ -28,20 +28,20 @@ class KeypointsMSESmoothLoss(nn.Module):
         dimension = keypoints_pred.shape[-1]
         diff = (keypoints_gt - keypoints_pred) ** 2 * keypoints_binary_validity
         diff = torch.where(diff > self.threshold, torch.pow(diff.clamp(min=1e-30), 0.1) * (self.threshold ** 0.9), diff)
-        return torch.sum(diff) / (dimension * max(1, torch.sum(keypoints_binary_validity).item()))
+        return torch.sum(diff) / (dimension * torch.clamp(torch.sum(keypoints_binary_validity), min=1))
 
 
 class KeypointsMAELoss(nn.Module):
     def forward(self, keypoints_pred, keypoints_gt, keypoints_binary_validity):
         dimension = keypoints_pred.shape[-1]
         loss = torch.sum(torch.abs(keypoints_gt - keypoints_pred) * keypoints_binary_validity)
-        return loss / (dimension * max(1, torch.sum(keypoints_binary_validity).item()))
+        return loss / (dimension * torch.clamp(torch.sum(keypoints_binary_validity), min=1))
 
 
 class KeypointsL2Loss(nn.Module):
     def forward(self, keypoints_pred, keypoints_gt, keypoints_binary_validity):
         loss = torch.sum(torch.sqrt(torch.sum((keypoints_gt - keypoints_pred) ** 2 * keypoints_binary_validity, dim=2)))
-        return loss / max(1, torch.sum(keypoints_binary_validity).item())
+        return loss / torch.clamp(torch.sum(keypoints_binary_validity), min=1)
 
 
 class _VolumetricCEFn(torch.autograd.Function):

@@ -130,7 +130,8 @@ class _VolTrainPlan:
         else:
             tape.replay(tape.fwd_ops, self.n_front)
         self.step_id += 1
-        feats_out = self.feats.t.reshape(B, NV, h, w, 32).permute(0, 1, 4, 2, 3).clone()
+        feats_out = torch.empty(B, NV, 32, h, w, dtype=torch.float32, device=device)          # the returned features, contiguous like the reference's
+        H.check(lib.lt_nhwc_to_nchw_f32(H.LT_F32, self.feats.t.data_ptr(), feats_out.data_ptr(), B * NV, 32, h * w, 32, st), "lt_nhwc_to_nchw_f32")
         base_points = self.geo[o_cen:o_rot].reshape(B, 3).clone()
         return self.kp.clone(), self.probs.clone(), feats_out, self.coords.clone(), base_points, position, sides
 
@@ -289,6 +290,12 @@ class VolumetricTriangulationNet(_PlannedNet):
         mult, sm = float(self.volume_multiplier), int(bool(self.volume_softmax))
         cl = int(logits.t.is_contiguous())   # channels-last rows of J floats, or planar (N, J, V, V, V) storage (bf16 pwchain tail)
         assert cl or logits.t.permute(0, 4, 1, 2, 3).is_contiguous()
+        # tail op: the RETURNED features (B, NV, 32, h, w) fp32, contiguous like the reference's (triangulation.py:346,355) -- one liblt_hip layout
+        # launch from the plan's channels-last map straight into the tensor forward() hands out (it was a permuted view + an ATen cast copy);
+        # skipped when the caller asked for views of the plan's buffers (copy_outputs = False)
+        b.custom(lambda st, outs=None: None if not outs or len(outs) < 3 or outs[2] is None else H.check(lib.lt_nhwc_to_nchw_f32(
+                     b.code, feats.t.data_ptr(), outs[2].data_ptr(), B * NV, 32, h * w, 32, st), "lt_nhwc_to_nchw_f32"),
+                 "features_out", nbytes=B * NV * h * w * 32 * (esz + 4), info={"feats": feats}, tail=True)
         # tail op (outside the captured graph): forward() points it at the tensors it returns, so the 17 x 64^3 probabilities
         # are written once, where the caller gets them, instead of being cloned out of a plan buffer (0.45 ms of copies per step)
         b.custom(lambda st, outs=None: H.check(lib.lt_softargmax3d_fwd(
@@ -391,6 +398,14 @@ class VolumetricTriangulationNet(_PlannedNet):
                tuple(p.requires_grad for p in params), id(getattr(self, "grad_reducer", None)), getattr(self, "train_precision", "fp32"))
         if getattr(self, "train_precision", "fp32") not in ("fp32", "bf16"):
             raise ValueError("train_precision must be 'fp32' (the reference's precision) or 'bf16' (bf16 MFMA convolutions, fp32 everything else)")
+        red = getattr(self, "grad_reducer", None)
+        if red is not None:
+            # DistributedDataParallel's semantics (reference train.py:453): rank 0's parameters and buffers at "construction" (here: the
+            # first training forward with this reducer, unless the caller has attached it already), rank 0's buffers at every forward
+            if not red.attached:
+                red.attach(self)
+            else:
+                red.sync_buffers()
         plans = self.__dict__.setdefault("_train_plans", OrderedDict())
         plan = plans.get(key)
         if plan is None:
@@ -399,9 +414,14 @@ class VolumetricTriangulationNet(_PlannedNet):
             plan = plans[key] = _VolTrainPlan(self, B, NV, images.shape[3], images.shape[4], images.device)
         plans.move_to_end(key)
         kp, probs, feats, coords, base_points = _VolTrainFn.apply(plan, images, batch, *params)
-        with torch.no_grad():
-            for c in bns:
-                c.num_batches_tracked += 1
+        # every BatchNorm's num_batches_tracked += 1 (what nn.BatchNorm does in train()): ONE liblt_hip launch over a table of the counters'
+        # addresses (209 one-element torch kernels per step before); the table is rebuilt only when a buffer has moved
+        nbt = [c.num_batches_tracked for c in bns]
+        tab_key = tuple(t.data_ptr() for t in nbt)
+        tab = self.__dict__.get("_nbt_table")
+        if tab is None or tab[0] != tab_key:
+            tab = self.__dict__["_nbt_table"] = (tab_key, torch.tensor(tab_key, dtype=torch.int64).to(images.device))
+        H.check(H.lib().lt_add_i64_multi(tab[1].data_ptr(), len(nbt), 1, torch.cuda.current_stream(images.device).cuda_stream), "lt_add_i64_multi")
         position, sides = self.__dict__.pop("_train_extra")
         cuboids = [volumetric.Cuboid3D(position[i], sides) for i in range(images.shape[0])]
         return kp, feats, probs, None, cuboids, coords, base_points
@@ -448,18 +468,18 @@ class VolumetricTriangulationNet(_PlannedNet):
                 plan.capture(st)
                 P["captured"] = True
             kp, probs, coords = P["kp"], P["probs"], P["coords"]
-            if self.copy_outputs:       # fresh result tensors like the reference's: the soft-argmax writes them directly
+            if self.copy_outputs:       # fresh result tensors like the reference's: the tail ops write them directly
                 kp, probs = torch.empty_like(kp), torch.empty_like(probs)
-                plan.run(st, (kp, probs))
+                feats = torch.empty(B, NV, 32, h, w, dtype=torch.float32, device=device)
+                plan.run(st, (kp, probs, feats))
             else:
                 plan.run(st)
-            feats = P["feats"].t.reshape(B, NV, h, w, 32).permute(0, 1, 4, 2, 3)
+                feats = P["feats"].t.reshape(B, NV, h, w, 32).permute(0, 1, 4, 2, 3)
             conf = P["conf"]
             o_pos, o_cen, o_rot = P["offs"]
             base_points = P["geo"][o_cen:o_rot].reshape(B, 3).clone()    # fp32(base), from the block that was just copied in
             if self.copy_outputs:
                 coords = coords.clone()
-                feats = feats.to(torch.float32, copy=True)
                 conf = None if conf is None else conf.clone()
             if conf is not None and self.volume_aggregation_method == "conf_norm":
                 conf = conf / conf.sum(dim=1, keepdim=True)   # the RETURNED confidences are the normalised ones (reference :268-269, :355)

@@ -106,6 +106,8 @@ def run_plan_on_cpu(plan):
                 conf = conf / conf.sum(dim=1, keepdim=True)
             out = O.unproject_heatmaps(hm, P, info["coords"], "conf" if agg.startswith("conf") else agg, conf)
             info["vol"].t.copy_(out.permute(0, 2, 3, 4, 1))
+        elif kind == "features_out":  # layout launch into the caller's tensor: nothing to interpret (the tests read info["feats"] of the unprojection)
+            pass
         elif kind == "softargmax3d":
             lg = info["logits"].t.float().permute(0, 4, 1, 2, 3) * info["mult"]
             kp, pr = O.integrate_tensor_3d_with_coordinates(lg, info["coords"], bool(info["softmax"]))

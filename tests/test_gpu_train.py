@@ -438,7 +438,7 @@ def _dp_grads(rank, reducer):
     return out
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, backend="gloo", own_device=False):
     import sys
     for p in (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "learnable-triangulation-pytorch_amd"),
               os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))):
@@ -446,26 +446,29 @@ def _dp_worker(rank, world, port, q):
             sys.path.insert(0, p)
     os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import lt_dist
-    lt_dist.init("gloo")           # one GPU on the box: both ranks share cuda:0, the exchange goes through gloo (RCCL needs a GPU per rank)
-    torch.cuda.set_device(0)
+    # one GPU on the box: both ranks share cuda:0, the exchange goes through gloo (RCCL needs a GPU per rank); with a GPU per rank
+    # (own_device) the backend is "nccl" = RCCL over xGMI and the model lives on the rank's own device
+    global DEV
+    if own_device:
+        os.environ["LOCAL_RANK"] = str(rank)
+        DEV = "cuda:%d" % rank
+    lt_dist.init(backend)
+    torch.cuda.set_device(rank if own_device else 0)
     red = lt_dist.GradReducer(bucket_bytes=4 << 20)
     g = _dp_grads(rank, red)
     q.put((rank, {it: {n: (float(np.linalg.norm(v.astype(np.float64))), v.reshape(-1)[::max(1, v.size // 64)][:64].copy()) for n, v in gi.items()} for it, gi in g.items()},
-           red.buckets_sent))
+           red.buckets_sent, lt_dist.comm_info(DEV)))
     lt_dist.barrier()
     lt_dist.shutdown()
 
 
-def test_data_parallel_two_ranks_gradient_mean():
-    """Data-parallel training (train.py:450-453): two ranks, each with its own samples, gradients averaged by lt_dist.GradReducer from
-    inside the recorded backward (bucket by bucket) -- equal to the mean of the two shards' single-process gradients, in the recording
-    step and in the replayed one."""
+def _two_rank_gradient_mean(backend, own_device, tag):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, backend, own_device)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
@@ -474,7 +477,30 @@ def test_data_parallel_two_ranks_gradient_mean():
         assert p.exitcode == 0
     single = [_dp_grads(r, None)[0] for r in range(2)]
     worst = 0.0
-    for rank, res, nb in got:
+    for rank, res, nb, info in got:
+        assert info["nranks"] == 2 and info["backend"] == backend, info
+        if own_device:
+            assert len(set(info["devices"])) == 2, info          # two different GPUs took part in the all-reduce
+    return _check_two_rank_gradients(got, single, tag)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_data_parallel_two_ranks_rccl():
+    """The N > 1 path on real hardware: two ranks, a GPU each, backend "nccl" (= RCCL over xGMI); construction-time broadcast, bucketed
+    ReduceOp.AVG all-reduce from inside the recorded backward.  Auto-skips on the 1-GPU boxes."""
+    _two_rank_gradient_mean("nccl", True, "train/data parallel 2 ranks over RCCL: averaged gradients vs mean of the shards' gradients")
+
+
+def test_data_parallel_two_ranks_gradient_mean():
+    """Data-parallel training (train.py:450-453): two ranks, each with its own samples, gradients averaged by lt_dist.GradReducer from
+    inside the recorded backward (bucket by bucket) -- equal to the mean of the two shards' single-process gradients, in the recording
+    step and in the replayed one."""
+    _two_rank_gradient_mean("gloo", False, "train/data parallel 2 ranks: averaged gradients vs mean of the shards' gradients")
+
+
+def _check_two_rank_gradients(got, single, tag):
+    worst = 0.0
+    for rank, res, nb, info in got:
         assert nb >= 4, nb          # several buckets per backward, two backwards
         for it in (0, 1):
             for n, (norm, sample) in res[it].items():
@@ -484,7 +510,7 @@ def test_data_parallel_two_ranks_gradient_mean():
                 if ZERO_GRAD.search(n):
                     continue
                 worst = max(worst, float(np.abs(sample - ws).max()) / scale, abs(norm - float(np.linalg.norm(want))) / max(float(np.linalg.norm(want)), 1e-12))
-    record("train/data parallel 2 ranks: averaged gradients vs mean of the shards' gradients", {"err": worst, "tol": 2e-3})
+    record(tag, {"err": worst, "tol": 2e-3})
     assert worst <= 2e-3, worst
 
 
@@ -506,12 +532,15 @@ t = torch.arange(1024, dtype=torch.float32, device="cuda:0")
 dist.all_reduce(t)
 dist.barrier()
 red = lt_dist.GradReducer(bucket_bytes=1 << 12)
-red.world = 2                      # force the collective path (sum over the one rank, then / 2)
+assert red.avg and red.backend == "nccl"      # RCCL averages inside the collective (ReduceOp.AVG): no division kernel per bucket
+red.world = 2                      # force the collective path (the mean over the one rank that exists)
 flat = torch.ones(4096, device="cuda:0")
 red.reduce_inplace(flat[:2048]); red.reduce_inplace(flat[2048:]); red.wait_all()
 torch.cuda.synchronize()
-assert float(t[5]) == 5.0 and float(flat.sum()) == 2048.0, (float(t[5]), float(flat.sum()))
-print("RCCL_OK", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else "")
+assert float(t[5]) == 5.0 and float(flat.sum()) == 4096.0, (float(t[5]), float(flat.sum()))
+info = lt_dist.comm_info("cuda:0")
+assert info["nranks"] == 1 and info["backend"] == "nccl" and len(info["devices"]) == 1, info
+print("RCCL_OK", info)
 dist.destroy_process_group()
 '''
     import socket
@@ -521,6 +550,64 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
     record("dist/RCCL single-rank process group (backend nccl) on the GPU box", r.stdout.strip().splitlines()[-1])
+
+
+def test_real_ddp_wrapper_world1_nccl():
+    """torch.nn.parallel.DistributedDataParallel (the reference's wrapper, train.py:453) around VolumetricTriangulationNet WORKS: the
+    training forward is one autograd node over the parameters, so DDP's gradient hooks see ordinary .grad accumulation.  World of one rank
+    on backend "nccl" (the box has one GPU); gradients equal the unwrapped model's."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+root = os.environ["LT_ROOT"]
+for p in (os.path.join(root, "learnable-triangulation-pytorch_amd"), root, os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["LT_PORT"])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="env://", world_size=1, rank=0)
+from oracle import spec, synth
+from mvn.models import loss as L
+from mvn.models.triangulation import VolumetricTriangulationNet
+from test_gpu_models import _cameras
+cfg = synth.vol_config(18, 32, "softmax", 1.0, "mpii")
+sd = synth.make_state_dict(spec.vol_net_spec(18, 17, False), seed=12, sharpen=60.0, basic_block=True)
+inp = synth.make_inputs(2, 3, 128, seed=30, inside=False)
+batch = {"cameras": _cameras(inp, 2), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+gt = torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float().cuda()
+val = torch.ones(2, 17, 1, device="cuda:0")
+def grads(wrap):
+    m = VolumetricTriangulationNet(cfg, device="cuda:0")
+    m.load_state_dict(sd, strict=True)
+    m.to("cuda:0").train()
+    net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0]) if wrap else m
+    out = None
+    for it in range(2):
+        np.random.seed(77)
+        kp, _, vols, _, _, cvs, _ = net(inp["images"].cuda(), None, batch)
+        loss = L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val) + 0.01 * L.VolumetricCELoss()(cvs, vols, gt, val)
+        for p in m.parameters():
+            p.grad = None
+        loss.backward()
+        torch.cuda.synchronize()
+        out = {n: p.grad.detach().double().cpu() for n, p in m.named_parameters() if p.grad is not None}
+    return out, float(loss)
+a, la = grads(False)
+b, lb = grads(True)
+assert set(a) == set(b) and len(a) > 50
+worst = max(float((a[n] - b[n]).abs().max() / max(float(a[n].abs().max()), 1e-12)) for n in a if float(a[n].abs().max()) > 0)
+print("DDP_OK", worst, la, lb)
+assert worst <= 2e-3 and abs(la - lb) <= 1e-4 * abs(la)
+dist.destroy_process_group()
+'''
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LT_ROOT=root, LT_PORT=str(port))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DDP_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+    record("dist/real DistributedDataParallel wrapper (world 1, backend nccl): gradients vs the unwrapped model", r.stdout.strip().splitlines()[-1])
 
 
 def test_training_api_semantics_accumulation_stale_backward_torch_optimizer():

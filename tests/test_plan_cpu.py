@@ -55,8 +55,8 @@ def test_recorded_plan_matches_oracle(nl, method, kind, Himg):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_plan_structure_pre_graph_tail(dt):
-    """What is captured into the hipGraph and what stays outside: the soft-argmax is the plan's only tail op (it writes the tensors
-    forward() returns); bf16 plans fuse the stem (one 'stem' op instead of conv + max pool) and chain the V2V tail; a dry-run plan
+    """What is captured into the hipGraph and what stays outside: the tail ops write the tensors forward() returns (the fp32 features by a layout
+    launch, joints and probabilities by the soft-argmax); bf16 plans fuse the stem (one 'stem' op instead of conv + max pool) and chain the V2V tail; a dry-run plan
     records no pre op (its interpreter reads the layout buffer, not the caller's images)."""
     from mvn.models.triangulation import VolumetricTriangulationNet
     cfg = synth.vol_config(18, 32, "softmax")     # 32^3 is the smallest cube V2V's five poolings accept
@@ -67,7 +67,7 @@ def test_plan_structure_pre_graph_tail(dt):
     plan = P["plan"]
     kinds = [meta["kind"] for _, meta in plan.ops]
     assert plan.npre == 0 and P["image_cell"] is None
-    assert plan.nhead == len(plan.ops) - 1 and kinds[-1] == "softargmax3d" and kinds.count("softargmax3d") == 1
+    assert plan.nhead == len(plan.ops) - 2 and kinds[-2:] == ["features_out", "softargmax3d"] and kinds.count("softargmax3d") == 1
     if dt == torch.bfloat16:
         assert kinds[0] == "stem" and kinds.count("pwchain") == 1 and kinds.count("maxpool") == 5   # the five 3D pools of V2V
     else:
