@@ -207,11 +207,14 @@ int lt_softargmax2d_fwd(const float* heatmaps, float mult, int32_t softmax, floa
  * (mvn/models/loss.py:52-80; the reference walks samples and joints in Python with a .cpu() per sample), and the
  * batch statistics of training-mode BatchNorm.  All gradients are fp32.
  *
- * lt_unproject_bwd: grad_out B,nvox,C (channels-last, fp32) -> grad_feats B,NV,h,w,C fp32 (MUST be zeroed by the caller; the
- *   bilinear scatter uses atomics, so the summation order -- not the result beyond fp32 rounding -- varies between runs),
- *   grad_conf B,NV,C (zeroed) or NULL.  Autograd semantics of op.py:113-162: nothing flows to the grid / projections;
- *   depth <= 0 samples pass no gradient but their zero takes part in the view softmax, d out/d x_v = w_v (1 + x_v - out);
- *   'max': the first maximal view; LT_AGG_CONF: g * conf_v (conf_norm: normalise outside).  NV <= 8, C % 4 == 0.
+ * lt_unproject_bwd: grad_out B,v0,v1,v2,C (channels-last, fp32; the coordinate volume's grid shape) -> grad_feats B,NV,h,w,C fp32 (written
+ *   completely, no pre-zeroing), grad_conf B,NV,C or NULL.  Autograd semantics of op.py:113-162: nothing flows to the grid / projections;
+ *   depth <= 0 samples pass no gradient but their zero takes part in the view softmax, d out/d x_v = w_v (1 + x_v - out); 'max': the first
+ *   maximal view; LT_AGG_CONF: g * conf_v and grad_conf_v = sum over voxels of g * x_v; LT_AGG_CONF_NORM: conf is the RAW head output,
+ *   normalised over the views as in the forward (triangulation.py:268-269), grad_conf is the gradient of the raw values.  NV <= 8,
+ *   C % 4 == 0.  A deterministic GATHER (bitwise repeatable; no global atomics): workspace from lt_unproject_bwd_workspace (bytes for the
+ *   whole batch; with less -- at least one sample's share -- the batch is walked in chunks).  C > 64 or not a power of two (and
+ *   LT_UNPROJ_BWD_ATOMICS=1): the round-2 scatter by float atomics (no workspace, not repeatable, no conf_norm).
  * lt_softargmax3d_bwd: probs B,J,nvox and kp B,J,3 are the forward's outputs; grad_kp B,J,3; an optional SPARSE gradient on the
  *   returned probabilities (one voxel per (b,j): gp_idx / gp_val, what lt_volumetric_ce_fwd produces) -> grad_logits
  *   (planar B,J,nvox, or channels-last B,nvox,J when channels_last != 0):  mult * p_i * (a_i - sum_j p_j a_j), a_i = g_kp . X_i + gp_i.
@@ -220,9 +223,10 @@ int lt_softargmax2d_fwd(const float* heatmaps, float mult, int32_t softmax, floa
  * lt_bn_stats_fwd: x rows x C channels-last -> per-channel mean and BIASED variance (fp64 accumulation); running statistics
  *   (may be NULL) are updated the way torch does: (1 - momentum) * running + momentum * stat, variance unbiased.
  * -------------------------------------------------------------------------------------------*/
+size_t lt_unproject_bwd_workspace(int32_t B, int32_t NV, int32_t C, int32_t v0, int32_t v1, int32_t v2);
 int lt_unproject_bwd(int32_t dtype, const void* feats, const float* proj, const float* coords, const float* conf, const float* grad_out,
-                     float* grad_feats, float* grad_conf, int32_t B, int32_t NV, int32_t C, int32_t h, int32_t w, int64_t nvox,
-                     int32_t agg, void* stream);
+                     float* grad_feats, float* grad_conf, int32_t B, int32_t NV, int32_t C, int32_t h, int32_t w, int32_t v0, int32_t v1,
+                     int32_t v2, int32_t agg, void* workspace, size_t workspace_bytes, void* stream);
 int lt_softargmax3d_bwd(const float* probs, const float* coords, const float* kp, const float* grad_kp, const int32_t* gp_idx,
                         const float* gp_val, float multiplier, int32_t softmax, int32_t channels_last, float* grad_logits, int32_t B,
                         int32_t J, int64_t nvox, void* stream);
@@ -239,9 +243,10 @@ int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32_t C, float
  *   from lt_bn_stats_fwd (batch statistics).  C % 4 == 0.
  * lt_bn_act_bwd : its autograd: g = dz * relu mask; dbeta = sum g; dgamma = sum g x^; dy = gamma invstd (g - dbeta/n - x^ dgamma/n);
  *   dres (may be NULL) = the residual input's gradient, added to the buffer when accumulate_res.  workspace: lt_bn_act_bwd_workspace.
- * lt_act_bwd    : layers without BatchNorm: dy = dz * mask(z, residual, flags) (+ dres).
+ * lt_act_bwd    : layers without BatchNorm: dy = dz * mask(z, residual, flags) (+ dres); LT_EPI_SIGMOID: dy = dz * z * (1 - z).
  * lt_channel_sum: out[c] (+)= sum over rows of x[row][c] (bias gradients), fp64 accumulation.
- * lt_maxpool_bwd: dx (pre-zeroed / accumulated) += dy at the first maximal element of every window (atomics).
+ * lt_maxpool_bwd: dx (pre-zeroed / accumulated) += dy at the first maximal element of every window; overlapping windows (k > s) are walked in
+ *   ceil(k / s)^3 classes of mutually disjoint windows, one launch each: no atomics, bitwise repeatable.
  * lt_conv_wgrad : dw[co][tap * Cin + ci] (=|+=) sum_m dy[m][co] * x[m @ tap][ci] over the GEMM rows m = (n, od, oh, ow) of the forward
  *   convolution described by (N, D, H, W, Cin, Do, Ho, Wo, stride, pad, taps); exact-fp32 MFMA, no atomics (the pixel range is cut into
  *   slabs whose partial sums are added in a fixed order: workspace of lt_conv_wgrad_workspace(rows = N*Do*Ho*Wo, cout_pad, k_pad) bytes,
@@ -277,6 +282,8 @@ int lt_zero(void* p, int64_t nbytes, void* stream);
 /* *ptrs[i] += delta for n int64 scalars in device memory (ptrs: device array of n pointers): BatchNorm's num_batches_tracked counters of a
  * whole network in one launch (torch: one `num_batches_tracked += 1` kernel per layer, pose_resnet.py / v2v.py BatchNorm modules in train()) */
 int lt_add_i64_multi(const void* ptrs, int32_t n, int64_t delta, void* stream);
+/* backward of lt_global_avgpool (GlobalAveragePoolingHead's mean over the map, pose_resnet.py:166-168): dx[n][p][c] (=|+=) dy[n][c] / HW */
+int lt_global_avgpool_bwd(const float* dy, float* dx, int32_t N, int32_t HW, int32_t C, int32_t accumulate, void* stream);
 /* fp32 -> bf16, round to nearest even (operands of the mixed-precision training convolutions); 16-byte aligned pointers */
 int lt_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* many gathers in one launch.  jobs (device memory): njobs records of

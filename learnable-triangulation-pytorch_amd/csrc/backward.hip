@@ -1,165 +1,15 @@
 // Backward kernels of the non-convolution ops of the volumetric path and the training-mode BatchNorm statistics
 // (BASELINE config 5): what torch.autograd derives for the reference from
-//   op.unproject_heatmaps (mvn/utils/op.py:99-166)            -> lt_unproject_bwd
+//   op.unproject_heatmaps (mvn/utils/op.py:99-166)            -> lt_unproject_bwd (csrc/unproject_bwd.hip)
 //   op.integrate_tensor_3d_with_coordinates (op.py:84-96)      -> lt_softargmax3d_bwd
 //   VolumetricCELoss (mvn/models/loss.py:52-80)                -> lt_volumetric_ce_fwd (+ its sparse gradient, consumed by lt_softargmax3d_bwd)
 //   nn.BatchNorm{2,3}d in training mode (batch statistics)     -> lt_bn_stats_fwd
 // Gradients are fp32.  Layouts are the forward's: channels-last feature maps / volumes, planar probabilities (B, J, V^3).
-//
-// Unprojection backward (autograd semantics of op.py:113-162): no gradient flows to the grid / projection / coordinates (none
-// requires grad); grid_sample's backward scatters wt_tap * g into the four taps of feat[b, v, c]; a sample with depth <= 0 is
-// zeroed IN PLACE after sampling (op.py:141), so it passes no gradient back but its 0 still enters the view softmax;
-// softmax aggregation out = sum_v w_v x_v, w = softmax_v(x):  d out / d x_v = w_v (1 + x_v - out).
-// The scatter is HBM/L2-atomic bound: NV x 4 taps x C fp32 atomics per voxel into maps that stay L2-resident
-// (4.7 MB per sample at config 2); one lane per (voxel, 4-channel vector), bricked voxel order like the forward.
 #include "colsum.h"
 
 using namespace lt;
 
 namespace {
-
-struct UnprojBwdArgs {
-    const void* feats;       // (B, NV, h, w, C) T
-    const float* proj;       // (B, NV, 3, 4)
-    const float* coords;     // (B, nvox, 3)
-    const float* conf;       // (B, NV, C) or null
-    const float* gout;       // (B, nvox, C) fp32: dL/d volume, channels-last
-    float* gfeats;           // (B, NV, h, w, C) fp32, ZEROED by the caller; accumulated with atomics
-    float* gconf;            // (B, NV, C) fp32 zeroed, or null
-    int B, NV, C, h, w, agg;
-    long long nvox;
-};
-
-struct Tap {                 // one view's projection of one voxel: four tap offsets (pixels) and weights; weight 0 = padding / masked
-    int o[4];
-    float k[4];
-};
-
-__device__ __forceinline__ Tap project_taps(const float* __restrict__ P, float X0, float X1, float X2, int h, int w) {
-    // the arithmetic of sample_view<float> in unproject.hip (IEEE divisions: this is the fp32 path)
-    const float px = __fadd_rn(fmaf(X2, P[2], fmaf(X1, P[1], __fmul_rn(X0, P[0]))), P[3]);
-    const float py = __fadd_rn(fmaf(X2, P[6], fmaf(X1, P[5], __fmul_rn(X0, P[4]))), P[7]);
-    float pz = __fadd_rn(fmaf(X2, P[10], fmaf(X1, P[9], __fmul_rn(X0, P[8]))), P[11]);
-    const bool invalid = pz <= 0.0f;
-    if (pz == 0.0f) pz = 1.0f;
-    const float u = __fdiv_rn(px, pz), v = __fdiv_rn(py, pz);
-    const float gx = __fmul_rn(2.0f, __fsub_rn(__fdiv_rn(u, (float)h), 0.5f));
-    const float gy = __fmul_rn(2.0f, __fsub_rn(__fdiv_rn(v, (float)w), 0.5f));
-    const float ix = __fmul_rn(__fadd_rn(gx, 1.0f), 0.5f * (float)(w - 1));
-    const float iy = __fmul_rn(__fadd_rn(gy, 1.0f), 0.5f * (float)(h - 1));
-    const float xw = floorf(ix), yn = floorf(iy);
-    const float we = __fsub_rn(ix, xw), ww = __fsub_rn(1.0f, we);
-    const float ws = __fsub_rn(iy, yn), wn = __fsub_rn(1.0f, ws);
-    const bool xw_ok = xw >= 0.f && xw <= (float)(w - 1), xe_ok = xw >= -1.f && xw <= (float)(w - 2);
-    const bool yn_ok = yn >= 0.f && yn <= (float)(h - 1), ys_ok = yn >= -1.f && yn <= (float)(h - 2);
-    const bool act = !invalid && (xw_ok || xe_ok) && (yn_ok || ys_ok);
-    const int x0 = act ? (int)xw : 0, y0 = act ? (int)yn : 0;
-    const int xwc = min(max(x0, 0), w - 1), xec = min(max(x0 + 1, 0), w - 1);
-    const int rn = min(max(y0, 0), h - 1) * w, rs = min(max(y0 + 1, 0), h - 1) * w;
-    Tap t;
-    t.o[0] = rn + xwc; t.o[1] = rn + xec; t.o[2] = rs + xwc; t.o[3] = rs + xec;
-    t.k[0] = (act && yn_ok && xw_ok) ? __fmul_rn(wn, ww) : 0.f;
-    t.k[1] = (act && yn_ok && xe_ok) ? __fmul_rn(wn, we) : 0.f;
-    t.k[2] = (act && ys_ok && xw_ok) ? __fmul_rn(ws, ww) : 0.f;
-    t.k[3] = (act && ys_ok && xe_ok) ? __fmul_rn(ws, we) : 0.f;
-    return t;
-}
-
-template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&f)[4]);
-template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&f)[4]) {
-    const float4 v = *(const float4*)p;
-    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-}
-template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&f)[4]) {
-    const uint2 v = *(const uint2*)p;
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-}
-
-constexpr int UB_MAXV = 8;   // views kept in registers
-
-template <typename T>
-__global__ __launch_bounds__(256) void unproject_bwd_kernel(const UnprojBwdArgs a) {
-    const int tpv = a.C >> 2;                              // lanes per voxel (4 channels each)
-    const long long items = a.nvox * tpv;
-    const int b = blockIdx.y;
-    const T* feats = (const T*)a.feats + (long long)b * a.NV * a.h * a.w * a.C;
-    float* gfeats = a.gfeats + (long long)b * a.NV * a.h * a.w * a.C;
-    const float* P = a.proj + (long long)b * a.NV * 12;
-    const float* coords = a.coords + (long long)b * a.nvox * 3;
-    const float* gout = a.gout + (long long)b * a.nvox * a.C;
-    const long long hw = (long long)a.h * a.w;
-    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < items; q += (long long)gridDim.x * 256) {
-        const long long vox = q / tpv;
-        const int c0 = (int)(q - vox * tpv) * 4;
-        const float X0 = coords[vox * 3], X1 = coords[vox * 3 + 1], X2 = coords[vox * 3 + 2];
-        float g[4];
-        ld4<float>(gout + vox * a.C + c0, g);
-        Tap tp[UB_MAXV];
-        float x[UB_MAXV][4];
-#pragma unroll
-        for (int v = 0; v < UB_MAXV; ++v) {
-            if (v < a.NV) {
-                tp[v] = project_taps(P + v * 12, X0, X1, X2, a.h, a.w);
-                const T* fm = feats + v * hw * a.C + c0;
-                float t0[4], t1[4], t2[4], t3[4];
-                ld4<T>(fm + (long long)tp[v].o[0] * a.C, t0); ld4<T>(fm + (long long)tp[v].o[1] * a.C, t1);
-                ld4<T>(fm + (long long)tp[v].o[2] * a.C, t2); ld4<T>(fm + (long long)tp[v].o[3] * a.C, t3);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[v][e] = t0[e] * tp[v].k[0] + t1[e] * tp[v].k[1] + t2[e] * tp[v].k[2] + t3[e] * tp[v].k[3];
-            }
-        }
-        // d out / d x_v per channel
-        float dx[UB_MAXV][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (a.agg == LT_AGG_SOFTMAX) {
-                float m = x[0][e];
-#pragma unroll
-                for (int v = 1; v < UB_MAXV; ++v) if (v < a.NV) m = fmaxf(m, x[v][e]);
-                float s = 0.f, tt = 0.f, ex[UB_MAXV];
-#pragma unroll
-                for (int v = 0; v < UB_MAXV; ++v) if (v < a.NV) { ex[v] = expf(x[v][e] - m); s += ex[v]; tt += x[v][e] * ex[v]; }
-                const float out = __fdiv_rn(tt, s);
-#pragma unroll
-                for (int v = 0; v < UB_MAXV; ++v) if (v < a.NV) dx[v][e] = g[e] * __fdiv_rn(ex[v], s) * (1.0f + x[v][e] - out);
-            } else if (a.agg == LT_AGG_MAX) {               // torch.max(dim): gradient to the FIRST maximal view
-                int am = 0;
-                float best = x[0][e];
-#pragma unroll
-                for (int v = 1; v < UB_MAXV; ++v) if (v < a.NV && x[v][e] > best) { best = x[v][e]; am = v; }
-#pragma unroll
-                for (int v = 0; v < UB_MAXV; ++v) if (v < a.NV) dx[v][e] = v == am ? g[e] : 0.f;
-            } else if (a.agg == LT_AGG_CONF) {
-#pragma unroll
-                for (int v = 0; v < UB_MAXV; ++v)
-                    if (v < a.NV) {
-                        const long long ci = ((long long)b * a.NV + v) * a.C + c0 + e;
-                        dx[v][e] = g[e] * a.conf[ci];
-                        if (a.gconf) atomicAdd(a.gconf + ci, g[e] * x[v][e]);
-                    }
-            } else {
-#pragma unroll
-                for (int v = 0; v < UB_MAXV; ++v) if (v < a.NV) dx[v][e] = g[e];
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < UB_MAXV; ++v) {
-            if (v < a.NV) {
-                float* gm = gfeats + v * hw * a.C + c0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float wk = tp[v].k[k];
-                    if (wk != 0.f) {
-                        float* dst = gm + (long long)tp[v].o[k] * a.C;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) atomicAdd(dst + e, wk * dx[v][e]);
-                    }
-                }
-            }
-        }
-    }
-}
 
 // ---- 3D soft-argmax backward -----------------------------------------------------------------------------------------------
 // forward: p = softmax_i(mult * l_i), kp = sum_i p_i X_i  (softmax = 0: p_i = relu(mult * l_i), no normalisation)
@@ -340,29 +190,6 @@ __global__ __launch_bounds__(256) void bn_finalize_vec_kernel(const double* __re
 }
 
 }  // namespace
-
-extern "C" int lt_unproject_bwd(int32_t dtype, const void* feats, const float* proj, const float* coords, const float* conf, const float* grad_out,
-                                float* grad_feats, float* grad_conf, int32_t B, int32_t NV, int32_t C, int32_t h, int32_t w, int64_t nvox,
-                                int32_t agg, void* stream) {
-    LT_REQUIRE(feats && proj && coords && grad_out && grad_feats, LT_ERR_INVALID, "lt_unproject_bwd: null argument");
-    LT_REQUIRE(dtype == LT_F32 || dtype == LT_BF16, LT_ERR_INVALID, "lt_unproject_bwd: bad dtype %d", dtype);
-    LT_REQUIRE(agg == LT_AGG_SUM || agg == LT_AGG_MAX || agg == LT_AGG_SOFTMAX || agg == LT_AGG_CONF, LT_ERR_UNSUPPORTED,
-               "lt_unproject_bwd: aggregation %d has no backward (conf_norm: normalise the confidences outside and pass LT_AGG_CONF)", agg);
-    LT_REQUIRE(agg != LT_AGG_CONF || conf, LT_ERR_INVALID, "lt_unproject_bwd: LT_AGG_CONF needs confidences");
-    LT_REQUIRE(B >= 1 && NV >= 1 && NV <= UB_MAXV && C >= 4 && C % 4 == 0 && h >= 2 && w >= 2 && nvox >= 1, LT_ERR_UNSUPPORTED,
-               "lt_unproject_bwd: needs 1 <= NV <= %d and C %% 4 == 0 (got NV=%d C=%d)", UB_MAXV, NV, C);
-    LT_REQUIRE((long long)NV * h * w * C < (1ll << 31), LT_ERR_UNSUPPORTED, "lt_unproject_bwd: feature maps too large");
-    UnprojBwdArgs a;
-    a.feats = feats; a.proj = proj; a.coords = coords; a.conf = conf; a.gout = grad_out; a.gfeats = grad_feats; a.gconf = grad_conf;
-    a.B = B; a.NV = NV; a.C = C; a.h = h; a.w = w; a.agg = agg; a.nvox = nvox;
-    const long long items = nvox * (C / 4);
-    const long long blocks = cdiv(items, 256);
-    dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536), (unsigned)B);
-    if (dtype == LT_F32) hipLaunchKernelGGL(unproject_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(unproject_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    LT_CHECK_LAUNCH("lt_unproject_bwd");
-    return LT_OK;
-}
 
 extern "C" int lt_softargmax3d_bwd(const float* probs, const float* coords, const float* kp, const float* grad_kp, const int32_t* gp_idx,
                                    const float* gp_val, float multiplier, int32_t softmax, int32_t channels_last, float* grad_logits, int32_t B,

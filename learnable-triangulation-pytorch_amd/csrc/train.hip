@@ -238,7 +238,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                                                       float* __restrict__ dy, float* __restrict__ dres, int flags, int accumulate_res, long long total) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         float m = 1.f;
-        if (flags & LT_EPI_RELU_POST) m = z[i] > 0.f ? 1.f : 0.f;                          // z = relu(v + res)
+        if (flags & LT_EPI_SIGMOID) m = z[i] * (1.f - z[i]);                               // z = sigmoid(v): the confidence heads' last layer
+        else if (flags & LT_EPI_RELU_POST) m = z[i] > 0.f ? 1.f : 0.f;                     // z = relu(v + res)
         else if (flags & LT_EPI_RELU_PRE) m = (z[i] - (res ? res[i] : 0.f)) > 0.f ? 1.f : 0.f;   // z = relu(v) + res
         const float g = dz[i] * m;
         dy[i] = g;
@@ -278,17 +279,22 @@ __global__ void channel_sum_finalize_kernel(const double* __restrict__ part, int
 }
 
 // max pool backward: one thread per (OUTPUT pixel, channel): finds the first maximal input of the window (scan order d, h, w like
-// ATen's CPU max_pool) and atomically adds dy there (windows overlap for k > s)
+// ATen's CPU max_pool) and adds dy there.  Windows overlap for k > s, so the outputs are walked in ceil(k / s)^3 CLASSES (output index
+// modulo ceil(k / s) per dimension), one launch each: two windows of one class never share an input, every launch adds with plain
+// read-add-write, and the order in which an input collects its (up to 4 for the stem's 3x3 / stride 2 pool) contributions is the class
+// order -- bitwise repeatable (round 2: float atomics in arbitrary order)
+struct PoolClass { int cd, ch, cw, md, mh, mw, nd, nh, nw; };      // class offset, class stride, outputs of the class per dimension
+
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int N, int D, int H, int W, int C,
-                                   int Do, int Ho, int Wo, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw) {
-    const long long total = (long long)N * Do * Ho * Wo * C;
+                                   int Do, int Ho, int Wo, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, PoolClass pc) {
+    const long long total = (long long)N * pc.nd * pc.nh * pc.nw * C;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(g % C);
         long long r = g / C;
-        const int ow = (int)(r % Wo); r /= Wo;
-        const int oh = (int)(r % Ho); r /= Ho;
-        const int od = (int)(r % Do);
-        const int n = (int)(r / Do);
+        const int ow = (int)(r % pc.nw) * pc.mw + pc.cw; r /= pc.nw;
+        const int oh = (int)(r % pc.nh) * pc.mh + pc.ch; r /= pc.nh;
+        const int od = (int)(r % pc.nd) * pc.md + pc.cd;
+        const int n = (int)(r / pc.nd);
         float best = -INFINITY;
         long long bi = -1;
         for (int a = 0; a < kd; ++a) {
@@ -306,7 +312,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
                 }
             }
         }
-        if (bi >= 0) unsafeAtomicAdd(dx + bi, dy[g]);
+        if (bi >= 0) dx[bi] += dy[((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + c];
     }
 }
 
@@ -991,10 +997,19 @@ extern "C" int lt_maxpool_bwd(const float* x, const float* dy, float* dx, int32_
     LT_REQUIRE(x && dy && dx && k && s && p, LT_ERR_INVALID, "lt_maxpool_bwd: null argument");
     const int Do = (D + 2 * p[0] - k[0]) / s[0] + 1, Ho = (H + 2 * p[1] - k[1]) / s[1] + 1, Wo = (W + 2 * p[2] - k[2]) / s[2] + 1;
     LT_REQUIRE(N >= 1 && C >= 1 && Do >= 1 && Ho >= 1 && Wo >= 1, LT_ERR_INVALID, "lt_maxpool_bwd: bad shape");
-    const long long total = (long long)N * Do * Ho * Wo * C;
-    const long long blocks = cdiv(total, 256);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, D, H, W, C, Do, Ho,
-                       Wo, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2]);
+    const int md = (int)cdiv(k[0], s[0]), mh = (int)cdiv(k[1], s[1]), mw = (int)cdiv(k[2], s[2]);
+    for (int cd = 0; cd < md && cd < Do; ++cd)
+        for (int ch = 0; ch < mh && ch < Ho; ++ch)
+            for (int cw = 0; cw < mw && cw < Wo; ++cw) {
+                PoolClass pc;
+                pc.cd = cd; pc.ch = ch; pc.cw = cw; pc.md = md; pc.mh = mh; pc.mw = mw;
+                pc.nd = (Do - cd + md - 1) / md; pc.nh = (Ho - ch + mh - 1) / mh; pc.nw = (Wo - cw + mw - 1) / mw;
+                const long long total = (long long)N * pc.nd * pc.nh * pc.nw * C;
+                const long long blocks = cdiv(total, 256);
+                hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, D, H, W, C,
+                                   Do, Ho, Wo, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2], pc);
+                LT_CHECK_LAUNCH("lt_maxpool_bwd");
+            }
     LT_CHECK_LAUNCH("lt_maxpool_bwd");
     return LT_OK;
 }
@@ -1186,10 +1201,29 @@ extern "C" int lt_pad_channels_f32(const float* src, float* dst, int64_t rows, i
     return LT_OK;
 }
 
+// d mean-over-the-map / d x: every pixel of sample n gets dy[n][c] / HW
+__global__ __launch_bounds__(256) void global_avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int HW, int C, int accumulate, long long total) {
+    const float inv = 1.f / (float)HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long np = i / C;
+        const int c = (int)(i - np * C);
+        const float g = dy[(np / HW) * C + c] * inv;
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+
 // BatchNorm's num_batches_tracked counters (int64 scalars scattered over the module tree): ONE launch adds delta to all of them
 __global__ void add_i64_multi_kernel(long long* const* __restrict__ ptrs, int n, long long delta) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) *ptrs[i] += delta;
+}
+
+extern "C" int lt_global_avgpool_bwd(const float* dy, float* dx, int32_t N, int32_t HW, int32_t C, int32_t accumulate, void* stream) {
+    LT_REQUIRE(dy && dx && N >= 1 && HW >= 1 && C >= 1, LT_ERR_INVALID, "lt_global_avgpool_bwd: bad argument");
+    const long long total = (long long)N * HW * C, blocks = cdiv(total, 256);
+    hipLaunchKernelGGL(global_avgpool_bwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, dy, dx, HW, C, accumulate, total);
+    LT_CHECK_LAUNCH("lt_global_avgpool_bwd");
+    return LT_OK;
 }
 
 extern "C" int lt_add_i64_multi(const void* ptrs, int32_t n, int64_t delta, void* stream) {

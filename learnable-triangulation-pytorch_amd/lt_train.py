@@ -98,7 +98,25 @@ class TrainTape:
         return False
 
     def global_avgpool(self, x):
-        raise NotImplementedError("training with the confidence heads (volume_aggregation_method conf*) is not built")
+        """Mean over the map of every sample (GlobalAveragePoolingHead, pose_resnet.py:166-168): x Act [N,1,H,W,C] -> Act [1,1,1,N,C]; backward
+        spreads dy / HW over the map (accumulating when the input already has a gradient)."""
+        N, D, Hh, W, Cc = x.shape
+        HW = D * Hh * W
+        y = self.alloc((1, 1, 1, N, Cc))
+        self.do(lambda st: H.check(H.lib().lt_global_avgpool(H.LT_F32, x.t.data_ptr(), y.t.data_ptr(), N, HW, Cc, st), "lt_global_avgpool"), "avgpool")
+
+        def bwd():
+            dy = self.grad_of(y)
+            if dy is None:
+                return
+            dx = self.grad_of(x)
+            acc = 1 if dx is not None else 0
+            if dx is None:
+                dx = torch.empty_like(x.t)
+                self._add_grad(x, dx)
+            self.do(lambda st: H.check(H.lib().lt_global_avgpool_bwd(dy.data_ptr(), dx.data_ptr(), N, HW, Cc, acc, st), "lt_global_avgpool_bwd"), "avgpool_bwd")
+        self.recorders.append(bwd)
+        return y
 
     def do(self, fn, label=None):
         """Run fn(stream) now and keep it for every later step (forward list while record() runs, backward list afterwards)."""
@@ -213,12 +231,19 @@ class TrainTape:
     # ---- layers --------------------------------------------------------------------------------------------------------------
     def conv(self, x, weight, bias=None, bn=None, stride=1, pad=0, transposed=False, relu=False, relu_pre=False, residual=None, out_f32=False,
              out=None, sigmoid=False):
-        if sigmoid:
-            raise NotImplementedError("sigmoid heads are not part of the training path")
         lib = H.lib()
-        flags = (H.EPI_RELU_POST if relu else 0) | (H.EPI_RELU_PRE if relu_pre else 0)
+        flags = (H.EPI_RELU_POST if relu else 0) | (H.EPI_RELU_PRE if relu_pre else 0) | (H.EPI_SIGMOID if sigmoid else 0)
+        if sigmoid and (bn is not None or relu or relu_pre or residual is not None):
+            raise NotImplementedError("a sigmoid epilogue next to BatchNorm / ReLU / a residual (the confidence heads end in Linear + Sigmoid only)")
         if bn is None:          # convolution (+ bias) -> activation in the conv epilogue, as in inference
-            z = self._live_conv(x, weight, None, bias, stride=stride, pad=pad, transposed=transposed, relu=relu, relu_pre=relu_pre, residual=residual)
+            if relu_pre and residual is not None:
+                # lt_act_bwd would rebuild the mask of z = relu(v) + res as (z - res) > 0, which drops a live gradient when 0 < relu(v) < ulp(res) / 2
+                # (ADVICE r2); the layers of these networks that add a residual behind a ReLU all carry BatchNorm (lt_bn_act_bwd recomputes v)
+                raise NotImplementedError("a BatchNorm-less layer with ReLU before a residual add")
+            kw = dict(stride=stride, pad=pad, transposed=transposed, relu=relu, relu_pre=relu_pre, residual=residual)
+            if sigmoid:
+                kw["sigmoid"] = True
+            z = self._live_conv(x, weight, None, bias, **kw)
             y_raw = stats = None
         else:
             y_raw = self._live_conv(x, weight, None, bias, stride=stride, pad=pad, transposed=transposed)
@@ -268,15 +293,18 @@ class TrainTape:
 
     # ---- parameter gradients -----------------------------------------------------------------------------------------------------
     def _grad_view(self, p):
-        if p in self.param_grads:
+        """Slice of the gradient arena for parameter ``p``; a same-size VIEW of a Parameter (a Linear weight handed over as a 1x1 convolution
+        filter, ``w[:, :, None, None]``) lands in its base Parameter's entry -- same memory order, the base's shape."""
+        base = p._base if (getattr(p, "_base", None) is not None and p._base.numel() == p.numel() and p.is_contiguous() and p._base.is_contiguous()) else p
+        if base in self.param_grads:
             raise NotImplementedError("a parameter shared by two layers (not the case in these networks)")
         n, off = p.numel(), self.arena_off
         if off + n > self.arena.numel():
             raise RuntimeError("parameter-gradient arena too small: pass every trainable parameter to TrainTape(params=...)")
         self.arena_off += (n + 3) // 4 * 4
-        v = self.arena[off:off + n].view(p.shape)
-        self.param_grads[p] = v
-        return v
+        v = self.arena[off:off + n]
+        self.param_grads[base] = v.view(base.shape)
+        return v.view(p.shape)
 
     def _grads_ready(self, final=False):
         """Called after the op that completes a parameter gradient has been recorded: a full bucket starts its all-reduce here, behind

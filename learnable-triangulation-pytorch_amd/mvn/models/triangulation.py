@@ -73,8 +73,7 @@ class _VolTrainPlan:
         if first:
             # layers in front of the unprojection (its launch needs the map size, the geometry block the launch reads needs the maps' size too)
             _, feats256, _, volc = model.backbone.record(tape, self.x_in, want_heatmaps=False)
-            if volc is not None:
-                raise NotImplementedError("training with volume_aggregation_method conf* is not built")
+            self.volc = volc          # conf / conf_norm: the vol_confidences head's sigmoid output, Act [1,1,1,B*NV,32] (pose_resnet.py:140-174)
             pf = model.process_features[0]
             self.feats = feats = tape.conv(feats256, pf.weight, pf.bias, None)
             h, w = feats.shape[2], feats.shape[3]
@@ -103,19 +102,27 @@ class _VolTrainPlan:
             step = float(np.float32(model.cuboid_side / (V - 1)))
             agg = H.AGG[model.volume_aggregation_method]
             cmu = int(bool(model.transfer_cmu_to_human36m))
+            volc = self.volc
+            conf_p = None if volc is None else volc.t.data_ptr()          # (B, NV, 32) raw confidences; 'conf_norm' is normalised inside the kernels
             tape.do(lambda s_: H.check(lib.lt_unproject_grid_fwd(H.LT_F32, feats.t.data_ptr(), gp, gp + 4 * o_pos, gp + 4 * o_cen, gp + 4 * o_rot, step, cmu,
-                                                                 coords.data_ptr(), None, vol.t.data_ptr(), B, NV, 32, h, w, V, agg, s_), "lt_unproject_grid_fwd"))
+                                                                 coords.data_ptr(), conf_p, vol.t.data_ptr(), B, NV, 32, h, w, V, agg, s_), "lt_unproject_grid_fwd"),
+                    "unproject")
 
             def unproject_bwd():
                 dvol = tape.grad_of(vol)
                 if dvol is None:
                     return
-                gfe = torch.empty_like(feats.t)
-                nb = gfe.numel() * 4
-                tape.do(lambda s_: H.check(lib.lt_zero(gfe.data_ptr(), nb, s_), "lt_zero"))
-                tape.do(lambda s_: H.check(lib.lt_unproject_bwd(H.LT_F32, feats.t.data_ptr(), gp, coords.data_ptr(), None, dvol.data_ptr(), gfe.data_ptr(), None,
-                                                                B, NV, 32, h, w, V ** 3, agg, s_), "lt_unproject_bwd"))
+                gfe = torch.empty_like(feats.t)                    # written completely by the gather (no zero fill)
+                gconf = None if volc is None else torch.empty_like(volc.t)
+                per_sample = lib.lt_unproject_bwd_workspace(1, NV, 32, V, V, V)
+                ws = torch.empty(max(16, min(per_sample * B, max(per_sample, 4 << 30))), dtype=torch.uint8, device=device)
+                nws = ws.numel()
+                tape.do(lambda s_: H.check(lib.lt_unproject_bwd(H.LT_F32, feats.t.data_ptr(), gp, coords.data_ptr(), conf_p, dvol.data_ptr(), gfe.data_ptr(),
+                                                                H.ptr(gconf), B, NV, 32, h, w, V, V, V, agg, ws.data_ptr(), nws, s_), "lt_unproject_bwd"),
+                        "unproject_bwd")
                 tape.seed(feats, gfe)
+                if volc is not None:
+                    tape.seed(volc, gconf)            # the head's backward (recorded earlier, so replayed later) starts from here
             tape.add_backward(unproject_bwd)
             self.logits = logits = model.volume_net.record(tape, vol)          # channels-last (B,V,V,V,J) fp32
             self.kp = kp = torch.empty(B, J, 3, dtype=torch.float32, device=device)
@@ -130,6 +137,12 @@ class _VolTrainPlan:
         else:
             tape.replay(tape.fwd_ops, self.n_front)
         self.step_id += 1
+        conf_out = None
+        if self.volc is not None:          # the returned vol_confidences (reference :266-269, :355): (B, NV, 32), normalised over the views for conf_norm
+            conf_out = self.volc.t.reshape(B, NV, 32).clone()
+            if model.volume_aggregation_method == "conf_norm":
+                conf_out = conf_out / conf_out.sum(dim=1, keepdim=True)
+        self.conf_out = conf_out
         feats_out = torch.empty(B, NV, 32, h, w, dtype=torch.float32, device=device)          # the returned features, contiguous like the reference's
         H.check(lib.lt_nhwc_to_nchw_f32(H.LT_F32, self.feats.t.data_ptr(), feats_out.data_ptr(), B * NV, 32, h * w, 32, st), "lt_nhwc_to_nchw_f32")
         base_points = self.geo[o_cen:o_rot].reshape(B, 3).clone()
@@ -378,9 +391,9 @@ class VolumetricTriangulationNet(_PlannedNet):
 
     def _forward_train(self, images, batch):
         """Training mode (any BatchNorm in train()): fp32, batch statistics, running statistics updated, random cuboid rotation; the
-        result carries the autograd node whose backward is liblt_hip's (lt_train.py).  Same 7-tuple as the inference forward."""
-        if self.volume_aggregation_method.startswith("conf"):
-            raise NotImplementedError("training with volume_aggregation_method conf* (the confidence heads) is not built")
+        result carries the autograd node whose backward is liblt_hip's (lt_train.py).  Same 7-tuple as the inference forward.  Every
+        ``volume_aggregation_method`` trains: for conf / conf_norm the gradient reaches the backbone through the vol_confidences head as
+        well (GlobalAveragePoolingHead, pose_resnet.py:140-174)."""
         bns = [c for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm)]
         if not all(c.training for c in bns):
             raise NotImplementedError("a mix of training-mode and eval-mode BatchNorm layers (frozen statistics) is not built: "
@@ -424,7 +437,7 @@ class VolumetricTriangulationNet(_PlannedNet):
         H.check(H.lib().lt_add_i64_multi(tab[1].data_ptr(), len(nbt), 1, torch.cuda.current_stream(images.device).cuda_stream), "lt_add_i64_multi")
         position, sides = self.__dict__.pop("_train_extra")
         cuboids = [volumetric.Cuboid3D(position[i], sides) for i in range(images.shape[0])]
-        return kp, feats, probs, None, cuboids, coords, base_points
+        return kp, feats, probs, plan.conf_out, cuboids, coords, base_points
 
     def _forward_chunk(self, images, batch, lo, hi):
         device = images.device

@@ -69,13 +69,17 @@ class _UnprojectFn(torch.autograd.Function):
         feats, P, cv, conf = ctx.saved_tensors
         conf = conf if ctx.has_conf else None
         B, NV, h, w, Cc = feats.shape
-        nvox = cv.shape[1] * cv.shape[2] * cv.shape[3]
         g = grad_out.permute(0, 2, 3, 4, 1).float().contiguous()               # (B, v0, v1, v2, C) channels-last fp32
-        gfeats = torch.zeros(B, NV, h, w, Cc, dtype=torch.float32, device=feats.device)
-        gconf = torch.zeros_like(conf) if conf is not None else None
-        H.check(H.lib().lt_unproject_bwd(H.dtype_code(feats.dtype), feats.data_ptr(), P.data_ptr(), cv.data_ptr(), H.ptr(conf), g.data_ptr(),
-                                         gfeats.data_ptr(), H.ptr(gconf), B, NV, Cc, h, w, nvox,
-                                         H.AGG["conf"] if conf is not None else H.AGG[ctx.method], H.cur_stream()), "lt_unproject_bwd")
+        gfeats = torch.empty(B, NV, h, w, Cc, dtype=torch.float32, device=feats.device)      # written completely by the gather
+        gconf = torch.empty_like(conf) if conf is not None else None
+        v0, v1, v2 = cv.shape[1:4]
+        lib = H.lib()
+        # deterministic gather: workspace for as many samples as fit 2 GiB at a time (the entry walks the batch in chunks)
+        per_sample = lib.lt_unproject_bwd_workspace(1, NV, Cc, v0, v1, v2)
+        ws = torch.empty(max(16, min(per_sample * B, max(per_sample, 2 << 30))), dtype=torch.uint8, device=feats.device)
+        H.check(lib.lt_unproject_bwd(H.dtype_code(feats.dtype), feats.data_ptr(), P.data_ptr(), cv.data_ptr(), H.ptr(conf), g.data_ptr(),
+                                     gfeats.data_ptr(), H.ptr(gconf), B, NV, Cc, h, w, v0, v1, v2,
+                                     H.AGG["conf"] if conf is not None else H.AGG[ctx.method], ws.data_ptr(), ws.numel(), H.cur_stream()), "lt_unproject_bwd")
         return gfeats.permute(0, 1, 4, 2, 3).to(feats.dtype), None, None, gconf, None
 
 

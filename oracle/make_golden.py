@@ -361,7 +361,7 @@ def _train_sub(t, n=129):
     return f[::max(1, f.numel() // n)][:n].numpy().copy()
 
 
-def gen_train(mvn):
+def gen_train(mvn, method="softmax", fname="train_step.npz"):
     """One full training step of the reference's VolumetricTriangulationNet on CPU (train.py:148-243): model.train() (BatchNorm on batch
     statistics, running statistics updated, random cuboid rotation), criterion MAE on keypoints * scale_keypoints_3d + 0.01 *
     VolumetricCELoss, total_loss.backward(), torch.optim.Adam with the three learning-rate groups of train.py:430-437, opt.step().
@@ -372,12 +372,16 @@ def gen_train(mvn):
     channel at V = 64; at V = 32 it would be 2, where a 1e-6 relative change of the images moves the reference's own gradients by
     6 % median).  So the reference is run three times -- 8 threads, 1 thread (another fp32 summation order), and with the images
     scaled by (1 + 1e-6) -- and the fixture stores, per parameter, how far the reference's gradient moves between them
-    (``noise/<name>``): the test gates ours against the reference within that measured self-noise."""
+    (``noise/<name>``): the test gates ours against the reference within that measured self-noise.
+
+    method = "conf_norm" (fixture train_step_conf_norm.npz): the same step with volume_aggregation_method conf_norm -- the backbone's
+    vol_confidences head (GlobalAveragePoolingHead, pose_resnet.py:140-174) is then part of the graph, its sigmoid output weights the
+    views (op.py:150-151) after normalisation over them (triangulation.py:268-269), and the returned confidences are stored too."""
     import mvn.models.loss as L
     torch.set_num_threads(8)          # the fixture's fp32 summation order (the 1-thread run below measures what another order changes)
     c = dict(nl=18, B=2, NV=3, H=128, V=64, seed=12)
-    cfg = synth.vol_config(c["nl"], c["V"], "softmax", 1.0, "mpii")
-    sp = spec.vol_net_spec(c["nl"], 17, False)
+    cfg = synth.vol_config(c["nl"], c["V"], method, 1.0, "mpii")
+    sp = spec.vol_net_spec(c["nl"], 17, method.startswith("conf"))
     sd = synth.make_state_dict(sp, seed=c["seed"], sharpen=60.0, basic_block=True)
     inp = synth.make_inputs(c["B"], c["NV"], c["H"], seed=c["seed"], inside=False)
     lr, pf_lr, vn_lr = 1e-4, 1e-3, 1e-3          # experiments/human36m/train/human36m_vol_softmax.yaml
@@ -393,14 +397,15 @@ def gen_train(mvn):
                                 {"params": ref.volume_net.parameters(), "lr": vn_lr}], lr=lr)
         batch = {"cameras": _cameras(mvn, inp["K"], inp["R"], inp["t"], c["B"]), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
         np.random.seed(c["seed"] + 100)
-        kp, feats, vols, _, cuboids, cvs, bps = ref(inp["images"] * (1.0 + eps), torch.zeros(c["B"], c["NV"], 3, 4), batch)
+        kp, feats, vols, vconf, cuboids, cvs, bps = ref(inp["images"] * (1.0 + eps), torch.zeros(c["B"], c["NV"], 3, 4), batch)
         if gt is None:
             gt = kp.detach() + dgt
         mae = L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val)
         ce = L.VolumetricCELoss()(cvs, vols, gt, val)
         opt.zero_grad()
         (mae + 0.01 * ce).backward()
-        return ref, opt, dict(kp=kp.detach(), feats=feats.detach(), vols=vols.detach(), gt=gt, mae=float(mae), ce=float(ce))
+        return ref, opt, dict(kp=kp.detach(), feats=feats.detach(), vols=vols.detach(), gt=gt, mae=float(mae), ce=float(ce),
+                              vconf=None if vconf is None else vconf.detach())
 
     np.random.seed(c["seed"] + 100)
     thetas = np.random.uniform(0.0, 2 * np.pi, size=c["B"])
@@ -417,6 +422,9 @@ def gen_train(mvn):
            "thetas": thetas, "lrs": np.array([lr, pf_lr, vn_lr]), "vol_sub": sub(r["vols"], 4), "kp_noise": np.array(kp_noise),
            "loss_noise": np.array(max(abs(o["mae"] - r["mae"]) / r["mae"] for o in (r1, rp))),
            "feat_sub": sub(r["feats"].reshape(c["B"] * c["NV"], *r["feats"].shape[2:]), 2)}
+    if r["vconf"] is not None:
+        out["vconf"] = r["vconf"].numpy()
+        out["vconf_noise"] = np.array(max(float((o["vconf"] - r["vconf"]).abs().max()) for o in (r1, rp)))
     names, no_grad, noises = [], [], []
     g1, gp = dict(ref1.named_parameters()), dict(refp.named_parameters())
     for n, p in ref.named_parameters():
@@ -445,7 +453,7 @@ def gen_train(mvn):
         time.time() - t0, r["mae"], r["ce"], len(names), len(no_grad), gn))
     print("  reference self-noise (threads / 1e-6 perturbation): kp %.2e; gradients median %.2e, 90%% %.2e, max %.2e" % (
         kp_noise, noises[len(noises) // 2], noises[int(len(noises) * 0.9)], noises[-1]))
-    np.savez_compressed(os.path.join(GOLD, "train_step.npz"), **out)
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 
 def run_vol_case(mvn, tag, num_layers, B, NV, H, V, method="softmax", multiplier=1.0, sharpen=False,
@@ -531,7 +539,7 @@ def main():
     torch.manual_seed(0)
     os.makedirs(GOLD, exist_ok=True)
     mvn = ref_loader.load()
-    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad", "train"]
+    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad", "train", "train_conf"]
     if "ops" in which:
         print("[ops]"); gen_ops(mvn)
     if "nets" in which:
@@ -559,6 +567,8 @@ def main():
         run_vol_case(mvn, "c4_sharp", 152, 1, 8, 384, 128, "softmax", sharpen=157.0, seed=8, stride=8)
     if "train" in which:
         print("[train]"); gen_train(mvn)
+    if "train_conf" in which:
+        print("[train_conf]"); gen_train(mvn, "conf_norm", "train_step_conf_norm.npz")
     if "alg" in which:
         print("[alg]"); gen_alg(mvn)
     if "caffe" in which:

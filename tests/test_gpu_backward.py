@@ -128,3 +128,42 @@ def test_batchnorm_batch_statistics_vs_torch(shape, dtype):
     check("bn stats var %s %s" % (shape, dtype), var.cpu(), var_ref, tol)
     check("bn running_mean %s" % (shape,), rmd.cpu(), rm_ref, tol)
     check("bn running_var %s" % (shape,), rvd.cpu(), rv_ref, tol)
+
+
+def test_unproject_backward_is_bitwise_repeatable_and_matches_the_scatter(golden_dir):
+    """Round 3: lt_unproject_bwd is a gather (one workgroup owns a 16 x 16 pixel tile of one view's gradient map and adds the taps that
+    fall into it in a fixed order) -- two runs are BITWISE equal, where the round-2 scatter by global float atomics
+    (LT_UNPROJ_BWD_ATOMICS=1, kept as the A/B reference) is only equal up to fp32 summation order.  Pipeline shape: 2 samples, 3 views,
+    camera 0 inside the cube (depth <= 0 samples), rotated cuboids, 32 channels, 32^3 voxels, 32 x 32 maps."""
+    from mvn.utils import op
+    gs = np.load(os.path.join(golden_dir, "vol_small_softmax.npz"))
+    cfg = synth.vol_config(18, 32, "softmax", 1.0, "mpii")
+    sd = synth.make_state_dict(spec.vol_net_spec(18, 17, False), seed=2, sharpen=True, basic_block=True)
+    inp = synth.make_inputs(2, 3, 128, seed=2, inside=True)
+    o = O.volumetric_forward(sd, cfg, inp["images"], inp["K"], inp["R"], inp["t"], inp["pred_keypoints_3d"], thetas=gs["thetas"], stages=True)
+    GV = torch.randn(o["unprojected"].shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+    P, cv = o["proj"].to(DEV), o["coord_volumes"].to(DEV)
+
+    def grad(method, conf=None):
+        f = o["features"].to(DEV).requires_grad_(True)
+        c = None if conf is None else conf.clone().requires_grad_(True)
+        (op.unproject_heatmaps(f, P, cv, method, c) * GV).sum().backward()
+        return f.grad.clone(), (None if c is None else c.grad.clone())
+
+    conf = torch.rand(2, 3, 32, generator=torch.Generator().manual_seed(6)).to(DEV) + 0.1
+    for method in ("softmax", "sum", "max", "conf"):
+        cf = conf if method == "conf" else None
+        g1, c1 = grad(method, cf)
+        g2, c2 = grad(method, cf)
+        assert torch.equal(g1, g2), method + ": the gather must be bitwise repeatable"
+        if c1 is not None:
+            assert torch.equal(c1, c2)
+        os.environ["LT_UNPROJ_BWD_ATOMICS"] = "1"
+        try:
+            gs_, cs_ = grad(method, cf)
+        finally:
+            del os.environ["LT_UNPROJ_BWD_ATOMICS"]
+        check("bwd/unproject gather vs round-2 scatter, %s: d/d features" % method, g1.cpu(), gs_.cpu(), 2e-5)
+        if c1 is not None:
+            check("bwd/unproject gather vs round-2 scatter, conf: d/d confidences", c1.cpu(), cs_.cpu(), 2e-5)
+    assert float(g1.abs().max()) > 0

@@ -97,8 +97,9 @@ def test_volumetric_forward_vs_reference_golden(golden_dir, tag):
     assert cvs.shape == (B, c["V"], c["V"], c["V"], 3) and bps.shape == (B, 3) and len(cuboids) == B
     check(tag + "/coord_volumes", cvs.cpu()[:, ::s, ::s, ::s], g["cv_sub"], 2e-7)
     check(tag + "/base_points", bps.cpu(), g["base_points"], 1e-7)
-    check(tag + "/features", _sub(feats.cpu().reshape(B * NV, *feats.shape[2:]), s), g["feat_sub"], 1e-4)
-    check(tag + "/volumes (softmaxed)", _sub(vols.cpu(), s), g["vol_sub"], 1e-3)
+    # intermediates within 1e-4 * max|ref|; features and logits are gated 5x tighter than that (measured 2e-6)
+    check(tag + "/features", _sub(feats.cpu().reshape(B * NV, *feats.shape[2:]), s), g["feat_sub"], 2e-5)
+    check(tag + "/volumes (softmaxed)", _sub(vols.cpu(), s), g["vol_sub"], 1e-4)
     assert np.allclose(np.stack([cb.position for cb in cuboids]), g["cuboid_pos"]) and np.allclose(cuboids[0].sides, g["cuboid_sides"][0])
     if conf is not None:
         check(tag + "/vol_confidences", conf.cpu(), g["vol_conf"], 1e-4)
@@ -123,7 +124,7 @@ def test_volumetric_forward_vs_reference_golden(golden_dir, tag):
     if out2 is not None:
         assert torch.equal(out2[0], kp) and torch.equal(out2[2], vols)
     logits = P["logits"].t.permute(0, 4, 1, 2, 3).float().cpu()
-    check(tag + "/v2v logits", _sub(logits, s), g["logits_sub"], 2e-4)
+    check(tag + "/v2v logits", _sub(logits, s), g["logits_sub"], 2e-5)
 
 
 @pytest.mark.parametrize("tag", ["small_softmax", "c2_sharp", "c2_default", "c2_b4", "c4_sharp"])
@@ -301,11 +302,18 @@ def test_algebraic_c1_vs_reference_golden(golden_dir):
 
 def test_loud_failure_modes():
     from mvn.models.triangulation import VolumetricTriangulationNet
-    m = VolumetricTriangulationNet(synth.vol_config(18, 32, "conf_norm"), device=DEV)    # training is built for softmax / sum / max only
+    m = VolumetricTriangulationNet(synth.vol_config(18, 32, "softmax"), device=DEV)
     inp = synth.make_inputs(1, 2, 64)
+    batch = {"cameras": _cameras(inp, 1), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
     m.train()
-    with pytest.raises(NotImplementedError):
-        m(inp["images"].to(DEV), None, {"cameras": _cameras(inp, 1), "pred_keypoints_3d": inp["pred_keypoints_3d"]})
+    with pytest.raises(RuntimeError, match="move the model"):            # training updates the parameters in place: they must live on the GPU
+        m(inp["images"].to(DEV), None, batch)
+    m.to(DEV)
+    m.backbone.eval()                                                     # a mix of train / eval BatchNorm (frozen statistics) is not built: said loudly
+    with pytest.raises(NotImplementedError, match="mix of training-mode and eval-mode"):
+        m(inp["images"].to(DEV), None, batch)
+    with pytest.raises(RuntimeError, match="GPU"):                        # no CPU fallback anywhere
+        m.eval()(inp["images"], None, batch)
     info = H.device_info()
     record("device", info)
     assert info["arch"].startswith("gfx950"), info

@@ -251,23 +251,27 @@ def test_adam_step_vs_torch():
 ZERO_GRAD = re.compile(r"^volume_net\.(.*\.(block\.0|res_branch\.0|res_branch\.3|skip_con\.0)|output_layer)\.bias$")
 
 
-def _train_case():
+def _train_case(method="softmax"):
     c = dict(nl=18, B=2, NV=3, H=128, V=64, seed=12)
-    cfg = synth.vol_config(c["nl"], c["V"], "softmax", 1.0, "mpii")
-    sd = synth.make_state_dict(spec.vol_net_spec(c["nl"], 17, False), seed=c["seed"], sharpen=60.0, basic_block=True)
+    cfg = synth.vol_config(c["nl"], c["V"], method, 1.0, "mpii")
+    sd = synth.make_state_dict(spec.vol_net_spec(c["nl"], 17, method.startswith("conf")), seed=c["seed"], sharpen=60.0, basic_block=True)
     inp = synth.make_inputs(c["B"], c["NV"], c["H"], seed=c["seed"], inside=False)
     return c, cfg, sd, inp
 
 
-def test_whole_training_step_vs_reference(golden_dir):
+@pytest.mark.parametrize("method", ["softmax", "conf_norm"])
+def test_whole_training_step_vs_reference(golden_dir, method):
     """model.train(); forward; MAE(kp * 0.1) + 0.01 * VolumetricCELoss; backward; Adam (train.py:148-243, :430-437) -- every parameter's
-    gradient, the BatchNorm running statistics and the parameters after the step against the reference's own step on CPU."""
+    gradient, the BatchNorm running statistics and the parameters after the step against the reference's own step on CPU.  conf_norm: the
+    vol_confidences head (pose_resnet.py:140-174) is part of the graph -- its gradients (through the view aggregation, op.py:150-151, and
+    the normalisation over the views, triangulation.py:268-269) and the backbone's second gradient path are gated the same way."""
     import lt_train
     from mvn.models import loss as L
     from mvn.models.triangulation import VolumetricTriangulationNet
     from test_gpu_models import _cameras
-    G = np.load(os.path.join(golden_dir, "train_step.npz"))
-    c, cfg, sd, inp = _train_case()
+    G = np.load(os.path.join(golden_dir, "train_step.npz" if method == "softmax" else "train_step_%s.npz" % method))
+    c, cfg, sd, inp = _train_case(method)
+    TAG = "" if method == "softmax" else "[%s] " % method
     m = VolumetricTriangulationNet(cfg, device=DEV)
     m.load_state_dict(sd, strict=True)
     m.to(DEV)
@@ -281,10 +285,17 @@ def test_whole_training_step_vs_reference(golden_dir):
     # the reference's own deviation between 1 and 8 threads / under a 1e-6 relative change of the images rides on every gate below
     kp_noise, loss_noise = float(G["kp_noise"]), float(G["loss_noise"])
     d = (kp.detach().cpu().double() - torch.from_numpy(G["kp"]).double()).abs() / torch.from_numpy(G["kp"]).double().abs().clamp(min=1.0)
-    record("train/step forward keypoints (train-mode BN), rel with 1 mm floor", {"err": float(d.max()), "tol": 1e-4 + 2 * kp_noise, "reference_self_noise": kp_noise})
+    record(TAG + "train/step forward keypoints (train-mode BN), rel with 1 mm floor", {"err": float(d.max()), "tol": 1e-4 + 2 * kp_noise, "reference_self_noise": kp_noise})
     assert float(d.max()) <= 1e-4 + 2 * kp_noise, float(d.max())
-    check("train/step forward volumes", vols.detach().cpu()[:, :, ::4, ::4, ::4], G["vol_sub"], 1e-3 + 10 * kp_noise)
-    check("train/step forward features", feats.detach().cpu().reshape(c["B"] * c["NV"], *feats.shape[2:])[:, :, ::2, ::2], G["feat_sub"], 1e-4)
+    check(TAG + "train/step forward volumes", vols.detach().cpu()[:, :, ::4, ::4, ::4], G["vol_sub"], 1e-3 + 10 * kp_noise)
+    check(TAG + "train/step forward features", feats.detach().cpu().reshape(c["B"] * c["NV"], *feats.shape[2:])[:, :, ::2, ::2], G["feat_sub"], 1e-4)
+    if method.startswith("conf"):
+        assert conf is not None and tuple(conf.shape) == tuple(G["vconf"].shape)
+        e_conf = float((conf.detach().cpu() - torch.from_numpy(G["vconf"])).abs().max())
+        record(TAG + "train/step returned vol_confidences (%s)" % method, {"err": e_conf, "tol": 1e-5 + 4 * float(G["vconf_noise"])})
+        assert e_conf <= 1e-5 + 4 * float(G["vconf_noise"]), e_conf
+    else:
+        assert conf is None
     gt, val = torch.from_numpy(G["gt"]).to(DEV), torch.from_numpy(G["val"]).to(DEV)
     mae = L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val)
     ce = L.VolumetricCELoss()(cvs, vols, gt, val)
@@ -318,7 +329,7 @@ def test_whole_training_step_vs_reference(golden_dir):
     table.sort(reverse=True)
     print("worst parameter gradients (err / gate, err, reference self-noise):", *["%.2f %.2e %.2e %s" % t for t in table[:8]], sep="\n  ")
     errs = sorted(t[1] for t in table)
-    record("train/step parameter gradients vs the reference's step (max|d|/max|ref| on samples, and norm; gate 1e-3 + 4 x reference self-noise)",
+    record(TAG + "train/step parameter gradients vs the reference's step (max|d|/max|ref| on samples, and norm; gate 1e-3 + 4 x reference self-noise)",
            {"worst_err_over_gate": table[0][0], "worst_err": errs[-1], "median_err": errs[len(errs) // 2], "parameters_compared": len(table),
             "zero_gradient_parameters": n_zero, "median_reference_self_noise": sorted(t[2] for t in table)[len(table) // 2]})
     assert table[0][0] <= 1.0, table[:8]
@@ -326,7 +337,7 @@ def test_whole_training_step_vs_reference(golden_dir):
         assert named[str(n)].grad is None
     gn = float(np.sqrt(gn2))
     assert abs(gn - float(G["grad_norm"])) <= 2e-3 * float(G["grad_norm"]), (gn, float(G["grad_norm"]))
-    record("train/step global gradient norm", {"ours": gn, "reference": float(G["grad_norm"])})
+    record(TAG + "train/step global gradient norm", {"ours": gn, "reference": float(G["grad_norm"])})
     # running statistics (momentum 0.1, unbiased variance)
     bufs = dict(m.named_buffers())
     w_rs = 0.0
@@ -336,7 +347,7 @@ def test_whole_training_step_vs_reference(golden_dir):
             sub = b[::max(1, b.numel() // 129)][:129]
             ref = torch.from_numpy(G[key]).double()
             w_rs = max(w_rs, float((sub - ref).abs().max() / ref.abs().max().clamp(min=1e-30)))
-    record("train/step BatchNorm running statistics", {"err": w_rs, "tol": 1e-4})
+    record(TAG + "train/step BatchNorm running statistics", {"err": w_rs, "tol": 1e-4})
     assert w_rs <= 1e-4, w_rs
     # the Adam step: parameter deltas (the first step moves every element by ~lr * sign(g); compare the moved parameters)
     opt.step()
@@ -359,7 +370,7 @@ def test_whole_training_step_vs_reference(golden_dir):
         e = float(((sub - ref).abs() * known).max()) / lr_n      # in units of one full Adam step
         if e > w_p:
             w_p, w_name = e, n
-    record("train/step parameters after Adam, worst |d| in units of lr", {"err": w_p, "tol": 2e-2, "name": w_name, "elements_compared": n_known})
+    record(TAG + "train/step parameters after Adam, worst |d| in units of lr", {"err": w_p, "tol": 2e-2, "name": w_name, "elements_compared": n_known})
     assert w_p <= 2e-2, (w_p, w_name)
     assert n_known > 1000, n_known
     # the REPLAYED training forward reads the updated parameters: same result as a fresh model (fresh recording) with the new state dict
@@ -372,7 +383,7 @@ def test_whole_training_step_vs_reference(golden_dir):
     sd_before = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
     np.random.seed(c["seed"] + 100)
     kp_fresh = m2(inp["images"].to(DEV), None, batch)[0].detach()
-    check("train/step replayed forward after Adam vs a fresh recording with the updated weights", kp_replay.cpu(), kp_fresh.cpu(), 1e-6)
+    check(TAG + "train/step replayed forward after Adam vs a fresh recording with the updated weights", kp_replay.cpu(), kp_fresh.cpu(), 1e-6)
     assert float((kp_replay.cpu() - torch.from_numpy(G["kp"])).abs().max()) > 1e-3      # and the step did move the prediction
     # and the next inference forward uses the UPDATED weights (plan cache fingerprint)
     m.eval()
@@ -510,8 +521,23 @@ def _check_two_rank_gradients(got, single, tag):
                 if ZERO_GRAD.search(n):
                     continue
                 worst = max(worst, float(np.abs(sample - ws).max()) / scale, abs(norm - float(np.linalg.norm(want))) / max(float(np.linalg.norm(want)), 1e-12))
-    record(tag, {"err": worst, "tol": 2e-3})
-    assert worst <= 2e-3, worst
+    # round 3: the unprojection backward is a gather and the max-pool backward walks disjoint window classes -- no float atomics left in
+    # the step, so the only difference to the mean of the shards' own gradients is the fp32 rounding of the sum (round 2: 2e-3)
+    record(tag, {"err": worst, "tol": 1e-5})
+    assert worst <= 1e-5, worst
+
+
+def test_training_step_is_bitwise_repeatable():
+    """Two independent recordings (fresh models, same weights / inputs / rotations) and their replays give BITWISE identical parameter
+    gradients: every reduction of the step has a fixed order (column sums in fp64 slabs, weight gradients by slab partials, the
+    unprojection backward as a gather, the max-pool backward by disjoint window classes)."""
+    a, b = _dp_grads(0, None), _dp_grads(0, None)
+    assert set(a[0]) == set(b[0]) and len(a[0]) > 50
+    for it in (0, 1):
+        for n in a[it]:
+            assert np.array_equal(a[it][n], b[it][n]), "gradient of %s differs between two runs (step %d)" % (n, it)
+    for n in a[0]:
+        assert np.array_equal(a[0][n], a[1][n]), "replayed step differs from the recorded one: " + n
 
 
 def test_rccl_single_rank_process_group_comes_up():

@@ -1,0 +1,55 @@
+#!/bin/bash
+# Round-3 GPU sessions (from the repo root on the GPU box): bash tools/gpu_r3.sh <stage> ...   -- everything under gpurun_out/r3/
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r3
+mkdir -p $OUT
+cd $R
+export PYTHONDONTWRITEBYTECODE=1
+for s in "$@"; do
+case $s in
+tests_fast)   # the tests this round touched
+  timeout 1500 python -m pytest tests/test_gpu_train.py tests/test_gpu_data.py tests/test_gpu_backward.py -m gpu -q --tb=short -x -p no:cacheprovider > $OUT/test_train.log 2>&1
+  echo "train/data rc=$?"; tail -5 $OUT/test_train.log
+  timeout 1200 python -m pytest tests/test_gpu_models.py -m gpu -q --tb=short -p no:cacheprovider > $OUT/test_models.log 2>&1
+  echo "models rc=$?"; tail -5 $OUT/test_models.log
+  ;;
+tests_all)
+  timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $OUT/test_all.log 2>&1
+  echo "all rc=$?"; tail -8 $OUT/test_all.log
+  ;;
+bench)        # the driver's command
+  timeout 1500 python bench.py --ops-json $OUT/bench_ops_bf16.json > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
+  echo "bench rc=$?"; python - <<PY
+import json
+try:
+    r = json.load(open("$OUT/bench_bf16.json"))
+    print({k: r[k] for k in ("value", "ms_per_step")}, "keys:", sorted(r.keys()))
+    for k in ("config4", "train"):
+        v = r.get(k, {})
+        print(k, {kk: v.get(kk) for kk in ("value", "ms_per_step", "error", "leg_wall_s", "stderr_tail")})
+except Exception as e:
+    print("bench parse failed", e)
+PY
+  tail -3 $OUT/bench_bf16.err
+  ;;
+bwd)          # the unprojection backward (gather) and the whole training step, both aggregation families
+  timeout 900 python -m pytest tests/test_gpu_backward.py -m gpu -q --tb=short -x -p no:cacheprovider > $OUT/test_bwd.log 2>&1
+  echo "backward rc=$?"; tail -15 $OUT/test_bwd.log
+  timeout 1200 python -m pytest tests/test_gpu_train.py -m gpu -q --tb=short -p no:cacheprovider -k "whole_training_step or two_ranks or api_semantics or ten_steps or op_level" > $OUT/test_train_sel.log 2>&1
+  echo "train selection rc=$?"; tail -25 $OUT/test_train_sel.log
+  ;;
+trainprof)    # per-op table of the recorded training step (B = 8 fp32) + the step rate
+  timeout 600 python tools/train_profile.py 8 > $OUT/train_profile_b8.log 2>&1; echo "trainprof rc=$?"
+  grep -E "^fwd|^bwd|unproject|zero" $OUT/train_profile_b8.log | head -12
+  cp gpurun_out/train_ops_b8.json $OUT/ 2>/dev/null
+  timeout 600 python bench.py --train --steps 10 --warmup 3 --batch 8 > $OUT/bench_train_b8.json 2> $OUT/bench_train_b8.err
+  echo "bench train rc=$?"; python -c "
+import json; r=json.load(open('$OUT/bench_train_b8.json')); print(r['value'], r['ms_per_step'], r['losses'])"
+  ;;
+smoke)
+  timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
+  ;;
+*) echo "unknown stage $s";;
+esac
+done
