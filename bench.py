@@ -188,6 +188,47 @@ def sub_leg(argv, timeout_s):
     return out
 
 
+def pmc_leg(args, timeout_s=150):
+    """HBM traffic and MFMA-busy of THIS run's kernels, measured now: three child runs of this script (one forward each after setup, eager
+    launches) under ``rocprofv3 --kernel-trace --pmc <counters>`` -- FETCH_SIZE, WRITE_SIZE and the SQ / GRBM counters in SEPARATE passes, as
+    MI355X_MICROARCH.md prescribes -- summarised by tools/pmc_summary.py (FETCH_SIZE x2 on gfx950, KiB -> bytes).  Returns None when
+    rocprofv3 is missing or a pass fails (the caller then falls back to the committed file and says so)."""
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    out = tempfile.mkdtemp(prefix="lt_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-profile", "--no-extras", "--no-graph",
+             "--preroll-s", "0", "--batch", str(args.batch), "--views", str(args.views), "--volume", str(args.volume), "--image", str(args.image),
+             "--layers", str(args.layers), "--dtype", args.dtype]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LT_BENCH_SELF_LAUNCHED"):
+        env.pop(k, None)
+    passes = (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]),
+              ("pmc_mfma", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"]))
+    t0 = time.perf_counter()
+    try:
+        for name, counters in passes:
+            cmd = [rp, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", os.path.join(out, name), "-o", "bench", "--"] + child
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
+            if r.returncode != 0:
+                return None
+        res = pmc_summary.summarise(out, 3, args.batch, args.dtype, args.views, args.volume, "", " --steps 1 --warmup 0 (3 forwards per pass), run by bench.py itself")
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    if not res.get("conv_family_bytes_per_step"):
+        return None
+    res.pop("per_kernel", None)
+    res["leg_wall_s"] = time.perf_counter() - t0
+    return res
+
+
 def time_steps(step, n, barrier):
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -299,6 +340,7 @@ def main():
     ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="--train: fp32 (the reference's precision, default) or bf16 = the "
                     "convolutions and their input gradients on the bf16 MFMA (bf16 copies of the operands, fp32 accumulation / storage), everything else fp32")
     ap.add_argument("--train", action="store_true", help="time the training step (fwd + bwd + Adam, fp32) instead of the forward; its own JSON line")
+    ap.add_argument("--no-pmc-leg", action="store_true", help="do not measure roofline.traffic live (rocprofv3 child runs, ~1 min); use the committed PMC file")
     ap.add_argument("--no-legs", action="store_true", help="skip the config-4 and training legs of the default (config 2, N = 1) run")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="CPU baseline leg: timed forwards of sample 0 until this many seconds (at least one)")
     ap.add_argument("--cpu-parity-samples", type=int, default=2, help="samples of the timed batch the CPU oracle evaluates as parity references")
@@ -410,9 +452,13 @@ def main():
             fam, conv = family_table(ops)
             peak = PEAK_TFLOPS[args.dtype]
             ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-            # HBM traffic per step from the committed PMC passes of this command (tools/pmc_summary.py; same batch and dtype only)
+            # HBM traffic per step: measured in THIS run by the PMC leg (rocprofv3 children of this script) when it is available; else from the
+            # committed PMC passes of this command (tools/pmc_summary.py; same batch and dtype only) -- traffic_source says which
             pmc, pmc_file = {}, None
-            for name in ("r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"):
+            live = None
+            if world == 1 and not args.no_extras and not args.no_pmc_leg:
+                live = pmc_leg(args)
+            for name in ([] if live else ["r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"]):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                 except (OSError, ValueError):
@@ -421,6 +467,10 @@ def main():
                     pmc, pmc_file = pm, "profiles/" + name
                     break
             src = None if pmc_file is None else pmc_file + " (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)"
+            if live:
+                pmc = live
+                src = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ counters, three child runs of this command (%s; %.0f s)" % (
+                    "eager launches, 3 forwards per pass", live["leg_wall_s"])
             result["roofline"] = {"kernel": "conv family: conv_igemm2/3/6, conv3d_halo*, conv_pw, stem_pool, pwchain (all %d launches of one step)" % conv["launches"],
                                   "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                   "traffic": pmc.get("conv_family_bytes_per_step"), "traffic_source": src,
@@ -484,7 +534,7 @@ def main():
                 torch.cuda.empty_cache()
                 result["config4"] = sub_leg(["--views", "8", "--volume", "128", "--batch", "16", "--steps", "3", "--warmup", "1", "--no-extras",
                                              "--cpu-budget-s", "1", "--cpu-parity-samples", "1", "--preroll-s", "0.3"], 600)
-                result["train"] = sub_leg(["--train", "--batch", "4", "--steps", "3", "--warmup", "2"], 600)
+                result["train"] = sub_leg(["--train", "--batch", "4", "--steps", "8", "--warmup", "2"], 600)
         if cpu_base is not None:
             result["cpu_baseline"] = cpu_base
     barrier()

@@ -72,22 +72,13 @@ def load(pattern, counters):
     return per
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("out_dir", nargs="?", default=os.path.join(ROOT, "gpurun_out"))
-    ap.add_argument("forwards", nargs="?", type=int, default=6)
-    ap.add_argument("batch", nargs="?", type=int, default=32)
-    ap.add_argument("--round", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--views", type=int, default=4)
-    ap.add_argument("--volume", type=int, default=64)
-    ap.add_argument("--suffix", default="")
-    a = ap.parse_args()
-    steps = a.forwards
-    fetch = load(os.path.join(a.out_dir, "pmc_fetch" + a.suffix, "*counter_collection.csv"), ["FETCH_SIZE"])["FETCH_SIZE"]
-    write = load(os.path.join(a.out_dir, "pmc_write" + a.suffix, "*counter_collection.csv"), ["WRITE_SIZE"])["WRITE_SIZE"]
+def summarise(out_dir, steps, batch=32, dtype="bf16", views=4, volume=64, suffix="", note_extra=""):
+    """The three passes under ``out_dir`` (pmc_fetch*/ pmc_write*/ pmc_mfma*/; a missing pass leaves its fields empty) -> the summary dict
+    (``steps`` = forwards in each profiled run).  Used by main() for the committed file and by bench.py for its in-run PMC leg."""
+    fetch = load(os.path.join(out_dir, "pmc_fetch" + suffix, "*counter_collection.csv"), ["FETCH_SIZE"])["FETCH_SIZE"]
+    write = load(os.path.join(out_dir, "pmc_write" + suffix, "*counter_collection.csv"), ["WRITE_SIZE"])["WRITE_SIZE"]
     sq_names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"]
-    sq = load(os.path.join(a.out_dir, "pmc_mfma" + a.suffix, "*counter_collection.csv"), sq_names)
+    sq = load(os.path.join(out_dir, "pmc_mfma" + suffix, "*counter_collection.csv"), sq_names)
     per = {}
     for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0])[0] * 2 + write.get(k, [0])[0])):
         f, nf = fetch.get(k, [0.0, 0]); w, nw = write.get(k, [0.0, 0])
@@ -113,23 +104,39 @@ def main():
             hbm[fam] = b
     conv_mf = sum(sq["SQ_VALU_MFMA_BUSY_CYCLES"][k][0] for k in sq["SQ_VALU_MFMA_BUSY_CYCLES"] if family(k) == "conv")
     conv_gui = sum(sq["GRBM_GUI_ACTIVE"][k][0] for k in sq["GRBM_GUI_ACTIVE"] if family(k) == "conv")
-    res = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters (separate passes, --kernel-trace only) over bench.py --steps 3 "
-                   "--warmup 1 --no-graph; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), KiB -> bytes; Infinity-Cache hits are included "
+    res = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters (separate passes, --kernel-trace only) over bench.py "
+                   "--no-graph" + note_extra + "; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), KiB -> bytes; Infinity-Cache hits are included "
                    "in both counters; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)",
-           "per_gpu_batch": a.batch, "dtype": a.dtype, "views": a.views, "volume": a.volume,
+           "per_gpu_batch": batch, "dtype": dtype, "views": views, "volume": volume, "forwards_profiled": steps,
            "total_fetch_bytes_per_step": sum(v.get("fetch_bytes_per_step_corrected", 0.0) for v in per.values()),
            "total_write_bytes_per_step": sum(v.get("write_bytes_per_step", 0.0) for v in per.values()),
-           "conv_family_bytes_per_step": tot("conv", "fetch_bytes_per_step_corrected") + tot("conv", "write_bytes_per_step"),
+           "conv_family_bytes_per_step": (tot("conv", "fetch_bytes_per_step_corrected") + tot("conv", "write_bytes_per_step")) if (fetch and write) else None,
            "conv_family_mfma_busy_frac": (conv_mf / (N_SIMD * conv_gui / N_XCD)) if conv_gui else None,
-           "hbm_kernels_bytes_per_step": hbm,
+           "hbm_kernels_bytes_per_step": hbm if (fetch and write) else {},
            "per_kernel": per}
+    assert "" not in per, "a kernel name parsed to the empty string"
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out_dir", nargs="?", default=os.path.join(ROOT, "gpurun_out"))
+    ap.add_argument("forwards", nargs="?", type=int, default=6)
+    ap.add_argument("batch", nargs="?", type=int, default=32)
+    ap.add_argument("--round", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--volume", type=int, default=64)
+    ap.add_argument("--suffix", default="")
+    a = ap.parse_args()
+    res = summarise(a.out_dir, a.forwards, a.batch, a.dtype, a.views, a.volume, a.suffix, " --steps 3 --warmup 1")
+    hbm = res["hbm_kernels_bytes_per_step"]
     name = "r%02d_hbm_traffic_pmc%s.json" % (a.round, a.suffix)
     dst = os.path.join(ROOT, "profiles", name)
     json.dump(res, open(dst, "w"), indent=1)
     print("wrote", dst, "total fetch %.2f GB write %.2f GB per step; conv family %.2f GB, MFMA busy %s; hbm kernels %s" %
-          (res["total_fetch_bytes_per_step"] / 1e9, res["total_write_bytes_per_step"] / 1e9, res["conv_family_bytes_per_step"] / 1e9,
+          (res["total_fetch_bytes_per_step"] / 1e9, res["total_write_bytes_per_step"] / 1e9, (res["conv_family_bytes_per_step"] or 0) / 1e9,
            res["conv_family_mfma_busy_frac"], {k: round(v / 1e9, 3) for k, v in hbm.items()}))
-    assert "" not in per, "a kernel name parsed to the empty string"
 
 
 if __name__ == "__main__":
