@@ -371,10 +371,11 @@ def main():
         barrier()
         value, total, dt = lt_dist.job_throughput(B * args.steps, el, dev)
         per_rank = lt_dist.gather_floats(B * args.steps / el, dev)
+        comm = lt_dist.comm_info(dev)          # the same communicator facts the GPU lines carry (backend gloo here)
         if rank == 0:
             print(json.dumps({"metric": "stub", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": 1e3 * dt / args.steps, "total_samples": total, "per_rank_samples_per_s": per_rank,
-                              "self_launched": os.environ.get("LT_BENCH_SELF_LAUNCHED") == "1", "backend": "gloo"}))
+                              "self_launched": os.environ.get("LT_BENCH_SELF_LAUNCHED") == "1", "backend": "gloo", "rccl": comm}))
         lt_dist.shutdown()
         return
 

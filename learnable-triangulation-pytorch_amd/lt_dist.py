@@ -229,12 +229,16 @@ def comm_info(device="cpu"):
             info["version"] = "unavailable (%s)" % type(e).__name__
         pr = torch.cuda.get_device_properties(dev)
         ident = "%s|%s" % (pr.name, getattr(pr, "pci_bus_id", getattr(pr, "uuid", dev.index)))
-        code = torch.zeros(64, dtype=torch.uint8, device=dev)
-        raw = ident.encode()[:64]
-        code[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
-        out = [torch.zeros_like(code) for _ in range(dist.get_world_size())]
-        dist.all_gather(out, code)
-        info["devices"] = [bytes(o.cpu().tolist()).rstrip(b"\0").decode(errors="replace") for o in out]
+    else:
+        ident = "cpu|pid %d" % os.getpid()
+    # every rank's device, gathered through the communicator (fixed-size byte strings)
+    raw = ident.encode()[:64]
+    code = torch.zeros(64, dtype=torch.uint8)
+    code[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+    code = code.to(dev)
+    out = [torch.zeros_like(code) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, code)
+    info["devices"] = [bytes(o.cpu().tolist()).rstrip(b"\0").decode(errors="replace") for o in out]
     return info
 
 

@@ -83,6 +83,8 @@ def test_bench_self_launches_n_ranks():
     env:// rendezvous on 127.0.0.1, barrier, SUM / MAX / all_gather of the timing, one JSON line from rank 0 -- is the real code."""
     res = _run_bench(["--gpus", "2", "--steps", "5", "--warmup", "1", "--batch", "4", "--stub-cpu"])
     assert res["n_gpus"] == 2 and res["self_launched"] is True and res["backend"] == "gloo"
+    # the communicator's own account of the job (what an N-GPU line carries under "rccl"): ranks counted by an all-reduce, every rank's device
+    assert res["rccl"]["nranks"] == 2 and res["rccl"]["world_size"] == 2 and len(set(res["rccl"]["devices"])) == 2
     assert res["total_samples"] == 2 * 5 * 4                      # whole-job aggregate over both ranks
     assert len(res["per_rank_samples_per_s"]) == 2
     # rank 1 sleeps twice as long per step: the job is judged on the slowest rank
