@@ -47,6 +47,28 @@ trainprof)    # per-op table of the recorded training step (B = 8 fp32) + the st
   echo "bench train rc=$?"; python -c "
 import json; r=json.load(open('$OUT/bench_train_b8.json')); print(r['value'], r['ms_per_step'], r['losses'])"
   ;;
+aten)         # which torch (at::native / elementwise) kernels still run inside a forward / a training step?
+  cd /tmp; export TMPDIR=/tmp
+  rm -rf $OUT/prof_fwd $OUT/prof_train
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_fwd -o fwd -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-profile --no-extras > $OUT/prof_fwd.json 2> $OUT/prof_fwd.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -o train -- python $R/bench.py --train --batch 4 --steps 10 --warmup 3 > $OUT/prof_train.json 2> $OUT/prof_train.err
+  cd $R
+  python - <<PY
+import csv, glob, json
+out = {}
+for tag, steps in (("fwd", 20 + 2 + 2), ("train", 10 + 3)):
+    f = glob.glob("$OUT/prof_%s/*kernel_stats.csv" % tag)
+    rows = list(csv.DictReader(open(f[0]))) if f else []
+    aten = [(r["Name"][:110], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6) for r in rows if "at::" in r["Name"] or "elementwise" in r["Name"].lower() or "Memcpy" in r["Name"]]
+    tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
+    out[tag] = {"steps_in_run": steps, "total_kernel_ms": tot, "torch_kernels": [{"name": n, "calls": c, "calls_per_step": c / steps, "ms": ms} for n, c, ms in sorted(aten, key=lambda t: -t[1])]}
+    print(tag, "total kernel ms %.1f; torch kernels:" % tot)
+    for n, c, ms in sorted(aten, key=lambda t: -t[1])[:12]:
+        print("   %6d calls (%.1f / step) %8.3f ms  %s" % (c, c / steps, ms, n))
+json.dump(out, open("$OUT/aten_kernels.json", "w"), indent=1)
+PY
+  for t in fwd train; do f=$(ls $OUT/prof_$t/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_$t.csv; done
+  ;;
 smoke)
   timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
   ;;
