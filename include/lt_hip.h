@@ -147,6 +147,14 @@ int lt_nchw_to_nhwc(int32_t dtype, const float* x, void* y, int32_t N, int32_t C
 /* channels-last `dtype` (pixel stride ld) -> N,C,HW fp32 (API outputs) */
 int lt_nhwc_to_nchw_f32(int32_t dtype, const void* x, float* y, int32_t N, int32_t C, int32_t HW, int32_t ld, void* stream);
 
+/* The reduction half of a split-K convolution: lt_conv_fwd run with S tap-group PHASES (identity epilogue, LT_EPI_STORE_F32, phase p
+ * writing depth slice p of a [N][S * Do][Ho][Wo][C] fp32 tensor) leaves S partial sums per output; this adds them in the order p = 0 ..
+ * S-1 (fp32) and applies the convolution's real epilogue -- (sum + bias) * scale + shift, LT_EPI_RELU_PRE, residual add, LT_EPI_RELU_POST
+ * -- like the conv kernels do.  partial: [N][S][rows_per_sample][C] fp32; residual / y: [N][rows_per_sample][C] of `dtype`.  Used for
+ * V2V's 3^3 128 -> 128 layers at the 8^3 / 4^3 / 2^3 levels (mvn/models/v2v.py:78-90), whose 54-step K loop is latency-bound. */
+int lt_splitk_reduce(int32_t dtype, const float* partial, int32_t S, int64_t N, int64_t rows_per_sample, int32_t C, const float* bias,
+                     const float* scale, const float* shift, const void* residual, void* y, int32_t flags, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Voxel-grid construction: mvn/models/triangulation.py:298-339 + volumetric.rotate_coord_volume
  * (mvn/utils/volumetric.py:102-114), fp32 in the reference's operation order:

@@ -253,6 +253,9 @@ class PlanBuilder:
         flags = ((H.EPI_RELU_POST if relu else 0) | (H.EPI_RELU_PRE if relu_pre else 0) | (H.EPI_STORE_F32 if out_f32 else 0)
                  | (H.EPI_SIGMOID if sigmoid else 0))
         spec = make_conv_spec(weight, bias, bn, x.shape, stride, pad, self.dtype, transposed, flags, output_padding)
+        S = self.splitk_slices(spec, weight, transposed, out_f32, sigmoid, out)
+        if S > 1:
+            return self._conv_splitk(x, weight, spec, S, residual)
         y = out or self.alloc((spec.N, spec.OD, spec.OH, spec.OW, spec.Cout), torch.float32 if out_f32 else self.dtype)
         self.keep.append(x.t)   # the launch closure holds raw pointers only
         if residual is not None:
@@ -319,6 +322,82 @@ class PlanBuilder:
                   rp=H.ptr(residual.t) if residual is not None else None, yp=y.t.data_ptr():
                   H.check(lib.lt_conv_fwd(C.byref(d), xp, bip, scp, shp, rp, yp, s), "lt_conv_fwd"),
                   "conv", label, 2 * macs, nbytes, {"spec": spec, "x": x, "y": y, "res": residual, "wdev": wdevs, "bias_dev": bi})
+        return y
+
+    # ---- split-K for the tiny levels of V2V ---------------------------------------------------------------------------------------
+    def splitk_slices(self, spec, weight, transposed, out_f32, sigmoid, out):
+        """Number of tap groups S the reduction of this convolution is cut into (1 = not split).  Taken for bf16 plans' 3 x 3 x 3 / stride 1
+        convolutions with >= 128 input channels on volumes of at most 8^3 voxels -- V2V's 128 -> 128 layers at the 8^3 / 4^3 / 2^3 levels
+        (v2v.py:78-90), 18 launches of ~30 us each whatever the batch: K = 3456 is a 54-step latency chain for the one or few workgroups
+        the few output rows give.  S is chosen so that tiles x S fills the chip (<= 8: lt_conv_fwd's phase limit)."""
+        if (self.dtype != torch.bfloat16 or transposed or out_f32 or sigmoid or out is not None or os.environ.get("LT_CONV_NO_SPLITK") == "1"
+                or self.tile_override):
+            return 1
+        if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or spec.stride != (1, 1, 1) or spec.pad != (1, 1, 1):
+            return 1
+        if spec.Cin < 128 or spec.Cin % 64 or spec.Cout % 4 or spec.Cout != spec.cout_pad or spec.D * spec.H * spec.W > 512:
+            return 1
+        rows = spec.N * spec.Do * spec.Ho * spec.Wo
+        bm = 128 if rows >= 8192 else 64
+        tiles = -(-rows // bm) * (spec.cout_pad // bm)
+        return max(1, min(8, 256 // tiles))
+
+    def _conv_splitk(self, x, weight, spec, S, residual):
+        """The convolution as S tap-group phases of ONE lt_conv_fwd launch (fp32 partial sums, depth-stacked) + lt_splitk_reduce (the
+        real epilogue).  Returns the output Act."""
+        ph0 = spec.phases[0]
+        ntaps, Cin = ph0.taps.shape[0], spec.Cin
+        bounds = [ntaps * i // S for i in range(S + 1)]            # contiguous tap groups, sizes differ by at most one
+        kstep = k_step_of(self.dtype)
+        kp = (max(bounds[i + 1] - bounds[i] for i in range(S)) * Cin + kstep - 1) // kstep * kstep
+        ident = (torch.zeros(spec.cout_pad), torch.ones(spec.cout_pad), torch.zeros(spec.cout_pad))
+        pspec = ConvSpec(spec.N, spec.D, spec.H, spec.W, Cin, spec.Do, spec.Ho, spec.Wo, spec.stride, spec.pad, S * spec.Do, spec.Ho, spec.Wo, (1, 1, 1),
+                         spec.Cout, spec.cout_pad, kp, H.EPI_STORE_F32, *ident)
+        for i in range(S):
+            t0, t1 = bounds[i], bounds[i + 1]
+            pspec.phases.append(ConvPhaseSpec(_pad_k(ph0.weight[:, t0 * Cin:t1 * Cin], spec.cout_pad, kp), ph0.taps[t0:t1].contiguous(), (i * spec.Do, 0, 0)))
+        part = self.alloc((spec.N, S * spec.Do, spec.Ho, spec.Wo, spec.Cout), torch.float32)
+        y = self.alloc((spec.N, spec.Do, spec.Ho, spec.Wo, spec.Cout))
+        self.keep.append(x.t)
+        if residual is not None:
+            assert residual.shape == y.shape and residual.t.dtype == self.dtype, (residual.shape, y.shape)
+            self.keep.append(residual.t)
+        rows = spec.N * spec.Do * spec.Ho * spec.Wo
+        d = H.ConvDesc()
+        d.dtype = self.code
+        d.N, d.D, d.H, d.W, d.Cin = spec.N, spec.D, spec.H, spec.W, Cin
+        d.Do, d.Ho, d.Wo = spec.Do, spec.Ho, spec.Wo
+        d.stride = H.i3(spec.stride); d.pad = H.i3(spec.pad)
+        d.OD, d.OH, d.OW = S * spec.Do, spec.Ho, spec.Wo
+        d.out_stride = H.i3((1, 1, 1))
+        d.Cout, d.ldc, d.cout_pad, d.k_pad = spec.Cout, spec.Cout, spec.cout_pad, kp
+        d.nphase, d.flags, d.stages = S, H.EPI_STORE_F32, self.stages
+        d.tile = H.TILE2_128x128 if rows >= 8192 else H.TILE2_64x64        # the generic implicit GEMM: its grid.y runs the phases side by side
+        wdevs = []
+        for i, ph in enumerate(pspec.phases):
+            wdev, tdev = self.const(ph.weight, self.dtype), self.const(ph.taps)
+            wdevs.append(wdev)
+            d.phase[i].weight = wdev.data_ptr(); d.phase[i].taps = tdev.data_ptr()
+            d.phase[i].ntaps = ph.taps.shape[0]; d.phase[i].out_off = H.i3(ph.out_off)
+        ibi, isc, ish = (self.const(t) for t in ident)
+        bi, sc, sh = self.const(spec.bias), self.const(spec.scale), self.const(spec.shift)
+        self.keep.append(d)
+        macs = rows * spec.Cout * ntaps * weight.shape[1]
+        self.flops += 2 * macs
+        lib = None if self.dry_run else H.lib()
+        label = "conv3x3x3 %d->%d @%s" % (Cin, spec.Cout, "x".join(str(v) for v in (spec.N, spec.Do, spec.Ho, spec.Wo)))
+        esz = x.t.element_size()
+        self._add(lambda s, d=d, xp=x.t.data_ptr(), bip=ibi.data_ptr(), scp=isc.data_ptr(), shp=ish.data_ptr(), yp=part.t.data_ptr():
+                  H.check(lib.lt_conv_fwd(C.byref(d), xp, bip, scp, shp, None, yp, s), "lt_conv_fwd(split-K)"),
+                  "conv", label + " split-K x%d" % S, 2 * macs, x.t.numel() * esz + part.t.numel() * 4 + sum(p.weight.numel() for p in pspec.phases) * esz,
+                  {"spec": pspec, "x": x, "y": part, "res": None, "wdev": wdevs, "bias_dev": ibi})
+        R = spec.Do * spec.Ho * spec.Wo
+        self._add(lambda s, pp=part.t.data_ptr(), bip=bi.data_ptr(), scp=sc.data_ptr(), shp=sh.data_ptr(),
+                  rp=H.ptr(residual.t) if residual is not None else None, yp=y.t.data_ptr(), a=(S, spec.N, R, spec.Cout, spec.flags):
+                  H.check(lib.lt_splitk_reduce(self.code, pp, a[0], a[1], a[2], a[3], bip, scp, shp, rp, yp, a[4], s), "lt_splitk_reduce"),
+                  "conv", label + " split-K reduce", 0, part.t.numel() * 4 + (y.t.numel() + (residual.t.numel() if residual is not None else 0)) * esz,
+                  {"splitk_reduce": True, "spec": spec, "S": S, "part": part, "res": residual, "y": y})
+        self.release(part)
         return y
 
     def can_chain_pointwise(self, x, layers):

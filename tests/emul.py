@@ -37,8 +37,10 @@ def emulate_conv(spec, x, residual=None):
         assert float(ph.weight[:, ph.taps.shape[0] * Cin:].abs().sum()) == 0.0
         v = (acc + spec.bias) * spec.scale + spec.shift
         v = v[..., :spec.Cout]
-        sl = (slice(None), slice(ph.out_off[0], None, spec.out_stride[0]), slice(ph.out_off[1], None, spec.out_stride[1]),
-              slice(ph.out_off[2], None, spec.out_stride[2]))
+        # the phase's outputs: (Do, Ho, Wo) positions starting at out_off with stride out_stride (parity phases of a transposed convolution;
+        # depth slices of a split-K partial tensor)
+        sl = (slice(None),) + tuple(slice(ph.out_off[i], ph.out_off[i] + spec.out_stride[i] * (n - 1) + 1, spec.out_stride[i])
+                                    for i, n in enumerate((spec.Do, spec.Ho, spec.Wo)))
         if spec.flags & EPI_RELU_PRE:
             v = torch.relu(v)
         if residual is not None:
@@ -61,7 +63,19 @@ def run_plan_on_cpu(plan):
     assert plan.dry_run
     for _, meta in plan.ops:
         kind, info = meta["kind"], meta["info"]
-        if kind == "conv":
+        if kind == "conv" and info.get("splitk_reduce"):      # lt_splitk_reduce: the S depth slices of the partial tensor, then the real epilogue
+            sp, S, part = info["spec"], info["S"], info["part"].t.float()
+            N, Do = sp.N, sp.Do
+            acc = part.reshape(N, S, Do, sp.Ho, sp.Wo, sp.Cout).sum(dim=1)
+            v = (acc + sp.bias[:sp.Cout]) * sp.scale[:sp.Cout] + sp.shift[:sp.Cout]
+            if sp.flags & EPI_RELU_PRE:
+                v = torch.relu(v)
+            if info["res"] is not None:
+                v = v + info["res"].t.float()
+            if sp.flags & EPI_RELU_POST:
+                v = torch.relu(v)
+            info["y"].t.copy_(v)
+        elif kind == "conv":
             res = None if info["res"] is None else info["res"].t.float().clone()
             out = emulate_conv(info["spec"], info["x"].t.float().clone(), res)
             info["y"].t.copy_(out)

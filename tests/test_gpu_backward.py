@@ -167,3 +167,47 @@ def test_unproject_backward_is_bitwise_repeatable_and_matches_the_scatter(golden
         if c1 is not None:
             check("bwd/unproject gather vs round-2 scatter, conf: d/d confidences", c1.cpu(), cs_.cpu(), 2e-5)
     assert float(g1.abs().max()) > 0
+
+
+@pytest.mark.parametrize("C,hw,vshape", [(4, (20, 37), (5, 6, 7)), (16, (33, 16), (8, 8, 8)), (64, (17, 40), (9, 4, 6)), (32, (96, 96), (12, 16, 20))])
+def test_unproject_backward_gather_every_channel_width_and_ragged_shapes(C, hw, vshape):
+    """Every instantiation of the gather (channels per wave 1 / 4 / 16 / 8: C = 64 is the one-hit-at-a-time form without half-waves), maps
+    that are not multiples of the 16 x 16 tile, coordinate grids that are not multiples of the 4 x 4 x 4 brick, a camera inside the grid
+    (depth <= 0 voxels): against the round-2 scatter (itself gated against the reference's autograd), all four aggregations with gradients,
+    bitwise repeatable."""
+    from mvn.utils import op
+    g = torch.Generator().manual_seed(100 + C)
+    B, NV = 2, 3
+    h, w = hw
+    K, R, t = synth.ring_cameras(NV, 4 * max(h, w))
+    t = t.copy(); t[0] = t[0] * 0.05                       # camera 0 almost at the origin: inside the grid
+    from mvn.utils import multiview
+    proj = multiview.resized_projections(np.stack([K] * B, 0), np.stack([R] * B, 0), np.stack([t] * B, 0), (4 * h, 4 * w), (h, w))
+    P = torch.from_numpy(np.asarray(proj, dtype=np.float32)).reshape(B, NV, 3, 4).to(DEV)
+    ax = [torch.linspace(-900.0, 900.0, n) for n in vshape]
+    cv = torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1)[None].repeat(B, 1, 1, 1, 1)
+    cv[1] += 37.0
+    cv = cv.to(DEV)
+    feats = torch.randn(B, NV, C, h, w, generator=g).to(DEV)
+    conf = (torch.rand(B, NV, C, generator=g) + 0.1).to(DEV)
+    G = torch.randn(B, C, *vshape, generator=g).to(DEV)
+
+    def grad(method):
+        f = feats.clone().requires_grad_(True)
+        c = conf.clone().requires_grad_(True) if method == "conf" else None
+        (op.unproject_heatmaps(f, P, cv, method, c) * G).sum().backward()
+        return f.grad.clone(), (None if c is None else c.grad.clone())
+
+    for method in ("softmax", "sum", "max", "conf"):
+        g1, c1 = grad(method)
+        g2, c2 = grad(method)
+        assert torch.equal(g1, g2) and (c1 is None or torch.equal(c1, c2)), "%s C=%d: not bitwise repeatable" % (method, C)
+        os.environ["LT_UNPROJ_BWD_ATOMICS"] = "1"
+        try:
+            gs_, cs_ = grad(method)
+        finally:
+            del os.environ["LT_UNPROJ_BWD_ATOMICS"]
+        assert float(gs_.abs().max()) > 0
+        check("bwd/unproject gather vs scatter C=%d %s %s: d/d features" % (C, hw, method), g1.cpu(), gs_.cpu(), 2e-5)
+        if c1 is not None:
+            check("bwd/unproject gather vs scatter C=%d %s: d/d confidences" % (C, hw), c1.cpu(), cs_.cpu(), 2e-5)

@@ -718,3 +718,31 @@ def test_unproject_grid_fused_vs_separate(NV, V, dtype, method, cmu):
     check("unproject_grid/NV%d_V%d_%s_%s_cmu%d vs separate" % (NV, V, str(dtype)[6:], method, cmu), out.permute(0, 4, 1, 2, 3).float().cpu(), sep.float().cpu(), tol)
     ref = O.unproject_heatmaps(bf16_round(hm) if dtype == torch.bfloat16 else hm, P, cv_ref.cpu(), method)
     check("unproject_grid/NV%d_V%d_%s_%s_cmu%d vs oracle" % (NV, V, str(dtype)[6:], method, cmu), out.permute(0, 4, 1, 2, 3).float().cpu(), ref, tol)
+
+
+@pytest.mark.parametrize("N,sp", [(1, (2, 2, 2)), (1, (8, 8, 8)), (5, (4, 4, 4)), (32, (2, 2, 2)), (32, (8, 8, 8))])
+def test_conv3d_splitk_tiny_levels(N, sp, monkeypatch):
+    """V2V's 3^3 128 -> 128 layers on <= 8^3 voxels (bf16 plans): S tap-group phases of one lt_conv_fwd (fp32 partial sums) +
+    lt_splitk_reduce (bias, folded BatchNorm, residual, ReLU) vs torch, and vs the single-launch path (LT_CONV_NO_SPLITK=1)."""
+    g = torch.Generator().manual_seed(N * 7 + sp[0])
+    x = torch.randn(N, 128, *sp, generator=g)
+    w = torch.randn(128, 128, 3, 3, 3, generator=g) * (1.0 / (128 * 27) ** 0.5)
+    bias = torch.randn(128, generator=g) * 0.1
+    bn = _bn(128, g)
+    res = torch.randn(N, 128, *sp, generator=g)
+    rd = bf16_round
+    ref = torch.relu(_bn_ref(F.conv3d(rd(x), rd(w), bias, 1, 1), bn) + rd(res))
+    monkeypatch.delenv("LT_CONV_NO_SPLITK", raising=False)
+    b = E.PlanBuilder(DEV, torch.bfloat16)
+    y = b.conv(E.Act(to_cl(x, None, torch.bfloat16)), w, bias, bn, stride=1, pad=1, relu=True, residual=E.Act(to_cl(res, None, torch.bfloat16)))
+    assert len(b.ops) == 2 and "split-K" in b.ops[0][1]["label"], [m["label"] for _, m in b.ops]
+    b.finish().run_eager(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = from_cl(y.t, 3)
+    check("conv3d split-K N%d %s/res+relu" % (N, sp), out, ref, 1.5e-2)
+    monkeypatch.setenv("LT_CONV_NO_SPLITK", "1")
+    single = run_conv(x, w, bias, bn, 1, 1, torch.bfloat16, 0, relu=True, residual=res)
+    check("conv3d split-K N%d %s vs the single launch" % (N, sp), out, single, 1e-2)
+    monkeypatch.delenv("LT_CONV_NO_SPLITK", raising=False)
+    out2 = run_conv(x, w, bias, bn, 1, 1, torch.bfloat16, 0, relu=False, residual=None)      # plain affine epilogue through the same pair
+    check("conv3d split-K N%d %s/plain" % (N, sp), out2, _bn_ref(F.conv3d(rd(x), rd(w), bias, 1, 1), bn), 1.5e-2)

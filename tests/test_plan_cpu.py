@@ -177,3 +177,45 @@ def test_sub_batching_limit():
     assert m.max_samples_per_launch(8, 384, 384) == 31
     m64 = VolumetricTriangulationNet(synth.vol_config(18, 64), device="cpu")
     assert m64.max_samples_per_launch(4, 384, 384) == 227     # bounded by the 256-channel quarter-resolution maps of 4 views
+
+
+def test_splitk_tiny_volume_convolutions_are_recorded_and_equal_the_unsplit_convolution():
+    """V2V's 3^3 128 -> 128 layers on volumes of <= 8^3 voxels are recorded as S tap-group phases of one lt_conv_fwd (fp32 partial sums,
+    identity epilogue) + lt_splitk_reduce (the real epilogue): the recorded pair, interpreted on the CPU, equals torch's conv3d + folded
+    BatchNorm + residual + ReLU; the tap groups partition the 27 taps; LT_CONV_NO_SPLITK=1 / fp32 plans record the single launch."""
+    import os
+    import torch.nn.functional as F
+    import lt_engine as E
+    g = torch.Generator().manual_seed(5)
+    for N, sp in ((1, (2, 2, 2)), (2, (4, 4, 4)), (3, (8, 8, 8))):
+        x = torch.randn(N, *sp, 128, generator=g)
+        w = torch.randn(128, 128, 3, 3, 3, generator=g) * 0.02
+        bias = torch.randn(128, generator=g) * 0.1
+        bn = (0.5 + torch.rand(128, generator=g), torch.randn(128, generator=g) * 0.1, torch.randn(128, generator=g) * 0.1, 0.5 + torch.rand(128, generator=g))
+        res = torch.randn(N, *sp, 128, generator=g)
+        b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
+        xa, ra = E.Act(x.clone().to(torch.bfloat16)), E.Act(res.clone().to(torch.bfloat16))
+        y = b.conv(xa, w, bias, bn, stride=1, pad=1, relu=True, residual=ra)
+        kinds = [(m["kind"], m["label"]) for _, m in b.ops]
+        assert len(b.ops) == 2 and "split-K x" in kinds[0][1] and kinds[1][1].endswith("split-K reduce"), kinds
+        pspec = b.ops[0][1]["info"]["spec"]
+        S = len(pspec.phases)
+        assert 2 <= S <= 8 and pspec.OD == S * sp[0] and sum(int(p.taps.shape[0]) for p in pspec.phases) == 27
+        assert [tuple(p.out_off) for p in pspec.phases] == [(i * sp[0], 0, 0) for i in range(S)]
+        plan = b.finish()
+        xa.t, ra.t, y.t = x.clone(), res.clone(), y.t.float()     # the interpreter computes in fp32: host logic, not bf16 rounding, is under test
+        run_plan_on_cpu(plan)
+        ref = F.conv3d(x.permute(0, 4, 1, 2, 3), w, bias, 1, 1)
+        ref = F.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.1, 1e-5)
+        ref = torch.relu(ref + res.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1)
+        assert float((y.t - ref).abs().max()) <= 2e-4 * float(ref.abs().max()), float((y.t - ref).abs().max())
+    os.environ["LT_CONV_NO_SPLITK"] = "1"
+    try:
+        b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
+        b.conv(E.Act(torch.zeros(1, 4, 4, 4, 128)), w, bias, bn, stride=1, pad=1, relu=True)
+        assert len(b.ops) == 1
+    finally:
+        del os.environ["LT_CONV_NO_SPLITK"]
+    b = E.PlanBuilder("cpu", torch.float32, dry_run=True)
+    b.conv(E.Act(torch.zeros(1, 4, 4, 4, 128)), w, bias, bn, stride=1, pad=1, relu=True)
+    assert len(b.ops) == 1          # the exact-fp32 parity mode keeps its single accumulation chain
