@@ -746,3 +746,4 @@ def test_conv3d_splitk_tiny_levels(N, sp, monkeypatch):
     monkeypatch.delenv("LT_CONV_NO_SPLITK", raising=False)
     out2 = run_conv(x, w, bias, bn, 1, 1, torch.bfloat16, 0, relu=False, residual=None)      # plain affine epilogue through the same pair
     check("conv3d split-K N%d %s/plain" % (N, sp), out2, _bn_ref(F.conv3d(rd(x), rd(w), bias, 1, 1), bn), 1.5e-2)
+
