@@ -432,7 +432,116 @@ __global__ void dlt_kernel(const float* __restrict__ proj, const float* __restri
     o[0] = (float)(V[0][best] / wv); o[1] = (float)(V[1][best] / wv); o[2] = (float)(V[2][best] / wv);
 }
 
+// ---- backward of the 2D soft-argmax and of the DLT (training of the algebraic model, train.py:189-236) ---------------------------------------
+// integrate_tensor_2d (op.py:11-47), softmax mode: p = softmax_i(mult * h_i), (X, Y) = sum_i p_i (x_i, y_i):
+//   d L / d h_i = mult * p_i * ((x_i - X) g_x + (y_i - Y) g_y).  One elementwise pass over the returned heatmaps p.
+__global__ __launch_bounds__(256) void sa2_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ coords, const float* __restrict__ gcoords,
+                                                       float mult, float* __restrict__ ghm, int h, int w) {
+    const long long base = (long long)blockIdx.y * h * w;
+    const float X = coords[blockIdx.y * 2], Y = coords[blockIdx.y * 2 + 1];
+    const float gx = gcoords[blockIdx.y * 2], gy = gcoords[blockIdx.y * 2 + 1];
+    const int n = h * w;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int yy = i / w, xx = i - yy * w;
+        ghm[base + i] = mult * probs[base + i] * (((float)xx - X) * gx + ((float)yy - Y) * gy);
+    }
+}
+
+// triangulate_point_from_multiple_views_linear_torch (multiview.py:141-168): X = v[:3] / v[3], v = right singular vector of A for its smallest
+// singular value = eigenvector of M = A^T A for its smallest eigenvalue lambda; rows of A: c_v (x_{v,r} P_v[2,:] - P_v[r,:]).  What autograd derives
+// through torch.svd there, written out:  g_v = (g_X / v3, -(g_X . v[:3]) / v3^2) (orthogonal to v: X does not depend on |v|),
+//   w = (lambda I - M)^+ g_v = sum_{i != min} e_i (e_i . g_v) / (lambda - lambda_i),   dL/dM = (w v^T + v w^T) / 2,   dL/dA = A (w v^T + v w^T),
+//   dL/dc_v = sum_r dL/dA[v,r,:] . (x P2 - Pr),   dL/dx_{v,r} = c_v dL/dA[v,r,:] . P_v[2,:].   fp64, one lane per (sample, joint).
+__global__ void dlt_bwd_kernel(const float* __restrict__ proj, const float* __restrict__ pts, const float* __restrict__ conf,
+                               const float* __restrict__ gout, float* __restrict__ gpts, float* __restrict__ gconf, int B, int NV, int J) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B * J) return;
+    const int b = g / J, j = g - b * J;
+    double Mx[4][4] = {};
+    for (int v = 0; v < NV; ++v) {
+        const float* P = proj + ((long long)b * NV + v) * 12;
+        const float* p = pts + (((long long)b * NV + v) * J + j) * 2;
+        const float c = conf ? conf[((long long)b * NV + v) * J + j] : 1.f;
+        for (int r = 0; r < 2; ++r) {
+            float arow[4];
+            for (int k = 0; k < 4; ++k) arow[k] = (P[8 + k] * p[r] - P[4 * r + k]) * c;
+            for (int i = 0; i < 4; ++i)
+                for (int k = 0; k < 4; ++k) Mx[i][k] += (double)arow[i] * (double)arow[k];
+        }
+    }
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 16; ++sweep) {          // the forward's cyclic Jacobi
+        double off = 0;
+        for (int p = 0; p < 4; ++p)
+            for (int q = p + 1; q < 4; ++q) off += Mx[p][q] * Mx[p][q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 4; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                if (Mx[p][q] == 0.0) continue;
+                const double theta = (Mx[q][q] - Mx[p][p]) / (2.0 * Mx[p][q]);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
+                for (int k = 0; k < 4; ++k) { const double akp = Mx[k][p], akq = Mx[k][q]; Mx[k][p] = cs * akp - sn * akq; Mx[k][q] = sn * akp + cs * akq; }
+                for (int k = 0; k < 4; ++k) { const double apk = Mx[p][k], aqk = Mx[q][k]; Mx[p][k] = cs * apk - sn * aqk; Mx[q][k] = sn * apk + cs * aqk; }
+                for (int k = 0; k < 4; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = cs * vkp - sn * vkq; V[k][q] = sn * vkp + cs * vkq; }
+            }
+    }
+    int best = 0;
+    for (int i = 1; i < 4; ++i)
+        if (Mx[i][i] < Mx[best][best]) best = i;
+    const double lam = Mx[best][best];
+    double vv[4], gv[4], wv[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k) vv[k] = V[k][best];
+    const double gX[3] = {(double)gout[g * 3], (double)gout[g * 3 + 1], (double)gout[g * 3 + 2]};
+    gv[0] = gX[0] / vv[3]; gv[1] = gX[1] / vv[3]; gv[2] = gX[2] / vv[3];
+    gv[3] = -(gX[0] * vv[0] + gX[1] * vv[1] + gX[2] * vv[2]) / (vv[3] * vv[3]);
+    for (int i = 0; i < 4; ++i) {
+        if (i == best) continue;
+        double dot = 0;
+        for (int k = 0; k < 4; ++k) dot += V[k][i] * gv[k];
+        const double f = dot / (lam - Mx[i][i]);
+        for (int k = 0; k < 4; ++k) wv[k] += V[k][i] * f;
+    }
+    for (int v = 0; v < NV; ++v) {
+        const float* P = proj + ((long long)b * NV + v) * 12;
+        const long long pi = ((long long)b * NV + v) * J + j;
+        const float* p = pts + pi * 2;
+        const double c = conf ? (double)conf[pi] : 1.0;
+        double gc = 0;
+        for (int r = 0; r < 2; ++r) {
+            double raw[4], arow[4], av = 0, aw = 0;
+            for (int k = 0; k < 4; ++k) { raw[k] = (double)(P[8 + k] * p[r] - P[4 * r + k]); arow[k] = raw[k] * c; av += arow[k] * vv[k]; aw += arow[k] * wv[k]; }
+            double gp = 0;
+            for (int k = 0; k < 4; ++k) {
+                const double ga = aw * vv[k] + av * wv[k];          // dL/dA[v,r,k] = (A (w v^T + v w^T))[row][k]
+                gc += ga * raw[k];
+                gp += ga * (double)P[8 + k];
+            }
+            gpts[pi * 2 + r] = (float)(gp * c);
+        }
+        if (gconf) gconf[pi] = (float)gc;
+    }
+}
+
 }  // namespace
+
+extern "C" int lt_softargmax2d_bwd(const float* probs, const float* coords, const float* grad_coords, float mult, int32_t softmax, float* grad_heatmaps,
+                                   int32_t NJ, int32_t h, int32_t w, void* stream) {
+    LT_REQUIRE(probs && coords && grad_coords && grad_heatmaps && NJ >= 1 && h >= 1 && w >= 1, LT_ERR_INVALID, "lt_softargmax2d_bwd: bad argument");
+    LT_REQUIRE(softmax, LT_ERR_UNSUPPORTED, "lt_softargmax2d_bwd: the ReLU variant (heatmap_softmax: false) has no backward here");
+    const int bx = (int)((h * w + 255) / 256);
+    hipLaunchKernelGGL(sa2_bwd_kernel, dim3(bx < 64 ? bx : 64, NJ), dim3(256), 0, (hipStream_t)stream, probs, coords, grad_coords, mult, grad_heatmaps, h, w);
+    LT_CHECK_LAUNCH("lt_softargmax2d_bwd");
+    return LT_OK;
+}
+
+extern "C" int lt_triangulate_dlt_bwd(const float* proj, const float* points, const float* conf, const float* grad_out, float* grad_points, float* grad_conf,
+                                      int32_t B, int32_t NV, int32_t J, void* stream) {
+    LT_REQUIRE(proj && points && grad_out && grad_points && B >= 1 && NV >= 2 && J >= 1, LT_ERR_INVALID, "lt_triangulate_dlt_bwd: bad argument");
+    hipLaunchKernelGGL(dlt_bwd_kernel, dim3((B * J + 63) / 64), dim3(64), 0, (hipStream_t)stream, proj, points, conf, grad_out, grad_points, grad_conf, B, NV, J);
+    LT_CHECK_LAUNCH("lt_triangulate_dlt_bwd");
+    return LT_OK;
+}
 
 extern "C" size_t lt_softargmax3d_workspace(int32_t B, int32_t J, int64_t nvox) {
     const int64_t nchunks = (nvox + SA_CHUNK - 1) / SA_CHUNK;

@@ -89,6 +89,8 @@ SIGNATURES = {
     "lt_add_f32": (C.c_int, [vp, vp, i64, vp]),
     "lt_pad_channels_f32": (C.c_int, [vp, vp, i64, i32, i32, vp]),
     "lt_zero": (C.c_int, [vp, i64, vp]),
+    "lt_softargmax2d_bwd": (C.c_int, [vp, vp, vp, C.c_float, i32, vp, i32, i32, i32, vp]),
+    "lt_triangulate_dlt_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "lt_splitk_reduce": (C.c_int, [i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp]),
     "lt_add_i64_multi": (C.c_int, [vp, i32, i64, vp]),
     "lt_cast_f32_bf16": (C.c_int, [vp, vp, i64, vp]),

@@ -35,12 +35,6 @@ def _bn_in_train_mode(m):
     return any(isinstance(c, nn.modules.batchnorm._BatchNorm) and c.training for c in m.modules())
 
 
-def _no_training(m):
-    if _bn_in_train_mode(m):
-        raise NotImplementedError("forward with BatchNorm in training mode (and backward) is not built for this network "
-                                  "(SURVEY.md section 8f row 1); call model.eval()")
-
-
 class _VolTrainPlan:
     """The training step of VolumetricTriangulationNet for one input shape, recorded once and replayed (lt_train.TrainTape): the first
     forward / backward run the layers while recording them; later steps re-launch the recorded closures over the same buffers.  What
@@ -194,6 +188,95 @@ class _VolTrainFn(torch.autograd.Function):
             pg = plan.backward(g_kp, idx, val)
         grads = tuple(pg.get(p) if p.requires_grad else None for p in ctx.params)
         return (None, None, None) + grads
+
+
+class _AlgTrainPlan:
+    """The training step of AlgebraicTriangulationNet's backbone for one input shape (lt_train.TrainTape, recorded once / replayed): images ->
+    heatmap logits (N, J, h, w) and, with ``use_confidences``, the alg_confidences head's sigmoid output (N, J).  The tail of the model -- 2D
+    soft-argmax, confidence normalisation, DLT -- runs on these two small tensors as ordinary autograd nodes (mvn.utils.op / multiview)."""
+
+    def __init__(self, model, N, Hh, W, device):
+        self.model, self.N, self.Hh, self.W, self.device = model, N, Hh, W, device
+        self.tape = None
+        self.step_id = 0
+
+    def forward(self, x):
+        import lt_train
+        model, N, Hh, W, device = self.model, self.N, self.Hh, self.W, self.device
+        lib = H.lib()
+        st = torch.cuda.current_stream(device).cuda_stream
+        first = self.tape is None
+        if first:
+            mixed = getattr(model, "train_precision", "fp32") == "bf16"
+            self.tape = tape = lt_train.TrainTape(device, params=list(model.parameters()), reducer=getattr(model, "grad_reducer", None), mixed=mixed)
+            self.x_in = tape.alloc((N, 1, Hh, W, E.min_cin_of(torch.bfloat16 if mixed else torch.float32)))
+            tape.no_grad_ids.add(id(self.x_in))
+        tape = self.tape
+        H.check(lib.lt_nchw_to_nhwc(H.LT_F32, x.data_ptr(), self.x_in.t.data_ptr(), N, 3, Hh * W, self.x_in.t.shape[-1], st), "lt_nchw_to_nhwc")
+        if first:
+            hm, _, algc, _ = model.backbone.record(tape, self.x_in, want_heatmaps=True)
+            self.hm, self.algc = hm, algc
+            self.g_hm = torch.empty_like(hm.t)
+            tape.seed(hm, self.g_hm)
+            self.g_conf = None
+            if algc is not None:
+                self.g_conf = torch.empty_like(algc.t)
+                tape.seed(algc, self.g_conf)
+        else:
+            tape.stream = st
+            tape._gather_all("fwd", tape.fwd_jobs)
+            tape.replay(tape.fwd_ops)
+        self.step_id += 1
+        _, _, h, w, J = self.hm.shape
+        hm_out = torch.empty(N, J, h, w, dtype=torch.float32, device=device)
+        H.check(lib.lt_nhwc_to_nchw_f32(H.LT_F32, self.hm.t.data_ptr(), hm_out.data_ptr(), N, J, h * w, J, st), "lt_nhwc_to_nchw_f32")
+        conf_out = self.algc.t.reshape(N, J).clone() if self.algc is not None else torch.empty(0, device=device)
+        return hm_out, conf_out
+
+    def backward(self, g_hm, g_conf):
+        N = self.N
+        _, _, h, w, J = self.hm.shape
+        lib = H.lib()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        if g_hm is None:
+            H.check(lib.lt_zero(self.g_hm.data_ptr(), self.g_hm.numel() * 4, st), "lt_zero")
+        else:
+            g = g_hm.float().contiguous()
+            H.check(lib.lt_nchw_to_nhwc(H.LT_F32, g.data_ptr(), self.g_hm.data_ptr(), N, J, h * w, J, st), "lt_nchw_to_nhwc")
+        if self.g_conf is not None:
+            if g_conf is None:
+                H.check(lib.lt_zero(self.g_conf.data_ptr(), self.g_conf.numel() * 4, st), "lt_zero")
+            else:
+                self.g_conf.view(N, J).copy_(g_conf.float())
+        pg = self.tape.run_backward()
+        flat = self.tape.arena.clone()          # autograd gets its own copy: the arena is overwritten by the next step
+        off = self.tape.arena.data_ptr()
+        return {p: flat[(v.data_ptr() - off) // 4:(v.data_ptr() - off) // 4 + v.numel()].view(v.shape) for p, v in pg.items()}
+
+
+class _AlgTrainFn(torch.autograd.Function):
+    """The training-mode backbone of AlgebraicTriangulationNet as ONE autograd node (the counterpart of _VolTrainFn).  Inputs: (plan, images
+    (N,3,H,W), *parameters); outputs: heatmap logits (N,J,h,w), raw confidences (N,J) (empty without the head)."""
+
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        ctx.set_materialize_grads(False)
+        with torch.cuda.device(x.device):
+            hm, conf = plan.forward(x)
+        ctx.plan, ctx.step_id, ctx.params = plan, plan.step_id, params
+        if conf.numel() == 0:
+            ctx.mark_non_differentiable(conf)
+        return hm, conf
+
+    @staticmethod
+    def backward(ctx, g_hm, g_conf):
+        plan = ctx.plan
+        if ctx.step_id != plan.step_id:
+            raise RuntimeError("only the LATEST training forward of a shape can be backpropagated (its activations live in the plan's buffers, "
+                               "which a newer forward has overwritten)")
+        with torch.cuda.device(plan.device):
+            pg = plan.backward(g_hm, g_conf)
+        return (None, None) + tuple(pg.get(p) if p.requires_grad else None for p in ctx.params)
 
 
 class _PlannedNet(E.PlanCache):
@@ -541,7 +624,8 @@ class AlgebraicTriangulationNet(_PlannedNet):
         """Returns (keypoints_3d (B,J,3), keypoints_2d (B,NV,J,2) in image pixels, heatmaps (B,NV,J,h,w) after
         softmax, alg_confidences (B,NV,J)) -- reference :149-200."""
         H.require_gpu(images, "images")
-        _no_training(self)
+        if _bn_in_train_mode(self):
+            return self._forward_train(images, proj_matricies)
         device = images.device
         B, NV = images.shape[:2]
         Hh, W = images.shape[3:]
@@ -549,6 +633,60 @@ class AlgebraicTriangulationNet(_PlannedNet):
         with torch.cuda.device(device):
             P = self._plan_for(key, lambda: self._build_plan(B, NV, Hh, W, device))
             return self._run(P, images, proj_matricies, B, NV, Hh, W, device)
+
+    def _forward_train(self, images, proj_matricies):
+        """Training mode (round 3; the reference's loop for model_type "alg", train.py:189-236): the backbone -- heatmap head and, with
+        ``use_confidences``, the alg_confidences head included -- runs its recorded training step (lt_train.TrainTape: batch-statistics
+        BatchNorm, liblt_hip backward); 2D soft-argmax, confidence normalisation and the DLT are autograd nodes over liblt_hip kernels
+        (lt_softargmax2d_bwd, lt_triangulate_dlt_bwd: what autograd derives through torch.svd in the reference).  Same 4-tuple as inference."""
+        bns = [c for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm)]
+        if not all(c.training for c in bns):
+            raise NotImplementedError("a mix of training-mode and eval-mode BatchNorm layers (frozen statistics) is not built: "
+                                      "model.train() or model.eval() as a whole (train.py:163-166)")
+        if any(c.momentum is None or abs(c.momentum - 0.1) > 1e-12 or not c.track_running_stats or not c.affine for c in bns):
+            raise NotImplementedError("BatchNorm with a momentum other than 0.1, without running statistics or without affine parameters")
+        if not self.heatmap_softmax:
+            raise NotImplementedError("training with heatmap_softmax: false (the ReLU variant of integrate_tensor_2d has no backward here)")
+        params = tuple(self.parameters())
+        off = [n for n, t in list(self.named_parameters()) + list(self.named_buffers()) if t.device != images.device]
+        if off:
+            raise RuntimeError("training updates the parameters where they live: move the model to %s first (model.to(device), as "
+                               "train.py:424 does); %d tensors are elsewhere, e.g. %s" % (images.device, len(off), off[0]))
+        device = images.device
+        B, NV = images.shape[:2]
+        Hh, W = images.shape[3:]
+        red = getattr(self, "grad_reducer", None)
+        if red is not None:          # DistributedDataParallel's semantics, as in the volumetric model
+            if not red.attached:
+                red.attach(self)
+            else:
+                red.sync_buffers()
+        key = (B * NV, Hh, W, device, tuple(p.requires_grad for p in params), id(red), getattr(self, "train_precision", "fp32"))
+        plans = self.__dict__.setdefault("_train_plans", OrderedDict())
+        plan = plans.get(key)
+        if plan is None:
+            while len(plans) >= 2:
+                plans.popitem(last=False)
+            plan = plans[key] = _AlgTrainPlan(self, B * NV, Hh, W, device)
+        plans.move_to_end(key)
+        x = images.reshape(B * NV, 3, Hh, W)
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        hm, conf_raw = _AlgTrainFn.apply(plan, x, *params)
+        nbt = [c.num_batches_tracked for c in bns]
+        tab_key = tuple(t.data_ptr() for t in nbt)
+        tab = self.__dict__.get("_nbt_table")
+        if tab is None or tab[0] != tab_key:
+            tab = self.__dict__["_nbt_table"] = (tab_key, torch.tensor(tab_key, dtype=torch.int64).to(device))
+        H.check(H.lib().lt_add_i64_multi(tab[1].data_ptr(), len(nbt), 1, torch.cuda.current_stream(device).cuda_stream), "lt_add_i64_multi")
+        N, J, h, w = hm.shape
+        kp2d, heatmaps = op.integrate_tensor_2d(hm * self.heatmap_multiplier, self.heatmap_softmax)      # reference :158
+        conf = conf_raw.reshape(B, NV, J) if conf_raw.numel() else torch.ones(B, NV, J, dtype=torch.float32, device=device)
+        conf = conf / conf.sum(dim=1, keepdim=True) + 1e-5                                                 # reference :173-174
+        scale = torch.tensor([W / w, Hh / h], dtype=torch.float32, device=device)
+        kp2d = kp2d.reshape(B, NV, J, 2) * scale                                                          # reference :181-184
+        kp3d = multiview.triangulate_batch_of_points(proj_matricies.to(device), kp2d, confidences_batch=conf)
+        return kp3d, kp2d, heatmaps.reshape(B, NV, J, h, w), conf
 
     def _run(self, P, images, proj_matricies, B, NV, Hh, W, device):
         h, w = P["hw"]; J = P["J"]

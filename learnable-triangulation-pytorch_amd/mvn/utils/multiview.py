@@ -93,14 +93,43 @@ def project_3d_points_to_image_plane_without_distortion(proj_matrix, points_3d, 
     return homogeneous_to_euclidean(res) if convert_back_to_euclidean else res
 
 
+class _TriangulateFn(torch.autograd.Function):
+    """lt_triangulate_dlt / lt_triangulate_dlt_bwd as one node: what autograd derives in the reference through torch.svd (:163) for the 2D
+    points and the confidences (the projection matrices get no gradient, as there)."""
+
+    @staticmethod
+    def forward(ctx, P, pts, conf):
+        B, NV, J = pts.shape[:3]
+        out = torch.empty(B, J, 3, dtype=torch.float32, device=pts.device)
+        H.check(H.lib().lt_triangulate_dlt(P.data_ptr(), pts.data_ptr(), H.ptr(conf), out.data_ptr(), B, NV, J, H.cur_stream()), "lt_triangulate_dlt")
+        ctx.save_for_backward(P, pts, conf if conf is not None else torch.empty(0, device=pts.device))
+        ctx.has_conf = conf is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        P, pts, conf = ctx.saved_tensors
+        conf = conf if ctx.has_conf else None
+        B, NV, J = pts.shape[:3]
+        g = g.float().contiguous()
+        gpts = torch.empty_like(pts)
+        gconf = torch.empty_like(conf) if conf is not None else None
+        H.check(H.lib().lt_triangulate_dlt_bwd(P.data_ptr(), pts.data_ptr(), H.ptr(conf), g.data_ptr(), gpts.data_ptr(), H.ptr(gconf), B, NV, J,
+                                               H.cur_stream()), "lt_triangulate_dlt_bwd")
+        return None, gpts, gconf
+
+
 def triangulate_batch_of_points(proj_matricies_batch, points_batch, confidences_batch=None):
     """Confidence-weighted DLT for every (sample, joint) in one launch (reference :171-183 loops B x J
-    torch.svd calls).  proj (B,NV,3,4), points (B,NV,J,2), confidences (B,NV,J) -> (B,J,3) fp32."""
+    torch.svd calls).  proj (B,NV,3,4), points (B,NV,J,2), confidences (B,NV,J) -> (B,J,3) fp32.  Differentiable with respect to the
+    points and the confidences when they require grad."""
     H.require_gpu(points_batch, "points_batch")
-    B, NV, J = points_batch.shape[:3]
     P = proj_matricies_batch.to(points_batch.device, torch.float32).contiguous()
     pts = points_batch.float().contiguous()
     conf = None if confidences_batch is None else confidences_batch.float().contiguous()
+    if torch.is_grad_enabled() and (pts.requires_grad or (conf is not None and conf.requires_grad)):
+        return _TriangulateFn.apply(P, pts, conf)
+    B, NV, J = pts.shape[:3]
     out = torch.empty(B, J, 3, dtype=torch.float32, device=pts.device)
     H.check(H.lib().lt_triangulate_dlt(P.data_ptr(), pts.data_ptr(), H.ptr(conf), out.data_ptr(), B, NV, J, H.cur_stream()),
             "lt_triangulate_dlt")

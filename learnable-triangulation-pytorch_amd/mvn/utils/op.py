@@ -204,9 +204,7 @@ def batchnorm_batch_stats(x, running_mean=None, running_var=None, momentum=0.1):
     return mean, var
 
 
-def integrate_tensor_2d(heatmaps, softmax=True):
-    """heatmaps (N,J,h,w) -> (coordinates (N,J,2) as (x,y), heatmaps after softmax / ReLU).  Reference: op.py:11-47."""
-    H.require_gpu(heatmaps, "heatmaps")
+def _softargmax2d_launch(heatmaps, softmax):
     N, J, h, w = heatmaps.shape
     hm = heatmaps.float().contiguous()
     coords = torch.empty(N, J, 2, dtype=torch.float32, device=hm.device)
@@ -214,3 +212,35 @@ def integrate_tensor_2d(heatmaps, softmax=True):
     H.check(H.lib().lt_softargmax2d_fwd(hm.data_ptr(), 1.0, int(bool(softmax)), coords.data_ptr(), probs.data_ptr(), N * J, h, w, H.cur_stream()),
             "lt_softargmax2d_fwd")
     return coords, probs
+
+
+class _SoftArgmax2dFn(torch.autograd.Function):
+    """lt_softargmax2d_fwd / _bwd as one node (the algebraic model's training, train.py:189-236): the gradient of the coordinates reaches the
+    heatmaps; a gradient on the returned (softmaxed) heatmaps is refused -- no loss of the reference uses them."""
+
+    @staticmethod
+    def forward(ctx, heatmaps, softmax):
+        coords, probs = _softargmax2d_launch(heatmaps, softmax)
+        ctx.save_for_backward(coords, probs)
+        ctx.softmax, ctx.in_dtype = bool(softmax), heatmaps.dtype
+        ctx.mark_non_differentiable(probs)
+        return coords, probs
+
+    @staticmethod
+    def backward(ctx, g_coords, g_probs):
+        coords, probs = ctx.saved_tensors
+        N, J, h, w = probs.shape
+        g = g_coords.float().contiguous()
+        ghm = torch.empty_like(probs)
+        H.check(H.lib().lt_softargmax2d_bwd(probs.data_ptr(), coords.data_ptr(), g.data_ptr(), 1.0, int(ctx.softmax), ghm.data_ptr(), N * J, h, w,
+                                            H.cur_stream()), "lt_softargmax2d_bwd")
+        return ghm.to(ctx.in_dtype), None
+
+
+def integrate_tensor_2d(heatmaps, softmax=True):
+    """heatmaps (N,J,h,w) -> (coordinates (N,J,2) as (x,y), heatmaps after softmax / ReLU).  Reference: op.py:11-47.  Differentiable with
+    respect to the heatmaps (through the coordinates) when they require grad."""
+    H.require_gpu(heatmaps, "heatmaps")
+    if torch.is_grad_enabled() and heatmaps.requires_grad:
+        return _SoftArgmax2dFn.apply(heatmaps, softmax)
+    return _softargmax2d_launch(heatmaps, softmax)

@@ -456,6 +456,101 @@ def gen_train(mvn, method="softmax", fname="train_step.npz"):
     np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 
+def gen_train_alg(mvn):
+    """One full training step of the reference's AlgebraicTriangulationNet on CPU (train.py:148-243 with model_type "alg"): model.train(), criterion
+    MSESmooth(threshold 400) on keypoints * scale_keypoints_3d (experiments/human36m/train/human36m_alg.yaml:9-19), total_loss.backward() through
+    triangulate_batch_of_points (torch.svd, multiview.py:163), the 2D soft-argmax, the alg_confidences head and the backbone, torch.optim.Adam.
+    ``heatmap_multiplier`` is 1 here (the yaml's 100 turns the soft-argmax of random-init heatmaps into a near-argmax whose DLT is ill-conditioned:
+    the reference's own gradients then move by orders of magnitude between two thread counts); the self-noise of the reference (8 threads / 1 thread /
+    images x (1 + 1e-6)) is stored per parameter like in gen_train."""
+    import mvn.models.loss as L
+    torch.set_num_threads(8)
+    c = dict(nl=18, B=2, NV=3, H=128, seed=21)
+    cfg = synth.alg_config(c["nl"], True)
+    cfg.model.heatmap_multiplier = 1.0
+    sp = spec.alg_net_spec(c["nl"], 17, True)
+    sd = synth.make_state_dict(sp, seed=c["seed"], basic_block=True)
+    inp = synth.make_inputs(c["B"], c["NV"], c["H"], seed=c["seed"], inside=False)
+    P = torch.from_numpy(inp["K"] @ np.concatenate([inp["R"], inp["t"]], -1)).float()[None].repeat(c["B"], 1, 1, 1)
+    lr = 1e-5
+    g = torch.Generator().manual_seed(44)
+    dgt = torch.randn(c["B"], 17, 3, generator=g) * 40
+    val = torch.ones(c["B"], 17, 1); val[0, 3] = 0
+
+    def step(eps=0.0, gt=None, dt=torch.float32):
+        ref = mvn.models.triangulation.AlgebraicTriangulationNet(cfg, device="cpu")
+        ref.load_state_dict(sd, strict=True)
+        ref.train()
+        ref.to(dt)
+        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, ref.parameters()), lr=lr)
+        kp3, kp2, hm, conf = ref((inp["images"] * (1.0 + eps)).to(dt), P.to(dt), {})
+        if gt is None:
+            gt = kp3.detach() + dgt
+        loss = L.KeypointsMSESmoothLoss(400)(kp3 * 0.1, gt.to(kp3.dtype) * 0.1, val.to(kp3.dtype))
+        opt.zero_grad()
+        loss.backward()
+        return ref, opt, dict(kp3=kp3.detach(), kp2=kp2.detach(), hm=hm.detach(), conf=conf.detach(), gt=gt, loss=float(loss))
+
+    t0 = time.time()
+    ref, opt, r = step()
+    torch.set_num_threads(1)
+    ref1, _, r1 = step(gt=r["gt"])
+    torch.set_num_threads(8)
+    refp, _, rp = step(eps=1e-6, gt=r["gt"])
+    kp = r["kp3"]
+    kp_noise = max(float(((o["kp3"] - kp).abs() / kp.abs().clamp(min=1.0)).max()) for o in (r1, rp))
+    out = {"kp3": kp.numpy(), "kp2": r["kp2"].numpy(), "conf": r["conf"].numpy(), "gt": r["gt"].numpy(), "val": val.numpy(), "loss": np.array(r["loss"]),
+           "P": P.numpy(), "lr": np.array(lr), "kp_noise": np.array(kp_noise), "loss_noise": np.array(max(abs(o["loss"] - r["loss"]) / r["loss"] for o in (r1, rp))),
+           "hm_sub": sub(r["hm"].reshape(c["B"] * c["NV"], *r["hm"].shape[2:]), 2)}
+    # how exact is the reference's OWN gradient through torch.svd in fp32?  The tail (DLT + loss) on the stored 2D keypoints / confidences, once in
+    # fp32 (what the step above did) and once in fp64: every parameter gradient of the step inherits this relative error, and no thread count shows it
+    def tail_grads(dt):
+        p2 = r["kp2"].to(dt).clone().requires_grad_(True)
+        cf = r["conf"].to(dt).clone().requires_grad_(True)
+        x3 = mvn.utils.multiview.triangulate_batch_of_points(P.to(dt), p2, confidences_batch=cf)
+        L.KeypointsMSESmoothLoss(400)(x3.to(dt) * 0.1, r["gt"].to(dt) * 0.1, val.to(dt)).backward()
+        return p2.grad.double(), cf.grad.double()
+    # ... and the WHOLE step with the reference's modules in fp64 (same code, .double()): the exact gradients the fp32 step approximates
+    ref64, _, r64 = step(gt=r["gt"], dt=torch.float64)
+    g64 = dict(ref64.named_parameters())
+    (p32, c32), (p64, c64) = tail_grads(torch.float32), tail_grads(torch.float64)
+    svd32 = max(float((p32 - p64).abs().max() / p64.abs().max()), float((c32 - c64).abs().max() / c64.abs().max()))
+    out["svd32_rel"] = np.array(svd32)
+    names, no_grad, noises = [], [], []
+    g1, gp = dict(ref1.named_parameters()), dict(refp.named_parameters())
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            no_grad.append(n)
+            continue
+        names.append(n)
+        gmax = float(p.grad.abs().max())
+        out["g/" + n] = _train_sub(p.grad)
+        out["gn/" + n] = np.array([float(p.grad.double().norm()), gmax, float(p.grad.double().sum())])
+        noise = max(float((o[n].grad - p.grad).abs().max()) for o in (g1, gp)) / max(gmax, 1e-30)
+        out["noise/" + n] = np.array(noise)
+        noises.append(noise)
+        out["g64/" + n] = _train_sub(g64[n].grad)
+        out["gn64/" + n] = np.array([float(g64[n].grad.norm()), float(g64[n].grad.abs().max())])
+    opt.step()
+    for n, p in ref.named_parameters():
+        if n in names:
+            out["p1/" + n] = _train_sub(p)
+    for n, b_ in ref.named_buffers():
+        if n.endswith("running_mean") or n.endswith("running_var"):
+            out["rs/" + n] = _train_sub(b_)
+    out["names"] = np.array(names); out["no_grad"] = np.array(no_grad)
+    gn = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in ref.parameters() if p.grad is not None)))
+    out["grad_norm"] = np.array(gn)
+    out["grad_norm64"] = np.array(float(torch.sqrt(sum(p.grad.pow(2).sum() for p in ref64.parameters() if p.grad is not None))))
+    dev32 = sorted(float((p.grad.double() - g64[n].grad).abs().max() / max(float(g64[n].grad.abs().max()), 1e-30)) for n, p in ref.named_parameters() if out["noise/" + n] <= 0.05)
+    print("  the reference's fp32 step against its fp64 step, per-parameter max|d|/max|g|: median %.2e, max %.2e" % (dev32[len(dev32) // 2], dev32[-1]))
+    noises = np.sort(np.array(noises))
+    print("  the reference's fp32 torch.svd backward against fp64 on the same tail inputs: %.2e (relative)" % svd32)
+    print("  alg train step x3: %.1fs; loss %.4f; %d parameters with gradients (%d without), global grad norm %.4e" % (time.time() - t0, r["loss"], len(names), len(no_grad), gn))
+    print("  reference self-noise: kp %.2e; gradients median %.2e, 90%% %.2e, max %.2e" % (kp_noise, noises[len(noises) // 2], noises[int(len(noises) * 0.9)], noises[-1]))
+    np.savez_compressed(os.path.join(GOLD, "train_step_alg.npz"), **out)
+
+
 def run_vol_case(mvn, tag, num_layers, B, NV, H, V, method="softmax", multiplier=1.0, sharpen=False,
                  inside=False, rotate=False, kind="mpii", seed=0, stride=4, cmu=False):
     cfg = synth.vol_config(num_layers, V, method, multiplier, kind)
@@ -539,7 +634,7 @@ def main():
     torch.manual_seed(0)
     os.makedirs(GOLD, exist_ok=True)
     mvn = ref_loader.load()
-    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad", "train", "train_conf"]
+    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad", "train", "train_conf", "train_alg"]
     if "ops" in which:
         print("[ops]"); gen_ops(mvn)
     if "nets" in which:
@@ -567,6 +662,8 @@ def main():
         run_vol_case(mvn, "c4_sharp", 152, 1, 8, 384, 128, "softmax", sharpen=157.0, seed=8, stride=8)
     if "train" in which:
         print("[train]"); gen_train(mvn)
+    if "train_alg" in which:
+        print("[train_alg]"); gen_train_alg(mvn)
     if "train_conf" in which:
         print("[train_conf]"); gen_train(mvn, "conf_norm", "train_step_conf_norm.npz")
     if "alg" in which:

@@ -211,3 +211,40 @@ def test_unproject_backward_gather_every_channel_width_and_ragged_shapes(C, hw, 
         check("bwd/unproject gather vs scatter C=%d %s %s: d/d features" % (C, hw, method), g1.cpu(), gs_.cpu(), 2e-5)
         if c1 is not None:
             check("bwd/unproject gather vs scatter C=%d %s: d/d confidences" % (C, hw), c1.cpu(), cs_.cpu(), 2e-5)
+
+
+def test_softargmax2d_and_dlt_backward_vs_autograd_of_the_reference_ops():
+    """The algebraic model's differentiable tail (train.py:189-236): d coordinates / d heatmaps of integrate_tensor_2d (op.py:11-47) and the
+    gradient of triangulate_batch_of_points (multiview.py:141-183, torch.svd in the reference) with respect to the 2D points and the
+    confidences -- against torch autograd through the oracle's restatement of both ops (the same torch calls as the reference, fp64)."""
+    from mvn.utils import multiview, op
+    g = torch.Generator().manual_seed(17)
+    hm = torch.randn(6, 5, 24, 20, generator=g) * 2.0
+    G = torch.randn(6, 5, 2, generator=g)
+    h64 = hm.double().requires_grad_(True)
+    c64, _ = O.integrate_tensor_2d(h64, True)
+    (c64 * G.double()).sum().backward()
+    hd = hm.to(DEV).requires_grad_(True)
+    c, p = op.integrate_tensor_2d(hd, True)
+    check("bwd/softargmax2d coordinates", c.detach().cpu(), c64.detach().float(), 1e-5)
+    (c * G.to(DEV)).sum().backward()
+    check("bwd/softargmax2d d/d heatmaps", hd.grad.cpu(), h64.grad.float(), 1e-4)
+    # DLT: 2 samples, 4 ring cameras, 7 joints near the origin, noisy 2D observations, confidences in (0.2, 1.2)
+    B, NV, J = 2, 4, 7
+    K, R, t = synth.ring_cameras(NV, 256)
+    P = torch.from_numpy(K @ np.concatenate([R, t], -1))[None].repeat(B, 1, 1, 1)                     # (B, NV, 3, 4) fp64
+    X = torch.randn(B, J, 3, generator=g).double() * 300
+    Xh = torch.cat([X, torch.ones(B, J, 1, dtype=torch.float64)], -1)
+    proj = torch.einsum("bvik,bjk->bvji", P, Xh)
+    pts = (proj[..., :2] / proj[..., 2:3] + torch.randn(B, NV, J, 2, generator=g).double() * 2.0)
+    conf = torch.rand(B, NV, J, generator=g).double() + 0.2
+    GX = torch.randn(B, J, 3, generator=g)
+    p64, c64 = pts.clone().requires_grad_(True), conf.clone().requires_grad_(True)
+    x64 = O.triangulate_batch_of_points(P, p64, c64)
+    (x64 * GX.double()).sum().backward()
+    pd, cd = pts.float().to(DEV).requires_grad_(True), conf.float().to(DEV).requires_grad_(True)
+    x = multiview.triangulate_batch_of_points(P.float().to(DEV), pd, cd)
+    check("bwd/dlt keypoints_3d", x.detach().cpu(), x64.detach().float(), 1e-4)
+    (x * GX.to(DEV)).sum().backward()
+    check("bwd/dlt d/d points", pd.grad.cpu(), p64.grad.float(), 2e-3)          # fp32 inputs of an inverse problem: the forward's own rows are fp32 (multiview.py:159-161)
+    check("bwd/dlt d/d confidences", cd.grad.cpu(), c64.grad.float(), 2e-3)

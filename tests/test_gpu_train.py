@@ -768,3 +768,112 @@ def test_mixed_precision_training_step_deviation_and_descent(golden_dir):
         losses.append(float(loss.detach()))
     record("train/mixed precision loss over 10 Adam steps", losses)
     assert losses[-1] < losses[0], losses
+
+
+def test_whole_algebraic_training_step_vs_reference(golden_dir):
+    """AlgebraicTriangulationNet in training mode (round 3; the reference's loop for model_type "alg", train.py:189-243): forward (batch-statistics
+    BatchNorm), KeypointsMSESmoothLoss(400) on keypoints * 0.1, backward through the DLT (torch.svd in the reference), the 2D soft-argmax, the
+    alg_confidences head and the backbone, Adam -- every parameter's gradient, the running statistics and the parameters after the step against the
+    reference's own CPU step (tests/golden/train_step_alg.npz, oracle/make_golden.py train_alg), gated within the reference's measured self-noise."""
+    import lt_train
+    from mvn.models import loss as L
+    from mvn.models.triangulation import AlgebraicTriangulationNet
+    G = np.load(os.path.join(golden_dir, "train_step_alg.npz"))
+    c = dict(nl=18, B=2, NV=3, H=128, seed=21)
+    cfg = synth.alg_config(c["nl"], True)
+    cfg.model.heatmap_multiplier = 1.0
+    cfg.model["heatmap_multiplier"] = 1.0
+    sd = synth.make_state_dict(spec.alg_net_spec(c["nl"], 17, True), seed=c["seed"], basic_block=True)
+    inp = synth.make_inputs(c["B"], c["NV"], c["H"], seed=c["seed"], inside=False)
+    m = AlgebraicTriangulationNet(cfg, device=DEV)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    m.train()
+    lr = float(G["lr"])
+    opt = lt_train.Adam([p for p in m.parameters() if p.requires_grad], lr=lr)
+    P = torch.from_numpy(G["P"]).to(DEV)
+    kp3, kp2, hm, conf = m(inp["images"].to(DEV), P, {})
+    kp_noise, loss_noise = float(G["kp_noise"]), float(G["loss_noise"])
+    d = (kp3.detach().cpu().double() - torch.from_numpy(G["kp3"]).double()).abs() / torch.from_numpy(G["kp3"]).double().abs().clamp(min=1.0)
+    record("train-alg/step forward keypoints_3d (train-mode BN), rel with 1 mm floor", {"err": float(d.max()), "tol": 1e-4 + 2 * kp_noise, "reference_self_noise": kp_noise})
+    assert float(d.max()) <= 1e-4 + 2 * kp_noise, float(d.max())
+    check("train-alg/step forward keypoints_2d", kp2.detach().cpu(), G["kp2"], 1e-4)
+    check("train-alg/step forward confidences", conf.detach().cpu(), G["conf"], 1e-4)
+    check("train-alg/step forward heatmaps", hm.detach().cpu().reshape(c["B"] * c["NV"], *hm.shape[2:])[:, :, ::2, ::2], G["hm_sub"], 1e-4)
+    gt, val = torch.from_numpy(G["gt"]).to(DEV), torch.from_numpy(G["val"]).to(DEV)
+    loss = L.KeypointsMSESmoothLoss(400)(kp3 * 0.1, gt * 0.1, val)
+    assert abs(float(loss.detach()) - float(G["loss"])) <= (1e-4 + 2 * loss_noise) * float(G["loss"]), (float(loss.detach()), float(G["loss"]))
+    opt.zero_grad()
+    loss.backward()
+    named = dict(m.named_parameters())
+    gn2, table, n_zero = 0.0, [], 0
+    gnorm_ref = float(G["grad_norm"])
+    for n in G["names"]:
+        n = str(n)
+        p = named[n]
+        assert p.grad is not None, "no gradient for " + n
+        gr = p.grad.detach().double().cpu()
+        ref_norm, ref_max, _ = [float(v) for v in G["gn/" + n]]
+        noise = float(G["noise/" + n])
+        gn2 += float(gr.pow(2).sum())
+        if noise > 0.05:          # a convolution bias in front of a training-mode BatchNorm: the exact gradient is 0, both sides hold rounding noise
+            assert float(gr.abs().max()) <= 10 * ref_max + 1e-6 * gnorm_ref, (n, float(gr.abs().max()), ref_max)
+            n_zero += 1
+            continue
+        # The gated reference is the reference's OWN step in fp64 (the same modules, .double()): its fp32 step is 1.4e-3 (median) / 1.2e-2 (max) of
+        # each parameter's max gradient away from that -- torch.svd's backward in fp32 alone moves the tail's gradients by 1.2e-3 (stored as
+        # svd32_rel) -- while lt_triangulate_dlt_bwd works in fp64 (3e-6 against fp64 autograd, test_softargmax2d_and_dlt_backward_...).  The
+        # deviation from the fp32 step is recorded next to it.
+        f = gr.reshape(-1)
+        sub = f[::max(1, f.numel() // 129)][:129]
+        n64, m64 = [float(v) for v in G["gn64/" + n]]
+        e = float((sub - torch.from_numpy(G["g64/" + n]).double()).abs().max()) / m64
+        en = abs(float(gr.norm()) - n64) / n64
+        e32 = max(float((sub - torch.from_numpy(G["g/" + n]).double()).abs().max()) / ref_max, abs(float(gr.norm()) - ref_norm) / ref_norm)
+        table.append((max(e, en) / (1e-3 + 4 * noise), max(e, en), noise, n, e32))
+    table.sort(reverse=True)
+    print("worst parameter gradients (err / gate, err vs the fp64 step, reference self-noise, name, err vs the fp32 step):", *["%.2f %.2e %.2e %s %.2e" % t for t in table[:8]], sep="\n  ")
+    errs = sorted(t[1] for t in table)
+    e32s = sorted(t[4] for t in table)
+    record("train-alg/step parameter gradients vs the reference's fp64 step (gate 1e-3 + 4 x reference self-noise)",
+           {"worst_err_over_gate": table[0][0], "worst_err": errs[-1], "median_err": errs[len(errs) // 2], "parameters_compared": len(table),
+            "zero_gradient_parameters": n_zero, "median_reference_self_noise": sorted(t[2] for t in table)[len(table) // 2],
+            "vs_the_fp32_step_median": e32s[len(e32s) // 2], "vs_the_fp32_step_worst": e32s[-1], "reference_fp32_svd_backward_rel_err": float(G["svd32_rel"])})
+    assert table[0][0] <= 1.0, table[:8]
+    assert e32s[-1] <= 3e-2, e32s[-1]          # and never far from the fp32 step either (its own distance to fp64: up to 1.2e-2)
+    assert len(G["no_grad"]) == 0 and len(table) > 60
+    gn = float(np.sqrt(gn2))
+    assert abs(gn - float(G["grad_norm64"])) <= 2e-3 * gnorm_ref and abs(gn - gnorm_ref) <= 1e-2 * gnorm_ref, (gn, gnorm_ref, float(G["grad_norm64"]))
+    bufs = dict(m.named_buffers())
+    w_rs = 0.0
+    for key in G.files:
+        if key.startswith("rs/"):
+            b = bufs[key[3:]].detach().double().cpu().reshape(-1)
+            sub = b[::max(1, b.numel() // 129)][:129]
+            ref = torch.from_numpy(G[key]).double()
+            w_rs = max(w_rs, float((sub - ref).abs().max() / ref.abs().max().clamp(min=1e-30)))
+    record("train-alg/step BatchNorm running statistics", {"err": w_rs, "tol": 1e-4})
+    assert w_rs <= 1e-4, w_rs
+    opt.step()
+    torch.cuda.synchronize()
+    w_p, w_name, n_known = 0.0, None, 0
+    for n in G["names"]:
+        n = str(n)
+        if float(G["noise/" + n]) > 0.05:
+            continue
+        f = named[n].detach().double().cpu().reshape(-1)
+        sub = f[::max(1, f.numel() // 129)][:129]
+        ref = torch.from_numpy(G["p1/" + n]).double()
+        gs = torch.from_numpy(G["g/" + n]).double().abs()
+        known = gs > 100 * (float(G["noise/" + n]) + 1e-3) * float(G["gn/" + n][1])
+        n_known += int(known.sum())
+        e = float(((sub - ref).abs() * known).max()) / lr
+        if e > w_p:
+            w_p, w_name = e, n
+    record("train-alg/step parameters after Adam, worst |d| in units of lr", {"err": w_p, "tol": 2e-2, "name": w_name, "elements_compared": n_known})
+    assert w_p <= 2e-2 and n_known > 300, (w_p, w_name, n_known)
+    # second step = the REPLAY of the recorded tape with the updated weights: finite, and the loss moves
+    kp3b = m(inp["images"].to(DEV), P, {})[0]
+    loss2 = L.KeypointsMSESmoothLoss(400)(kp3b * 0.1, gt * 0.1, val)
+    opt.zero_grad(); loss2.backward(); opt.step()
+    assert torch.isfinite(kp3b).all() and float(loss2.detach()) != float(loss.detach())
