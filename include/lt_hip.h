@@ -41,7 +41,9 @@ enum {
     LT_EPI_RELU_PRE = 1,  /* ReLU before the residual add  (Upsample3DBlock + skip, v2v.py:121-136) */
     LT_EPI_RELU_POST = 2, /* ReLU after the residual add   (Bottleneck / Res3DBlock, pose_resnet.py:92-93, v2v.py:42) */
     LT_EPI_STORE_F32 = 4, /* store fp32 even when dtype is bf16 (V2V logits feeding the soft-argmax) */
-    LT_EPI_SIGMOID = 8    /* v = 1/(1+exp(-v)) last (GlobalAveragePoolingHead, pose_resnet.py:160) */
+    LT_EPI_SIGMOID = 8,   /* v = 1/(1+exp(-v)) last (GlobalAveragePoolingHead, pose_resnet.py:160) */
+    LT_BN_FROZEN = 32     /* lt_bn_act_bwd only: mean / var are FROZEN running statistics (a BatchNorm module in eval() inside a training step):
+                             dy = gamma invstd g, without the batch-statistics terms; dgamma / dbeta as usual */
 };
 
 const char* lt_last_error(void);
@@ -257,7 +259,8 @@ int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32_t C, float
  * (train.py:233-243: zero_grad / backward / step) -- see lt_train.py for the tape that strings them together.
  * lt_bn_act_fwd : z = act(gamma (y - mean) / sqrt(var + eps) + beta, residual) with lt_conv_fwd's LT_EPI_RELU_* flags; mean / var
  *   from lt_bn_stats_fwd (batch statistics).  C % 4 == 0.
- * lt_bn_act_bwd : its autograd: g = dz * relu mask; dbeta = sum g; dgamma = sum g x^; dy = gamma invstd (g - dbeta/n - x^ dgamma/n);
+ * lt_bn_act_bwd : its autograd: g = dz * relu mask; dbeta = sum g; dgamma = sum g x^; dy = gamma invstd (g - dbeta/n - x^ dgamma/n)
+ *   (LT_BN_FROZEN in flags: mean / var are running statistics that do not depend on the batch: dy = gamma invstd g);
  *   dres (may be NULL) = the residual input's gradient, added to the buffer when accumulate_res.  workspace: lt_bn_act_bwd_workspace.
  * lt_act_bwd    : layers without BatchNorm: dy = dz * mask(z, residual, flags) (+ dres); LT_EPI_SIGMOID: dy = dz * z * (1 - z).
  * lt_channel_sum: out[c] (+)= sum over rows of x[row][c] (bias gradients), fp64 accumulation.

@@ -125,7 +125,7 @@ __global__ void bn_bwd_finalize_kernel(const BnBwdArgs a) {
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     const long long total = a.rows * a.C;
-    const float inv_n = 1.0f / (float)a.rows;
+    const float inv_n = (a.flags & LT_BN_FROZEN) ? 0.f : 1.0f / (float)a.rows;       // frozen statistics: no batch-statistics terms
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % a.C);
         float xh;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdArgs a
     const int rl = threadIdx.x / cw4, cv = threadIdx.x - rl * cw4;
     const int c = (blockIdx.y * 256 + cv) * 4;
     if (c >= a.C) return;
-    const float inv_n = 1.0f / (float)a.rows;
+    const float inv_n = (a.flags & LT_BN_FROZEN) ? 0.f : 1.0f / (float)a.rows;       // frozen statistics: no batch-statistics terms
     float invstd[4], mean[4], gam[4], bet[4], k1[4], kb[4], kg[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

@@ -64,6 +64,17 @@ class ConvSpec:
     phases: List[ConvPhaseSpec] = field(default_factory=list)
 
 
+class BnParams(tuple):
+    """(weight, bias, running_mean, running_var) of a BatchNorm module -- unpacks like the plain 4-tuple the plan code takes -- that also
+    remembers whether the module is in training mode (``.training``): the training tape normalises with batch statistics there and with the
+    FROZEN running statistics for a module left in eval() (fine-tuning with a frozen backbone)."""
+
+    def __new__(cls, bn):
+        self = super().__new__(cls, (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        self.training = bool(bn.training)
+        return self
+
+
 def fold_bn(cout, bias, bn, cout_pad):
     """Epilogue constants of y = (acc + bias) * scale + shift, as fp32 arrays of cout_pad entries.
 

@@ -250,12 +250,18 @@ class TrainTape:
             gamma, beta, rmean, rvar = bn
             Cc = y_raw.shape[-1]
             rows = y_raw.t.numel() // Cc
-            mean = torch.empty(Cc, dtype=torch.float32, device=self.device)
-            var = torch.empty(Cc, dtype=torch.float32, device=self.device)
-            self._ws_need(lib.lt_bn_stats_workspace(rows, Cc))
-            mom = float(self.momentum)
-            self.do(lambda st: H.check(lib.lt_bn_stats_fwd(H.LT_F32, y_raw.t.data_ptr(), rows, Cc, mean.data_ptr(), var.data_ptr(), rmean.data_ptr(),
-                                                           rvar.data_ptr(), mom, self._ws.data_ptr(), st), "lt_bn_stats_fwd"), "bn_stats %dx%d" % (rows, Cc))
+            if getattr(bn, "training", True):
+                mean = torch.empty(Cc, dtype=torch.float32, device=self.device)
+                var = torch.empty(Cc, dtype=torch.float32, device=self.device)
+                self._ws_need(lib.lt_bn_stats_workspace(rows, Cc))
+                mom = float(self.momentum)
+                self.do(lambda st: H.check(lib.lt_bn_stats_fwd(H.LT_F32, y_raw.t.data_ptr(), rows, Cc, mean.data_ptr(), var.data_ptr(), rmean.data_ptr(),
+                                                               rvar.data_ptr(), mom, self._ws.data_ptr(), st), "lt_bn_stats_fwd"), "bn_stats %dx%d" % (rows, Cc))
+            else:
+                # a BatchNorm module left in eval() inside a training step (frozen statistics, e.g. a frozen backbone): normalise with the LIVE
+                # running statistics (read where they are at every replay), no statistics pass, no update; the backward drops the batch terms
+                mean, var = rmean, rvar
+                flags |= H.BN_FROZEN
             z = self.alloc(y_raw.shape)
             rp = residual.t if residual is not None else None
             z16 = None

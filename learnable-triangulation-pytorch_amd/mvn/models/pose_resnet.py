@@ -24,7 +24,7 @@ def _bn(c):
 
 
 def bn_tuple(bn):
-    return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    return E.BnParams(bn)
 
 
 class ResidualBlock(nn.Module):

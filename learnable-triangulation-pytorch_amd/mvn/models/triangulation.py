@@ -455,7 +455,7 @@ class VolumetricTriangulationNet(_PlannedNet):
         stream).  Batches beyond ``max_samples_per_launch`` (BASELINE config 4: 32 samples of 128^3 voxels are exactly 2^31
         elements) run as consecutive sub-batches of one plan."""
         H.require_gpu(images, "images")
-        if _bn_in_train_mode(self):
+        if _bn_in_train_mode(self):          # any BatchNorm module in train(): the training step (modules left in eval() keep frozen statistics)
             return self._forward_train(images, batch)
         B, NV = images.shape[:2]
         cap = self.max_samples_per_launch(NV, images.shape[3], images.shape[4])
@@ -477,10 +477,9 @@ class VolumetricTriangulationNet(_PlannedNet):
         result carries the autograd node whose backward is liblt_hip's (lt_train.py).  Same 7-tuple as the inference forward.  Every
         ``volume_aggregation_method`` trains: for conf / conf_norm the gradient reaches the backbone through the vol_confidences head as
         well (GlobalAveragePoolingHead, pose_resnet.py:140-174)."""
-        bns = [c for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm)]
-        if not all(c.training for c in bns):
-            raise NotImplementedError("a mix of training-mode and eval-mode BatchNorm layers (frozen statistics) is not built: "
-                                      "model.train() or model.eval() as a whole (train.py:163-166)")
+        # BatchNorm modules in train() use batch statistics (and update the running ones); modules left in eval() -- a frozen backbone while V2V
+        # is fine-tuned, say -- normalise with their frozen running statistics (round 3; lt_train.TrainTape.conv)
+        bns = [c for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm) and c.training]
         if any(c.momentum is None or abs(c.momentum - 0.1) > 1e-12 or not c.track_running_stats or not c.affine for c in bns):
             raise NotImplementedError("BatchNorm with a momentum other than 0.1, without running statistics or without affine parameters")
         params = tuple(self.parameters())
@@ -491,7 +490,8 @@ class VolumetricTriangulationNet(_PlannedNet):
         B, NV = images.shape[:2]
         key = (B, NV, images.shape[3], images.shape[4], images.device, self.volume_size, float(self.cuboid_side), float(self.volume_multiplier),
                bool(self.volume_softmax), self.volume_aggregation_method, bool(self.transfer_cmu_to_human36m), self.num_joints,
-               tuple(p.requires_grad for p in params), id(getattr(self, "grad_reducer", None)), getattr(self, "train_precision", "fp32"))
+               tuple(p.requires_grad for p in params), id(getattr(self, "grad_reducer", None)), getattr(self, "train_precision", "fp32"),
+               tuple(c.training for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm)))
         if getattr(self, "train_precision", "fp32") not in ("fp32", "bf16"):
             raise ValueError("train_precision must be 'fp32' (the reference's precision) or 'bf16' (bf16 MFMA convolutions, fp32 everything else)")
         red = getattr(self, "grad_reducer", None)
@@ -639,10 +639,9 @@ class AlgebraicTriangulationNet(_PlannedNet):
         ``use_confidences``, the alg_confidences head included -- runs its recorded training step (lt_train.TrainTape: batch-statistics
         BatchNorm, liblt_hip backward); 2D soft-argmax, confidence normalisation and the DLT are autograd nodes over liblt_hip kernels
         (lt_softargmax2d_bwd, lt_triangulate_dlt_bwd: what autograd derives through torch.svd in the reference).  Same 4-tuple as inference."""
-        bns = [c for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm)]
-        if not all(c.training for c in bns):
-            raise NotImplementedError("a mix of training-mode and eval-mode BatchNorm layers (frozen statistics) is not built: "
-                                      "model.train() or model.eval() as a whole (train.py:163-166)")
+        # BatchNorm modules in train() use batch statistics (and update the running ones); modules left in eval() -- a frozen backbone while V2V
+        # is fine-tuned, say -- normalise with their frozen running statistics (round 3; lt_train.TrainTape.conv)
+        bns = [c for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm) and c.training]
         if any(c.momentum is None or abs(c.momentum - 0.1) > 1e-12 or not c.track_running_stats or not c.affine for c in bns):
             raise NotImplementedError("BatchNorm with a momentum other than 0.1, without running statistics or without affine parameters")
         if not self.heatmap_softmax:
@@ -661,7 +660,8 @@ class AlgebraicTriangulationNet(_PlannedNet):
                 red.attach(self)
             else:
                 red.sync_buffers()
-        key = (B * NV, Hh, W, device, tuple(p.requires_grad for p in params), id(red), getattr(self, "train_precision", "fp32"))
+        key = (B * NV, Hh, W, device, tuple(p.requires_grad for p in params), id(red), getattr(self, "train_precision", "fp32"),
+               tuple(c.training for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm)))
         plans = self.__dict__.setdefault("_train_plans", OrderedDict())
         plan = plans.get(key)
         if plan is None:

@@ -13,7 +13,7 @@ import lt_hip as H
 
 
 def bn_tuple(bn):
-    return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    return E.BnParams(bn)
 
 
 class Basic3DBlock(nn.Module):  # conv k^3 + BN + ReLU (reference :7-17)

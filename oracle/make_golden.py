@@ -361,7 +361,7 @@ def _train_sub(t, n=129):
     return f[::max(1, f.numel() // n)][:n].numpy().copy()
 
 
-def gen_train(mvn, method="softmax", fname="train_step.npz"):
+def gen_train(mvn, method="softmax", fname="train_step.npz", freeze_backbone_bn=False):
     """One full training step of the reference's VolumetricTriangulationNet on CPU (train.py:148-243): model.train() (BatchNorm on batch
     statistics, running statistics updated, random cuboid rotation), criterion MAE on keypoints * scale_keypoints_3d + 0.01 *
     VolumetricCELoss, total_loss.backward(), torch.optim.Adam with the three learning-rate groups of train.py:430-437, opt.step().
@@ -393,6 +393,10 @@ def gen_train(mvn, method="softmax", fname="train_step.npz"):
         ref = mvn.models.triangulation.VolumetricTriangulationNet(cfg, device="cpu")
         ref.load_state_dict(sd, strict=True)
         ref.train()
+        if freeze_backbone_bn:          # fine-tuning with frozen backbone statistics: the backbone's BatchNorm modules in eval(), everything still trainable
+            for mod in ref.backbone.modules():
+                if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                    mod.eval()
         opt = torch.optim.Adam([{"params": ref.backbone.parameters()}, {"params": ref.process_features.parameters(), "lr": pf_lr},
                                 {"params": ref.volume_net.parameters(), "lr": vn_lr}], lr=lr)
         batch = {"cameras": _cameras(mvn, inp["K"], inp["R"], inp["t"], c["B"]), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
@@ -634,7 +638,7 @@ def main():
     torch.manual_seed(0)
     os.makedirs(GOLD, exist_ok=True)
     mvn = ref_loader.load()
-    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad", "train", "train_conf", "train_alg"]
+    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad", "train", "train_conf", "train_alg", "train_frozen"]
     if "ops" in which:
         print("[ops]"); gen_ops(mvn)
     if "nets" in which:
@@ -662,6 +666,8 @@ def main():
         run_vol_case(mvn, "c4_sharp", 152, 1, 8, 384, 128, "softmax", sharpen=157.0, seed=8, stride=8)
     if "train" in which:
         print("[train]"); gen_train(mvn)
+    if "train_frozen" in which:
+        print("[train_frozen]"); gen_train(mvn, "softmax", "train_step_frozen_bn.npz", freeze_backbone_bn=True)
     if "train_alg" in which:
         print("[train_alg]"); gen_train_alg(mvn)
     if "train_conf" in which:

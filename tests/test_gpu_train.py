@@ -259,7 +259,7 @@ def _train_case(method="softmax"):
     return c, cfg, sd, inp
 
 
-@pytest.mark.parametrize("method", ["softmax", "conf_norm"])
+@pytest.mark.parametrize("method", ["softmax", "conf_norm", "frozen_bn"])
 def test_whole_training_step_vs_reference(golden_dir, method):
     """model.train(); forward; MAE(kp * 0.1) + 0.01 * VolumetricCELoss; backward; Adam (train.py:148-243, :430-437) -- every parameter's
     gradient, the BatchNorm running statistics and the parameters after the step against the reference's own step on CPU.  conf_norm: the
@@ -269,13 +269,20 @@ def test_whole_training_step_vs_reference(golden_dir, method):
     from mvn.models import loss as L
     from mvn.models.triangulation import VolumetricTriangulationNet
     from test_gpu_models import _cameras
+    # frozen_bn: softmax aggregation with the BACKBONE's BatchNorm modules left in eval() (frozen running statistics, everything still trainable --
+    # fine-tuning with a frozen backbone); the reference's step of the same setting: tests/golden/train_step_frozen_bn.npz
+    frozen = method == "frozen_bn"
     G = np.load(os.path.join(golden_dir, "train_step.npz" if method == "softmax" else "train_step_%s.npz" % method))
-    c, cfg, sd, inp = _train_case(method)
+    c, cfg, sd, inp = _train_case("softmax" if frozen else method)
     TAG = "" if method == "softmax" else "[%s] " % method
     m = VolumetricTriangulationNet(cfg, device=DEV)
     m.load_state_dict(sd, strict=True)
     m.to(DEV)
     m.train()
+    if frozen:
+        for mod in m.backbone.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.eval()
     lr, pf_lr, vn_lr = [float(v) for v in G["lrs"]]
     opt = lt_train.Adam([{"params": list(m.backbone.parameters())}, {"params": list(m.process_features.parameters()), "lr": pf_lr},
                          {"params": list(m.volume_net.parameters()), "lr": vn_lr}], lr=lr)
@@ -380,6 +387,10 @@ def test_whole_training_step_vs_reference(golden_dir, method):
     m2.load_state_dict(m.state_dict(), strict=True)
     m2.to(DEV)
     m2.train()
+    if frozen:
+        for mod in m2.backbone.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.eval()
     sd_before = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
     np.random.seed(c["seed"] + 100)
     kp_fresh = m2(inp["images"].to(DEV), None, batch)[0].detach()
