@@ -212,7 +212,7 @@ int lt_softargmax2d_fwd(const float* heatmaps, float mult, int32_t softmax, floa
                         int32_t h, int32_t w, void* stream);
 /* Backward of the two ops above and of lt_triangulate_dlt (training of AlgebraicTriangulationNet, train.py:189-236): what autograd derives in the
  * reference through softmax / sums (op.py:23-45) and through torch.svd (multiview.py:163).  lt_softargmax2d_bwd: probs / coords are the forward's
- * outputs, grad_coords N*J,2 -> grad_heatmaps (softmax mode only; a gradient on the returned heatmaps is not supported).  lt_triangulate_dlt_bwd:
+ * outputs, grad_coords N*J,2 -> grad_heatmaps (both modes; a gradient on the returned heatmaps is not supported).  lt_triangulate_dlt_bwd:
  * grad_out B,J,3 -> grad_points B,NV,J,2 and grad_conf B,NV,J (may be NULL); fp64 inside, the forward's Jacobi eigen-decomposition recomputed. */
 int lt_softargmax2d_bwd(const float* probs, const float* coords, const float* grad_coords, float mult, int32_t softmax, float* grad_heatmaps,
                         int32_t NJ, int32_t h, int32_t w, void* stream);

@@ -435,15 +435,26 @@ __global__ void dlt_kernel(const float* __restrict__ proj, const float* __restri
 // ---- backward of the 2D soft-argmax and of the DLT (training of the algebraic model, train.py:189-236) ---------------------------------------
 // integrate_tensor_2d (op.py:11-47), softmax mode: p = softmax_i(mult * h_i), (X, Y) = sum_i p_i (x_i, y_i):
 //   d L / d h_i = mult * p_i * ((x_i - X) g_x + (y_i - Y) g_y).  One elementwise pass over the returned heatmaps p.
+// ReLU mode (heatmap_softmax: false): e_i = relu(mult h_i) (the returned heatmaps), (X, Y) = sum_i e_i (x_i, y_i) / S, S = sum_i e_i:
+//   d L / d h_i = mult [e_i > 0] ((x_i - X) g_x + (y_i - Y) g_y) / S   (every workgroup re-adds S: h x w is a few thousand values).
 __global__ __launch_bounds__(256) void sa2_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ coords, const float* __restrict__ gcoords,
-                                                       float mult, float* __restrict__ ghm, int h, int w) {
+                                                       float mult, int softmax, float* __restrict__ ghm, int h, int w) {
+    __shared__ float red[4];
     const long long base = (long long)blockIdx.y * h * w;
     const float X = coords[blockIdx.y * 2], Y = coords[blockIdx.y * 2 + 1];
     const float gx = gcoords[blockIdx.y * 2], gy = gcoords[blockIdx.y * 2 + 1];
     const int n = h * w;
+    float invS = 1.f;
+    if (!softmax) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) s += probs[base + i];
+        invS = 1.f / block_reduce(s, red, false);
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int yy = i / w, xx = i - yy * w;
-        ghm[base + i] = mult * probs[base + i] * (((float)xx - X) * gx + ((float)yy - Y) * gy);
+        const float pi = probs[base + i];
+        const float wgt = softmax ? pi : (pi > 0.f ? invS : 0.f);
+        ghm[base + i] = mult * wgt * (((float)xx - X) * gx + ((float)yy - Y) * gy);
     }
 }
 
@@ -528,9 +539,8 @@ __global__ void dlt_bwd_kernel(const float* __restrict__ proj, const float* __re
 extern "C" int lt_softargmax2d_bwd(const float* probs, const float* coords, const float* grad_coords, float mult, int32_t softmax, float* grad_heatmaps,
                                    int32_t NJ, int32_t h, int32_t w, void* stream) {
     LT_REQUIRE(probs && coords && grad_coords && grad_heatmaps && NJ >= 1 && h >= 1 && w >= 1, LT_ERR_INVALID, "lt_softargmax2d_bwd: bad argument");
-    LT_REQUIRE(softmax, LT_ERR_UNSUPPORTED, "lt_softargmax2d_bwd: the ReLU variant (heatmap_softmax: false) has no backward here");
     const int bx = (int)((h * w + 255) / 256);
-    hipLaunchKernelGGL(sa2_bwd_kernel, dim3(bx < 64 ? bx : 64, NJ), dim3(256), 0, (hipStream_t)stream, probs, coords, grad_coords, mult, grad_heatmaps, h, w);
+    hipLaunchKernelGGL(sa2_bwd_kernel, dim3(bx < 64 ? bx : 64, NJ), dim3(256), 0, (hipStream_t)stream, probs, coords, grad_coords, mult, softmax, grad_heatmaps, h, w);
     LT_CHECK_LAUNCH("lt_softargmax2d_bwd");
     return LT_OK;
 }

@@ -644,8 +644,6 @@ class AlgebraicTriangulationNet(_PlannedNet):
         bns = [c for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm) and c.training]
         if any(c.momentum is None or abs(c.momentum - 0.1) > 1e-12 or not c.track_running_stats or not c.affine for c in bns):
             raise NotImplementedError("BatchNorm with a momentum other than 0.1, without running statistics or without affine parameters")
-        if not self.heatmap_softmax:
-            raise NotImplementedError("training with heatmap_softmax: false (the ReLU variant of integrate_tensor_2d has no backward here)")
         params = tuple(self.parameters())
         off = [n for n, t in list(self.named_parameters()) + list(self.named_buffers()) if t.device != images.device]
         if off:

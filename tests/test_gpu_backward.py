@@ -229,6 +229,14 @@ def test_softargmax2d_and_dlt_backward_vs_autograd_of_the_reference_ops():
     check("bwd/softargmax2d coordinates", c.detach().cpu(), c64.detach().float(), 1e-5)
     (c * G.to(DEV)).sum().backward()
     check("bwd/softargmax2d d/d heatmaps", hd.grad.cpu(), h64.grad.float(), 1e-4)
+    h64r = hm.double().requires_grad_(True)                       # ReLU mode (heatmap_softmax: false)
+    c64r, _ = O.integrate_tensor_2d(h64r, False)
+    (c64r * G.double()).sum().backward()
+    hdr = hm.to(DEV).requires_grad_(True)
+    cr, _ = op.integrate_tensor_2d(hdr, False)
+    check("bwd/softargmax2d relu mode coordinates", cr.detach().cpu(), c64r.detach().float(), 1e-5)
+    (cr * G.to(DEV)).sum().backward()
+    check("bwd/softargmax2d relu mode d/d heatmaps", hdr.grad.cpu(), h64r.grad.float(), 1e-4)
     # DLT: 2 samples, 4 ring cameras, 7 joints near the origin, noisy 2D observations, confidences in (0.2, 1.2)
     B, NV, J = 2, 4, 7
     K, R, t = synth.ring_cameras(NV, 256)
