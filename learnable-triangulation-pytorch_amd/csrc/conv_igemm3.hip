@@ -1214,13 +1214,6 @@ int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_ta
         const long long tiles_m = cdiv(a.M, BM3), nblk = tiles_m * (cout_pad / BN);
         if (nblk < 200) return 0;
         if (tiles_m * BM3 - a.M > a.M / 16) return 0;
-        // one workgroup per CU: a grid that ends in a mostly empty round wastes it (320 tiles = 1.25 rounds run as long as 512: layer2's 3x3 at 10
-        // samples, 65 us here against 51 us on conv_igemm2's 128 x 64 tiles, tools/conv_bench.py) -- leave those to the small tiles
-        {
-            const int ncu = device_cu_count8() > 0 ? device_cu_count8() : 256;
-            const long long rounds = cdiv(nblk, ncu);
-            if (nblk * 5 < rounds * ncu * 4) return 0;          // < 80 % of the slots of its rounds
-        }
         // short-K layers (the 1x1 expand convs) are bound by their epilogue traffic: many small tiles overlap one workgroup's
         // stores with the next one's loads better than one big tile per CU (measured: 128x64 beats this kernel below K = 512)
         if (a.k_pad < 512) return 0;
