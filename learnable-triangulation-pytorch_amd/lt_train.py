@@ -55,6 +55,7 @@ class TrainTape:
         self.fwd_ops, self.bwd_ops = [], []                     # fn(stream) closures, in launch order
         self._cur = self.fwd_ops
         self.recorders = []                                     # one per layer: records (= runs once) that layer's backward
+        self.layer_outputs = []                                 # (label, output Act) of every convolution layer, in forward order
         self.grads = {}                                         # id(Act) -> (Act, gradient tensor of act.t's shape)
         self.momentum = momentum
         self.no_grad_ids = set()                                # id(Act) of inputs that need no gradient (the images)
@@ -272,6 +273,7 @@ class TrainTape:
                                                          z.t.data_ptr(), H.ptr(z16), rows, Cc, BN_EPS, flags, st), "lt_bn_act_fwd"), "bn_act %dx%d" % (rows, Cc))
             stats = (mean, var)
         self.recorders.append(lambda: self._conv_bwd(x, weight, bias, bn, stride, pad, transposed, flags, residual, y_raw, stats, z))
+        self.layer_outputs.append(("%s %s" % ("deconv" if transposed else "conv", "x".join(map(str, weight.shape))), z))      # diagnostics (tools/mixed_trace.py)
         return z
 
     def maxpool(self, x, k, s, p, nd):
