@@ -464,6 +464,12 @@ class VolumetricTriangulationNet(_PlannedNet):
                 return self._forward_chunk(images, batch, 0, B)
         n = -(-B // cap)
         size = -(-B // n)            # equal-sized chunks (one plan), a shorter last one only if B does not divide
+        if not self.__dict__.get("_warned_sub_batches"):
+            import warnings
+            warnings.warn("VolumetricTriangulationNet.forward: %d samples exceed the %d per launch that liblt_hip's 32-bit element offsets allow at this "
+                          "shape (%d views, %d^3 voxels); running %d consecutive sub-batches of %d (results identical, one plan)" %
+                          (B, cap, NV, self.volume_size, n, size), stacklevel=2)
+            self.__dict__["_warned_sub_batches"] = True
         parts = []
         with torch.cuda.device(images.device):
             for lo in range(0, B, size):
