@@ -1,0 +1,60 @@
+"""CPU: the measurement plumbing of bench.py / tools/pmc_summary.py that runs in the driver's benchmark command -- the PMC summary arithmetic
+(MI355X_MICROARCH.md corrections), the fallback when rocprofv3 is not there, and the child-leg runner's failure paths."""
+import csv
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _write_pass(d, name, rows):
+    os.makedirs(os.path.join(d, name), exist_ok=True)
+    with open(os.path.join(d, name, "bench_counter_collection.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["Kernel_Name", "Counter_Name", "Counter_Value"])
+        w.writeheader()
+        for r in rows:
+            w.writerow(dict(zip(w.fieldnames, r)))
+
+
+def test_pmc_summary_arithmetic(tmp_path):
+    """FETCH_SIZE is in KiB and counts 64 B per 128-byte request on gfx950 (x2), WRITE_SIZE in KiB as is; per-step = / forwards; kernels are
+    grouped into families by their demangled names; MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)."""
+    import pmc_summary
+    d = str(tmp_path)
+    conv = "void (anonymous namespace)::conv_igemm6_kernel<1, 1>(lt::ConvArgs)"
+    unp = "(anonymous namespace)::unproject_qn_kernel<1, true>((anonymous namespace)::UnprojArgs) [clone .kd]"
+    sa = "void (anonymous namespace)::sa3_partial_planar_kernel((anonymous namespace)::SA3Args)"
+    _write_pass(d, "pmc_fetch", [(conv, "FETCH_SIZE", 1000.0)] * 3 + [(unp, "FETCH_SIZE", 10.0)] * 3 + [(sa, "FETCH_SIZE", 300.0)] * 3)
+    _write_pass(d, "pmc_write", [(conv, "WRITE_SIZE", 500.0)] * 3 + [(unp, "WRITE_SIZE", 200.0)] * 3 + [(sa, "WRITE_SIZE", 0.0)] * 3)
+    _write_pass(d, "pmc_mfma", [(conv, "SQ_VALU_MFMA_BUSY_CYCLES", 1024 * 1000.0 * 0.25), (conv, "GRBM_GUI_ACTIVE", 8 * 1000.0), (conv, "SQ_WAVE_CYCLES", 100.0),
+                                (conv, "SQ_WAIT_ANY", 40.0), (conv, "SQ_WAIT_INST_ANY", 30.0), (conv, "SQ_ACTIVE_INST_ANY", 20.0)])
+    r = pmc_summary.summarise(d, 3, batch=32)
+    assert r["conv_family_bytes_per_step"] == pytest.approx(1000 * 1024 * 2 + 500 * 1024)
+    assert r["hbm_kernels_bytes_per_step"]["unproject"] == pytest.approx(10 * 1024 * 2 + 200 * 1024)
+    assert r["hbm_kernels_bytes_per_step"]["softargmax3d"] == pytest.approx(300 * 1024 * 2)
+    assert r["conv_family_mfma_busy_frac"] == pytest.approx(0.25)
+    k = r["per_kernel"]["conv_igemm6_kernel<1, 1>"]
+    assert k["family"] == "conv" and k["launches_per_step"] == 1.0 and k["wave_wait_any_frac"] == pytest.approx(0.4)
+    assert "unproject_qn_kernel<1, true>" in r["per_kernel"]
+    # a missing pass leaves the traffic empty instead of inventing numbers
+    r2 = pmc_summary.summarise(os.path.join(d, "nothing_here"), 3)
+    assert r2["conv_family_bytes_per_step"] is None and r2["hbm_kernels_bytes_per_step"] == {}
+
+
+def test_bench_pmc_leg_and_sub_leg_fail_soft(monkeypatch, tmp_path):
+    import bench
+    monkeypatch.setattr("shutil.which", lambda name: None)
+    monkeypatch.setattr(os.path, "exists", lambda p, _e=os.path.exists: False if p == "/opt/rocm/bin/rocprofv3" else _e(p))
+
+    class A:
+        batch, views, volume, image, layers, dtype = 32, 4, 64, 384, 152, "bf16"
+    assert bench.pmc_leg(A()) is None                          # no rocprofv3: the caller falls back to the committed file and says so
+    bad = bench.sub_leg(["--no-such-flag"], 60)                # a child that exits non-zero: an error record, not an exception
+    assert "error" in bad and bad["argv"] == ["--no-such-flag"]
+    ok = bench.sub_leg(["--gpus", "1", "--steps", "2", "--warmup", "0", "--batch", "3", "--stub-cpu"], 120)
+    assert ok.get("metric") == "stub" and ok["total_samples"] == 6 and ok["leg_wall_s"] > 0
