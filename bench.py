@@ -188,7 +188,7 @@ def sub_leg(argv, timeout_s):
     return out
 
 
-def pmc_leg(args, timeout_s=150):
+def pmc_leg(args, timeout_s=90):
     """HBM traffic and MFMA-busy of THIS run's kernels, measured now: three child runs of this script (one forward each after setup, eager
     launches) under ``rocprofv3 --kernel-trace --pmc <counters>`` -- FETCH_SIZE, WRITE_SIZE and the SQ / GRBM counters in SEPARATE passes, as
     MI355X_MICROARCH.md prescribes -- summarised by tools/pmc_summary.py (FETCH_SIZE x2 on gfx950, KiB -> bytes).  Returns None when
