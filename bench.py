@@ -340,6 +340,7 @@ def main():
     ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="--train: fp32 (the reference's precision, default) or bf16 = the "
                     "convolutions and their input gradients on the bf16 MFMA (bf16 copies of the operands, fp32 accumulation / storage), everything else fp32")
     ap.add_argument("--train", action="store_true", help="time the training step (fwd + bwd + Adam, fp32) instead of the forward; its own JSON line")
+    ap.add_argument("--force-pmc-leg", action="store_true", help="measure roofline.traffic live even with --no-extras (the config-4 child leg of the default run)")
     ap.add_argument("--no-pmc-leg", action="store_true", help="do not measure roofline.traffic live (rocprofv3 child runs, ~1 min); use the committed PMC file")
     ap.add_argument("--no-legs", action="store_true", help="skip the config-4 and training legs of the default (config 2, N = 1) run")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="CPU baseline leg: timed forwards of sample 0 until this many seconds (at least one)")
@@ -457,7 +458,7 @@ def main():
             # committed PMC passes of this command (tools/pmc_summary.py; same batch and dtype only) -- traffic_source says which
             pmc, pmc_file = {}, None
             live = None
-            if world == 1 and not args.no_extras and not args.no_pmc_leg:
+            if world == 1 and not args.no_pmc_leg and (not args.no_extras or args.force_pmc_leg):
                 live = pmc_leg(args)
             for name in ([] if live else ["r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"]):
                 try:
@@ -534,7 +535,7 @@ def main():
                 model.invalidate_plans()
                 torch.cuda.empty_cache()
                 result["config4"] = sub_leg(["--views", "8", "--volume", "128", "--batch", "16", "--steps", "3", "--warmup", "1", "--no-extras",
-                                             "--cpu-budget-s", "1", "--cpu-parity-samples", "1", "--preroll-s", "0.3"], 600)
+                                             "--cpu-budget-s", "1", "--cpu-parity-samples", "1", "--preroll-s", "0.3", "--force-pmc-leg"], 600)
                 result["train"] = sub_leg(["--train", "--batch", "4", "--steps", "8", "--warmup", "2"], 600)
         if cpu_base is not None:
             result["cpu_baseline"] = cpu_base
