@@ -290,6 +290,19 @@ size_t lt_conv_wgrad_workspace(int64_t rows, int32_t cout_pad, int32_t k_pad);
 int lt_conv_wgrad(const float* dy, const float* x, const int32_t* taps, float* dw, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin, int32_t Do,
                   int32_t Ho, int32_t Wo, const int32_t stride[3], const int32_t pad[3], int32_t Cout, int32_t ldy, int32_t cout_pad, int32_t k_pad,
                   int32_t ntaps, int32_t accumulate, void* workspace, void* stream);
+/* The same weight gradient on the bf16 MFMA (mixed-precision training, BASELINE config 5): the reduction index is the pixel and the 16-bit MFMA
+ * wants 8 consecutive K values per lane, so the operands are IMAGE-OCTET packed -- the one axis no tap ever shifts:
+ *   lt_pack_n8_bf16: src [N][P][ld >= C] fp32 (P pixels per image) -> dst [ceil(N / 8)][P][C] elements of 8 bf16 (16 bytes) = the values of images
+ *   8g .. 8g+7 at that pixel and channel, zero for images past N; dst is 16-byte aligned, lt_pack_n8_bf16_bytes(N, P, C) bytes.
+ *   lt_conv_wgrad_bf16: arguments as lt_conv_wgrad with dy16 = pack of dy [N][Do*Ho*Wo][ldy] and x16 = pack of x [N][D*H*W][Cin]; fp32
+ *   accumulation, fixed summation order (slabs + ordered reduce: bitwise repeatable); workspace of lt_conv_wgrad_bf16_workspace(
+ *   ceil(N / 8) * Do*Ho*Wo, cout_pad, k_pad) bytes.  Result = lt_conv_wgrad of the bf16-rounded operands up to fp32 summation order. */
+size_t lt_pack_n8_bf16_bytes(int32_t N, int64_t P, int32_t C);
+int lt_pack_n8_bf16(const float* src, void* dst, int32_t N, int64_t P, int32_t C, int32_t ld, void* stream);
+size_t lt_conv_wgrad_bf16_workspace(int64_t octet_rows, int32_t cout_pad, int32_t k_pad);
+int lt_conv_wgrad_bf16(const void* dy16, const void* x16, const int32_t* taps, float* dw, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin, int32_t Do,
+                       int32_t Ho, int32_t Wo, const int32_t stride[3], const int32_t pad[3], int32_t Cout, int32_t ldy, int32_t cout_pad, int32_t k_pad,
+                       int32_t ntaps, int32_t accumulate, void* workspace, void* stream);
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- the layout changes between a Parameter's own layout and the GEMM layouts of its layer
  * (forward weights, input-gradient weights, weight-gradient blocks), with index maps built once when a training plan is recorded */
 int lt_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, void* stream);

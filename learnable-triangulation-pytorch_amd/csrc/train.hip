@@ -21,6 +21,7 @@
 // parity-phase transposed convolution (stride-2 layers) or as a strided convolution (the transposed layers) -- see lt_train.py.
 #include "colsum.h"
 #include "conv_common.h"
+#include "wgrad_reduce.h"
 
 using namespace lt;
 
@@ -769,14 +770,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_brick_kernel(const Brick2
             }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long n, int S, int accumulate) {
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
-        float s = accumulate ? dw[i] : 0.f;
-        for (int z = 0; z < S; ++z) s += ws[(size_t)z * n + i];
-        dw[i] = s;
-    }
-}
-
 __global__ void gather_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long long n) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
         const int j = idx[i];
@@ -1014,16 +1007,6 @@ extern "C" int lt_maxpool_bwd(const float* x, const float* dy, float* dx, int32_
     return LT_OK;
 }
 
-// a whole number of workgroups per CU where possible (320 workgroups on 256 CUs take as long as 512)
-static long long balance_slabs(long long blocks, long long S) {
-    const long long wgs = blocks * S;
-    if (wgs > 256 && blocks <= 256) {
-        const long long r = (wgs / 256) * 256 / blocks;
-        if (r >= 1) return r;
-    }
-    return S;
-}
-
 struct BrickPlan { int nbricks, bricks_per_slab, S; };
 
 // 3x3x3, stride 1, pad 1, channel counts multiples of 32 that are their own padding, the volume a whole number of bricks
@@ -1083,7 +1066,7 @@ extern "C" int lt_conv_wgrad(const float* dy, const float* x, const int32_t* tap
         hipLaunchKernelGGL(conv3d_wgrad_brick_kernel, dim3(Cout / 32, Cin / 32, bp.S), dim3(256), 0, st, b);
         LT_CHECK_LAUNCH("lt_conv_wgrad(brick)");
         const long long n = (long long)cout_pad * k_pad;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096)), dim3(256), 0, st, (const float*)workspace, dw, n, bp.S,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid(n)), dim3(256), 0, st, (const float*)workspace, dw, n, bp.S,
                            accumulate);
         LT_CHECK_LAUNCH("lt_conv_wgrad(reduce)");
         return LT_OK;
@@ -1107,7 +1090,7 @@ extern "C" int lt_conv_wgrad(const float* dy, const float* x, const int32_t* tap
         hipLaunchKernelGGL(wgrad_pw_kernel, dim3((unsigned)cdiv(cout_pad, 128), (unsigned)cdiv(k_pad, 128), (unsigned)S), dim3(256), 0, st, b);
         LT_CHECK_LAUNCH("lt_conv_wgrad(pointwise)");
         const long long n = (long long)cout_pad * k_pad;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096)), dim3(256), 0, st, (const float*)workspace, dw, n, (int)S, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid(n)), dim3(256), 0, st, (const float*)workspace, dw, n, (int)S, accumulate);
         LT_CHECK_LAUNCH("lt_conv_wgrad(reduce)");
         return LT_OK;
     }
@@ -1130,7 +1113,7 @@ extern "C" int lt_conv_wgrad(const float* dy, const float* x, const int32_t* tap
         hipLaunchKernelGGL(conv2d_wgrad_brick_kernel, dim3(Cout / 32, (unsigned)cdiv(Cin, 128), (unsigned)S), dim3(256), 0, st, b);
         LT_CHECK_LAUNCH("lt_conv_wgrad(brick2d)");
         const long long n = (long long)cout_pad * k_pad;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096)), dim3(256), 0, st, (const float*)workspace, dw, n, (int)S, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid(n)), dim3(256), 0, st, (const float*)workspace, dw, n, (int)S, accumulate);
         LT_CHECK_LAUNCH("lt_conv_wgrad(reduce)");
         return LT_OK;
     }
@@ -1148,7 +1131,7 @@ extern "C" int lt_conv_wgrad(const float* dy, const float* x, const int32_t* tap
         hipLaunchKernelGGL(conv3d_wgrad_k7_kernel, dim3(7, 1, (unsigned)S), dim3(256), 0, st, b);
         LT_CHECK_LAUNCH("lt_conv_wgrad(7^3)");
         const long long n = (long long)cout_pad * k_pad;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096)), dim3(256), 0, st, (const float*)workspace, dw, n, (int)S, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid(n)), dim3(256), 0, st, (const float*)workspace, dw, n, (int)S, accumulate);
         LT_CHECK_LAUNCH("lt_conv_wgrad(reduce)");
         return LT_OK;
     }
@@ -1168,7 +1151,7 @@ extern "C" int lt_conv_wgrad(const float* dy, const float* x, const int32_t* tap
     LT_CHECK_LAUNCH("lt_conv_wgrad");
     if (p.S > 1) {
         const long long n = (long long)cout_pad * k_pad;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096)), dim3(256), 0, st, (const float*)workspace, dw, n, p.S,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid(n)), dim3(256), 0, st, (const float*)workspace, dw, n, p.S,
                            accumulate);
         LT_CHECK_LAUNCH("lt_conv_wgrad(reduce)");
     }

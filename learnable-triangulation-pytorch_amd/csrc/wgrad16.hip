@@ -1,0 +1,525 @@
+// Weight gradients of the mixed-precision training step on the bf16 MFMA (BASELINE config 5; reference: autograd of the convolutions in
+// pose_resnet.py / v2v.py inside train.py:217-243's backward).
+//
+//   dW[co][tap * Cin + ci] = sum over pixels m of dY[m][co] * X[m @ tap][ci]
+//
+// The reduction index of this GEMM is the PIXEL, and v_mfma_f32_32x32x16_bf16 wants 8 consecutive K values per lane: with channels-last
+// tensors that is a column of 8 pixels -- a transposed operand.  Transposing along a SPATIAL axis would collide with the taps (a tap shifts the
+// pixel, so X octets would be misaligned against dY octets and half-empty at the padding).  The axis no tap ever moves is the IMAGE index:
+//
+//   lt_pack_n8_bf16   [N][P][C] fp32  ->  [ceil(N / 8)][P][C][8] bf16     (element (g, p, c) = the 8 images 8g .. 8g+7 at pixel p, channel c,
+//                                                                          16 bytes, zero for images past N)
+//
+// With that layout one 16-byte load IS an MFMA operand (8 K values = the same pixel of 8 images), a tap shifts whole octets, padding is valid
+// or not for a whole octet, strides and transposed layers need nothing special, and every address computation of the fp32 kernels carries
+// over with "pixel" read as "pixel octet".  An MFMA covers two octet rows (lane half 0 / 1), i.e. 16 of the K = N * Do * Ho * Wo products.
+//
+//   conv_wgrad16_kernel<CT, KT>     any layer: operands straight from L2 / L1 (the fp32 conv_wgrad_kernel's structure: one wave owns a
+//                                   (32 CT) x (32 KT) block of dW, software pipeline of three register sets, slabs + deterministic reduce)
+//   conv3d_wgrad16_brick_kernel     3^3 / stride 1 / pad 1 (V2V): dY brick (2 x 2 x 8 voxels) and X halo brick (4 x 4 x 10) in LDS as octets,
+//                                   every wave takes every fourth 32-column block of (tap, ci) -- one ds_read_b128 per MFMA operand
+//   conv3d_wgrad16_k7_kernel        the 7^3 front layer (32 -> 16): one kd plane of the filter per workgroup on the 16x16x32 MFMA
+#include "conv_common.h"
+#include "wgrad_reduce.h"
+
+using namespace lt;
+
+namespace {
+
+__device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+
+// ---- image-octet packing ----------------------------------------------------------------------------------------------------------------
+// thread = (octet group g = blockIdx.y, pixel p, four channels): eight float4 loads (one per image; a wave reads 1 KB runs of each image's
+// rows), four 16-byte stores (64 contiguous bytes per thread)
+__global__ __launch_bounds__(256) void pack_n8_vec_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int N, long long P, int C, int ld) {
+    const int C4 = C >> 2;
+    const long long total = P * C4;
+    const int g = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+        const long long p = i / C4;
+        const int c = (int)(i - p * C4) * 4;
+        float4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = 8 * g + e;
+            v[e] = n < N ? *(const float4*)(src + ((size_t)n * P + p) * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        uint4* o = dst + ((size_t)g * P + p) * C + c;
+        o[0] = make_uint4(pack_bf16x2(v[0].x, v[1].x), pack_bf16x2(v[2].x, v[3].x), pack_bf16x2(v[4].x, v[5].x), pack_bf16x2(v[6].x, v[7].x));
+        o[1] = make_uint4(pack_bf16x2(v[0].y, v[1].y), pack_bf16x2(v[2].y, v[3].y), pack_bf16x2(v[4].y, v[5].y), pack_bf16x2(v[6].y, v[7].y));
+        o[2] = make_uint4(pack_bf16x2(v[0].z, v[1].z), pack_bf16x2(v[2].z, v[3].z), pack_bf16x2(v[4].z, v[5].z), pack_bf16x2(v[6].z, v[7].z));
+        o[3] = make_uint4(pack_bf16x2(v[0].w, v[1].w), pack_bf16x2(v[2].w, v[3].w), pack_bf16x2(v[4].w, v[5].w), pack_bf16x2(v[6].w, v[7].w));
+    }
+}
+
+// any channel count / row stride (the 17-joint output layer, the 3-channel image)
+__global__ __launch_bounds__(256) void pack_n8_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int N, long long P, int C, int ld) {
+    const long long total = P * C;
+    const int g = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+        const long long p = i / C;
+        const int c = (int)(i - p * C);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = 8 * g + e;
+            v[e] = n < N ? src[((size_t)n * P + p) * ld + c] : 0.f;
+        }
+        dst[((size_t)g * P + p) * C + c] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    }
+}
+
+// ---- generic kernel ----------------------------------------------------------------------------------------------------------------------
+struct W16Args {
+    const uint4* dy;         // [G * Do*Ho*Wo][ldy] octets: gradient of the convolution output, GEMM row m = (g, od, oh, ow)
+    const uint4* x;          // [G][D][H][W][Cin] octets
+    const int4* taps;        // [ntaps] = (dd, dh, dw, unused)
+    float* out;              // S == 1: dw [cout_pad][k_pad];  S > 1: workspace [S][cout_pad][k_pad] of per-slab partial sums
+    int D, H, W, Cin, log2Cin, Do, Ho, Wo, sd, sh, sw, pd, ph, pw;
+    int Cout, ldy, k_pad, ntaps, M, accumulate, cout_pad;          // M = G * Do * Ho * Wo octet rows
+    int n_k_t, n_tiles, rows_per_slab;
+};
+
+// bits t = 0 .. 7 with 0 <= i0 + t < size
+__device__ __forceinline__ int range_mask16(int i0, int size) {
+    const int lo = max(0, -i0), hi = min(7, size - 1 - i0);          // hi < lo: empty
+    return hi >= lo ? ((2 << hi) - 1) & ~((1 << lo) - 1) : 0;
+}
+
+template <int CT, int KT, int NS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(const W16Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // every XCD gets a contiguous range of (slab, tile group) pairs, slab-major: the tiles of one slab (same dY / X rows) meet in one L2
+    const int total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int lin2 = (total & 7) ? lin : (lin & 7) * (total >> 3) + (lin >> 3);
+    const int slab = lin2 / (int)gridDim.x, tgroup = lin2 - slab * (int)gridDim.x;
+    const int t = tgroup * 4 + wave;
+    if (t >= a.n_tiles) return;
+    const int co0 = (t / a.n_k_t) * (32 * CT), k0 = (t % a.n_k_t) * (32 * KT);
+    const int col = lane & 31, half = lane >> 5;          // A: co = co0 + 32 c + col, octet row m + half;  B: k = k0 + 32 j + col, octet row m + half
+    int tsel[KT], toff[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const int k = k0 + 32 * j + col;
+        const int tap = k >> a.log2Cin;
+        if (tap < a.ntaps) {
+            const int4 tp = a.taps[tap];
+            tsel[j] = (1 << tp.x) | (1 << (8 + tp.y)) | (1 << (16 + tp.z));
+            toff[j] = ((tp.x * a.H + tp.y) * a.W + tp.z) * a.Cin + (k & (a.Cin - 1));
+        } else {
+            tsel[j] = (int)0x80000000; toff[j] = 0;
+        }
+    }
+    bool co_ok[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) co_ok[c] = co0 + 32 * c + col < a.Cout;
+    f32x16 acc[CT][KT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[c][j][e] = 0.f;
+    const int m_begin = slab * a.rows_per_slab;
+    const int m_end = min(a.M, m_begin + a.rows_per_slab);
+    int m = m_begin + half;
+    const int hw = a.Ho * a.Wo, dhw = a.Do * hw;
+    int g = m / dhw, r = m - g * dhw;
+    int od = r / hw; r -= od * hw;
+    int oh = r / a.Wo, ow = r - oh * a.Wo;
+
+    // branch-free loads, validity bits applied in mma() (behind the loads of the next pipeline stages) -- see conv_wgrad_kernel in train.hip
+    auto load = [&](uint4 (&av)[CT], uint4 (&bv)[KT], unsigned& okbits) {
+        const bool m_ok = m < m_end;
+        unsigned bits = 0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const bool ok = m_ok & co_ok[c];
+            av[c] = a.dy[ok ? (size_t)m * a.ldy + co0 + 32 * c + col : (size_t)0];
+            bits |= ok ? 1u << (KT + c) : 0u;
+        }
+        const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+        const int pix = (((g * a.D + id0) * a.H + ih0) * a.W + iw0) * a.Cin;          // may point in front of the tensor (padding): only in-bounds taps are read
+        const int rmask = m_ok ? (range_mask16(id0, a.D) | (range_mask16(ih0, a.H) << 8) | (range_mask16(iw0, a.W) << 16)) : 0;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+            const bool ok = (rmask & tsel[j]) == tsel[j];
+            bv[j] = a.x[ok ? (unsigned)(pix + toff[j]) : 0u];
+            bits |= ok ? 1u << j : 0u;
+        }
+        okbits = bits;
+        m += 2; ow += 2;
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) { const int w = ow >= a.Wo; ow -= w ? a.Wo : 0; oh += w; }
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) { const int w = oh >= a.Ho; oh -= w ? a.Ho : 0; od += w; }
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) { const int w = od >= a.Do; od -= w ? a.Do : 0; g += w; }
+    };
+    auto mma = [&](const uint4 (&av)[CT], const uint4 (&bv)[KT], unsigned bits) {
+        V16 af[CT], bf[KT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) af[c].u = (bits >> (KT + c)) & 1u ? av[c] : zero4();
+#pragma unroll
+        for (int j = 0; j < KT; ++j) bf[j].u = (bits >> j) & 1u ? bv[j] : zero4();
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int j = 0; j < KT; ++j) acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c].h, bf[j].h, acc[c][j], 0, 0, 0);
+    };
+    // two octet-row pairs in flight ahead of the one in the MFMAs (rows past m_end load nothing: the extra MFMAs add zeros)
+    // (NS = 2 for the 32 x 256 wave tile: nine operands per set, a third set would spill)
+    uint4 av0[CT], bv0[KT], av1[CT], bv1[KT];
+    unsigned ok0, ok1;
+    const int nit = (m_end - m_begin + 1) >> 1;
+    if constexpr (NS == 3) {
+        uint4 av2[CT], bv2[KT];
+        unsigned ok2;
+        load(av0, bv0, ok0); load(av1, bv1, ok1);
+        for (int it = 0; it < nit; it += 3) {
+            load(av2, bv2, ok2); mma(av0, bv0, ok0);
+            load(av0, bv0, ok0); mma(av1, bv1, ok1);
+            load(av1, bv1, ok1); mma(av2, bv2, ok2);
+        }
+    } else {
+        load(av0, bv0, ok0);
+        for (int it = 0; it < nit; it += 2) {
+            load(av1, bv1, ok1); mma(av0, bv0, ok0);
+            load(av0, bv0, ok0); mma(av1, bv1, ok1);
+        }
+    }
+    float* out = a.out + (size_t)slab * a.cout_pad * a.k_pad;
+    const bool direct_acc = a.accumulate && gridDim.y == 1;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = co0 + 32 * c + 8 * (e >> 2) + 4 * half + (e & 3);       // C layout of the 32x32 MFMA: row = co, column = k
+                const int k = k0 + 32 * j + col;
+                if (k < a.k_pad && row < a.cout_pad) {
+                    float* dst = out + (size_t)row * a.k_pad + k;
+                    *dst = direct_acc ? *dst + acc[c][j][e] : acc[c][j][e];
+                }
+            }
+}
+
+struct Plan16 { int variant, n_co_t, n_k_t, S, rows_per_slab; };
+
+// tile shape by layer shape as in the fp32 kernel; an octet row carries eight times the work of a pixel row and the MFMA is 16x faster, so the
+// partial sums (written once, read once by the reduce) are the cost to watch: capped at 16 MiB, at least 16 octet rows per slab
+Plan16 plan16(long long M, int cout_pad, int k_pad) {
+    Plan16 p;
+    p.variant = k_pad <= 64 ? 0 : cout_pad <= 32 ? 2 : 1;
+    const int ct = p.variant == 0 ? 4 : p.variant == 1 ? 2 : 1, kt = 8 / ct;
+    p.n_co_t = (int)cdiv(cout_pad, 32 * ct); p.n_k_t = (int)cdiv(k_pad, 32 * kt);
+    const long long wgs = cdiv((long long)p.n_co_t * p.n_k_t, 4);
+    long long S = cdiv(512, wgs);
+    const long long cap = (16ll << 20) / ((long long)cout_pad * k_pad * 4);
+    if (S > cap) S = cap;
+    if (S > M / 16) S = M / 16;
+    if (S < 1) S = 1;
+    if (S >= 8) S &= ~7ll;          // a multiple of 8: the kernel gives each XCD a contiguous range of slabs
+    long long rps = cdiv(M, S);
+    rps += rps & 1;
+    p.rows_per_slab = (int)rps;
+    p.S = (int)S;                   // trailing slabs may be empty (they write zeros)
+    return p;
+}
+
+// ---- 3^3 / stride 1 / pad 1 from LDS bricks of octets ---------------------------------------------------------------------------------------
+constexpr int B16_D = 2, B16_H = 2, B16_W = 8, B16_VOX = B16_D * B16_H * B16_W;                                   // 32 voxels = 16 MFMA K steps
+constexpr int B16_HD = B16_D + 2, B16_HH = B16_H + 2, B16_HW = B16_W + 2, B16_HVOX = B16_HD * B16_HH * B16_HW;    // 160 halo voxels
+
+struct Brick16Args {
+    const uint4* dy;         // [G * D*H*W][ldy] octets
+    const uint4* x;          // [G][D][H][W][Cin] octets
+    const int4* taps;        // 27 x (dd, dh, dw, -)
+    float* out;              // [S][cout_pad][k_pad]
+    int D, H, W, Cin, ldy, cout_pad, k_pad;
+    int cib;                 // ci per workgroup: min(Cin, 32) (16 or 32)
+    int nblk;                // 32-column blocks of the (tap, ci within the workgroup's cib) space: ceil(27 * cib / 32)
+    int nbd, nbh, nbw;       // bricks per dimension
+    int nbricks, bricks_per_slab;          // over (g, bd, bh, bw)
+};
+
+// workgroup = (32 co, cib ci, slab of bricks); wave w takes the column blocks w, w + 4, ... (at most 7: 27 taps x 32 ci = 27 blocks).
+// LDS: X halo brick [160][cib] octets (80 KB at cib = 32) + dY brick [32][32] octets (16 KB); lanes of a half-wave read 512 contiguous bytes.
+__global__ __launch_bounds__(256) void conv3d_wgrad16_brick_kernel(const Brick16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    uint4* xs = (uint4*)smem16;                           // [B16_HVOX][cib]
+    uint4* ds = xs + B16_HVOX * a.cib;                    // [B16_VOX][32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * a.cib;
+    const int l2c = a.cib == 32 ? 5 : 4;
+    int toff[7], kcol[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int b = wave + 4 * i;
+        const int c = 32 * b + col;                       // column of the (tap, ci) space of this workgroup
+        const int tap = c >> l2c, cil = c & (a.cib - 1);
+        if (b < a.nblk && tap < 27) {
+            const int4 tp = a.taps[tap];
+            toff[i] = ((tp.x * B16_HH + tp.y) * B16_HW + tp.z) * a.cib + cil;
+            kcol[i] = tap * a.Cin + ci0 + cil;
+        } else {
+            toff[i] = 0; kcol[i] = -1;
+        }
+    }
+    f32x16 acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const int b_begin = blockIdx.z * a.bricks_per_slab, b_end = min(a.nbricks, b_begin + a.bricks_per_slab);
+    const int qsh = l2c;                                  // octets per halo voxel = cib
+    for (int b = b_begin; b < b_end; ++b) {
+        int r = b;
+        const int bw = r % a.nbw; r /= a.nbw;
+        const int bh = r % a.nbh; r /= a.nbh;
+        const int bd = r % a.nbd;
+        const int g = r / a.nbd;
+        const int d0 = bd * B16_D, h0 = bh * B16_H, w0 = bw * B16_W;
+        __syncthreads();          // the previous brick's reads are done
+        for (int i = threadIdx.x; i < (B16_HVOX << qsh); i += 256) {
+            const int v = i >> qsh, q = i & (a.cib - 1);
+            const int hw_ = v % B16_HW, t2 = v / B16_HW;
+            const int hh_ = t2 % B16_HH, hd_ = t2 / B16_HH;
+            const int d = d0 + hd_ - 1, h = h0 + hh_ - 1, w = w0 + hw_ - 1;
+            uint4 val = zero4();
+            if ((unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+                val = a.x[((((size_t)g * a.D + d) * a.H + h) * a.W + w) * a.Cin + ci0 + q];
+            xs[i] = val;
+        }
+        for (int i = threadIdx.x; i < B16_VOX * 32; i += 256) {
+            const int v = i >> 5, q = i & 31;
+            const int w = v % B16_W, t2 = v / B16_W;
+            const int h = t2 % B16_H, d = t2 / B16_H;
+            const size_t row = (((size_t)g * a.D + d0 + d) * a.H + h0 + h) * a.W + w0 + w;
+            ds[i] = a.dy[row * a.ldy + co0 + q];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int p = 0; p < B16_VOX / 2; ++p) {
+            const int v = 2 * p + half;                       // brick-linear voxel (w fastest): a pair never straddles a row
+            const int w = v % B16_W, t2 = v / B16_W;
+            const int h = t2 % B16_H, d = t2 / B16_H;
+            V16 av; av.u = ds[v * 32 + col];
+            const int hb = ((d * B16_HH + h) * B16_HW + w) * a.cib;          // halo voxel of tap (0, 0, 0)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                V16 bv; bv.u = xs[hb + toff[i]];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.h, bv.h, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    float* out = a.out + (size_t)blockIdx.z * a.cout_pad * a.k_pad;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        if (kcol[i] < 0) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = co0 + 8 * (e >> 2) + 4 * half + (e & 3);
+            out[(size_t)row * a.k_pad + kcol[i]] = acc[i][e];
+        }
+    }
+}
+
+// ---- the 7^3 front layer (32 -> 16) ---------------------------------------------------------------------------------------------------------
+// One workgroup owns ONE kd plane of the filter: 49 taps x 16 co x 32 ci = 98 blocks of the 16x16x32 MFMA (K = 4 voxels x 8 images), 24-25 blocks
+// of 4 registers per wave.  Bricks of 1 x 2 x 8 voxels: dY brick (16 voxels x 16 co octets, 4 KB) and the X plane the kd needs with a 3-voxel
+// (h, w) halo (8 x 14 voxels x 32 ci octets, 56 KB) in LDS: two workgroups per CU.  Taps must be in (kd, kh, kw) order.
+constexpr int K16_H = 2, K16_W = 8, K16_VOX = K16_H * K16_W, K16_HH = K16_H + 6, K16_HW = K16_W + 6, K16_HVOX = K16_HH * K16_HW;
+
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad16_k7_kernel(const Brick16Args a) {
+    __shared__ __attribute__((aligned(16))) uint4 xs[K16_HVOX * 32];          // 56 KB
+    __shared__ __attribute__((aligned(16))) uint4 ds[K16_VOX * 16];           // 4 KB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;            // MFMA 16x16x32: A row / B column = lane % 16, K group (voxel of the quad) = lane / 16
+    const int kd = blockIdx.x;
+    int boff[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+        const int b = wave + 4 * i;
+        const int t = b < 98 ? b >> 1 : 0;
+        const int4 tp = a.taps[kd * 49 + t];
+        if (tp.x != kd) __builtin_trap();
+        boff[i] = (tp.y * K16_HW + tp.z) * 32 + (b & 1) * 16;
+    }
+    f32x4 acc[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int b_begin = blockIdx.z * a.bricks_per_slab, b_end = min(a.nbricks, b_begin + a.bricks_per_slab);
+    for (int br = b_begin; br < b_end; ++br) {
+        int r = br;
+        const int bw = r % a.nbw; r /= a.nbw;
+        const int bh = r % a.nbh; r /= a.nbh;
+        const int d = r % a.D;                            // bricks are one plane deep: nbd = D
+        const int g = r / a.D;
+        const int h0 = bh * K16_H, w0 = bw * K16_W;
+        const int dx_ = d + kd - 3;                       // the X plane this kd reads for output plane d
+        __syncthreads();
+        const bool plane_ok = (unsigned)dx_ < (unsigned)a.D;
+        for (int i = threadIdx.x; i < K16_HVOX * 32; i += 256) {
+            const int v = i >> 5, q = i & 31;
+            const int hw_ = v % K16_HW, hh_ = v / K16_HW;
+            const int h = h0 + hh_ - 3, w = w0 + hw_ - 3;
+            uint4 val = zero4();
+            if (plane_ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+                val = a.x[((((size_t)g * a.D + dx_) * a.H + h) * a.W + w) * 32 + q];
+            xs[i] = val;
+        }
+        for (int i = threadIdx.x; i < K16_VOX * 16; i += 256) {
+            const int v = i >> 4, q = i & 15;
+            const int w = v % K16_W, h = v / K16_W;
+            const size_t row = (((size_t)g * a.D + d) * a.H + h0 + h) * a.W + w0 + w;
+            ds[i] = a.dy[row * a.ldy + q];
+        }
+        __syncthreads();
+        if (plane_ok) {
+#pragma unroll 2
+            for (int s4 = 0; s4 < K16_VOX / 4; ++s4) {
+                const int v = 4 * s4 + kq;                        // four voxels along w per MFMA (8 wide: a quad never straddles a row)
+                const int w = v % K16_W, h = v / K16_W;
+                V16 av; av.u = ds[v * 16 + col];
+                const uint4* xb = xs + (h * K16_HW + w) * 32 + col;
+#pragma unroll
+                for (int i = 0; i < 25; ++i) {
+                    V16 bv; bv.u = xb[boff[i]];
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av.h, bv.h, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* out = a.out + (size_t)blockIdx.z * a.cout_pad * a.k_pad;
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+        const int b = wave + 4 * i;
+        if (b >= 98) break;
+        const int k = (kd * 49 + (b >> 1)) * 32 + (b & 1) * 16 + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[(size_t)(4 * kq + e) * a.k_pad + k] = acc[i][e];       // C: row = 4 (lane / 16) + e = co, column = lane % 16 = ci
+    }
+}
+
+bool brick16_ok(int D, int H, int W, int Cin, int Do, int Ho, int Wo, const int32_t* stride, const int32_t* pad, int Cout, int cout_pad, int k_pad, int ntaps) {
+    if (ntaps != 27 || D != Do || H != Ho || W != Wo || stride[0] != 1 || stride[1] != 1 || stride[2] != 1 || pad[0] != 1 || pad[1] != 1 || pad[2] != 1) return false;
+    if ((Cin != 16 && Cin % 32) || Cout % 32 || cout_pad != Cout || k_pad != 27 * Cin) return false;
+    return D % B16_D == 0 && H % B16_H == 0 && W % B16_W == 0;
+}
+
+void reduce16(const void* workspace, float* dw, long long n, int S, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_grid(n)), dim3(256), 0, st, (const float*)workspace, dw, n, S, accumulate);
+}
+
+}  // namespace
+
+extern "C" size_t lt_pack_n8_bf16_bytes(int32_t N, int64_t P, int32_t C) {
+    if (N < 1 || P < 1 || C < 1) return 0;
+    return (size_t)cdiv(N, 8) * (size_t)P * (size_t)C * 16;
+}
+
+extern "C" int lt_pack_n8_bf16(const float* src, void* dst, int32_t N, int64_t P, int32_t C, int32_t ld, void* stream) {
+    LT_REQUIRE(src && dst && N >= 1 && P >= 1 && C >= 1 && ld >= C, LT_ERR_INVALID, "lt_pack_n8_bf16: bad argument");
+    LT_REQUIRE((size_t)dst % 16 == 0, LT_ERR_INVALID, "lt_pack_n8_bf16: dst must be 16-byte aligned");
+    const int G = (int)cdiv(N, 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0 && ld % 4 == 0 && (size_t)src % 16 == 0) {
+        const long long blocks = cdiv(P * (C / 4), 256);
+        hipLaunchKernelGGL(pack_n8_vec_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192), (unsigned)G), dim3(256), 0, st, src, (uint4*)dst, N, (long long)P, C, ld);
+    } else {
+        const long long blocks = cdiv(P * C, 256);
+        hipLaunchKernelGGL(pack_n8_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192), (unsigned)G), dim3(256), 0, st, src, (uint4*)dst, N, (long long)P, C, ld);
+    }
+    LT_CHECK_LAUNCH("lt_pack_n8_bf16");
+    return LT_OK;
+}
+
+// partial sums of any kernel behind lt_conv_wgrad_bf16: at most 16 MiB, or one slab set of 256 workgroups for the brick kernels
+extern "C" size_t lt_conv_wgrad_bf16_workspace(int64_t octet_rows, int32_t cout_pad, int32_t k_pad) {
+    if (octet_rows < 1 || cout_pad < 1 || k_pad < 1) return 0;
+    const size_t n = (size_t)cout_pad * k_pad * sizeof(float);
+    const Plan16 p = plan16(octet_rows, cout_pad, k_pad);
+    size_t need = p.S > 1 ? (size_t)p.S * n : 0;
+    const size_t brick = (size_t)512 * n < ((size_t)64 << 20) ? (size_t)512 * n : ((size_t)64 << 20);
+    if (brick > need) need = brick;
+    return need;
+}
+
+extern "C" int lt_conv_wgrad_bf16(const void* dy16, const void* x16, const int32_t* taps, float* dw, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
+                                  int32_t Do, int32_t Ho, int32_t Wo, const int32_t stride[3], const int32_t pad[3], int32_t Cout, int32_t ldy,
+                                  int32_t cout_pad, int32_t k_pad, int32_t ntaps, int32_t accumulate, void* workspace, void* stream) {
+    LT_REQUIRE(dy16 && x16 && taps && dw && stride && pad, LT_ERR_INVALID, "lt_conv_wgrad_bf16: null argument");
+    const int l2 = ilog2_exact(Cin);
+    LT_REQUIRE(l2 >= 0, LT_ERR_UNSUPPORTED, "lt_conv_wgrad_bf16: Cin=%d must be a power of two", Cin);
+    LT_REQUIRE(Cout >= 1 && ldy >= Cout && cout_pad >= Cout && k_pad >= ntaps * Cin && ntaps >= 1 && N >= 1, LT_ERR_INVALID, "lt_conv_wgrad_bf16: bad sizes");
+    const int G = (int)cdiv(N, 8);
+    const long long M = (long long)G * Do * Ho * Wo;
+    LT_REQUIRE(M >= 1 && M < (1ll << 31) && (long long)G * D * H * W * Cin < (1ll << 31) && M * ldy < (1ll << 40), LT_ERR_UNSUPPORTED,
+               "lt_conv_wgrad_bf16: too many rows / elements for 32-bit offsets");
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)cout_pad * k_pad;
+    const size_t ws_bytes = lt_conv_wgrad_bf16_workspace(M, cout_pad, k_pad);
+    const bool unit = stride[0] == 1 && stride[1] == 1 && stride[2] == 1 && D == Do && H == Ho && W == Wo;
+    if (brick16_ok(D, H, W, Cin, Do, Ho, Wo, stride, pad, Cout, cout_pad, k_pad, ntaps)) {
+        LT_REQUIRE(workspace, LT_ERR_INVALID, "lt_conv_wgrad_bf16: this shape needs a workspace of lt_conv_wgrad_bf16_workspace() bytes");
+        Brick16Args b;
+        b.dy = (const uint4*)dy16; b.x = (const uint4*)x16; b.taps = (const int4*)taps; b.out = (float*)workspace;
+        b.D = D; b.H = H; b.W = W; b.Cin = Cin; b.ldy = ldy; b.cout_pad = cout_pad; b.k_pad = k_pad;
+        b.cib = Cin < 32 ? Cin : 32; b.nblk = (int)cdiv(27 * b.cib, 32);
+        b.nbd = D / B16_D; b.nbh = H / B16_H; b.nbw = W / B16_W; b.nbricks = G * b.nbd * b.nbh * b.nbw;
+        const long long blocks = (long long)(Cout / 32) * (Cin / b.cib);
+        long long S = cdiv(256, blocks);                  // one workgroup per CU (96 KB of LDS each): exactly one round
+        const long long cap = (long long)(ws_bytes / ((size_t)n * 4));
+        S = S > cap ? cap : S;
+        S = S > b.nbricks ? b.nbricks : S;
+        S = S < 1 ? 1 : S;
+        b.bricks_per_slab = (int)cdiv(b.nbricks, S);
+        S = cdiv(b.nbricks, b.bricks_per_slab);
+        const size_t lds = (size_t)(B16_HVOX * b.cib + B16_VOX * 32) * 16;
+        hipLaunchKernelGGL(conv3d_wgrad16_brick_kernel, dim3(Cout / 32, Cin / b.cib, (unsigned)S), dim3(256), lds, st, b);
+        LT_CHECK_LAUNCH("lt_conv_wgrad_bf16(brick)");
+        reduce16(workspace, dw, n, (int)S, accumulate, st);
+        LT_CHECK_LAUNCH("lt_conv_wgrad_bf16(reduce)");
+        return LT_OK;
+    }
+    if (unit && ntaps == 343 && pad[0] == 3 && pad[1] == 3 && pad[2] == 3 && Cin == 32 && Cout == 16 && cout_pad == 16 && k_pad == 343 * 32 && ldy >= 16 &&
+        H % K16_H == 0 && W % K16_W == 0 && workspace) {
+        Brick16Args b;
+        b.dy = (const uint4*)dy16; b.x = (const uint4*)x16; b.taps = (const int4*)taps; b.out = (float*)workspace;
+        b.D = D; b.H = H; b.W = W; b.Cin = Cin; b.ldy = ldy; b.cout_pad = cout_pad; b.k_pad = k_pad; b.cib = 32; b.nblk = 0;
+        b.nbd = D; b.nbh = H / K16_H; b.nbw = W / K16_W; b.nbricks = G * b.nbd * b.nbh * b.nbw;
+        long long S = 73;                                  // 7 kd planes x 73 slabs = 511 workgroups, two per CU
+        const long long cap = (long long)(ws_bytes / ((size_t)n * 4));
+        S = S > cap ? cap : S;
+        S = S > b.nbricks ? b.nbricks : S;
+        S = S < 1 ? 1 : S;
+        b.bricks_per_slab = (int)cdiv(b.nbricks, S);
+        S = cdiv(b.nbricks, b.bricks_per_slab);
+        hipLaunchKernelGGL(conv3d_wgrad16_k7_kernel, dim3(7, 1, (unsigned)S), dim3(256), 0, st, b);
+        LT_CHECK_LAUNCH("lt_conv_wgrad_bf16(7^3)");
+        reduce16(workspace, dw, n, (int)S, accumulate, st);
+        LT_CHECK_LAUNCH("lt_conv_wgrad_bf16(reduce)");
+        return LT_OK;
+    }
+    const Plan16 p = plan16(M, cout_pad, k_pad);
+    LT_REQUIRE(p.S == 1 || workspace, LT_ERR_INVALID, "lt_conv_wgrad_bf16: this shape needs a workspace of lt_conv_wgrad_bf16_workspace() bytes");
+    W16Args a;
+    a.dy = (const uint4*)dy16; a.x = (const uint4*)x16; a.taps = (const int4*)taps; a.out = p.S > 1 ? (float*)workspace : dw;
+    a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.log2Cin = l2; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+    a.sd = stride[0]; a.sh = stride[1]; a.sw = stride[2]; a.pd = pad[0]; a.ph = pad[1]; a.pw = pad[2];
+    a.Cout = Cout; a.ldy = ldy; a.k_pad = k_pad; a.ntaps = ntaps; a.M = (int)M; a.accumulate = accumulate; a.cout_pad = cout_pad;
+    a.n_k_t = p.n_k_t; a.n_tiles = p.n_co_t * p.n_k_t; a.rows_per_slab = p.rows_per_slab;
+    const dim3 grid((unsigned)cdiv(a.n_tiles, 4), (unsigned)p.S);
+    if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad16_kernel<4, 2, 3>), grid, dim3(256), 0, st, a);
+    else if (p.variant == 1) hipLaunchKernelGGL((conv_wgrad16_kernel<2, 4, 3>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad16_kernel<1, 8, 2>), grid, dim3(256), 0, st, a);
+    LT_CHECK_LAUNCH("lt_conv_wgrad_bf16");
+    if (p.S > 1) {
+        reduce16(workspace, dw, n, p.S, accumulate, st);
+        LT_CHECK_LAUNCH("lt_conv_wgrad_bf16(reduce)");
+    }
+    return LT_OK;
+}

@@ -69,7 +69,13 @@ class TrainTape:
         self.side = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._ws2 = torch.empty(64 << 20, dtype=torch.uint8, device=self.device)         # >= the 48 MiB cap of lt_conv_wgrad's partial sums
         self._n_wgrad = 0
-        self.wgrad_main_every = int(os.environ.get("LT_TRAIN_WGRAD_MAIN_EVERY", "6" if mixed else "0"))
+        # mixed precision: the weight gradients run on the bf16 MFMA too (lt_conv_wgrad_bf16 over image-octet packed operands, packed by
+        # lt_pack_n8_bf16 into scratch buffers right in front of the kernel, on the stream the kernel runs on).  LT_TRAIN_WGRAD_FP32=1 keeps
+        # them on the exact-fp32 MFMA (then every sixth one stays on the main stream: the side stream would be the longer one).
+        self.wgrad16 = self.mixed and os.environ.get("LT_TRAIN_WGRAD_FP32") is None
+        self.wgrad_main_every = int(os.environ.get("LT_TRAIN_WGRAD_MAIN_EVERY", "6" if (mixed and not self.wgrad16) else "0"))
+        self._pk_main = [torch.empty(16, dtype=torch.uint8, device=self.device) for _ in range(2)]          # octet-packed dY / X of the layer in flight
+        self._pk_side = [torch.empty(16, dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.keep = []
         self.labels, self._label = {}, "op"              # id(closure) -> label, for profile()
         self.batched, self.fwd_jobs, self.bwd_jobs, self._job_tabs = {}, [], [], {}      # parameter gathers: one launch per replay
@@ -401,7 +407,14 @@ class TrainTape:
                 imap = ar[:cin_t].reshape(cin_t, *ks3, Cout).permute(0, 4, 1, 2, 3)
             imap = (imap[:, :, 0] if nd == 2 else imap).contiguous().reshape(-1).to(self.device)
             dw = torch.empty(cop, kp, dtype=torch.float32, device=self.device)
-            need = lib.lt_conv_wgrad_workspace(wrows, cop, kp)
+            use16 = self.wgrad16
+            n_img = geo[0]
+            pa_px, pb_px = geo[5] * geo[6] * geo[7], geo[1] * geo[2] * geo[3]          # pixels per image of the dY-role / X-role tensor
+            if use16:
+                need = lib.lt_conv_wgrad_bf16_workspace((n_img + 7) // 8 * pa_px, cop, kp)
+                pk_need = (lib.lt_pack_n8_bf16_bytes(n_img, pa_px, geo[9]), lib.lt_pack_n8_bf16_bytes(n_img, pb_px, geo[4]))
+            else:
+                need = lib.lt_conv_wgrad_workspace(wrows, cop, kp)
             self.keep += [taps_all, a_ptr, b_ptr, imap, dw]
             gview = self._grad_view(weight)
             ng = gview.numel()
@@ -416,15 +429,29 @@ class TrainTape:
             elif self._ws2.numel() < need:
                 self._ws2.record_stream(self.side)          # a side-stream kernel of the recording step may still be using it: not to be handed out before that
                 self._ws2 = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            if use16:
+                pk = self._pk_main if ev is None else self._pk_side
+                for i in range(2):
+                    if pk[i].numel() < pk_need[i]:
+                        if ev is not None:
+                            pk[i].record_stream(self.side)
+                        pk[i] = torch.empty(int(pk_need[i]), dtype=torch.uint8, device=self.device)
 
             def wgrad(st):
                 if ev is not None:          # dY (and this layer's BatchNorm / bias gradients) are complete on the main stream: the side stream may go
                     ev.record(torch.cuda.current_stream(self.device))
                     self.side.wait_event(ev)
                     st = self.side.cuda_stream
-                H.check(lib.lt_conv_wgrad(a_ptr.data_ptr(), b_ptr.data_ptr(), taps_all.data_ptr(), dw.data_ptr(), geo[0], geo[1], geo[2], geo[3], geo[4], geo[5], geo[6],
-                                          geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, (self._ws if ev is None else self._ws2).data_ptr(), st),
-                        "lt_conv_wgrad")
+                ws = (self._ws if ev is None else self._ws2).data_ptr()
+                if use16:
+                    pk = self._pk_main if ev is None else self._pk_side
+                    H.check(lib.lt_pack_n8_bf16(a_ptr.data_ptr(), pk[0].data_ptr(), n_img, pa_px, geo[9], geo[9], st), "lt_pack_n8_bf16")
+                    H.check(lib.lt_pack_n8_bf16(b_ptr.data_ptr(), pk[1].data_ptr(), n_img, pb_px, geo[4], geo[4], st), "lt_pack_n8_bf16")
+                    H.check(lib.lt_conv_wgrad_bf16(pk[0].data_ptr(), pk[1].data_ptr(), taps_all.data_ptr(), dw.data_ptr(), geo[0], geo[1], geo[2], geo[3], geo[4],
+                                                   geo[5], geo[6], geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, ws, st), "lt_conv_wgrad_bf16")
+                else:
+                    H.check(lib.lt_conv_wgrad(a_ptr.data_ptr(), b_ptr.data_ptr(), taps_all.data_ptr(), dw.data_ptr(), geo[0], geo[1], geo[2], geo[3], geo[4], geo[5],
+                                              geo[6], geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, ws, st), "lt_conv_wgrad")
                 H.check(lib.lt_gather_f32(dw.data_ptr(), imap.data_ptr(), gview.data_ptr(), ng, st), "lt_gather_f32")      # into the Parameter's layout
             self.do(wgrad, label)
         self._grads_ready()

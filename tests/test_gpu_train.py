@@ -231,6 +231,75 @@ def test_tape_layer_gradients(case, mode, mixed):
         check(tag + " db", pg[bp].cpu(), bd.grad, T2)
 
 
+W16_CASES = [  # N, (D, H, W), Cin, Cout, k (taps per dim), stride, pad
+    (11, (1, 9, 7), 64, 96, (1, 1, 1), 1, 0),        # pointwise, two octet groups with a ragged second one, Cout not a multiple of 32
+    (8, (1, 10, 12), 32, 64, (1, 3, 3), 1, 1),       # 2D 3x3
+    (3, (1, 12, 16), 32, 64, (1, 3, 3), 2, 1),       # strided
+    (16, (1, 6, 8), 8, 64, (1, 7, 7), 2, 3),         # the stem's shape family: 49 taps x 8 channels
+    (5, (4, 6, 8), 16, 32, (1, 1, 1), 1, 0),         # K <= 64: the 128 x 64 wave tile
+    (2, (4, 4, 8), 32, 17, (1, 1, 1), 1, 0),         # 17 joints: scalar pack path, 32 x 256 wave tile
+    (8, (4, 4, 8), 32, 32, (3, 3, 3), 1, 1),         # LDS bricks of octets
+    (9, (2, 4, 16), 64, 32, (3, 3, 3), 1, 1),        # ... two ci blocks, two octet groups
+    (4, (4, 2, 8), 16, 32, (3, 3, 3), 1, 1),         # ... 16 input channels: two taps per column block
+    (8, (6, 6, 6), 32, 32, (3, 3, 3), 1, 1),         # 3^3 whose volume is no whole number of bricks: generic kernel
+    (8, (3, 4, 8), 32, 16, (7, 7, 7), 1, 3),         # the 7^3 front layer: one kd plane per workgroup on the 16x16x32 MFMA
+]
+
+
+@pytest.mark.parametrize("case", W16_CASES, ids=lambda c: "N%d_%s_%dto%d_k%s_s%d" % (c[0], "x".join(map(str, c[1])), c[2], c[3], "".join(map(str, c[4])), c[5]))
+def test_conv_wgrad_bf16_vs_fp32_kernel_on_rounded_operands(case):
+    """lt_pack_n8_bf16 + lt_conv_wgrad_bf16 (image-octet operands on the bf16 MFMA) against lt_conv_wgrad (exact-fp32 MFMA) fed with the SAME
+    bf16-rounded operands: products are exact in both, only the fp32 summation order differs (gate 2e-5 of max); against the fp32 kernel on
+    the unrounded operands the difference is bf16 rounding of the operands (recorded, gate 2e-2).  Twice: bitwise repeatable."""
+    H, lib = _lib()
+    N, (D, Hh, W), Cin, Cout, ks, s, p = case
+    g = torch.Generator().manual_seed(N * 131 + Cin + Cout)
+    pd = tuple(p if k > 1 else 0 for k in ks)
+    st3 = tuple(s if k > 1 else 1 for k in ks) if any(k > 1 for k in ks) else (1, 1, 1)
+    Do, Ho, Wo = [(n + 2 * q - k) // t + 1 for n, q, k, t in zip((D, Hh, W), pd, ks, st3)]
+    x = torch.randn(N, D, Hh, W, Cin, generator=g).to(DEV)
+    dy = torch.randn(N, Do, Ho, Wo, Cout, generator=g).to(DEV)
+    taps = torch.tensor([(a, b, c, 0) for a in range(ks[0]) for b in range(ks[1]) for c in range(ks[2])], dtype=torch.int32, device=DEV)
+    ntaps = taps.shape[0]
+    import lt_engine as E
+    cop, kp = E.cout_pad_of(Cout), ntaps * Cin
+    rows = N * Do * Ho * Wo
+
+    def fp32(dyt, xt):
+        dw = torch.zeros(cop, kp, device=DEV)
+        ws = torch.empty(max(int(lib.lt_conv_wgrad_workspace(rows, cop, kp)), 16), dtype=torch.uint8, device=DEV)
+        H.check(lib.lt_conv_wgrad(dyt.data_ptr(), xt.data_ptr(), taps.data_ptr(), dw.data_ptr(), N, D, Hh, W, Cin, Do, Ho, Wo, H.i3(st3), H.i3(pd), Cout, Cout, cop, kp,
+                                  ntaps, 0, ws.data_ptr(), _st()), "lt_conv_wgrad")
+        return dw
+
+    def bf16():
+        pa = torch.empty(int(lib.lt_pack_n8_bf16_bytes(N, Do * Ho * Wo, Cout)), dtype=torch.uint8, device=DEV)
+        pb = torch.empty(int(lib.lt_pack_n8_bf16_bytes(N, D * Hh * W, Cin)), dtype=torch.uint8, device=DEV)
+        H.check(lib.lt_pack_n8_bf16(dy.data_ptr(), pa.data_ptr(), N, Do * Ho * Wo, Cout, Cout, _st()), "lt_pack_n8_bf16")
+        H.check(lib.lt_pack_n8_bf16(x.data_ptr(), pb.data_ptr(), N, D * Hh * W, Cin, Cin, _st()), "lt_pack_n8_bf16")
+        dw = torch.full((cop, kp), float("nan"), device=DEV)
+        ws = torch.empty(max(int(lib.lt_conv_wgrad_bf16_workspace((N + 7) // 8 * Do * Ho * Wo, cop, kp)), 16), dtype=torch.uint8, device=DEV)
+        H.check(lib.lt_conv_wgrad_bf16(pa.data_ptr(), pb.data_ptr(), taps.data_ptr(), dw.data_ptr(), N, D, Hh, W, Cin, Do, Ho, Wo, H.i3(st3), H.i3(pd), Cout, Cout,
+                                       cop, kp, ntaps, 0, ws.data_ptr(), _st()), "lt_conv_wgrad_bf16")
+        return dw, pa
+
+    ours, pa = bf16()
+    again, _ = bf16()
+    torch.cuda.synchronize()
+    # the pack itself: octet (g, p, c) = the eight images' values, bf16 round-to-nearest-even, zeros past N
+    G = (N + 7) // 8
+    pk = pa.view(torch.bfloat16).reshape(G, Do * Ho * Wo, Cout, 8).float().cpu()
+    want = torch.zeros(G * 8, Do * Ho * Wo, Cout)
+    want[:N] = dy.reshape(N, -1, Cout).bfloat16().float().cpu()
+    assert torch.equal(pk, want.reshape(G, 8, -1, Cout).permute(0, 2, 3, 1))
+    assert torch.equal(ours[:Cout], again[:Cout]), "not bitwise repeatable"
+    ref_r = fp32(dy.bfloat16().float(), x.bfloat16().float())
+    ref = fp32(dy, x)
+    tag = "train/wgrad_bf16 N%d %s %d->%d k%s s%d" % (N, "x".join(map(str, (D, Hh, W))), Cin, Cout, "".join(map(str, ks)), s)
+    check(tag + " vs fp32 kernel on rounded operands", ours[:Cout].cpu(), ref_r[:Cout].cpu(), 2e-5)
+    check(tag + " vs fp32 kernel", ours[:Cout].cpu(), ref[:Cout].cpu(), 2e-2)
+
+
 def test_adam_step_vs_torch():
     import lt_train
     g = torch.Generator().manual_seed(3)

@@ -69,6 +69,19 @@ json.dump(out, open("$OUT/aten_kernels.json", "w"), indent=1)
 PY
   for t in fwd train; do f=$(ls $OUT/prof_$t/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_$t.csv; done
   ;;
+mixedprof)    # mixed-precision step at B = 8: per-op table on ONE stream (weight gradients visible), then the step rate
+  LT_TRAIN_NO_OVERLAP=1 timeout 600 python tools/train_profile.py 8 bf16 > $OUT/train_profile_b8_bf16.log 2>&1; echo "mixedprof rc=$?"
+  grep -E "^fwd|^bwd" $OUT/train_profile_b8_bf16.log | head -4
+  grep -E " wgrad | pack " $OUT/train_profile_b8_bf16.log | head -24
+  cp gpurun_out/train_ops_b8_bf16.json $OUT/ 2>/dev/null
+  timeout 600 python bench.py --train --train-dtype bf16 --steps 10 --warmup 3 --batch 8 > $OUT/bench_train_bf16mma_b8.json 2> $OUT/bench_train_bf16mma_b8.err
+  echo "bench mixed rc=$?"; python -c "
+import json; r=json.load(open('$OUT/bench_train_bf16mma_b8.json')); print(r['value'], r['ms_per_step'], r['losses'])"
+  ;;
+wgradtests)
+  timeout 900 python -m pytest tests/test_gpu_train.py -m gpu -q --tb=short -x -p no:cacheprovider -k "op_level or wgrad or layer" > $OUT/test_wgrad.log 2>&1
+  echo "wgrad tests rc=$?"; tail -6 $OUT/test_wgrad.log
+  ;;
 smoke)
   timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
   ;;
