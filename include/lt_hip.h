@@ -299,6 +299,8 @@ int lt_conv_wgrad(const float* dy, const float* x, const int32_t* taps, float* d
  *   ceil(N / 8) * Do*Ho*Wo, cout_pad, k_pad) bytes.  Result = lt_conv_wgrad of the bf16-rounded operands up to fp32 summation order. */
 size_t lt_pack_n8_bf16_bytes(int32_t N, int64_t P, int32_t C);
 int lt_pack_n8_bf16(const float* src, void* dst, int32_t N, int64_t P, int32_t C, int32_t ld, void* stream);
+/* the same from a bf16 tensor [N][P][ld] (the operand copy the mixed-precision convolutions read): C, ld multiples of 8, 16-byte aligned */
+int lt_pack_n8_from_bf16(const void* src_bf16, void* dst, int32_t N, int64_t P, int32_t C, int32_t ld, void* stream);
 size_t lt_conv_wgrad_bf16_workspace(int64_t octet_rows, int32_t cout_pad, int32_t k_pad);
 int lt_conv_wgrad_bf16(const void* dy16, const void* x16, const int32_t* taps, float* dw, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin, int32_t Do,
                        int32_t Ho, int32_t Wo, const int32_t stride[3], const int32_t pad[3], int32_t Cout, int32_t ldy, int32_t cout_pad, int32_t k_pad,

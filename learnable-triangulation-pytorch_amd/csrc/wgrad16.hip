@@ -69,6 +69,37 @@ __global__ __launch_bounds__(256) void pack_n8_kernel(const float* __restrict__ 
     }
 }
 
+// the same from a bf16 [N][P][ld] tensor (the copy the mixed-precision convolutions already read): thread = (g, p, eight channels), eight
+// 16-byte loads (one per image), an 8 x 8 transpose of 16-bit values with v_perm_b32, eight 16-byte stores (128 contiguous bytes)
+__global__ __launch_bounds__(256) void pack_n8_from_bf16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int N, long long P, int C, int ld) {
+    const int C8 = C >> 3, ld8 = ld >> 3;
+    const long long total = P * C8;
+    const int g = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += 256ll * gridDim.x) {
+        const long long p = i / C8;
+        const int c8 = (int)(i - p * C8);
+        uint4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = 8 * g + e;
+            v[e] = n < N ? src[((size_t)n * P + p) * ld8 + c8] : zero4();
+        }
+        uint4* o = dst + ((size_t)g * P + p) * C + c8 * 8;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {          // dword d of every image holds channels 2d (low half) and 2d + 1 (high half)
+            const unsigned w0 = d == 0 ? v[0].x : d == 1 ? v[0].y : d == 2 ? v[0].z : v[0].w, w1 = d == 0 ? v[1].x : d == 1 ? v[1].y : d == 2 ? v[1].z : v[1].w;
+            const unsigned w2 = d == 0 ? v[2].x : d == 1 ? v[2].y : d == 2 ? v[2].z : v[2].w, w3 = d == 0 ? v[3].x : d == 1 ? v[3].y : d == 2 ? v[3].z : v[3].w;
+            const unsigned w4 = d == 0 ? v[4].x : d == 1 ? v[4].y : d == 2 ? v[4].z : v[4].w, w5 = d == 0 ? v[5].x : d == 1 ? v[5].y : d == 2 ? v[5].z : v[5].w;
+            const unsigned w6 = d == 0 ? v[6].x : d == 1 ? v[6].y : d == 2 ? v[6].z : v[6].w, w7 = d == 0 ? v[7].x : d == 1 ? v[7].y : d == 2 ? v[7].z : v[7].w;
+            // __builtin_amdgcn_perm(hi, lo, sel): bytes 0-3 of the result pick from {lo: 0-3, hi: 4-7}
+            o[2 * d] = make_uint4(__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u), __builtin_amdgcn_perm(w5, w4, 0x05040100u),
+                                  __builtin_amdgcn_perm(w7, w6, 0x05040100u));
+            o[2 * d + 1] = make_uint4(__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u), __builtin_amdgcn_perm(w5, w4, 0x07060302u),
+                                      __builtin_amdgcn_perm(w7, w6, 0x07060302u));
+        }
+    }
+}
+
 // ---- generic kernel ----------------------------------------------------------------------------------------------------------------------
 struct W16Args {
     const uint4* dy;         // [G * Do*Ho*Wo][ldy] octets: gradient of the convolution output, GEMM row m = (g, od, oh, ow)
@@ -244,70 +275,96 @@ struct Brick16Args {
     int nbricks, bricks_per_slab;          // over (g, bd, bh, bw)
 };
 
-// workgroup = (32 co, cib ci, slab of bricks); wave w takes the column blocks w, w + 4, ... (at most 7: 27 taps x 32 ci = 27 blocks).
-// LDS: X halo brick [160][cib] octets (80 KB at cib = 32) + dY brick [32][32] octets (16 KB); lanes of a half-wave read 512 contiguous bytes.
+// workgroup = (32 co, CIB ci, slab of bricks); wave w takes the column blocks w, w + 4, ... (at most 7: 27 taps x 32 ci = 27 blocks).
+// LDS: X halo brick [160][CIB] octets (80 KB at CIB = 32) + dY brick [32][32] octets (16 KB); lanes of a half-wave read 512 contiguous bytes.
+// The NEXT brick's operands are loaded into registers (up to 24 x 16 bytes per thread) before the MFMA loop of the current one and written to
+// LDS behind it: the global-memory latency hides behind the MFMAs (one workgroup per CU, so nothing else would).
+template <int CIB>
 __global__ __launch_bounds__(256) void conv3d_wgrad16_brick_kernel(const Brick16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
-    uint4* xs = (uint4*)smem16;                           // [B16_HVOX][cib]
-    uint4* ds = xs + B16_HVOX * a.cib;                    // [B16_VOX][32]
+    constexpr int L2C = CIB == 32 ? 5 : 4;
+    constexpr int NX = B16_HVOX * CIB / 256;              // X octets per thread (20 / 10)
+    constexpr int NY = B16_VOX * 32 / 256;                // dY octets per thread (4)
+    uint4* xs = (uint4*)smem16;                           // [B16_HVOX][CIB]
+    uint4* ds = xs + B16_HVOX * CIB;                      // [B16_VOX][32]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, half = lane >> 5;
-    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * a.cib;
-    const int l2c = a.cib == 32 ? 5 : 4;
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * CIB;
     int toff[7], kcol[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         const int b = wave + 4 * i;
         const int c = 32 * b + col;                       // column of the (tap, ci) space of this workgroup
-        const int tap = c >> l2c, cil = c & (a.cib - 1);
+        const int tap = c >> L2C, cil = c & (CIB - 1);
         if (b < a.nblk && tap < 27) {
             const int4 tp = a.taps[tap];
-            toff[i] = ((tp.x * B16_HH + tp.y) * B16_HW + tp.z) * a.cib + cil;
+            toff[i] = ((tp.x * B16_HH + tp.y) * B16_HW + tp.z) * CIB + cil;
             kcol[i] = tap * a.Cin + ci0 + cil;
         } else {
             toff[i] = 0; kcol[i] = -1;
         }
     }
+    // staging slots of this thread: X octet k = halo voxel (tid >> L2C) + (256 >> L2C) k, channel tid & (CIB - 1); coordinates packed once
+    const int xq = threadIdx.x & (CIB - 1);
+    int xco[NX];                                          // hd | hh << 8 | hw << 16 of the halo voxel
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        const int v = (threadIdx.x >> L2C) + (256 >> L2C) * k;
+        const int hw_ = v % B16_HW, t2 = v / B16_HW;
+        xco[k] = (t2 / B16_HH) | ((t2 % B16_HH) << 8) | (hw_ << 16);
+    }
+    const int yq = threadIdx.x & 31;
     f32x16 acc[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     const int b_begin = blockIdx.z * a.bricks_per_slab, b_end = min(a.nbricks, b_begin + a.bricks_per_slab);
-    const int qsh = l2c;                                  // octets per halo voxel = cib
-    for (int b = b_begin; b < b_end; ++b) {
+    uint4 rx[NX], ry[NY];
+    unsigned okm = 0;
+    auto issue = [&](int b) {
         int r = b;
         const int bw = r % a.nbw; r /= a.nbw;
         const int bh = r % a.nbh; r /= a.nbh;
         const int bd = r % a.nbd;
         const int g = r / a.nbd;
         const int d0 = bd * B16_D, h0 = bh * B16_H, w0 = bw * B16_W;
-        __syncthreads();          // the previous brick's reads are done
-        for (int i = threadIdx.x; i < (B16_HVOX << qsh); i += 256) {
-            const int v = i >> qsh, q = i & (a.cib - 1);
-            const int hw_ = v % B16_HW, t2 = v / B16_HW;
-            const int hh_ = t2 % B16_HH, hd_ = t2 / B16_HH;
-            const int d = d0 + hd_ - 1, h = h0 + hh_ - 1, w = w0 + hw_ - 1;
-            uint4 val = zero4();
-            if ((unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
-                val = a.x[((((size_t)g * a.D + d) * a.H + h) * a.W + w) * a.Cin + ci0 + q];
-            xs[i] = val;
+        const uint4* xg = a.x + (size_t)g * a.D * a.H * a.W * a.Cin + ci0 + xq;
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int d = d0 + (xco[k] & 255) - 1, h = h0 + ((xco[k] >> 8) & 255) - 1, w = w0 + (xco[k] >> 16) - 1;
+            const bool ok = (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            rx[k] = xg[ok ? (unsigned)(((d * a.H + h) * a.W + w) * a.Cin) : 0u];          // (validity applied when the registers go to LDS)
+            m |= ok ? 1u << k : 0u;
         }
-        for (int i = threadIdx.x; i < B16_VOX * 32; i += 256) {
-            const int v = i >> 5, q = i & 31;
+        okm = m;
+        const uint4* yg = a.dy + co0 + yq;
+#pragma unroll
+        for (int k = 0; k < NY; ++k) {
+            const int v = (threadIdx.x >> 5) + 8 * k;
             const int w = v % B16_W, t2 = v / B16_W;
             const int h = t2 % B16_H, d = t2 / B16_H;
             const size_t row = (((size_t)g * a.D + d0 + d) * a.H + h0 + h) * a.W + w0 + w;
-            ds[i] = a.dy[row * a.ldy + co0 + q];
+            ry[k] = yg[row * a.ldy];
         }
+    };
+    if (b_begin < b_end) issue(b_begin);
+    for (int b = b_begin; b < b_end; ++b) {
+        __syncthreads();          // the previous brick's reads are done
+#pragma unroll
+        for (int k = 0; k < NX; ++k) xs[threadIdx.x + 256 * k] = (okm >> k) & 1u ? rx[k] : zero4();
+#pragma unroll
+        for (int k = 0; k < NY; ++k) ds[threadIdx.x + 256 * k] = ry[k];
         __syncthreads();
+        if (b + 1 < b_end) issue(b + 1);                  // in flight during the MFMAs below
 #pragma unroll 2
         for (int p = 0; p < B16_VOX / 2; ++p) {
             const int v = 2 * p + half;                       // brick-linear voxel (w fastest): a pair never straddles a row
             const int w = v % B16_W, t2 = v / B16_W;
             const int h = t2 % B16_H, d = t2 / B16_H;
             V16 av; av.u = ds[v * 32 + col];
-            const int hb = ((d * B16_HH + h) * B16_HW + w) * a.cib;          // halo voxel of tap (0, 0, 0)
+            const int hb = ((d * B16_HH + h) * B16_HW + w) * CIB;          // halo voxel of tap (0, 0, 0)
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
                 V16 bv; bv.u = xs[hb + toff[i]];
@@ -437,6 +494,17 @@ extern "C" int lt_pack_n8_bf16(const float* src, void* dst, int32_t N, int64_t P
     return LT_OK;
 }
 
+extern "C" int lt_pack_n8_from_bf16(const void* src, void* dst, int32_t N, int64_t P, int32_t C, int32_t ld, void* stream) {
+    LT_REQUIRE(src && dst && N >= 1 && P >= 1 && C >= 8 && ld >= C && C % 8 == 0 && ld % 8 == 0, LT_ERR_INVALID, "lt_pack_n8_from_bf16: bad argument (C, ld multiples of 8)");
+    LT_REQUIRE((size_t)dst % 16 == 0 && (size_t)src % 16 == 0, LT_ERR_INVALID, "lt_pack_n8_from_bf16: 16-byte aligned pointers");
+    const int G = (int)cdiv(N, 8);
+    const long long blocks = cdiv(P * (C / 8), 256);
+    hipLaunchKernelGGL(pack_n8_from_bf16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192), (unsigned)G), dim3(256), 0, (hipStream_t)stream, (const uint4*)src,
+                       (uint4*)dst, N, (long long)P, C, ld);
+    LT_CHECK_LAUNCH("lt_pack_n8_from_bf16");
+    return LT_OK;
+}
+
 // partial sums of any kernel behind lt_conv_wgrad_bf16: at most 16 MiB, or one slab set of 256 workgroups for the brick kernels
 extern "C" size_t lt_conv_wgrad_bf16_workspace(int64_t octet_rows, int32_t cout_pad, int32_t k_pad) {
     if (octet_rows < 1 || cout_pad < 1 || k_pad < 1) return 0;
@@ -479,7 +547,8 @@ extern "C" int lt_conv_wgrad_bf16(const void* dy16, const void* x16, const int32
         b.bricks_per_slab = (int)cdiv(b.nbricks, S);
         S = cdiv(b.nbricks, b.bricks_per_slab);
         const size_t lds = (size_t)(B16_HVOX * b.cib + B16_VOX * 32) * 16;
-        hipLaunchKernelGGL(conv3d_wgrad16_brick_kernel, dim3(Cout / 32, Cin / b.cib, (unsigned)S), dim3(256), lds, st, b);
+        if (b.cib == 32) hipLaunchKernelGGL(conv3d_wgrad16_brick_kernel<32>, dim3(Cout / 32, Cin / 32, (unsigned)S), dim3(256), lds, st, b);
+        else hipLaunchKernelGGL(conv3d_wgrad16_brick_kernel<16>, dim3(Cout / 32, 1, (unsigned)S), dim3(256), lds, st, b);
         LT_CHECK_LAUNCH("lt_conv_wgrad_bf16(brick)");
         reduce16(workspace, dw, n, (int)S, accumulate, st);
         LT_CHECK_LAUNCH("lt_conv_wgrad_bf16(reduce)");

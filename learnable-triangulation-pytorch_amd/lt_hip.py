@@ -100,6 +100,7 @@ SIGNATURES = {
     "lt_conv_wgrad_workspace": (C.c_size_t, [i64, i32, i32]),
     "lt_pack_n8_bf16_bytes": (C.c_size_t, [i32, i64, i32]),
     "lt_pack_n8_bf16": (C.c_int, [vp, vp, i32, i64, i32, i32, vp]),
+    "lt_pack_n8_from_bf16": (C.c_int, [vp, vp, i32, i64, i32, i32, vp]),
     "lt_conv_wgrad_bf16_workspace": (C.c_size_t, [i64, i32, i32]),
     "lt_conv_wgrad_bf16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32, i32, i32, i32, i32, i32, vp, vp]),
     "lt_conv_wgrad": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32, i32, i32, i32, i32, i32, vp, vp]),

@@ -413,6 +413,12 @@ class TrainTape:
             if use16:
                 need = lib.lt_conv_wgrad_bf16_workspace((n_img + 7) // 8 * pa_px, cop, kp)
                 pk_need = (lib.lt_pack_n8_bf16_bytes(n_img, pa_px, geo[9]), lib.lt_pack_n8_bf16_bytes(n_img, pb_px, geo[4]))
+                # where the bf16 copy the convolutions read exists already (same layout), the pack reads that: 2 instead of 4 bytes per element
+                x16e = self._bf16.get(id(x))
+                x16 = x16e[1] if x16e is not None and x16e[1].shape == x.t.shape and cin_buf % 8 == 0 else None
+                d16 = dy16 if (bn is not None and dy16 is not None and Cout % 8 == 0) else None
+                a16, b16 = (d16, x16) if not transposed else (x16, d16)
+                self.keep += [t for t in (a16, b16) if t is not None]
             else:
                 need = lib.lt_conv_wgrad_workspace(wrows, cop, kp)
             self.keep += [taps_all, a_ptr, b_ptr, imap, dw]
@@ -445,8 +451,11 @@ class TrainTape:
                 ws = (self._ws if ev is None else self._ws2).data_ptr()
                 if use16:
                     pk = self._pk_main if ev is None else self._pk_side
-                    H.check(lib.lt_pack_n8_bf16(a_ptr.data_ptr(), pk[0].data_ptr(), n_img, pa_px, geo[9], geo[9], st), "lt_pack_n8_bf16")
-                    H.check(lib.lt_pack_n8_bf16(b_ptr.data_ptr(), pk[1].data_ptr(), n_img, pb_px, geo[4], geo[4], st), "lt_pack_n8_bf16")
+                    for src, src16, dst, px, ch in ((a_ptr, a16, pk[0], pa_px, geo[9]), (b_ptr, b16, pk[1], pb_px, geo[4])):
+                        if src16 is not None:
+                            H.check(lib.lt_pack_n8_from_bf16(src16.data_ptr(), dst.data_ptr(), n_img, px, ch, ch, st), "lt_pack_n8_from_bf16")
+                        else:
+                            H.check(lib.lt_pack_n8_bf16(src.data_ptr(), dst.data_ptr(), n_img, px, ch, ch, st), "lt_pack_n8_bf16")
                     H.check(lib.lt_conv_wgrad_bf16(pk[0].data_ptr(), pk[1].data_ptr(), taps_all.data_ptr(), dw.data_ptr(), geo[0], geo[1], geo[2], geo[3], geo[4],
                                                    geo[5], geo[6], geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, ws, st), "lt_conv_wgrad_bf16")
                 else:

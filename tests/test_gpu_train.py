@@ -292,6 +292,11 @@ def test_conv_wgrad_bf16_vs_fp32_kernel_on_rounded_operands(case):
     want = torch.zeros(G * 8, Do * Ho * Wo, Cout)
     want[:N] = dy.reshape(N, -1, Cout).bfloat16().float().cpu()
     assert torch.equal(pk, want.reshape(G, 8, -1, Cout).permute(0, 2, 3, 1))
+    if Cout % 8 == 0:          # the same octets from the bf16 copy of the tensor
+        pa2 = torch.empty_like(pa)
+        H.check(lib.lt_pack_n8_from_bf16(dy.bfloat16().contiguous().data_ptr(), pa2.data_ptr(), N, Do * Ho * Wo, Cout, Cout, _st()), "lt_pack_n8_from_bf16")
+        torch.cuda.synchronize()
+        assert torch.equal(pa2, pa)
     assert torch.equal(ours[:Cout], again[:Cout]), "not bitwise repeatable"
     ref_r = fp32(dy.bfloat16().float(), x.bfloat16().float())
     ref = fp32(dy, x)

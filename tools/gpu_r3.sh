@@ -82,6 +82,16 @@ wgradtests)
   timeout 900 python -m pytest tests/test_gpu_train.py -m gpu -q --tb=short -x -p no:cacheprovider -k "op_level or wgrad or layer" > $OUT/test_wgrad.log 2>&1
   echo "wgrad tests rc=$?"; tail -6 $OUT/test_wgrad.log
   ;;
+mixedstats)   # rocprofv3 kernel totals of the mixed-precision step at B = 8 on ONE stream
+  cd /tmp; export TMPDIR=/tmp
+  rm -rf $OUT/prof_mixed
+  LT_TRAIN_NO_OVERLAP=1 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mixed -o mixed -- python $R/bench.py --train --train-dtype bf16 --batch 8 --steps 5 --warmup 2 > $OUT/prof_mixed.json 2> $OUT/prof_mixed.err < /dev/null
+  echo "mixedstats rc=$?"
+  cd $R
+  f=$(ls $OUT/prof_mixed/*kernel_stats.csv 2>/dev/null | head -1)
+  if [ -n "$f" ]; then cp "$f" $OUT/kernel_stats_mixed_b8.csv; head -36 "$f" | cut -c1-160; else tail -5 $OUT/prof_mixed.err; fi
+  rm -rf $OUT/prof_mixed
+  ;;
 smoke)
   timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
   ;;
