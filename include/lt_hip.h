@@ -42,6 +42,8 @@ enum {
     LT_EPI_RELU_POST = 2, /* ReLU after the residual add   (Bottleneck / Res3DBlock, pose_resnet.py:92-93, v2v.py:42) */
     LT_EPI_STORE_F32 = 4, /* store fp32 even when dtype is bf16 (V2V logits feeding the soft-argmax) */
     LT_EPI_SIGMOID = 8,   /* v = 1/(1+exp(-v)) last (GlobalAveragePoolingHead, pose_resnet.py:160) */
+    LT_EPI_RES_F32 = 64,  /* with LT_EPI_STORE_F32 on a bf16 convolution: the residual is fp32 too (the mixed-precision training step adds the input
+                             gradient that is already there in the epilogue of the next input-gradient convolution) */
     LT_BN_FROZEN = 32     /* lt_bn_act_bwd only: mean / var are FROZEN running statistics (a BatchNorm module in eval() inside a training step):
                              dy = gamma invstd g, without the batch-statistics terms; dgamma / dbeta as usual */
 };

@@ -1131,6 +1131,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
     }
     const EpiFloors fl = epi_floors(a.flags);
     const bool has_res = a.res != nullptr;
+    const bool store_f32 = (a.flags & LT_EPI_STORE_F32) != 0;
     const unsigned no_res = has_res ? 0u : 0x80008000u;  // zeros -> -0.0 pairs: v + -0.0 == v
     const size_t ldc = (size_t)a.ldc;
     const size_t voff0 = (((size_t)wave * a.H + (vl >> 3)) * a.W + (vl & 7)) * ldc + 8 * hh;
@@ -1173,6 +1174,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
         constexpr int p = decltype(pc)::value, I = p >> 1, Q = p & 1;
         const unsigned rr[4] = {rq[p].x | no_res, rq[p].y | no_res, rq[p].z | no_res, rq[p].w | no_res};
         unsigned o[4];
+        float vf[8];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int e = 8 * Q + 2 * d;
@@ -1180,12 +1182,19 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
             float v1 = fmaf(pacc[I][e + 1], esc[e + 1], esf[e + 1]);
             v0 = epi_apply(v0, fl, __uint_as_float(rr[d] << 16));
             v1 = epi_apply(v1, fl, __uint_as_float(rr[d] & 0xffff0000u));
+            vf[2 * d] = v0; vf[2 * d + 1] = v1;
             o[d] = pack_bf16x2(v0, v1);
         }
 #ifdef LT_ABL_NO_STORE
         if (a.N < 0)
 #endif
-        *(uint4*)((T*)a.y + pbase + I * vstep + 16 * Q) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (store_f32) {          // LT_EPI_STORE_F32 (the mixed-precision training step): the same eight channels as two float4
+            float* yp = (float*)a.y + pbase + I * vstep + 16 * Q;
+            *(float4*)yp = make_float4(vf[0], vf[1], vf[2], vf[3]);
+            *(float4*)(yp + 4) = make_float4(vf[4], vf[5], vf[6], vf[7]);
+        } else {
+            *(uint4*)((T*)a.y + pbase + I * vstep + 16 * Q) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
     };
     auto tap_loop = [&](auto epi_c) {
         constexpr bool EPI = decltype(epi_c)::value;
@@ -1794,7 +1803,11 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     const PhaseArg& p0 = c.phase[0];
     if (nphase != 1 || c.sd != 1 || c.sh != 1 || c.sw != 1 || c.osd != 1 || c.osh != 1 || c.osw != 1) return 0;
     if (p0.ood || p0.ooh || p0.oow || c.D != c.Do || c.H != c.Ho || c.W != c.Wo || c.OD != c.Do || c.OH != c.Ho || c.OW != c.Wo) return 0;
-    if (c.flags & (LT_EPI_STORE_F32 | LT_EPI_SIGMOID)) return 0;
+    if (c.flags & LT_EPI_SIGMOID) return 0;
+    // fp32 output (LT_EPI_STORE_F32: the mixed-precision training step) exists in the column-walk kernel only, and without a residual (the kernels read
+    // the residual in the activation type)
+    const bool f32_out = (c.flags & LT_EPI_STORE_F32) != 0;
+    if (f32_out && (c.res || dtype != LT_BF16)) return 0;
     int ks = 0;
     if (p0.ntaps == 27 && c.pd == 1 && c.ph == 1 && c.pw == 1) ks = 3;
     else if (p0.ntaps == 343 && c.pd == 3 && c.ph == 3 && c.pw == 3) ks = 7;
@@ -1828,9 +1841,11 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
             int rc = launch_halo_col<bf16_t>(a, s);
             return rc == LT_OK ? 1 : rc;
         }
+        if (f32_out) return 0;
         int rc = launch_halo_persist<bf16_t, 32, 32>(a, s);
         return rc == LT_OK ? 1 : rc;
     }
+    if (f32_out) return 0;
     // halo-only LDS, weights as fragments from global memory (lt_conv_pack_weights_t32): 64 -> 64, 32 -> 64, 128 -> 128
     if (bf && ks == 3 && c.Cout == cout_pad && c.ldc % 8 == 0 && a.wfrag && !getenv("LT_HALO_NO_WREG")) {
         int rc = 1;

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                     const size_t off = (size_t)pix * a.ldc + col;
                     float val = (acc[i][j][e] + bi) * sc + sf;
                     if (relu_pre) val = fmaxf(val, 0.f);
-                    if (res) val += elt<T>::ld(res + off);
+                    if (res) val += (sizeof(T) == 2 && (a.flags & LT_EPI_RES_F32)) ? ((const float*)a.res)[off] : elt<T>::ld(res + off);
                     if (relu_post) val = fmaxf(val, 0.f);
                     if (sigm) val = 1.f / (1.f + expf(-val));
                     if (store_f32) ((float*)a.y)[off] = val;
@@ -229,7 +229,7 @@ __global__ void conv_direct_kernel(const ConvArgs a) {
     const size_t off = pix * a.ldc + co;
     float val = (acc + (a.bias ? a.bias[co] : 0.f)) * (a.scale ? a.scale[co] : 1.f) + (a.shift ? a.shift[co] : 0.f);
     if (a.flags & LT_EPI_RELU_PRE) val = fmaxf(val, 0.f);
-    if (a.res) val += elt<T>::ld((const T*)a.res + off);
+    if (a.res) val += (sizeof(T) == 2 && (a.flags & LT_EPI_RES_F32)) ? ((const float*)a.res)[off] : elt<T>::ld((const T*)a.res + off);
     if (a.flags & LT_EPI_RELU_POST) val = fmaxf(val, 0.f);
     if (a.flags & LT_EPI_SIGMOID) val = 1.f / (1.f + expf(-val));
     if (a.flags & LT_EPI_STORE_F32) ((float*)a.y)[off] = val;
@@ -323,6 +323,8 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bi
     LT_REQUIRE(d->nphase >= 1 && d->nphase <= LT_CONV_MAX_PHASES, LT_ERR_INVALID, "lt_conv_fwd: nphase=%d", d->nphase);
     LT_REQUIRE(d->k_pad > 0 && d->k_pad % (8 * vec) == 0, LT_ERR_INVALID, "lt_conv_fwd: k_pad=%d not a multiple of %d", d->k_pad, 8 * vec);
     LT_REQUIRE(d->Cout >= 1 && d->ldc >= d->Cout && d->cout_pad >= d->Cout, LT_ERR_INVALID, "lt_conv_fwd: Cout/ldc/cout_pad");
+    LT_REQUIRE(!(d->flags & LT_EPI_RES_F32) || ((d->flags & LT_EPI_STORE_F32) && d->dtype == LT_BF16), LT_ERR_INVALID,
+               "lt_conv_fwd: LT_EPI_RES_F32 goes with LT_EPI_STORE_F32 on a bf16 convolution");
     const long long M = (long long)d->N * d->Do * d->Ho * d->Wo;
     const long long in_elems = (long long)d->N * d->D * d->H * d->W * d->Cin;
     const long long out_pix = (long long)d->N * d->OD * d->OH * d->OW;

@@ -452,6 +452,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     const bool sigm = a.flags & LT_EPI_SIGMOID;
     const bool store_f32 = (a.flags & LT_EPI_STORE_F32) != 0 || sizeof(T) == 4;
     const bool has_res = a.res != nullptr;
+    const bool res_f32 = (a.flags & LT_EPI_RES_F32) != 0 && sizeof(T) == 2;      // fp32 residual of a bf16 convolution that stores fp32
     const int col0 = n0 + wn * WN;                 // first output channel of this wave's sub-tile
     const int veco = store_f32 ? 4 : 8;
     const bool vec_ok = (a.Cout % veco == 0) && (a.ldc % veco == 0);
@@ -489,7 +490,8 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                                 rr[it][2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);                               \
                             }                                                                                          \
                         } else {                                                                                       \
-                            _Pragma("unroll") for (int e = 0; e < VECO; ++e) rr[it][e] = bf16_to_f32(((const bf16_t*)a.res)[off + e]); \
+                            if (res_f32) OutVec<VECO>::ld_res((const float*)a.res + off, rr[it]);                    \
+                            else { _Pragma("unroll") for (int e = 0; e < VECO; ++e) rr[it][e] = bf16_to_f32(((const bf16_t*)a.res)[off + e]); } \
                         }                                                                                              \
                     }                                                                                                  \
                 }                                                                                                      \
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
             const int pix = row_pix(wm * WM + r);
             if (pix < 0 || col >= a.Cout) continue;
             const size_t off = (size_t)pix * a.ldc + col;
-            const float rr = has_res ? elt<T>::ld((const T*)a.res + off) : -0.0f;
+            const float rr = has_res ? (res_f32 ? ((const float*)a.res)[off] : elt<T>::ld((const T*)a.res + off)) : -0.0f;
             const float val = epi_act(ep[r * EP_LD + cc], fl, rr, sigm);
             if (store_f32) ((float*)a.y)[off] = val;
             else elt<T>::st((T*)a.y + off, val);

@@ -238,20 +238,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad16_kernel(const W16Args a) {
 
 struct Plan16 { int variant, n_co_t, n_k_t, S, rows_per_slab; };
 
-// tile shape by layer shape as in the fp32 kernel; an octet row carries eight times the work of a pixel row and the MFMA is 16x faster, so the
-// partial sums (written once, read once by the reduce) are the cost to watch: capped at 16 MiB, at least 16 octet rows per slab
+// tile shape by layer shape as in the fp32 kernel.  Slab count: an octet row carries eight times the work of a pixel row and the MFMA is 16x faster,
+// so the partial sums (written once, read once by the reduce) cost as much as the GEMM itself: S minimises a two-term model -- the kernel
+// (rounds of 512 resident workgroups x octet-row pairs per slab x 8 MFMAs at ~1.5x their issue time) plus the reduce (S x n floats at ~3 TB/s)
 Plan16 plan16(long long M, int cout_pad, int k_pad) {
     Plan16 p;
     p.variant = k_pad <= 64 ? 0 : cout_pad <= 32 ? 2 : 1;
     const int ct = p.variant == 0 ? 4 : p.variant == 1 ? 2 : 1, kt = 8 / ct;
     p.n_co_t = (int)cdiv(cout_pad, 32 * ct); p.n_k_t = (int)cdiv(k_pad, 32 * kt);
     const long long wgs = cdiv((long long)p.n_co_t * p.n_k_t, 4);
-    long long S = cdiv(512, wgs);
-    const long long cap = (16ll << 20) / ((long long)cout_pad * k_pad * 4);
-    if (S > cap) S = cap;
-    if (S > M / 16) S = M / 16;
-    if (S < 1) S = 1;
-    if (S >= 8) S &= ~7ll;          // a multiple of 8: the kernel gives each XCD a contiguous range of slabs
+    const double n_bytes = (double)cout_pad * k_pad * 4.0;
+    const long long cap = (long long)(((size_t)48 << 20) / (size_t)n_bytes);
+    long long best = 1;
+    double best_t = 1e30;
+    for (long long S = 1; S <= 512; S = S < 8 ? S + 1 : S + 8) {
+        if (S > 1 && (S > cap || S > M / 16)) break;
+        const double rounds = (double)cdiv(wgs * S, 512);
+        const double kernel_us = rounds * (double)cdiv(M, 2 * S) * 0.226;
+        const double reduce_us = S > 1 ? 3.0 + S * n_bytes / 3.0e6 : 0.0;
+        if (kernel_us + reduce_us < best_t) { best_t = kernel_us + reduce_us; best = S; }
+    }
+    long long S = best;                 // >= 8: a multiple of 8 (the kernel gives each XCD a contiguous range of slabs)
     long long rps = cdiv(M, S);
     rps += rps & 1;
     p.rows_per_slab = (int)rps;

@@ -259,10 +259,12 @@ class PlanBuilder:
         self.ops.append((fn, meta))
 
     def conv(self, x, weight, bias=None, bn=None, stride=1, pad=0, transposed=False, relu=False, relu_pre=False,
-             residual=None, out_f32=False, out=None, sigmoid=False, output_padding=0):
-        """x: Act.  Returns the output Act [N, OD, OH, OW, Cout]."""
+             residual=None, out_f32=False, out=None, sigmoid=False, output_padding=0, residual_f32=False):
+        """x: Act.  Returns the output Act [N, OD, OH, OW, Cout].  ``residual_f32`` (bf16 plans, with ``out_f32``): the residual is an fp32 tensor
+        (LT_EPI_RES_F32: the training tape's input-gradient accumulation)."""
         flags = ((H.EPI_RELU_POST if relu else 0) | (H.EPI_RELU_PRE if relu_pre else 0) | (H.EPI_STORE_F32 if out_f32 else 0)
-                 | (H.EPI_SIGMOID if sigmoid else 0))
+                 | (H.EPI_SIGMOID if sigmoid else 0) | (H.EPI_RES_F32 if residual_f32 else 0))
+        assert not residual_f32 or (out_f32 and residual is not None and self.dtype == torch.bfloat16)
         spec = make_conv_spec(weight, bias, bn, x.shape, stride, pad, self.dtype, transposed, flags, output_padding)
         S = self.splitk_slices(spec, weight, transposed, out_f32, sigmoid, out)
         if S > 1:
@@ -272,7 +274,7 @@ class PlanBuilder:
         if residual is not None:
             self.keep.append(residual.t)
         if residual is not None:
-            assert residual.shape == y.shape and residual.t.dtype == self.dtype, (residual.shape, y.shape)
+            assert residual.shape == y.shape and residual.t.dtype == (torch.float32 if residual_f32 else self.dtype), (residual.shape, y.shape)
         d = H.ConvDesc()
         d.dtype = self.code
         d.N, d.D, d.H, d.W, d.Cin = spec.N, spec.D, spec.H, spec.W, spec.Cin

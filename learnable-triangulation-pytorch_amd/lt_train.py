@@ -204,6 +204,12 @@ class TrainTape:
             x16 = self._bf16_of(x)
             spec_idx = E.make_conv_spec(idx, None, None, x16.shape, kw.get("stride", 1), kw.get("pad", 0), torch.bfloat16, kw.get("transposed", False), 0,
                                         kw.get("output_padding", 0))
+            # the fp32 gradient that is already there rides in the epilogue (LT_EPI_RES_F32) -- except on the 3^3 32 -> 32 layers, whose column-walk
+            # kernel has no fp32 residual path and is worth more than the saved pass (LT_TRAIN_NO_FUSED_RES=1: always the separate pass)
+            col_walk = tuple(idx.shape) == (32, 32, 3, 3, 3) and kw.get("stride", 1) == 1 and not kw.get("transposed", False)
+            fuse_res = residual is not None and not col_walk and os.environ.get("LT_TRAIN_NO_FUSED_RES") is None
+            if fuse_res:
+                kw = dict(kw, residual=residual, residual_f32=True)
             y = self.pbh.conv(x16, torch.zeros(idx.shape), bias, None, out_f32=True, **kw)
             fn, info = self.pbh.ops[-1][0], self.pbh.last_info
             assert len(spec_idx.phases) == len(info["wdev"])
@@ -218,7 +224,7 @@ class TrainTape:
                 bmap[:bias.numel()] = torch.arange(bias.numel(), dtype=torch.int32)
                 self._gather(bias, bmap.to(self.device), bi, "w")
             self.do(fn, ("dgrad " if self._cur is self.bwd_ops else "conv ") + self.pbh.ops[-1][1]["label"])
-            if residual is not None:          # the fp32 gradient that is already there cannot ride in a bf16 kernel's epilogue
+            if residual is not None and not fuse_res:
                 yt, rt = y.t, residual.t
                 n_add = yt.numel()
                 self.do(lambda st: H.check(H.lib().lt_add_f32(yt.data_ptr(), rt.data_ptr(), n_add, st), "lt_add_f32"), "add")

@@ -315,6 +315,51 @@ def test_softargmax3d_planar_ragged(V, J):
         check("integrate3d/%d^3 J=%d softmax=%d planar volumes" % (V, J, sm), p.cpu(), rv.float(), 1e-5)
 
 
+def test_conv3d_column_walk_fp32_store(monkeypatch):
+    """The 3^3 32 -> 32 column-walk kernel with LT_EPI_STORE_F32 (the V2V layers of the mixed-precision training step: bf16 operands, fp32
+    accumulation AND fp32 output) against the implicit-GEMM path on the same operands (LT_HALO_NO_COL=1: summation order only) and torch."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(4, 32, 16, 64, 64, generator=g)
+    w = torch.randn(32, 32, 3, 3, 3, generator=g) * (1.0 / (32 * 27) ** 0.5)
+    bias = torch.randn(32, generator=g) * 0.1
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        b = E.PlanBuilder(DEV, torch.bfloat16)
+        y = b.conv(E.Act(to_cl(x, None, torch.bfloat16)), w, bias, None, stride=1, pad=1, out_f32=True)
+        b.finish().run_eager(st); torch.cuda.synchronize()
+        assert y.t.dtype == torch.float32
+        return from_cl(y.t, 3)
+    monkeypatch.delenv("LT_HALO_NO_COL", raising=False)
+    col = run()
+    monkeypatch.setenv("LT_HALO_NO_COL", "1")
+    igemm = run()
+    monkeypatch.delenv("LT_HALO_NO_COL", raising=False)
+    check("conv3d 32->32 column walk, fp32 store vs implicit GEMM", col, igemm, 2e-5)
+    check("conv3d 32->32 column walk, fp32 store vs torch on bf16 operands", col, F.conv3d(bf16_round(x), bf16_round(w), bias, 1, 1), 1e-4)
+
+
+def test_conv_fp32_residual_on_a_bf16_convolution():
+    """LT_EPI_RES_F32 (with LT_EPI_STORE_F32): bf16 operands, fp32 accumulation, an fp32 residual added in the epilogue, fp32 output -- the
+    input-gradient accumulation of the mixed-precision training step.  Vector and ragged-channel epilogues, strided / transposed phases."""
+    g = torch.Generator().manual_seed(21)
+    st = torch.cuda.current_stream().cuda_stream
+    cases = [(2, 64, 128, 3, 1, 1, False, (20, 24)), (3, 32, 17, 1, 1, 0, False, (4, 6, 8)), (2, 32, 64, 4, 2, 1, True, (6, 8)), (3, 32, 64, 3, 1, 1, False, (4, 8, 8))]
+    for nd, cin, cout, k, s_, p_, tr, sp in cases:
+        x = torch.randn(2, cin, *sp, generator=g)
+        w = torch.randn(*((cin, cout) if tr else (cout, cin)), *([k] * nd), generator=g) * (1.0 / (cin * k ** nd) ** 0.5)
+        conv = {(2, False): F.conv2d, (3, False): F.conv3d, (2, True): F.conv_transpose2d, (3, True): F.conv_transpose3d}[(nd, tr)]
+        ref0 = conv(bf16_round(x), bf16_round(w), None, stride=s_, padding=p_)
+        res = torch.randn(ref0.shape, generator=g) * 3.0 + 1e-3 * torch.randn(ref0.shape, generator=g)      # not representable in bf16
+        for tile in ((0, 4, 14) if not tr else (0,)):
+            b = E.PlanBuilder(DEV, torch.bfloat16, tile_override=tile)
+            y = b.conv(E.Act(to_cl(x, None, torch.bfloat16)), w, None, None, stride=s_, pad=p_, transposed=tr, residual=E.Act(to_cl(res, None, torch.float32)),
+                       out_f32=True, residual_f32=True)
+            b.finish().run_eager(st); torch.cuda.synchronize()
+            out = from_cl(y.t, nd)
+            check("conv bf16 + fp32 residual nd%d %d->%d k%d%s tile%d" % (nd, cin, cout, k, " T" if tr else "", tile), out - res, ref0, 1e-4)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_conv_epilogue_variants(dtype):
     """fp32 store from bf16 compute (V2V logits), sigmoid head (linear as 1x1 conv over an N-pixel row), ragged Cout."""
