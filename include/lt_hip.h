@@ -310,6 +310,8 @@ int lt_conv_wgrad_bf16(const void* dy16, const void* x16, const int32_t* taps, f
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- the layout changes between a Parameter's own layout and the GEMM layouts of its layer
  * (forward weights, input-gradient weights, weight-gradient blocks), with index maps built once when a training plan is recorded */
 int lt_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, void* stream);
+/* the same with the result rounded to bf16 (the live weights of the mixed-precision step in the layout its bf16 convolutions read) */
+int lt_gather_f32_bf16(const float* src, const int32_t* idx, void* dst_bf16, int64_t n, void* stream);
 /* small helpers of the training tape, so that no torch op sits between the launches: y += x; dst[r][c] = c < C ? src[r][c] : 0 (dY of
  * the 17-joint layer widened to the power-of-two channel count lt_conv_fwd wants on its input); zero fill (scatter targets) */
 int lt_add_f32(float* y, const float* x, int64_t n, void* stream);
@@ -323,8 +325,9 @@ int lt_global_avgpool_bwd(const float* dy, float* dx, int32_t N, int32_t HW, int
 /* fp32 -> bf16, round to nearest even (operands of the mixed-precision training convolutions); 16-byte aligned pointers */
 int lt_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* many gathers in one launch.  jobs (device memory): njobs records of
- *   { const float* src; const int32_t* idx; float* dst; int64_t n; int32_t first_block; int32_t pad; }   (40 bytes)
- * with first_block = running sum of ceil(n / 1024) over the preceding jobs; total_blocks = that sum over all jobs. */
+ *   { const float* src; const int32_t* idx; float* dst; int64_t n; int32_t first_block; int32_t out_bf16; }   (40 bytes)
+ * with first_block = running sum of ceil(n / 1024) over the preceding jobs; total_blocks = that sum over all jobs; out_bf16 != 0: dst is a bf16
+ * array (the values are rounded to nearest even). */
 int lt_gather_f32_multi(const void* jobs, int32_t njobs, int32_t total_blocks, void* stream);
 /* the same update for MANY tensors in one launch.  jobs (device memory): njobs records of
  *   { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; int64_t n; float lr; int32_t first_block; }   (48 bytes)

@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restri
     }
 }
 
-struct GatherJob { const float* src; const int* idx; float* dst; long long n; int first_block; int pad_; };
+struct GatherJob { const float* src; const int* idx; float* dst; long long n; int first_block; int out_bf16; };          // out_bf16: dst is a bf16 array
 
 // many gathers in ONE launch (a layer's gather is a few-microsecond kernel: 750 of them per training step were launch-bound);
 // a workgroup serves 1024 consecutive elements of the job its index falls into
@@ -828,7 +828,17 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(const GatherJob* __re
         const long long i = base + u * 256 + threadIdx.x;
         if (i >= j.n) break;
         const int k = j.idx[i];
-        j.dst[i] = k >= 0 ? j.src[k] : 0.f;
+        const float v = k >= 0 ? j.src[k] : 0.f;
+        if (j.out_bf16) ((bf16_t*)j.dst)[i] = f32_to_bf16(v);
+        else j.dst[i] = v;
+    }
+}
+
+// the bf16 weights of the mixed-precision step straight from the live fp32 Parameter (gather + round to nearest even in one pass)
+__global__ void gather_bf16_kernel(const float* __restrict__ src, const int* __restrict__ idx, bf16_t* __restrict__ dst, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.x) {
+        const int j = idx[i];
+        dst[i] = f32_to_bf16(j >= 0 ? src[j] : 0.f);
     }
 }
 
@@ -1234,6 +1244,15 @@ extern "C" int lt_gather_f32_multi(const void* jobs, int32_t njobs, int32_t tota
     LT_REQUIRE(jobs && njobs >= 1 && total_blocks >= 1, LT_ERR_INVALID, "lt_gather_f32_multi: bad argument");
     hipLaunchKernelGGL(gather_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const GatherJob*)jobs, njobs);
     LT_CHECK_LAUNCH("lt_gather_f32_multi");
+    return LT_OK;
+}
+
+extern "C" int lt_gather_f32_bf16(const float* src, const int32_t* idx, void* dst_bf16, int64_t n, void* stream) {
+    LT_REQUIRE(src && idx && dst_bf16 && n >= 1, LT_ERR_INVALID, "lt_gather_f32_bf16: bad argument");
+    const long long blocks = cdiv(n, 256);
+    hipLaunchKernelGGL(gather_bf16_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, src, (const int*)idx, (bf16_t*)dst_bf16,
+                       (long long)n);
+    LT_CHECK_LAUNCH("lt_gather_f32_bf16");
     return LT_OK;
 }
 

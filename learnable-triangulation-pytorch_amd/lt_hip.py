@@ -98,6 +98,7 @@ SIGNATURES = {
     "lt_cast_f32_bf16": (C.c_int, [vp, vp, i64, vp]),
     "lt_gather_f32_multi": (C.c_int, [vp, i32, i32, vp]),
     "lt_gather_f32": (C.c_int, [vp, vp, vp, i64, vp]),
+    "lt_gather_f32_bf16": (C.c_int, [vp, vp, vp, i64, vp]),
     "lt_conv_wgrad_workspace": (C.c_size_t, [i64, i32, i32]),
     "lt_pack_n8_bf16_bytes": (C.c_size_t, [i32, i64, i32]),
     "lt_pack_n8_bf16": (C.c_int, [vp, vp, i32, i64, i32, i32, vp]),

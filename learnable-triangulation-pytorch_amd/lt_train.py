@@ -168,7 +168,10 @@ class TrainTape:
         change in between) -- 750 few-microsecond kernels per step were launch-bound."""
         self.keep += [imap, dst]
         n = dst.numel()
-        fn = lambda st: H.check(H.lib().lt_gather_f32(src.data_ptr(), imap.data_ptr(), dst.data_ptr(), n, st), "lt_gather_f32")
+        if dst.dtype == torch.bfloat16:          # mixed precision: the bf16 weights straight from the fp32 Parameter
+            fn = lambda st: H.check(H.lib().lt_gather_f32_bf16(src.data_ptr(), imap.data_ptr(), dst.data_ptr(), n, st), "lt_gather_f32_bf16")
+        else:
+            fn = lambda st: H.check(H.lib().lt_gather_f32(src.data_ptr(), imap.data_ptr(), dst.data_ptr(), n, st), "lt_gather_f32")
         self.do(fn, "gather")
         if group is not None:
             self.batched[id(fn)] = True
@@ -215,9 +218,7 @@ class TrainTape:
             assert len(spec_idx.phases) == len(info["wdev"])
             for ph, wdev in zip(spec_idx.phases, info["wdev"]):
                 assert tuple(ph.weight.shape) == tuple(wdev.shape)
-                stage = torch.empty(wdev.shape, dtype=torch.float32, device=self.device)          # fp32 GEMM layout, then the bf16 copy the kernel reads
-                self._gather(wparam, (ph.weight.round().to(torch.int32) - 1).contiguous().to(self.device), stage, "w")
-                self._cast(stage, wdev)
+                self._gather(wparam, (ph.weight.round().to(torch.int32) - 1).contiguous().to(self.device), wdev, "w")      # fp32 Parameter -> bf16 GEMM layout
             if bias is not None:
                 bi = info["bias_dev"]
                 bmap = torch.full((bi.numel(),), -1, dtype=torch.int32)
@@ -523,7 +524,7 @@ class TrainTape:
             arr = np.zeros(len(jobs), dtype=self.JOB)
             fb = 0
             for i, (src, imap, dst, n) in enumerate(jobs):
-                arr[i] = (src.data_ptr(), imap.data_ptr(), dst.data_ptr(), n, fb, 0)
+                arr[i] = (src.data_ptr(), imap.data_ptr(), dst.data_ptr(), n, fb, 1 if dst.dtype == torch.bfloat16 else 0)
                 fb += (n + 1023) // 1024
             dev = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
             tab = self._job_tabs[which] = (key, dev, len(jobs), fb)
