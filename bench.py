@@ -537,6 +537,9 @@ def main():
                 result["config4"] = sub_leg(["--views", "8", "--volume", "128", "--batch", "16", "--steps", "3", "--warmup", "1", "--no-extras",
                                              "--cpu-budget-s", "1", "--cpu-parity-samples", "1", "--preroll-s", "0.3", "--force-pmc-leg"], 600)
                 result["train"] = sub_leg(["--train", "--batch", "4", "--steps", "8", "--warmup", "2"], 600)
+                # config 5's reduced-precision step (bf16 MFMA for the convolutions, their input AND weight gradients; fp32 activations, BatchNorm,
+                # master weights and optimiser): not a parity mode -- its loss values are printed next to the fp32 leg's, same seeds
+                result["train_mixed"] = sub_leg(["--train", "--train-dtype", "bf16", "--batch", "8", "--steps", "6", "--warmup", "2"], 600)
         if cpu_base is not None:
             result["cpu_baseline"] = cpu_base
     barrier()

@@ -25,7 +25,7 @@ import json
 try:
     r = json.load(open("$OUT/bench_bf16.json"))
     print({k: r[k] for k in ("value", "ms_per_step")}, "keys:", sorted(r.keys()))
-    for k in ("config4", "train"):
+    for k in ("config4", "train", "train_mixed"):
         v = r.get(k, {})
         print(k, {kk: v.get(kk) for kk in ("value", "ms_per_step", "error", "leg_wall_s", "stderr_tail")})
 except Exception as e:
