@@ -92,6 +92,36 @@ mixedstats)   # rocprofv3 kernel totals of the mixed-precision step at B = 8 on 
   if [ -n "$f" ]; then cp "$f" $OUT/kernel_stats_mixed_b8.csv; head -36 "$f" | cut -c1-160; else tail -5 $OUT/prof_mixed.err; fi
   rm -rf $OUT/prof_mixed
   ;;
+mixedpmc)     # MFMA-busy fraction of the kernels of the mixed-precision step (one PMC pass, single stream)
+  cd /tmp; export TMPDIR=/tmp
+  rm -rf $OUT/pmc_mixed
+  LT_TRAIN_NO_OVERLAP=1 timeout 420 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mixed -o mixed -- python $R/bench.py --train --train-dtype bf16 --batch 8 --steps 2 --warmup 1 > $OUT/pmc_mixed.json 2> $OUT/pmc_mixed.err < /dev/null
+  echo "mixedpmc rc=$?"
+  cd $R
+  python - <<PY
+import csv, glob, collections, json, sys
+sys.path.insert(0, "tools")
+from pmc_summary import kernel_key
+f = glob.glob("$OUT/pmc_mixed/*counter_collection.csv")
+if not f:
+    print("no counter csv"); raise SystemExit
+acc = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for r in csv.DictReader(open(f[0])):
+    k = kernel_key(r["Kernel_Name"]); v = float(r["Counter_Value"])
+    a = acc[k]
+    if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES": a[1] += v; a[0] += 1
+    elif r["Counter_Name"] == "GRBM_GUI_ACTIVE": a[2] += v
+rows = []
+for k, (n, mf, ga) in acc.items():
+    if ga > 0:
+        rows.append({"kernel": k, "dispatches": n, "gui_active_cycles_per_xcd": ga / 8, "mfma_busy_frac": mf / (1024 * ga / 8)})
+rows.sort(key=lambda r: -r["gui_active_cycles_per_xcd"])
+json.dump({"what": "bench.py --train --train-dtype bf16 --batch 8 (3 steps incl. the recording one), one stream; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)", "kernels": rows[:40]}, open("$OUT/pmc_mixed_summary.json", "w"), indent=1)
+for r in rows[:22]:
+    print("%-62s n=%5d  cycles %.3g  mfma_busy %.3f" % (r["kernel"][:62], r["dispatches"], r["gui_active_cycles_per_xcd"], r["mfma_busy_frac"]))
+PY
+  rm -rf $OUT/pmc_mixed
+  ;;
 smoke)
   timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
   ;;
