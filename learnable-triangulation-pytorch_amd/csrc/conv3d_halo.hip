@@ -954,7 +954,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_persist_kernel(const HaloArgs
 //   * the epilogue of tile i-1 (affine, ReLU floors, residual, 8-byte stores) is issued in eight pieces between the MFMA
 //     units of tile i, out of a copy of the accumulators; the residual of tile i is requested in the middle of its own tap
 //     loop, after the pieces have consumed the previous one; tile coordinates advance by a stride (no divisions per tile).
-template <typename T>
+// F32OUT: LT_EPI_STORE_F32 (the mixed-precision training step) as its own instantiation -- the inference kernel keeps its registers and schedule.
+template <typename T, bool F32OUT>
 __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, const int total_cols) {
     constexpr int KS = 3, CIN = 32, CP = 32, TD = 4, TH = 8, TW = 8;
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, 9, 2> C;
@@ -1131,7 +1132,6 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
     }
     const EpiFloors fl = epi_floors(a.flags);
     const bool has_res = a.res != nullptr;
-    const bool store_f32 = (a.flags & LT_EPI_STORE_F32) != 0;
     const unsigned no_res = has_res ? 0u : 0x80008000u;  // zeros -> -0.0 pairs: v + -0.0 == v
     const size_t ldc = (size_t)a.ldc;
     const size_t voff0 = (((size_t)wave * a.H + (vl >> 3)) * a.W + (vl & 7)) * ldc + 8 * hh;
@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
         constexpr int p = decltype(pc)::value, I = p >> 1, Q = p & 1;
         const unsigned rr[4] = {rq[p].x | no_res, rq[p].y | no_res, rq[p].z | no_res, rq[p].w | no_res};
         unsigned o[4];
-        float vf[8];
+        float vf[F32OUT ? 8 : 1];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int e = 8 * Q + 2 * d;
@@ -1182,13 +1182,13 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
             float v1 = fmaf(pacc[I][e + 1], esc[e + 1], esf[e + 1]);
             v0 = epi_apply(v0, fl, __uint_as_float(rr[d] << 16));
             v1 = epi_apply(v1, fl, __uint_as_float(rr[d] & 0xffff0000u));
-            vf[2 * d] = v0; vf[2 * d + 1] = v1;
-            o[d] = pack_bf16x2(v0, v1);
+            if constexpr (F32OUT) { vf[2 * d] = v0; vf[2 * d + 1] = v1; }
+            else o[d] = pack_bf16x2(v0, v1);
         }
 #ifdef LT_ABL_NO_STORE
         if (a.N < 0)
 #endif
-        if (store_f32) {          // LT_EPI_STORE_F32 (the mixed-precision training step): the same eight channels as two float4
+        if constexpr (F32OUT) {   // the same eight channels as two float4
             float* yp = (float*)a.y + pbase + I * vstep + 16 * Q;
             *(float4*)yp = make_float4(vf[0], vf[1], vf[2], vf[3]);
             *(float4*)(yp + 4) = make_float4(vf[4], vf[5], vf[6], vf[7]);
@@ -1771,12 +1771,18 @@ int launch_halo_col(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<T, 3, 32, 32, 4, 8, 8, 9, 2> C;
     constexpr int W_BYTES = ((C::NTAPS * C::SLAB + 1023) / 1024) * 1024;
     constexpr int LDS = W_BYTES + 4 * 4 * C::HH * C::PW * C::CINB;
-    auto kern = conv3d_halo_col_kernel<T>;
-    LT_OPT_IN_LDS(kern, 160 * 1024);
     const int n_cu = lt::device_cu_count8();
     const int total_cols = a.N * a.tiles_h * a.tiles_w;  // % 8 == 0 (checked by the caller)
     const int grid = total_cols < n_cu ? total_cols : n_cu;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, total_cols);
+    if (a.flags & LT_EPI_STORE_F32) {
+        auto kern = conv3d_halo_col_kernel<T, true>;
+        LT_OPT_IN_LDS(kern, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, total_cols);
+    } else {
+        auto kern = conv3d_halo_col_kernel<T, false>;
+        LT_OPT_IN_LDS(kern, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, total_cols);
+    }
     LT_CHECK_LAUNCH("lt_conv_fwd(halo, column walk)");
     return LT_OK;
 }
