@@ -44,8 +44,10 @@ enum {
     LT_EPI_SIGMOID = 8,   /* v = 1/(1+exp(-v)) last (GlobalAveragePoolingHead, pose_resnet.py:160) */
     LT_EPI_RES_F32 = 64,  /* with LT_EPI_STORE_F32 on a bf16 convolution: the residual is fp32 too (the mixed-precision training step adds the input
                              gradient that is already there in the epilogue of the next input-gradient convolution) */
-    LT_BN_FROZEN = 32     /* lt_bn_act_bwd only: mean / var are FROZEN running statistics (a BatchNorm module in eval() inside a training step):
+    LT_BN_FROZEN = 32,    /* lt_bn_act_bwd only: mean / var are FROZEN running statistics (a BatchNorm module in eval() inside a training step):
                              dy = gamma invstd g, without the batch-statistics terms; dgamma / dbeta as usual */
+    LT_BN_Y_BF16 = 128    /* lt_bn_act_fwd / lt_bn_act_bwd: the convolution output y is a bf16 tensor (the mixed-precision training step stores it in
+                             16 bits; lt_bn_stats_fwd takes dtype = LT_BF16 for the same tensor); C % 4 == 0 */
 };
 
 const char* lt_last_error(void);
@@ -275,11 +277,11 @@ int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32_t C, float
  *   stride 2): dw[ci][tap * Cout + co].
  * lt_adam_step  : torch.optim.Adam's single-tensor update (bias-corrected, eps outside the sqrt).
  * -------------------------------------------------------------------------------------------*/
-int lt_bn_act_fwd(const float* y, const float* mean, const float* var, const float* gamma, const float* beta, const float* residual, float* z,
+int lt_bn_act_fwd(const void* y /* fp32, or bf16 with LT_BN_Y_BF16 */, const float* mean, const float* var, const float* gamma, const float* beta, const float* residual, float* z,
                   void* z_bf16 /* optional: a bf16 copy of z on the way (mixed-precision training), or NULL */, int64_t rows, int32_t C, float eps,
                   int32_t flags, void* stream);
 size_t lt_bn_act_bwd_workspace(int64_t rows, int32_t C);
-int lt_bn_act_bwd(const float* dz, const float* y, const float* residual, const float* mean, const float* var, const float* gamma, const float* beta,
+int lt_bn_act_bwd(const float* dz, const void* y /* fp32, or bf16 with LT_BN_Y_BF16 */, const float* residual, const float* mean, const float* var, const float* gamma, const float* beta,
                   float* dy, void* dy_bf16 /* optional bf16 copy of dy, or NULL */, float* dgamma, float* dbeta, float* dres, int32_t accumulate_res,
                   int64_t rows, int32_t C, float eps, int32_t flags, void* workspace, void* stream);
 int lt_act_bwd(const float* dz, const float* z, const float* residual, float* dy, float* dres, int32_t accumulate_res, int64_t total, int32_t flags,

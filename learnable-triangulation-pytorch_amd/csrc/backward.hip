@@ -157,16 +157,16 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, long long ro
 }
 
 struct BnStatLoad {
-    const float* x; int C;
+    const void* x; int C, is_bf16;
     __device__ __forceinline__ void operator()(long long row, int c, float (&q)[2][4]) const {
-        const float4 v = *(const float4*)(x + (size_t)row * C + c);
+        const float4 v = ld4_f32_or_bf16(x, (size_t)row * C + c, is_bf16);
         q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w;
         q[1][0] = v.x * v.x; q[1][1] = v.y * v.y; q[1][2] = v.z * v.z; q[1][3] = v.w * v.w;
     }
 };
 
-__global__ __launch_bounds__(256) void bn_partial_vec_kernel(const float* __restrict__ x, long long rows, int C, int nslab, int cw4, int rl, double* __restrict__ part) {
-    colsum_partial<2>(rows, C, nslab, cw4, rl, part, BnStatLoad{x, C});
+__global__ __launch_bounds__(256) void bn_partial_vec_kernel(const void* __restrict__ x, int is_bf16, long long rows, int C, int nslab, int cw4, int rl, double* __restrict__ part) {
+    colsum_partial<2>(rows, C, nslab, cw4, rl, part, BnStatLoad{x, C, is_bf16});
 }
 
 struct BnStatFin {
@@ -231,9 +231,10 @@ extern "C" int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32
     LT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), LT_ERR_INVALID, "lt_bn_stats_fwd: running_mean and running_var come together");
     LT_REQUIRE(rows >= 1 && C >= 1 && C <= 4096, LT_ERR_INVALID, "lt_bn_stats_fwd: bad shape rows=%lld C=%d", (long long)rows, C);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == LT_F32 && colsum_fast(C)) {       // the training path: float4 lanes, four rows in flight, parallel finalize (colsum.h)
+    if (colsum_fast(C)) {       // the training path: four-channel lanes, four rows in flight, parallel finalize (colsum.h); fp32 or bf16 input
         const ColsumPlan p = colsum_plan(rows, C);
-        hipLaunchKernelGGL(bn_partial_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, (const float*)x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
+        hipLaunchKernelGGL(bn_partial_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, x, dtype == LT_BF16 ? 1 : 0, (long long)rows, C, p.nslab, p.cw4, p.rl,
+                           (double*)workspace);
         LT_CHECK_LAUNCH("lt_bn_stats_fwd(partial)");
         hipLaunchKernelGGL(bn_finalize_vec_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, C, p.nslab,
                            BnStatFin{(long long)rows, mean, var, running_mean, running_var, momentum});

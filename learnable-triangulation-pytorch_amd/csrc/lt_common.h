@@ -103,6 +103,18 @@ template <> struct elt<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// a BatchNorm input that is either fp32 or bf16 (LT_BN_Y_BF16: the mixed-precision training step stores its convolution outputs in bf16)
+__device__ __forceinline__ float4 ld4_f32_or_bf16(const void* p, size_t off, int is_bf16) {
+    if (is_bf16) {
+        const uint2 u = *(const uint2*)((const bf16_t*)p + off);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    }
+    return *(const float4*)((const float*)p + off);
+}
+__device__ __forceinline__ float ld1_f32_or_bf16(const void* p, size_t off, int is_bf16) {
+    return is_bf16 ? __uint_as_float((unsigned)((const unsigned short*)p)[off] << 16) : ((const float*)p)[off];
+}
+
 static inline int ilog2_exact(int v) {  // -1 when v is not a power of two
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;

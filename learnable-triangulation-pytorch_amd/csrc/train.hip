@@ -30,13 +30,13 @@ namespace {
 __device__ __forceinline__ float relu_mask_post(float v) { return v > 0.f ? 1.f : 0.f; }
 
 struct BnActArgs {
-    const float* y;        // rows x C: convolution output (bias included)
+    const void* y;         // rows x C: convolution output (bias included), fp32 or (y16) bf16
     const float* mean; const float* var; const float* gamma; const float* beta;
     const float* res;      // rows x C or null
     float* z;
     bf16_t* z16;           // optional bf16 copy of z (mixed-precision training: the next convolution's operand), or null
     float eps;
-    int flags, C;
+    int flags, C, y16;
     long long rows;
 };
 
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActArgs a) {
         const long long row = g / (a.C >> 2);
         const int c = (int)(g - row * (a.C >> 2)) * 4;
         const size_t off = (size_t)row * a.C + c;
-        const float4 y4 = *(const float4*)(a.y + off);
+        const float4 y4 = ld4_f32_or_bf16(a.y, off, a.y16);
         const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
         float rr[4] = {-0.0f, -0.0f, -0.0f, -0.0f};
         if (a.res) { const float4 r4 = *(const float4*)(a.res + off); rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w; }
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActArgs a) {
 }
 
 struct BnBwdArgs {
-    const float* dz; const float* y; const float* res;     // rows x C
+    const float* dz; const void* y; const float* res;      // rows x C (y: fp32 or, with y16, bf16)
     const float* mean; const float* var; const float* gamma; const float* beta;
     double* part;            // [nslab][C][2]: sum g, sum g x^
     float* dgamma; float* dbeta;
@@ -73,7 +73,7 @@ struct BnBwdArgs {
     bf16_t* dy16;            // optional bf16 copy of dy (mixed-precision training: the input-gradient convolution's operand), or null
     float* dres;             // rows x C or null: gradient of the residual input (accumulated when accumulate_res)
     float eps;
-    int flags, C, nslab, accumulate_res;
+    int flags, C, nslab, accumulate_res, y16;
     long long rows;
 };
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
             for (long long r = r0 + rl; r < r1; r += RL) {
                 const size_t off = (size_t)r * a.C + c;
                 float xh;
-                const float g = bn_g(a, a.dz[off], a.y[off], a.res ? a.res[off] : 0.f, c, xh);
+                const float g = bn_g(a, a.dz[off], ld1_f32_or_bf16(a.y, off, a.y16), a.res ? a.res[off] : 0.f, c, xh);
                 s += (double)g; q += (double)g * (double)xh;
             }
         ss[threadIdx.x] = s; sq[threadIdx.x] = q;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
         float xh;
         const float r = a.res ? a.res[i] : 0.f;
         const float dzv = a.dz[i];
-        const float g = bn_g(a, dzv, a.y[i], r, c, xh);
+        const float g = bn_g(a, dzv, ld1_f32_or_bf16(a.y, (size_t)i, a.y16), r, c, xh);
         const float invstd = 1.0f / sqrtf(a.var[c] + a.eps);
         a.dy[i] = a.gamma[c] * invstd * (g - a.dbeta[c] * inv_n - xh * a.dgamma[c] * inv_n);
         if (a.dres) {
@@ -147,7 +147,7 @@ struct BnBwdLoad {
     BnBwdArgs a;
     __device__ __forceinline__ void operator()(long long row, int c, float (&q)[2][4]) const {
         const size_t off = (size_t)row * a.C + c;
-        const float4 dz4 = *(const float4*)(a.dz + off), y4 = *(const float4*)(a.y + off);
+        const float4 dz4 = *(const float4*)(a.dz + off), y4 = ld4_f32_or_bf16(a.y, off, a.y16);
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.res) r4 = *(const float4*)(a.res + off);
         const float dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdArgs a
     const bool post = a.flags & LT_EPI_RELU_POST, pre = a.flags & LT_EPI_RELU_PRE;
     for (long long r = r0 + rl; r < r1; r += rl_n) {
         const size_t off = (size_t)r * a.C + c;
-        const float4 dz4 = *(const float4*)(a.dz + off), y4 = *(const float4*)(a.y + off);
+        const float4 dz4 = *(const float4*)(a.dz + off), y4 = ld4_f32_or_bf16(a.y, off, a.y16);
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.res) r4 = *(const float4*)(a.res + off);
         const float dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
@@ -909,12 +909,13 @@ int slabs_for(long long rows) { return (int)(rows < 1024 ? 1 : (rows / 256 < 102
 
 }  // namespace
 
-extern "C" int lt_bn_act_fwd(const float* y, const float* mean, const float* var, const float* gamma, const float* beta, const float* residual,
+extern "C" int lt_bn_act_fwd(const void* y, const float* mean, const float* var, const float* gamma, const float* beta, const float* residual,
                              float* z, void* z_bf16, int64_t rows, int32_t C, float eps, int32_t flags, void* stream) {
     LT_REQUIRE(y && mean && var && gamma && beta && z, LT_ERR_INVALID, "lt_bn_act_fwd: null argument");
     LT_REQUIRE(rows >= 1 && C >= 4 && C % 4 == 0, LT_ERR_UNSUPPORTED, "lt_bn_act_fwd: C %% 4 == 0 required (C=%d)", C);
     BnActArgs a;
     a.y = y; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.res = residual; a.z = z; a.z16 = (bf16_t*)z_bf16; a.eps = eps; a.flags = flags; a.C = C; a.rows = rows;
+    a.y16 = (flags & LT_BN_Y_BF16) ? 1 : 0;
     const long long blocks = cdiv(rows * (C / 4), 256);
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, a);
     LT_CHECK_LAUNCH("lt_bn_act_fwd");
@@ -926,7 +927,7 @@ extern "C" size_t lt_bn_act_bwd_workspace(int64_t rows, int32_t C) {
     return generic > fast ? generic : fast;
 }
 
-extern "C" int lt_bn_act_bwd(const float* dz, const float* y, const float* residual, const float* mean, const float* var, const float* gamma,
+extern "C" int lt_bn_act_bwd(const float* dz, const void* y, const float* residual, const float* mean, const float* var, const float* gamma,
                              const float* beta, float* dy, void* dy_bf16, float* dgamma, float* dbeta, float* dres, int32_t accumulate_res, int64_t rows,
                              int32_t C, float eps, int32_t flags, void* workspace, void* stream) {
     LT_REQUIRE(dz && y && mean && var && gamma && beta && dy && dgamma && dbeta && workspace, LT_ERR_INVALID, "lt_bn_act_bwd: null argument");
@@ -936,6 +937,8 @@ extern "C" int lt_bn_act_bwd(const float* dz, const float* y, const float* resid
     a.dz = dz; a.y = y; a.res = residual; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.part = (double*)workspace;
     a.dgamma = dgamma; a.dbeta = dbeta; a.dy = dy; a.dy16 = (bf16_t*)dy_bf16; a.dres = dres; a.eps = eps; a.flags = flags; a.C = C; a.nslab = slabs_for(rows);
     a.accumulate_res = accumulate_res; a.rows = rows;
+    a.y16 = (flags & LT_BN_Y_BF16) ? 1 : 0;
+    LT_REQUIRE(!a.y16 || C % 4 == 0, LT_ERR_UNSUPPORTED, "lt_bn_act_bwd: a bf16 y needs C %% 4 == 0 (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
     if (colsum_fast(C)) {
         const ColsumPlan p = colsum_plan(rows, C);

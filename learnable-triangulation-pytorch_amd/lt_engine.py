@@ -219,6 +219,10 @@ class PlanBuilder:
         self.pool = {}         # nbytes -> [tensor]
         self.tile_override = tile_override
         self.stages = stages
+        # lt_train.TrainTape sets this on its bf16 builder: the weights of its convolutions are re-gathered from the live Parameters every step, so no
+        # copy in MFMA fragment order may be packed at build time (a kernel reading one would compute with the build-time values), and no split-K
+        # pair (two ops per convolution) is recorded
+        self.live_weights = False
         self.flops = 0         # 2*MAC of the recorded convolutions
         self.bytes_alloc = 0
         self.ntail = 0         # trailing ops kept out of the captured graph (PlanBuilder.custom(tail=True))
@@ -293,7 +297,9 @@ class PlanBuilder:
             d.phase[i].ntaps = ph.taps.shape[0]; d.phase[i].out_off = H.i3(ph.out_off)
             # wide bf16 layers also get their weights in MFMA fragment order (B operand read straight from global memory by
             # the 288 x 256 kernel); packed once, here
-            if self.dtype == torch.bfloat16 and not self.dry_run and spec.cout_pad % 256 == 0 and spec.k_pad % 64 == 0:
+            if self.live_weights:
+                pass
+            elif self.dtype == torch.bfloat16 and not self.dry_run and spec.cout_pad % 256 == 0 and spec.k_pad % 64 == 0:
                 wfr = torch.empty_like(wdev)
                 # the 288-row layers get their weights in the fragment order of the 32x32x16 MFMA (conv_igemm7: +1 % end to end over
                 # conv_igemm6, 3x3 256->256 90.8 -> 87.4 us, 1x1 1024->256 50.9 -> 48.2 us inside the forward; LT_CONV_NO_V7=1 when the
@@ -343,7 +349,7 @@ class PlanBuilder:
         convolutions with >= 128 input channels on volumes of at most 8^3 voxels -- V2V's 128 -> 128 layers at the 8^3 / 4^3 / 2^3 levels
         (v2v.py:78-90), 18 launches of ~30 us each whatever the batch: K = 3456 is a 54-step latency chain for the one or few workgroups
         the few output rows give.  S is chosen so that tiles x S fills the chip (<= 8: lt_conv_fwd's phase limit)."""
-        if (self.dtype != torch.bfloat16 or transposed or out_f32 or sigmoid or out is not None or os.environ.get("LT_CONV_NO_SPLITK") == "1"
+        if (self.dtype != torch.bfloat16 or self.live_weights or transposed or out_f32 or sigmoid or out is not None or os.environ.get("LT_CONV_NO_SPLITK") == "1"
                 or self.tile_override):
             return 1
         if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or spec.stride != (1, 1, 1) or spec.pad != (1, 1, 1):

@@ -17,6 +17,7 @@ AGG = {"sum": 0, "max": 1, "softmax": 2, "conf": 3, "conf_norm": 4}
 EPI_RELU_PRE, EPI_RELU_POST, EPI_STORE_F32, EPI_SIGMOID = 1, 2, 4, 8
 EPI_RES_F32 = 64
 BN_FROZEN = 32
+BN_Y_BF16 = 128
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_256x32, TILE_256x16, TILE_64x64, TILE_DIRECT = 0, 1, 2, 3, 4, 5, 99
 TILE2_128x128, TILE2_128x64, TILE2_256x32, TILE2_256x16, TILE2_64x64 = 11, 12, 13, 14, 15
 TILE_HALO = 20
