@@ -236,7 +236,7 @@ extern "C" int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32
         hipLaunchKernelGGL(bn_partial_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, x, dtype == LT_BF16 ? 1 : 0, (long long)rows, C, p.nslab, p.cw4, p.rl,
                            (double*)workspace);
         LT_CHECK_LAUNCH("lt_bn_stats_fwd(partial)");
-        hipLaunchKernelGGL(bn_finalize_vec_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, C, p.nslab,
+        hipLaunchKernelGGL(bn_finalize_vec_kernel, dim3((unsigned)cdiv(C, COLSUM_FIN_C)), dim3(256), 0, st, (const double*)workspace, C, p.nslab,
                            BnStatFin{(long long)rows, mean, var, running_mean, running_var, momentum});
         LT_CHECK_LAUNCH("lt_bn_stats_fwd(finalize)");
         return LT_OK;

@@ -4,7 +4,7 @@
 //                    CW4 float4 channel lanes (consecutive threads read consecutive 16-byte vectors of one row); every thread keeps
 //                    four rows in flight, accumulates in fp64, the row lanes are combined through LDS, one fp64 partial per
 //                    (slab, channel, quantity) goes to the workspace;
-//   colsum_finalize  16 slab lanes x 16 channels per workgroup add the partials in a fixed order and hand the NQ totals to a functor.
+//   colsum_finalize  64 slab lanes x 4 channels per workgroup add the partials in a fixed order and hand the NQ totals to a functor.
 // The slab count keeps >= 4 rows per thread, <= 1024 workgroups and <= 4 MB of partials.
 #pragma once
 #include "lt_common.h"
@@ -94,24 +94,39 @@ __device__ __forceinline__ void colsum_partial(long long rows, int C, int nslab,
             for (int q = 0; q < NQ; ++q) part[((long long)slab * C + c + e) * NQ + q] = acc[q][e];
 }
 
-// Fin: void operator()(int c, const double (&tot)[NQ])
+// Fin: void operator()(int c, const double (&tot)[NQ]).  64 slab lanes x COLSUM_FIN_C channels per workgroup: with 16 slab lanes a thread walked up to 64
+// partials one dependent load after the other -- 16 us per launch for a few KB, 6.6 ms of a training step over its ~420 finalize launches.
+constexpr int COLSUM_FIN_C = 4;
 template <int NQ, class Fin>
 __device__ __forceinline__ void colsum_finalize(const double* __restrict__ part, int C, int nslab, const Fin& fin) {
-    __shared__ double red[16][16][NQ];
-    const int kl = threadIdx.x >> 4, cl = threadIdx.x & 15;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double red[64][COLSUM_FIN_C][NQ];
+    const int kl = threadIdx.x / COLSUM_FIN_C, cl = threadIdx.x % COLSUM_FIN_C;
+    const int c = blockIdx.x * COLSUM_FIN_C + cl;
     double tot[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) tot[q] = 0.0;
-    if (c < C)
-        for (int k = kl; k < nslab; k += 16)
+    if (c < C) {
+        int k = kl;
+        for (; k + 192 < nslab; k += 256) {          // four partials in flight
+            double v[4][NQ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) v[u][q] = part[((long long)(k + 64 * u) * C + c) * NQ + q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) tot[q] += v[u][q];
+        }
+        for (; k < nslab; k += 64)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) tot[q] += part[((long long)k * C + c) * NQ + q];
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) red[kl][cl][q] = tot[q];
     __syncthreads();
     if (kl == 0 && c < C) {
-        for (int k = 1; k < 16; ++k)
+        for (int k = 1; k < 64; ++k)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) tot[q] += red[k][cl][q];
         fin(c, tot);

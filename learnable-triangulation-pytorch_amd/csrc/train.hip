@@ -945,7 +945,7 @@ extern "C" int lt_bn_act_bwd(const float* dz, const void* y, const float* residu
         a.nslab = p.nslab;
         hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, a, p.cw4, p.rl);
         LT_CHECK_LAUNCH("lt_bn_act_bwd(reduce)");
-        hipLaunchKernelGGL(bn_bwd_finalize_vec_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(bn_bwd_finalize_vec_kernel, dim3((unsigned)cdiv(C, COLSUM_FIN_C)), dim3(256), 0, st, a);
         LT_CHECK_LAUNCH("lt_bn_act_bwd(finalize)");
         long long ns = rows / ((long long)p.rl * 2);          // >= 2 rows per thread, <= 4096 workgroups
         ns = ns < 1 ? 1 : ns > 4096 / p.ncb ? 4096 / p.ncb : ns;
@@ -986,7 +986,7 @@ extern "C" int lt_channel_sum(const float* x, int64_t rows, int32_t C, float* ou
         const ColsumPlan p = colsum_plan(rows, C);
         hipLaunchKernelGGL(channel_sum_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
         LT_CHECK_LAUNCH("lt_channel_sum(partial)");
-        hipLaunchKernelGGL(channel_sum_finalize_vec_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, C, p.nslab, ChanSumFin{out, accumulate});
+        hipLaunchKernelGGL(channel_sum_finalize_vec_kernel, dim3((unsigned)cdiv(C, COLSUM_FIN_C)), dim3(256), 0, st, (const double*)workspace, C, p.nslab, ChanSumFin{out, accumulate});
         LT_CHECK_LAUNCH("lt_channel_sum(finalize)");
         return LT_OK;
     }
