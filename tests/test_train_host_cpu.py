@@ -174,3 +174,78 @@ def test_adam_groups_follow_the_reference_config():
     assert n == len(list(m.parameters()))          # every parameter in exactly one group
     opt = lt_train.Adam(g, lr=Opt.lr)
     assert [pg["lr"] for pg in opt.param_groups] == [1e-4, 1e-3, 2e-3]
+
+
+def _pack_n8(t):
+    """CPU restatement of lt_pack_n8_bf16 (include/lt_hip.h): [N, D, H, W, C] -> [ceil(N / 8), D, H, W, C, 8], element (g, ..., c, e) = the bf16-rounded
+    value of image 8 g + e, zero past N."""
+    N = t.shape[0]
+    G = (N + 7) // 8
+    out = torch.zeros(G * 8, *t.shape[1:], dtype=torch.float32)
+    out[:N] = t.float().bfloat16().float()
+    return out.reshape(G, 8, *t.shape[1:]).permute(0, 2, 3, 4, 5, 1).contiguous()
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+@pytest.mark.parametrize("N", [3, 11])
+def test_weight_gradient_from_image_octets(case, N):
+    """The formulation behind lt_conv_wgrad_bf16 (csrc/wgrad16.hip): with the operands packed as octets of 8 IMAGES per (pixel, channel) a tap
+    shifts whole octets and padding is valid or not for a whole octet, so dW[co][tap * Cin + ci] = sum over octet rows (g, od, oh, ow) of
+    <dY octet [co], X octet at the tap-shifted pixel [ci]> -- the 8-term dot product IS one lane's share of a 16-bit MFMA's K dimension.  Zero
+    images past N contribute nothing.  Against torch.autograd on the bf16-rounded operands, ragged N (one / two octet groups), strides and the
+    transposed role."""
+    nd, Cin, Cout, k, s, p, tr, sp = case
+    g = torch.Generator().manual_seed(7 * Cin + Cout + k + N)
+    rd = lambda t: t.float().bfloat16().double()
+    x = rd(torch.randn(N, Cin, *sp, generator=g))
+    w = torch.randn(*((Cin, Cout) if tr else (Cout, Cin)), *([k] * nd), generator=g, dtype=torch.float64).requires_grad_(True)
+    conv = {(2, False): F.conv2d, (3, False): F.conv3d, (2, True): F.conv_transpose2d, (3, True): F.conv_transpose3d}[(nd, tr)]
+    y = conv(x, w, None, stride=s, padding=p)
+    dy = rd(torch.randn(y.shape, generator=g))
+    (y * dy).sum().backward()
+    ks3 = (1,) + (k,) * 2 if nd == 2 else (k,) * 3
+    st3 = (1, s, s) if nd == 2 else (s, s, s)
+    pd3 = (0, p, p) if nd == 2 else (p, p, p)
+    xc, dyc = _cl(x), _cl(dy)
+    rows_t, gath_t, cr, cg = (dyc, xc, Cout, Cin) if not tr else (xc, dyc, Cin, Cout)
+    ro, ga = _pack_n8(rows_t).double(), _pack_n8(gath_t).double()          # [G, D, H, W, C, 8]
+    G = ro.shape[0]
+    assert G == (N + 7) // 8 and float(ro[-1, ..., (N - 1) % 8 + 1:].abs().sum()) == 0.0          # images past N are zeros
+    kp = ks3[0] * ks3[1] * ks3[2] * cg
+    dw = torch.zeros(cr, kp, dtype=torch.float64)
+    _, Dr, Hr, Wr, _, _ = ro.shape
+    _, Dg, Hg, Wg, _, _ = ga.shape
+    t = 0
+    for a in range(ks3[0]):
+        for b in range(ks3[1]):
+            for c in range(ks3[2]):
+                for od in range(Dr):
+                    i_d = od * st3[0] - pd3[0] + a
+                    for oh in range(Hr):
+                        i_h = oh * st3[1] - pd3[1] + b
+                        for ow in range(Wr):
+                            i_w = ow * st3[2] - pd3[2] + c
+                            if 0 <= i_d < Dg and 0 <= i_h < Hg and 0 <= i_w < Wg:          # one validity test per OCTET
+                                dw[:, t * cg:(t + 1) * cg] += torch.einsum("gce,gke->ck", ro[:, od, oh, ow], ga[:, i_d, i_h, i_w])
+                t += 1
+    ar = torch.arange(cr * kp).reshape(cr, kp)
+    if not tr:
+        imap = ar.reshape(Cout, *ks3, Cin).permute(0, 4, 1, 2, 3)
+    else:
+        imap = ar.reshape(Cin, *ks3, Cout).permute(0, 4, 1, 2, 3)
+    imap = (imap[:, :, 0] if nd == 2 else imap).contiguous().reshape(-1)
+    gw = dw.reshape(-1)[imap].reshape(w.shape)
+    assert float((gw - w.grad).abs().max()) <= 1e-10 * float(w.grad.abs().max())
+
+
+def test_octet_pack_and_workspace_sizes_through_the_c_abi():
+    """Host-side entry points of the bf16 weight gradients (no GPU needed): lt_pack_n8_bf16_bytes = ceil(N / 8) * P * C * 16, and the workspace of
+    lt_conv_wgrad_bf16 is positive, bounded (64 MiB) and covers at least one fp32 copy of dW."""
+    import lt_hip as H
+    lib = H.lib()
+    assert lib.lt_pack_n8_bf16_bytes(8, 576, 256) == 1 * 576 * 256 * 16
+    assert lib.lt_pack_n8_bf16_bytes(11, 100, 17) == 2 * 100 * 17 * 16
+    assert lib.lt_pack_n8_bf16_bytes(0, 100, 17) == 0
+    for rows, cop, kp in ((2304, 256, 2304), (2304, 1024, 256), (262144, 32, 864), (262144, 16, 10976), (8, 128, 3456), (147456, 64, 392)):
+        ws = lib.lt_conv_wgrad_bf16_workspace(rows, cop, kp)
+        assert cop * kp * 4 <= ws <= (64 << 20), (rows, cop, kp, ws)
