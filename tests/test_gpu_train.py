@@ -514,7 +514,7 @@ def test_training_loss_decreases_over_steps():
     assert losses[-1] < losses[0], losses
 
 
-def _dp_grads(rank, reducer):
+def _dp_grads(rank, reducer, precision="fp32"):
     """One training forward / backward of the small case on shard ``rank`` (its own samples); returns {name: gradient (cpu)}."""
     from mvn.models import loss as L
     from mvn.models.triangulation import VolumetricTriangulationNet
@@ -526,6 +526,7 @@ def _dp_grads(rank, reducer):
     m.load_state_dict(sd, strict=True)
     m.to(DEV)
     m.train()
+    m.train_precision = precision
     m.grad_reducer = reducer
     batch = {"cameras": _cameras(inp, 2), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
     gt = torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float().to(DEV)
@@ -621,11 +622,13 @@ def _check_two_rank_gradients(got, single, tag):
     assert worst <= 1e-5, worst
 
 
-def test_training_step_is_bitwise_repeatable():
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_step_is_bitwise_repeatable(precision):
     """Two independent recordings (fresh models, same weights / inputs / rotations) and their replays give BITWISE identical parameter
-    gradients: every reduction of the step has a fixed order (column sums in fp64 slabs, weight gradients by slab partials, the
-    unprojection backward as a gather, the max-pool backward by disjoint window classes)."""
-    a, b = _dp_grads(0, None), _dp_grads(0, None)
+    gradients: every reduction of the step has a fixed order (column sums in fp64 slabs, weight gradients by slab partials -- on the fp32
+    MFMA and, in the mixed step, on the bf16 MFMA over image octets -- the unprojection backward as a gather, the max-pool backward by
+    disjoint window classes)."""
+    a, b = _dp_grads(0, None, precision), _dp_grads(0, None, precision)
     assert set(a[0]) == set(b[0]) and len(a[0]) > 50
     for it in (0, 1):
         for n in a[it]:
