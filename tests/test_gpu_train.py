@@ -1046,3 +1046,50 @@ def test_mixed_precision_step_tracks_fp32_on_a_bottleneck_backbone(y16, monkeypa
     assert abs(l16[0] - l32[0]) <= 0.01 * abs(l32[0]), (l16, l32)
     assert all(abs(a - b) <= 0.05 * abs(a) for a, b in zip(l32, l16)), (l32, l16)
     assert stats["backbone"]["median_cosine"] > 0.9, stats
+
+
+def test_algebraic_training_step_in_mixed_precision_tracks_fp32(golden_dir):
+    """AlgebraicTriangulationNet through the mixed-precision tape (bf16 MFMA convolutions incl. the heatmap head and the alg_confidences head's
+    layers, bf16 weight gradients over image octets -- 6 images: one ragged octet group): the first step's keypoints and loss against the fp32
+    tape on the same weights, inputs and projection matrices; every parameter receives a finite gradient and the whole gradient keeps its
+    direction (cosine with the fp32 step's gradient)."""
+    from mvn.models import loss as L
+    from mvn.models.triangulation import AlgebraicTriangulationNet
+    G = np.load(os.path.join(golden_dir, "train_step_alg.npz"))
+    cfg = synth.alg_config(18, True)
+    cfg.model.heatmap_multiplier = 1.0
+    cfg.model["heatmap_multiplier"] = 1.0
+    sd = synth.make_state_dict(spec.alg_net_spec(18, 17, True), seed=21, basic_block=True)
+    inp = synth.make_inputs(2, 3, 128, seed=21, inside=False)
+    P = torch.from_numpy(G["P"]).to(DEV)
+    gt, val = torch.from_numpy(G["gt"]).to(DEV), torch.from_numpy(G["val"]).to(DEV)
+
+    def run(prec):
+        m = AlgebraicTriangulationNet(cfg, device=DEV)
+        m.load_state_dict(sd, strict=True)
+        m.to(DEV).train()
+        m.train_precision = prec
+        kp3, kp2, hm, conf = m(inp["images"].to(DEV), P, {})
+        loss = L.KeypointsMSESmoothLoss(400)(kp3 * 0.1, gt * 0.1, val)
+        loss.backward()
+        torch.cuda.synchronize()
+        g = {n: p.grad.detach().double().cpu().reshape(-1) for n, p in m.named_parameters() if p.grad is not None}
+        return kp3.detach().cpu().double(), float(loss.detach()), g, (kp2.detach().cpu().double(), hm.detach().cpu().double(), conf.detach().cpu().double())
+
+    k32, l32, g32, i32 = run("fp32")
+    k16, l16, g16, i16 = run("bf16")
+    assert set(g16) == set(g32) and all(bool(torch.isfinite(v).all()) for v in g16.values())
+    d_kp2 = float((i32[0] - i16[0]).abs().max())
+    d_hm = float((i32[1] - i16[1]).abs().max() / i32[1].abs().max())
+    d_conf = float((i32[2] - i16[2]).abs().max())
+    d_kp3 = float(((k16 - k32).abs() / k32.abs().clamp(min=1.0)).max())
+    a, b = torch.cat([g32[n] for n in sorted(g32)]), torch.cat([g16[n] for n in sorted(g32)])
+    cos = float((a @ b) / (a.norm() * b.norm()))
+    # The DLT of a RANDOM-INIT network is ill-conditioned (all 2D estimates sit near the image centre, the three rays are nearly dependent): 0.05 px on
+    # the 2D keypoints moves the triangulated points of this fixture by metres -- in any precision.  So the gates sit on what the tape computes
+    # (heatmaps, 2D keypoints, confidences) and on the direction of the gradient; the 3D deviation and the losses are recorded.
+    record("train-alg/mixed precision vs fp32, first step (ResNet-18 fixture, 2 samples x 3 views)",
+           {"heatmaps_rel": d_hm, "keypoints_2d_max_abs_px": d_kp2, "confidences_max_abs": d_conf, "gradient_cosine": cos,
+            "keypoints_3d_max_rel_1mm_floor (ill-conditioned DLT at random init)": d_kp3, "loss_fp32": l32, "loss_bf16": l16})
+    print(d_hm, d_kp2, d_conf, cos, d_kp3, l32, l16)
+    assert d_hm < 3e-2 and d_kp2 < 0.25 and d_conf < 3e-2 and cos > 0.9, (d_hm, d_kp2, d_conf, cos)
