@@ -638,7 +638,7 @@ def main():
     torch.manual_seed(0)
     os.makedirs(GOLD, exist_ok=True)
     mvn = ref_loader.load()
-    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad", "train", "train_conf", "train_alg", "train_frozen"]
+    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad", "train", "train_conf", "train_alg", "train_frozen", "train_sum", "train_max"]
     if "ops" in which:
         print("[ops]"); gen_ops(mvn)
     if "nets" in which:
@@ -672,6 +672,10 @@ def main():
         print("[train_alg]"); gen_train_alg(mvn)
     if "train_conf" in which:
         print("[train_conf]"); gen_train(mvn, "conf_norm", "train_step_conf_norm.npz")
+    if "train_sum" in which:          # the two aggregation methods without learned view weights: mean over the views / per-voxel maximum (op.py:143-148)
+        print("[train_sum]"); gen_train(mvn, "sum", "train_step_sum.npz")
+    if "train_max" in which:
+        print("[train_max]"); gen_train(mvn, "max", "train_step_max.npz")
     if "alg" in which:
         print("[alg]"); gen_alg(mvn)
     if "caffe" in which:

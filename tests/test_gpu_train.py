@@ -342,7 +342,7 @@ def _train_case(method="softmax"):
     return c, cfg, sd, inp
 
 
-@pytest.mark.parametrize("method", ["softmax", "conf_norm", "frozen_bn"])
+@pytest.mark.parametrize("method", ["softmax", "conf_norm", "frozen_bn", "sum", "max"])
 def test_whole_training_step_vs_reference(golden_dir, method):
     """model.train(); forward; MAE(kp * 0.1) + 0.01 * VolumetricCELoss; backward; Adam (train.py:148-243, :430-437) -- every parameter's
     gradient, the BatchNorm running statistics and the parameters after the step against the reference's own step on CPU.  conf_norm: the
