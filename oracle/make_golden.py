@@ -556,8 +556,8 @@ def gen_train_alg(mvn):
 
 
 def run_vol_case(mvn, tag, num_layers, B, NV, H, V, method="softmax", multiplier=1.0, sharpen=False,
-                 inside=False, rotate=False, kind="mpii", seed=0, stride=4, cmu=False):
-    cfg = synth.vol_config(num_layers, V, method, multiplier, kind)
+                 inside=False, rotate=False, kind="mpii", seed=0, stride=4, cmu=False, volume_softmax=True):
+    cfg = synth.vol_config(num_layers, V, method, multiplier, kind, volume_softmax=volume_softmax)
     if cmu:
         cfg.model.transfer_cmu_to_human36m = True
     sp = spec.vol_net_spec(num_layers, 17, method.startswith("conf"))
@@ -594,7 +594,7 @@ def run_vol_case(mvn, tag, num_layers, B, NV, H, V, method="softmax", multiplier
     # error of their own (2.9e-4 relative at 128^3: the fp32 probabilities sum to 1 +- 2.9e-4), which a more accurate kernel
     # cannot -- and should not -- reproduce; the fixture stores both so that tests can gate against the exact value
     lg64 = (o["logits"].double() * multiplier).reshape(B, 17, -1)
-    p64 = torch.softmax(lg64, dim=2)
+    p64 = torch.softmax(lg64, dim=2) if volume_softmax else torch.relu(lg64)          # (volume_softmax: false -- ReLU volumes, no normalisation, op.py:91-93)
     kp64 = torch.einsum("bjn,bnc->bjc", p64, cvs.double().reshape(B, -1, 3))
     self_rel = float(((kp.double() - kp64).abs() / kp64.abs().clamp(min=1.0)).max())
     print("  reference fp32 soft-argmax vs the fp64 soft-argmax of its own logits: max rel %.3e" % self_rel)
@@ -634,11 +634,33 @@ def gen_alg(mvn):
                         hm_sub=sub(hm.reshape(8, 17, 64, 64), 4), sd_digest=np.array(synth.state_dict_checksum(sd)))
 
 
+def gen_alg2(mvn):
+    """AlgebraicTriangulationNet with the two switches alg_c1 does not flip: use_confidences false (all-ones weights, triangulation.py:137-143) and
+    heatmap_softmax false (ReLU heatmaps normalised by their mass, op.py:11-18); ResNet-18, 2 x 3 views of 128^2."""
+    cfg = synth.alg_config(18, False)
+    cfg.model.heatmap_softmax = False
+    cfg.model.heatmap_multiplier = 1.0
+    sp = spec.alg_net_spec(18, 17, False)
+    sd = synth.make_state_dict(sp, seed=51, basic_block=True)
+    inp = synth.make_inputs(2, 3, 128, seed=9)
+    ref = mvn.models.triangulation.AlgebraicTriangulationNet(cfg, device="cpu")
+    assert list(ref.state_dict().keys()) == list(sp.keys())
+    ref.load_state_dict(sd, strict=True); ref.eval()
+    P = torch.from_numpy(inp["K"] @ np.concatenate([inp["R"], inp["t"]], -1)).float()[None].repeat(2, 1, 1, 1)
+    with torch.no_grad():
+        kp3, kp2, hm, conf = ref(inp["images"], P, {})
+    o = O.algebraic_forward(sd, cfg, inp["images"], inp["K"], inp["R"], inp["t"])
+    _check("alg2 keypoints_2d", o["keypoints_2d"], kp2, 1e-4)
+    _check("alg2 confidences", o["alg_confidences"], conf, 1e-6)
+    np.savez_compressed(os.path.join(GOLD, "alg_relu_noconf.npz"), kp3=kp3.numpy(), kp2=kp2.numpy(), conf=conf.numpy(),
+                        hm_sub=sub(hm.reshape(6, 17, 32, 32), 2), sd_digest=np.array(synth.state_dict_checksum(sd)))
+
+
 def main():
     torch.manual_seed(0)
     os.makedirs(GOLD, exist_ok=True)
     mvn = ref_loader.load()
-    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "alg", "caffe", "pipe2d", "data", "grad", "train", "train_conf", "train_alg", "train_frozen", "train_sum", "train_max", "train_r50"]
+    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "vol3", "alg", "alg2", "caffe", "pipe2d", "data", "grad", "train", "train_conf", "train_alg", "train_frozen", "train_sum", "train_max", "train_r50"]
     if "ops" in which:
         print("[ops]"); gen_ops(mvn)
     if "nets" in which:
@@ -655,6 +677,11 @@ def main():
         run_vol_case(mvn, "c2_default", 152, 1, 4, 384, 64, "softmax", sharpen=False, seed=0, stride=4)
         std = run_vol_case(mvn, "c2_sharp", 152, 1, 4, 384, 64, "softmax", sharpen=True, seed=0, stride=4)
         print("  (calibration) sharpened logit std = %.3f with SHARPEN_GAIN=%.1f" % (std, synth.SHARPEN_GAIN))
+    if "vol3" in which:
+        print("[vol3]")
+        # round 3: the two switches no other case flips -- volume_softmax: false (ReLU volumes, unnormalised integration, op.py:84-96) with the plain
+        # `conf` aggregation (sigmoid confidences as they are, op.py:150-151)
+        run_vol_case(mvn, "small_relu_conf", 18, 2, 3, 128, 32, "conf", sharpen=False, seed=7, stride=2, volume_softmax=False)
     if "vol2" in which:
         print("[vol2]")
         # BASELINE config 2 shape at B = 4 (four different samples; batch kernels and XCD pinning see a real batch)
@@ -680,6 +707,8 @@ def main():
         print("[train_max]"); gen_train(mvn, "max", "train_step_max.npz")
     if "alg" in which:
         print("[alg]"); gen_alg(mvn)
+    if "alg2" in which:
+        print("[alg2]"); gen_alg2(mvn)
     if "caffe" in which:
         print("[caffe]"); gen_caffe(mvn)
     if "pipe2d" in which:
