@@ -234,3 +234,48 @@ def test_c_abi_exports_every_declared_symbol():
     # planar output: voxels per sample must be a multiple of 64 that divides rows
     pd.flags[1], pd.rows, pd.plane = H.EPI_STORE_F32, 128, 96
     assert l.lt_pwchain_fwd(ctypes.byref(pd), 1, 1, None) == -1 and b"plane" in l.lt_last_error()
+
+
+REF_EXPERIMENTS = "/root/reference/experiments/human36m"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXPERIMENTS), reason="the reference checkout is only present in the build container")
+def test_reference_experiment_yamls_build_the_models():
+    """north_star: "keeps ... the experiments/*.yaml config surface".  Every vol / alg experiment file of the reference (train and eval), read with
+    mvn.utils.cfg.load_config exactly as train.py:397 does, constructs the model class train.py:400-404 picks -- with the keys the constructors read
+    (volume_aggregation_method, volume_softmax, volume_multiplier, volume_size, cuboid_side, kind, use_gt_pelvis, use_confidences, heatmap_*,
+    backbone.*) -- and the state dict has the reference layout (oracle/spec.py, pinned against the reference's own modules by make_golden).  Only
+    ``init_weights`` is switched off (the checkpoints are not part of the repository); the ransac file is SURVEY's out-of-scope CPU baseline."""
+    import glob
+    from mvn.utils import cfg
+    from mvn.models.triangulation import AlgebraicTriangulationNet, VolumetricTriangulationNet
+    from oracle import spec
+    files = sorted(glob.glob(os.path.join(REF_EXPERIMENTS, "*", "*.yaml")))
+    assert len(files) >= 5
+    seen = set()
+    for f in files:
+        c = cfg.load_config(f)
+        name = c.model.name
+        if name == "ransac":
+            continue
+        c.model.init_weights = False
+        c.model.backbone.init_weights = False
+        nl, nj = c.model.backbone.num_layers, c.model.backbone.num_joints
+        if name == "vol":
+            m = VolumetricTriangulationNet(c, device="cpu")
+            assert m.volume_aggregation_method == c.model.volume_aggregation_method and m.volume_size == c.model.volume_size
+            assert m.volume_softmax == c.model.volume_softmax and m.volume_multiplier == c.model.volume_multiplier
+            assert m.cuboid_side == c.model.cuboid_side and m.kind == c.model.kind and m.use_gt_pelvis == c.model.use_gt_pelvis
+            want = spec.vol_net_spec(nl, nj, c.model.volume_aggregation_method.startswith("conf"))
+        else:
+            assert name == "alg"
+            m = AlgebraicTriangulationNet(c, device="cpu")
+            assert m.use_confidences == c.model.use_confidences and m.heatmap_softmax == c.model.heatmap_softmax
+            assert m.heatmap_multiplier == c.model.heatmap_multiplier
+            want = spec.alg_net_spec(nl, nj, c.model.use_confidences)
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(want.keys()), os.path.basename(f)
+        assert all(tuple(sd[k].shape) == tuple(want[k][0]) for k in want), os.path.basename(f)
+        assert c.opt.scale_keypoints_3d == 0.1 and c.image_shape == [384, 384]
+        seen.add((name, os.path.basename(os.path.dirname(f))))
+    assert {("vol", "train"), ("vol", "eval"), ("alg", "train"), ("alg", "eval")} <= seen
