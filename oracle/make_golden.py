@@ -460,7 +460,7 @@ def gen_train(mvn, method="softmax", fname="train_step.npz", freeze_backbone_bn=
     np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 
-def gen_train_alg(mvn):
+def gen_train_alg(mvn, use_conf=True, fname="train_step_alg.npz"):
     """One full training step of the reference's AlgebraicTriangulationNet on CPU (train.py:148-243 with model_type "alg"): model.train(), criterion
     MSESmooth(threshold 400) on keypoints * scale_keypoints_3d (experiments/human36m/train/human36m_alg.yaml:9-19), total_loss.backward() through
     triangulate_batch_of_points (torch.svd, multiview.py:163), the 2D soft-argmax, the alg_confidences head and the backbone, torch.optim.Adam.
@@ -470,9 +470,9 @@ def gen_train_alg(mvn):
     import mvn.models.loss as L
     torch.set_num_threads(8)
     c = dict(nl=18, B=2, NV=3, H=128, seed=21)
-    cfg = synth.alg_config(c["nl"], True)
+    cfg = synth.alg_config(c["nl"], use_conf)          # use_conf False: experiments/human36m/train/human36m_alg_no_conf.yaml (uniform view weights, no head)
     cfg.model.heatmap_multiplier = 1.0
-    sp = spec.alg_net_spec(c["nl"], 17, True)
+    sp = spec.alg_net_spec(c["nl"], 17, use_conf)
     sd = synth.make_state_dict(sp, seed=c["seed"], basic_block=True)
     inp = synth.make_inputs(c["B"], c["NV"], c["H"], seed=c["seed"], inside=False)
     P = torch.from_numpy(inp["K"] @ np.concatenate([inp["R"], inp["t"]], -1)).float()[None].repeat(c["B"], 1, 1, 1)
@@ -552,7 +552,7 @@ def gen_train_alg(mvn):
     print("  the reference's fp32 torch.svd backward against fp64 on the same tail inputs: %.2e (relative)" % svd32)
     print("  alg train step x3: %.1fs; loss %.4f; %d parameters with gradients (%d without), global grad norm %.4e" % (time.time() - t0, r["loss"], len(names), len(no_grad), gn))
     print("  reference self-noise: kp %.2e; gradients median %.2e, 90%% %.2e, max %.2e" % (kp_noise, noises[len(noises) // 2], noises[int(len(noises) * 0.9)], noises[-1]))
-    np.savez_compressed(os.path.join(GOLD, "train_step_alg.npz"), **out)
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 
 def run_vol_case(mvn, tag, num_layers, B, NV, H, V, method="softmax", multiplier=1.0, sharpen=False,
@@ -660,7 +660,7 @@ def main():
     torch.manual_seed(0)
     os.makedirs(GOLD, exist_ok=True)
     mvn = ref_loader.load()
-    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "vol3", "alg", "alg2", "caffe", "pipe2d", "data", "grad", "train", "train_conf", "train_alg", "train_frozen", "train_sum", "train_max", "train_r50"]
+    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "vol3", "alg", "alg2", "caffe", "pipe2d", "data", "grad", "train", "train_conf", "train_alg", "train_frozen", "train_sum", "train_max", "train_r50", "train_alg_noconf"]
     if "ops" in which:
         print("[ops]"); gen_ops(mvn)
     if "nets" in which:
@@ -697,6 +697,8 @@ def main():
         print("[train_frozen]"); gen_train(mvn, "softmax", "train_step_frozen_bn.npz", freeze_backbone_bn=True)
     if "train_alg" in which:
         print("[train_alg]"); gen_train_alg(mvn)
+    if "train_alg_noconf" in which:
+        print("[train_alg_noconf]"); gen_train_alg(mvn, False, "train_step_alg_noconf.npz")
     if "train_conf" in which:
         print("[train_conf]"); gen_train(mvn, "conf_norm", "train_step_conf_norm.npz")
     if "train_r50" in which:

@@ -869,7 +869,8 @@ def test_mixed_precision_training_step_deviation_and_descent(golden_dir):
     assert losses[-1] < losses[0], losses
 
 
-def test_whole_algebraic_training_step_vs_reference(golden_dir):
+@pytest.mark.parametrize("use_conf", [True, False], ids=["alg", "alg_no_conf"])
+def test_whole_algebraic_training_step_vs_reference(golden_dir, use_conf):
     """AlgebraicTriangulationNet in training mode (round 3; the reference's loop for model_type "alg", train.py:189-243): forward (batch-statistics
     BatchNorm), KeypointsMSESmoothLoss(400) on keypoints * 0.1, backward through the DLT (torch.svd in the reference), the 2D soft-argmax, the
     alg_confidences head and the backbone, Adam -- every parameter's gradient, the running statistics and the parameters after the step against the
@@ -877,12 +878,14 @@ def test_whole_algebraic_training_step_vs_reference(golden_dir):
     import lt_train
     from mvn.models import loss as L
     from mvn.models.triangulation import AlgebraicTriangulationNet
-    G = np.load(os.path.join(golden_dir, "train_step_alg.npz"))
+    # alg_no_conf: experiments/human36m/train/human36m_alg_no_conf.yaml -- no alg_confidences head, uniform view weights (train_step_alg_noconf.npz)
+    G = np.load(os.path.join(golden_dir, "train_step_alg.npz" if use_conf else "train_step_alg_noconf.npz"))
+    TA = "train-alg/" if use_conf else "train-alg-no-conf/"
     c = dict(nl=18, B=2, NV=3, H=128, seed=21)
-    cfg = synth.alg_config(c["nl"], True)
+    cfg = synth.alg_config(c["nl"], use_conf)
     cfg.model.heatmap_multiplier = 1.0
     cfg.model["heatmap_multiplier"] = 1.0
-    sd = synth.make_state_dict(spec.alg_net_spec(c["nl"], 17, True), seed=c["seed"], basic_block=True)
+    sd = synth.make_state_dict(spec.alg_net_spec(c["nl"], 17, use_conf), seed=c["seed"], basic_block=True)
     inp = synth.make_inputs(c["B"], c["NV"], c["H"], seed=c["seed"], inside=False)
     m = AlgebraicTriangulationNet(cfg, device=DEV)
     m.load_state_dict(sd, strict=True)
@@ -894,11 +897,11 @@ def test_whole_algebraic_training_step_vs_reference(golden_dir):
     kp3, kp2, hm, conf = m(inp["images"].to(DEV), P, {})
     kp_noise, loss_noise = float(G["kp_noise"]), float(G["loss_noise"])
     d = (kp3.detach().cpu().double() - torch.from_numpy(G["kp3"]).double()).abs() / torch.from_numpy(G["kp3"]).double().abs().clamp(min=1.0)
-    record("train-alg/step forward keypoints_3d (train-mode BN), rel with 1 mm floor", {"err": float(d.max()), "tol": 1e-4 + 2 * kp_noise, "reference_self_noise": kp_noise})
+    record(TA + "step forward keypoints_3d (train-mode BN), rel with 1 mm floor", {"err": float(d.max()), "tol": 1e-4 + 2 * kp_noise, "reference_self_noise": kp_noise})
     assert float(d.max()) <= 1e-4 + 2 * kp_noise, float(d.max())
-    check("train-alg/step forward keypoints_2d", kp2.detach().cpu(), G["kp2"], 1e-4)
-    check("train-alg/step forward confidences", conf.detach().cpu(), G["conf"], 1e-4)
-    check("train-alg/step forward heatmaps", hm.detach().cpu().reshape(c["B"] * c["NV"], *hm.shape[2:])[:, :, ::2, ::2], G["hm_sub"], 1e-4)
+    check(TA + "step forward keypoints_2d", kp2.detach().cpu(), G["kp2"], 1e-4)
+    check(TA + "step forward confidences", conf.detach().cpu(), G["conf"], 1e-4)
+    check(TA + "step forward heatmaps", hm.detach().cpu().reshape(c["B"] * c["NV"], *hm.shape[2:])[:, :, ::2, ::2], G["hm_sub"], 1e-4)
     gt, val = torch.from_numpy(G["gt"]).to(DEV), torch.from_numpy(G["val"]).to(DEV)
     loss = L.KeypointsMSESmoothLoss(400)(kp3 * 0.1, gt * 0.1, val)
     assert abs(float(loss.detach()) - float(G["loss"])) <= (1e-4 + 2 * loss_noise) * float(G["loss"]), (float(loss.detach()), float(G["loss"]))
@@ -934,7 +937,7 @@ def test_whole_algebraic_training_step_vs_reference(golden_dir):
     print("worst parameter gradients (err / gate, err vs the fp64 step, reference self-noise, name, err vs the fp32 step):", *["%.2f %.2e %.2e %s %.2e" % t for t in table[:8]], sep="\n  ")
     errs = sorted(t[1] for t in table)
     e32s = sorted(t[4] for t in table)
-    record("train-alg/step parameter gradients vs the reference's fp64 step (gate 1e-3 + 4 x reference self-noise)",
+    record(TA + "step parameter gradients vs the reference's fp64 step (gate 1e-3 + 4 x reference self-noise)",
            {"worst_err_over_gate": table[0][0], "worst_err": errs[-1], "median_err": errs[len(errs) // 2], "parameters_compared": len(table),
             "zero_gradient_parameters": n_zero, "median_reference_self_noise": sorted(t[2] for t in table)[len(table) // 2],
             "vs_the_fp32_step_median": e32s[len(e32s) // 2], "vs_the_fp32_step_worst": e32s[-1], "reference_fp32_svd_backward_rel_err": float(G["svd32_rel"])})
@@ -951,7 +954,7 @@ def test_whole_algebraic_training_step_vs_reference(golden_dir):
             sub = b[::max(1, b.numel() // 129)][:129]
             ref = torch.from_numpy(G[key]).double()
             w_rs = max(w_rs, float((sub - ref).abs().max() / ref.abs().max().clamp(min=1e-30)))
-    record("train-alg/step BatchNorm running statistics", {"err": w_rs, "tol": 1e-4})
+    record(TA + "step BatchNorm running statistics", {"err": w_rs, "tol": 1e-4})
     assert w_rs <= 1e-4, w_rs
     opt.step()
     torch.cuda.synchronize()
@@ -969,8 +972,8 @@ def test_whole_algebraic_training_step_vs_reference(golden_dir):
         e = float(((sub - ref).abs() * known).max()) / lr
         if e > w_p:
             w_p, w_name = e, n
-    record("train-alg/step parameters after Adam, worst |d| in units of lr", {"err": w_p, "tol": 2e-2, "name": w_name, "elements_compared": n_known})
-    assert w_p <= 2e-2 and n_known > 300, (w_p, w_name, n_known)
+    record(TA + "step parameters after Adam, worst |d| in units of lr", {"err": w_p, "tol": 2e-2, "name": w_name, "elements_compared": n_known})
+    assert w_p <= 2e-2 and n_known > (300 if use_conf else 200), (w_p, w_name, n_known)          # (the no-conf fixture is the noisier one: 292 robust signs)
     # second step = the REPLAY of the recorded tape with the updated weights: finite, and the loss moves
     kp3b = m(inp["images"].to(DEV), P, {})[0]
     loss2 = L.KeypointsMSESmoothLoss(400)(kp3b * 0.1, gt * 0.1, val)
