@@ -361,7 +361,7 @@ def _train_sub(t, n=129):
     return f[::max(1, f.numel() // n)][:n].numpy().copy()
 
 
-def gen_train(mvn, method="softmax", fname="train_step.npz", freeze_backbone_bn=False, nl=18):
+def gen_train(mvn, method="softmax", fname="train_step.npz", freeze_backbone_bn=False, nl=18, kind="mpii", cmu=False):
     """One full training step of the reference's VolumetricTriangulationNet on CPU (train.py:148-243): model.train() (BatchNorm on batch
     statistics, running statistics updated, random cuboid rotation), criterion MAE on keypoints * scale_keypoints_3d + 0.01 *
     VolumetricCELoss, total_loss.backward(), torch.optim.Adam with the three learning-rate groups of train.py:430-437, opt.step().
@@ -380,7 +380,9 @@ def gen_train(mvn, method="softmax", fname="train_step.npz", freeze_backbone_bn=
     import mvn.models.loss as L
     torch.set_num_threads(8)          # the fixture's fp32 summation order (the 1-thread run below measures what another order changes)
     c = dict(nl=nl, B=2, NV=3, H=128, V=64, seed=12)          # nl = 50: BOTTLENECK blocks (1x1 reduce / 3x3 / 1x1 expand, strided downsample convolutions -- ResNet-152's)
-    cfg = synth.vol_config(c["nl"], c["V"], method, 1.0, "mpii")
+    cfg = synth.vol_config(c["nl"], c["V"], method, 1.0, kind)          # kind "coco": the cuboid is centred between the hips (triangulation.py:282-288)
+    if cmu:                                                              # ... and the CMU -> Human3.6M axis permutation of the grid (triangulation.py:336-339)
+        cfg.model.transfer_cmu_to_human36m = True
     sp = spec.vol_net_spec(c["nl"], 17, method.startswith("conf"))
     sd = synth.make_state_dict(sp, seed=c["seed"], sharpen=60.0, basic_block=nl < 50)
     inp = synth.make_inputs(c["B"], c["NV"], c["H"], seed=c["seed"], inside=False)
@@ -660,7 +662,7 @@ def main():
     torch.manual_seed(0)
     os.makedirs(GOLD, exist_ok=True)
     mvn = ref_loader.load()
-    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "vol3", "alg", "alg2", "caffe", "pipe2d", "data", "grad", "train", "train_conf", "train_alg", "train_frozen", "train_sum", "train_max", "train_r50", "train_alg_noconf"]
+    which = sys.argv[1:] or ["ops", "nets", "vol", "vol2", "vol3", "alg", "alg2", "caffe", "pipe2d", "data", "grad", "train", "train_conf", "train_alg", "train_frozen", "train_sum", "train_max", "train_r50", "train_alg_noconf", "train_cmu"]
     if "ops" in which:
         print("[ops]"); gen_ops(mvn)
     if "nets" in which:
@@ -703,6 +705,8 @@ def main():
         print("[train_conf]"); gen_train(mvn, "conf_norm", "train_step_conf_norm.npz")
     if "train_r50" in which:
         print("[train_r50]"); gen_train(mvn, "softmax", "train_step_r50.npz", nl=50)
+    if "train_cmu" in which:
+        print("[train_cmu]"); gen_train(mvn, "softmax", "train_step_cmu.npz", kind="coco", cmu=True)
     if "train_sum" in which:          # the two aggregation methods without learned view weights: mean over the views / per-voxel maximum (op.py:143-148)
         print("[train_sum]"); gen_train(mvn, "sum", "train_step_sum.npz")
     if "train_max" in which:

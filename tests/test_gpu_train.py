@@ -334,15 +334,18 @@ def test_adam_step_vs_torch():
 ZERO_GRAD = re.compile(r"^volume_net\.(.*\.(block\.0|res_branch\.0|res_branch\.3|skip_con\.0)|output_layer)\.bias$")
 
 
-def _train_case(method="softmax", nl=18):
+def _train_case(method="softmax", nl=18, cmu=False):
     c = dict(nl=nl, B=2, NV=3, H=128, V=64, seed=12)
-    cfg = synth.vol_config(c["nl"], c["V"], method, 1.0, "mpii")
+    cfg = synth.vol_config(c["nl"], c["V"], method, 1.0, "coco" if cmu else "mpii")
+    if cmu:
+        cfg.model.transfer_cmu_to_human36m = True
+        cfg.model["transfer_cmu_to_human36m"] = True
     sd = synth.make_state_dict(spec.vol_net_spec(c["nl"], 17, method.startswith("conf")), seed=c["seed"], sharpen=60.0, basic_block=nl < 50)
     inp = synth.make_inputs(c["B"], c["NV"], c["H"], seed=c["seed"], inside=False)
     return c, cfg, sd, inp
 
 
-@pytest.mark.parametrize("method", ["softmax", "conf_norm", "frozen_bn", "sum", "max", "r50"])
+@pytest.mark.parametrize("method", ["softmax", "conf_norm", "frozen_bn", "sum", "max", "r50", "cmu"])
 def test_whole_training_step_vs_reference(golden_dir, method):
     """model.train(); forward; MAE(kp * 0.1) + 0.01 * VolumetricCELoss; backward; Adam (train.py:148-243, :430-437) -- every parameter's
     gradient, the BatchNorm running statistics and the parameters after the step against the reference's own step on CPU.  conf_norm: the
@@ -356,9 +359,11 @@ def test_whole_training_step_vs_reference(golden_dir, method):
     # fine-tuning with a frozen backbone); the reference's step of the same setting: tests/golden/train_step_frozen_bn.npz
     # r50: softmax aggregation over a BOTTLENECK backbone (ResNet-50: 1x1 reduce / 3x3 / 1x1 expand blocks, strided downsample convolutions -- the block type
     # of ResNet-152); the reference's step of the same network: tests/golden/train_step_r50.npz
-    frozen, r50 = method == "frozen_bn", method == "r50"
+    # cmu: kind "coco" (cuboid centred between the hips) with transfer_cmu_to_human36m (the grid's axis permutation, triangulation.py:336-339) -- the
+    # CMU Panoptic setting, whose unprojection backward walks the permuted grid: tests/golden/train_step_cmu.npz
+    frozen, r50, cmu = method == "frozen_bn", method == "r50", method == "cmu"
     G = np.load(os.path.join(golden_dir, "train_step.npz" if method == "softmax" else "train_step_%s.npz" % method))
-    c, cfg, sd, inp = _train_case("softmax" if (frozen or r50) else method, 50 if r50 else 18)
+    c, cfg, sd, inp = _train_case("softmax" if (frozen or r50 or cmu) else method, 50 if r50 else 18, cmu)
     TAG = "" if method == "softmax" else "[%s] " % method
     m = VolumetricTriangulationNet(cfg, device=DEV)
     m.load_state_dict(sd, strict=True)
