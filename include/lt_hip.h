@@ -404,6 +404,29 @@ int lt_stem_pack_weights(const void* weight, int32_t k_pad, void* packed, void* 
 int lt_stem_pool_fwd(const lt_stem_desc* desc, const void* x, void* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * A whole identity Bottleneck block in one launch: Bottleneck.forward of the reference
+ * (mvn/models/pose_resnet.py:75-95 with downsample == None and stride 1):
+ *   t1 = relu(bn1(conv1x1(x)));  t2 = relu(bn2(conv3x3(t1), pad 1));  y = relu(bn3(conv1x1(t2)) + x)
+ * with eval-mode BatchNorm folded like lt_conv_fwd's epilogue ((acc + bias) * scale + shift).  The two
+ * intermediate tensors never leave LDS (they are rounded to bf16 exactly where the three separate launches
+ * would store them); x is read once (plus the 1-pixel halo of an 8 x 16 pixel tile) and y written once.
+ * x, y: N,H,W,C channels-last bf16, y != x;  (C, P) = (256, 64) or (512, 128) (ResNet layer1 / layer2);
+ * H % 8 == 0, W % 16 == 0.  weight[i]: lt_conv_pack_weights_t32 of the lt_conv_fwd packing of layer i
+ * (i = 0: [P][C], ntaps 1, cin C;  1: [P][9 P], ntaps 9, cin P;  2: [C][P], ntaps 1, cin P);
+ * bias[i] may be NULL; scale / shift hold the layer's output-channel count of floats.
+ * -------------------------------------------------------------------------------------------*/
+typedef struct {
+    int32_t dtype;                       /* LT_BF16 */
+    int32_t N, H, W;
+    int32_t C, P;                        /* block width, bottleneck width (C == 4 P) */
+    const void* weight[3];
+    const float* bias[3];
+    const float* scale[3];
+    const float* shift[3];
+} lt_bneck_desc;
+int lt_bottleneck_fwd(const lt_bneck_desc* desc, const void* x, void* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * hipGraph + event helpers (the forward is ~230 launches: replay it as one graph)
  * -------------------------------------------------------------------------------------------*/
 int lt_graph_begin(void* stream);

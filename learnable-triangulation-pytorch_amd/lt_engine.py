@@ -476,6 +476,61 @@ class PlanBuilder:
                   "pwchain", label, flops, nbytes, {"specs": specs, "x": x, "y": y})
         return y
 
+    # ---- whole identity Bottleneck block in one launch (ResNet layer1 / layer2) -----------------------------------------------------
+    def can_bottleneck(self, x, convs, strides):
+        """True when lt_bottleneck_fwd covers the block: bf16 plan over build-time weights, 2D map, three stride-1 convolutions
+        1x1 C->P, 3x3 P->P, 1x1 P->C with (C, P) = (256, 64) or (512, 128), no downsample (the caller checks), H % 8 == 0 and W % 16 == 0."""
+        if self.dtype != torch.bfloat16 or self.live_weights or self.tile_override or os.environ.get("LT_NO_BNECK") == "1":
+            return False
+        N, D, Hh, W, Cc = x.shape
+        if D != 1 or len(convs) != 3 or any(s != 1 for s in strides):
+            return False
+        P = convs[0].shape[0]
+        if (Cc, P) not in ((256, 64), (512, 128)):
+            return False
+        if (tuple(convs[0].shape) != (P, Cc, 1, 1) or tuple(convs[1].shape) != (P, P, 3, 3) or tuple(convs[2].shape) != (Cc, P, 1, 1)):
+            return False
+        return Hh % 8 == 0 and W % 16 == 0 and N * Hh * W * Cc < 2 ** 31
+
+    def bottleneck(self, x, convs, bns):
+        """relu(bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x)))))))) + x) in ONE launch (lt_bottleneck_fwd: the two bottleneck-width tensors
+        stay in LDS).  convs: the three Conv2d weights, bns: their BatchNorm tuples.  Returns the output Act (a new buffer: the kernel
+        cannot run in place)."""
+        assert self.can_bottleneck(x, convs, (1, 1, 1))
+        N, _, Hh, W, Cc = x.shape
+        P = convs[0].shape[0]
+        specs = []
+        shape = x.shape
+        for i, (w, bn) in enumerate(zip(convs, bns)):
+            spec = make_conv_spec(w, None, bn, shape, 1, 1 if i == 1 else 0, self.dtype, False, H.EPI_RELU_POST)
+            specs.append(spec)
+            shape = (N, 1, Hh, W, spec.Cout)
+        y = self.alloc((N, 1, Hh, W, Cc))
+        d = H.BneckDesc()
+        d.dtype, d.N, d.H, d.W, d.C, d.P = self.code, N, Hh, W, Cc, P
+        lib = None if self.dry_run else H.lib()
+        flops = 0
+        for i, spec in enumerate(specs):
+            wdev = self.const(spec.phases[0].weight, self.dtype)
+            assert spec.cout_pad == spec.Cout and spec.k_pad == spec.phases[0].taps.shape[0] * spec.Cin, (spec.cout_pad, spec.k_pad)
+            sc, sh = self.const(spec.scale), self.const(spec.shift)
+            wfr = torch.empty_like(wdev)
+            if not self.dry_run:
+                H.check(lib.lt_conv_pack_weights_t32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, spec.Cin, int(spec.phases[0].taps.shape[0]),
+                                                     wfr.data_ptr(), H.cur_stream()), "lt_conv_pack_weights_t32")
+            self.keep.append(wfr)
+            d.weight[i], d.bias[i], d.scale[i], d.shift[i] = wfr.data_ptr(), None, sc.data_ptr(), sh.data_ptr()
+            flops += 2 * N * Hh * W * spec.Cout * spec.phases[0].taps.shape[0] * spec.Cin
+        self.keep.append(x.t)
+        self.keep.append(d)
+        self.flops += flops
+        esz = x.t.element_size()
+        nbytes = (x.t.numel() + y.t.numel()) * esz + sum(sp.phases[0].weight.numel() for sp in specs) * esz
+        label = "bneck %d->%d->%d @%s" % (Cc, P, Cc, "x".join(str(v) for v in (N, 1, Hh, W)))
+        self._add(lambda s, d=d, xp=x.t.data_ptr(), yp=y.t.data_ptr(): H.check(lib.lt_bottleneck_fwd(C.byref(d), xp, yp, s), "lt_bottleneck_fwd"),
+                  "conv", label, flops, nbytes, {"bneck": True, "specs": specs, "x": x, "y": y})
+        return y
+
     def can_stem_pool(self, x, weight, stride, pad, pool):
         """True when lt_stem_pool_fwd covers conv -> BN -> ReLU -> max pool: bf16 plan, 2D map with 8 (padded) channels,
         7x7 / stride 2 / pad 3 convolution to 64 channels, 3x3 / stride 2 / pad 1 pool."""

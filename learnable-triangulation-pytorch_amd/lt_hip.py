@@ -55,6 +55,11 @@ class StemDesc(C.Structure):
                 ("weight", vp), ("bias", vp), ("scale", vp), ("shift", vp), ("x_layout", i32)]
 
 
+class BneckDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("N", i32), ("H", i32), ("W", i32), ("C", i32), ("P", i32),
+                ("weight", vp * 3), ("bias", vp * 3), ("scale", vp * 3), ("shift", vp * 3)]
+
+
 # symbol -> (restype, argtypes); must list every symbol include/lt_hip.h declares
 SIGNATURES = {
     "lt_last_error": (C.c_char_p, []),
@@ -67,6 +72,7 @@ SIGNATURES = {
     "lt_conv_pack_weights32": (C.c_int, [vp, i32, i32, vp, vp]),
     "lt_pwchain_fwd": (C.c_int, [C.POINTER(PwChainDesc), vp, vp, vp]),
     "lt_stem_pool_fwd": (C.c_int, [C.POINTER(StemDesc), vp, vp, vp]),
+    "lt_bottleneck_fwd": (C.c_int, [C.POINTER(BneckDesc), vp, vp, vp]),
     "lt_stem_packed_bytes": (C.c_size_t, []),
     "lt_stem_pack_weights": (C.c_int, [vp, i32, vp, vp]),
     "lt_maxpool_fwd": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32 * 3, vp]),

@@ -49,6 +49,11 @@ class ResidualBlock(nn.Module):
 
     def record(self, b, x):
         n = len(self.strides)
+        if self.kind == "bottleneck" and self.downsample is None:
+            # identity blocks of layer1 / layer2 in bf16 plans: the whole block in one launch, the two bottleneck-width tensors stay in LDS
+            convs = [self.conv1.weight, self.conv2.weight, self.conv3.weight]
+            if b.can_bottleneck(x, convs, self.strides):
+                return b.bottleneck(x, convs, [bn_tuple(self.bn1), bn_tuple(self.bn2), bn_tuple(self.bn3)])
         res = x
         if self.downsample is not None:
             res = b.conv(x, self.downsample[0].weight, None, bn_tuple(self.downsample[1]), stride=self.downsample[0].stride[0], pad=0)

@@ -75,6 +75,12 @@ def run_plan_on_cpu(plan):
             if sp.flags & EPI_RELU_POST:
                 v = torch.relu(v)
             info["y"].t.copy_(v)
+        elif kind == "conv" and info.get("bneck"):           # lt_bottleneck_fwd: the three layers, the two inner tensors rounded to the plan dtype
+            x = info["x"].t.float().clone()
+            s1, s2, s3 = info["specs"]
+            t1 = emulate_conv(s1, x).to(info["x"].t.dtype).float()
+            t2 = emulate_conv(s2, t1).to(info["x"].t.dtype).float()
+            info["y"].t.copy_(emulate_conv(s3, t2, x))
         elif kind == "conv":
             res = None if info["res"] is None else info["res"].t.float().clone()
             out = emulate_conv(info["spec"], info["x"].t.float().clone(), res)

@@ -792,3 +792,55 @@ def test_conv3d_splitk_tiny_levels(N, sp, monkeypatch):
     out2 = run_conv(x, w, bias, bn, 1, 1, torch.bfloat16, 0, relu=False, residual=None)      # plain affine epilogue through the same pair
     check("conv3d split-K N%d %s/plain" % (N, sp), out2, _bn_ref(F.conv3d(rd(x), rd(w), bias, 1, 1), bn), 1.5e-2)
 
+
+
+def _bneck_layers(C, P, g):
+    ws = [torch.randn(P, C, 1, 1, generator=g) / C ** 0.5, torch.randn(P, P, 3, 3, generator=g) / (9 * P) ** 0.5, torch.randn(C, P, 1, 1, generator=g) / P ** 0.5]
+    return ws, [_bn(P, g), _bn(P, g), _bn(C, g)]
+
+
+def _bneck_run(x_cl, ws, bns, fused, monkeypatch):
+    """The identity Bottleneck block through the plan builder: one lt_bottleneck_fwd (fused) or three lt_conv_fwd launches."""
+    if fused:
+        monkeypatch.delenv("LT_NO_BNECK", raising=False)
+    else:
+        monkeypatch.setenv("LT_NO_BNECK", "1")
+    b = E.PlanBuilder(DEV, torch.bfloat16)
+    xa = E.Act(x_cl)
+    if fused:
+        assert b.can_bottleneck(xa, ws, (1, 1, 1))
+        y = b.bottleneck(xa, ws, bns)
+    else:
+        t1 = b.conv(xa, ws[0], None, bns[0], relu=True)
+        t2 = b.conv(t1, ws[1], None, bns[1], pad=1, relu=True)
+        y = b.conv(t2, ws[2], None, bns[2], relu=True, residual=xa)
+    plan = b.finish()
+    assert len(plan.ops) == (1 if fused else 3)
+    plan.run_eager(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return y.t
+
+
+@pytest.mark.parametrize("C,P,N,Hh,W", [(256, 64, 1, 8, 16), (256, 64, 3, 24, 32), (512, 128, 1, 8, 16), (512, 128, 2, 16, 48), (256, 64, 9, 16, 16)])
+def test_bottleneck_fused(C, P, N, Hh, W, monkeypatch):
+    """lt_bottleneck_fwd (pose_resnet.py:75-95, identity block) against (a) torch fp32 on bf16-rounded operands with the two inner tensors
+    rounded to bf16 where the separate launches store them, (b) the three lt_conv_fwd launches it replaces.  One-tile maps (every halo pixel
+    outside the image), several tiles per image (halo exchange across tile borders, both directions) and an odd image count (XCD remap)."""
+    g = torch.Generator().manual_seed(C + N + Hh)
+    x = torch.randn(N, C, Hh, W, generator=g)
+    ws, bns = _bneck_layers(C, P, g)
+    x_cl = to_cl(x, None, torch.bfloat16)
+    y = _bneck_run(x_cl, ws, bns, True, monkeypatch)
+    assert y.data_ptr() != x_cl.data_ptr() and tuple(y.shape) == (N, 1, Hh, W, C)
+    rd = bf16_round
+    xr = rd(x)
+    t1 = rd(torch.relu(_bn_ref(F.conv2d(xr, rd(ws[0])), bns[0])))
+    t2 = rd(torch.relu(_bn_ref(F.conv2d(t1, rd(ws[1]), None, 1, 1), bns[1])))
+    ref = torch.relu(_bn_ref(F.conv2d(t2, rd(ws[2])), bns[2]) + xr)
+    name = "bneck/%d_%d/%dx%dx%d" % (C, P, N, Hh, W)
+    check(name + "/vs_torch", from_cl(y, 2), ref, 1.5e-2)
+    y3 = _bneck_run(x_cl, ws, bns, False, monkeypatch)
+    check(name + "/vs_three_launches", from_cl(y, 2), from_cl(y3, 2), 1.5e-2)
+    # the three launches and the fused kernel agree to bf16 rounding noise: a structural mistake (one tap, one halo row) is far above this
+    record(name + "/rms_vs_three_launches", float((y.float() - y3.float()).pow(2).mean().sqrt() / y3.float().pow(2).mean().sqrt()))
+    assert float((y.float() - y3.float()).pow(2).mean().sqrt() / y3.float().pow(2).mean().sqrt()) < 2e-3

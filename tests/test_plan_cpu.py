@@ -219,3 +219,41 @@ def test_splitk_tiny_volume_convolutions_are_recorded_and_equal_the_unsplit_conv
     b = E.PlanBuilder("cpu", torch.float32, dry_run=True)
     b.conv(E.Act(torch.zeros(1, 4, 4, 4, 128)), w, bias, bn, stride=1, pad=1, relu=True)
     assert len(b.ops) == 1          # the exact-fp32 parity mode keeps its single accumulation chain
+
+
+def test_identity_bottlenecks_are_recorded_as_one_launch_in_bf16_plans(monkeypatch):
+    """bf16 plans run the identity Bottleneck blocks of ResNet layer1 / layer2 (256 / 64 and 512 / 128 wide, maps of 8 x 16 pixel tiles) as ONE
+    lt_bottleneck_fwd each; the recorded block must be the same function as the three lt_conv_fwd launches LT_NO_BNECK=1 records, and
+    blocks with a downsample branch / other widths / ragged maps keep the three launches."""
+    import lt_engine as E
+    from mvn.models.pose_resnet import PoseResNet
+    torch.manual_seed(11)
+    m = PoseResNet("bottleneck", [3, 4, 6, 3], 17).eval()
+    for bn in [mm for mm in m.modules() if isinstance(mm, torch.nn.BatchNorm2d)]:
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.1)
+    x = torch.randn(1, 1, 16, 32, 256)
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("LT_NO_BNECK", "1")
+        b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
+        inp = b.alloc(tuple(x.shape)); inp.pooled = False
+        y = m.layer1[1].record(b, inp)
+        plan = b.finish()
+        labels = [meta["label"] for _, meta in plan.ops]
+        assert len(labels) == (1 if fused else 3) and labels[0].startswith("bneck 256->64->256" if fused else "conv1x1 256->64")
+        inp.t.copy_(x)
+        run_plan_on_cpu(plan)
+        outs[fused] = y.t.float().clone()
+        assert y.t.data_ptr() != inp.t.data_ptr()
+    assert torch.equal(outs[True], outs[False])           # the interpreter rounds the inner tensors where the launches would store them
+    monkeypatch.delenv("LT_NO_BNECK")
+    # what does NOT fuse: the first block of a level (downsample branch), fp32 plans, maps that are not whole tiles, layer3's width
+    for blk, shape, dt in ((m.layer1[0], (1, 1, 16, 32, 64), torch.bfloat16), (m.layer1[1], (1, 1, 16, 32, 256), torch.float32),
+                           (m.layer1[1], (1, 1, 12, 32, 256), torch.bfloat16), (m.layer3[1], (1, 1, 8, 16, 1024), torch.bfloat16)):
+        b = E.PlanBuilder("cpu", dt, dry_run=True)
+        blk.record(b, b.alloc(shape))
+        assert all(not meta["label"].startswith("bneck") for _, meta in b.finish().ops)
+    b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
+    m.layer2[3].record(b, b.alloc((2, 1, 8, 16, 512)))
+    assert [meta["label"] for _, meta in b.finish().ops] == ["bneck 512->128->512 @2x1x8x16"]

@@ -50,7 +50,7 @@ def kernel_key(name):
 def family(k):
     if k.startswith(("conv_pack", "stem_pack")):
         return "setup"          # one-time weight packing at plan build, not part of a step
-    if k.startswith(("conv", "pwchain", "stem_pool")):
+    if k.startswith(("conv", "pwchain", "stem_pool", "bneck")):
         return "conv"
     if k.startswith("unproject"):
         return "unproject"
