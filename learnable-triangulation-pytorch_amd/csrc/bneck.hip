@@ -31,6 +31,19 @@ namespace {
 
 __device__ uint4 g_zero_page_b[2];
 
+// -DLT_BNECK_TRACE: shader-clock stamps at the phase boundaries of every wave of the first LT_BNECK_TRACE_WG workgroups (profiling builds only,
+// read back with lt_bneck_trace_read; tools/bneck_bench.py --trace)
+#ifdef LT_BNECK_TRACE
+#define LT_BNECK_TRACE_WG 4096
+__device__ unsigned long long g_bneck_trace[LT_BNECK_TRACE_WG * 4 * 8];
+#define BN_STAMP(k)                                                                                                  \
+    do {                                                                                                             \
+        if (blockIdx.x < LT_BNECK_TRACE_WG && lane == 0) g_bneck_trace[(blockIdx.x * 4 + wave) * 8 + (k)] = clock64(); \
+    } while (0)
+#else
+#define BN_STAMP(k)
+#endif
+
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct BneckArgs {
@@ -63,8 +76,31 @@ __device__ __forceinline__ void wait_vm(int n) {
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
         case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
+}
+
+// Phase 1 issue order of a wave (all of it inline asm, so the waits are counted by hand; loads return in order): prologue W1 fragments A(0 .. D-1)
+// [2 loads each], ring stages DMA(0 .. AHEAD-1) [3 pieces each]; K step s issues A(s + D) and then DMA(s + AHEAD) while they exist.  Returns
+// how many operations may still be outstanding at the top of step ks so that A(ks) and this wave's pieces of stage ks have landed.
+template <int NK1, int AHEAD, int D>
+constexpr int bneck_after(int ks) {
+    int total = 0, last = 0;
+    for (int k = 0; k < D && k < NK1; ++k) { total += 2; if (k == ks) last = total; }
+    for (int k = 0; k < AHEAD && k < NK1; ++k) { total += 3; if (k == ks && total > last) last = total; }
+    for (int s = 0; s < ks; ++s) {
+        if (s + D < NK1) { total += 2; if (s + D == ks && total > last) last = total; }
+        if (s + AHEAD < NK1) { total += 3; if (s + AHEAD == ks && total > last) last = total; }
+    }
+    return total - last;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_c() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 __device__ __forceinline__ void frag_ready_b(V16& f) {
@@ -93,7 +129,7 @@ __device__ __forceinline__ void gload16b(V16& d, const void* sbase, unsigned vof
 
 __device__ __forceinline__ int swz64_b(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
 
-template <int C, int P, int NST>
+template <int C, int P, int NSTR, int NHELD>
 __global__ __launch_bounds__(256, 2) void bneck_kernel(const BneckArgs a) {
     typedef bf16_t T;
     constexpr int TH = 8, TW = 16, HPI = TW + 2, HROWS = (TH + 2) * HPI;   // 10 x 18 = 180 halo pixels
@@ -102,13 +138,16 @@ __global__ __launch_bounds__(256, 2) void bneck_kernel(const BneckArgs a) {
     constexpr int RB = 2 * P, NSL = P / 8;                                  // bytes / 16-byte slots per t1 / t2 row
     constexpr int T1_BYTES = HROWS * RB;
     constexpr int STAGE = HROWS * 64;                                       // a ring stage: 180 rows x 32 channels
-    constexpr int RING_OFF = T1_BYTES, RING_BYTES = (NST - 1) * STAGE + 192 * 64;
-    constexpr int T2_OFF = RING_OFF;                                        // t2 takes the ring's place once phase 1 is over
-    constexpr int AHEAD = NST - 1;
+    // the x ring of phase 1 covers the WHOLE allocation: t1 is only written when the K loop is over, so its bytes are NT1 more stages
+    // (bytes in flight are what the L2 / HBM -> LDS stream is bound by: 2 x 11.5 KB per workgroup gave 2.7k cycles per K step)
+    constexpr int NT1 = T1_BYTES / STAGE, NST = NT1 + NSTR;
+    constexpr int T2_OFF = T1_BYTES;                                        // t2 takes the place of the ring stages behind t1 once phase 1 is over
+    constexpr int AHEAD = NST - 1 < NK1 ? NST - 1 : NK1;
     constexpr int NPB1 = NCB == 4 ? 6 : 3, NPB2 = NCB == 4 ? 4 : 2, NOBW = NOB / 4;
     static_assert(NCB == 2 || NCB == 4, "bottleneck width 64 or 128");
-    static_assert(NPB * 32 * RB <= RING_BYTES, "t2 fits the ring");
-    static_assert(NK1 % 2 == 0 && NK1 >= AHEAD, "K steps");
+    static_assert(T1_BYTES % STAGE == 0, "t1 is a whole number of ring stages");
+    static_assert(NPB * 32 * RB <= (NSTR - 1) * STAGE + 192 * 64, "t2 fits behind t1");
+    static_assert(NK1 % 2 == 0 && NHELD <= NOBW && NHELD <= 2, "K steps / held residual blocks");
     static_assert(T1_BYTES % 256 == 0 && STAGE % 256 == 0, "the XOR / bank arguments assume 256-byte aligned regions");
     auto fsw = [](int hp) -> int { return NSL == 16 ? (hp & 15) : ((hp >> 1) & 7); };
 
@@ -134,11 +173,52 @@ __global__ __launch_bounds__(256, 2) void bneck_kernel(const BneckArgs a) {
     const int n31 = lane & 31, hk = lane >> 5;
     const int cb = NCB == 4 ? wave : (wave & 1);           // this wave's 32-channel block of the bottleneck width (phases 1 and 2)
     const int whalf = NCB == 4 ? 0 : (wave >> 1);
+    // output pixel of (block pb, lane n31): tile row 2 pb + r, column c with the odd row rotated by two columns (bank argument above)
+    const int prr = n31 >> 4, pcc = ((n31 & 15) - 2 * prr) & 15;
 
+    // the residual of this wave's first NHELD output-channel blocks (ob = wave + 4 q): K step ks of phase 1 streams channels 32 ks .. + 31 of
+    // every halo pixel through the ring, i.e. exactly the residual of block ob = ks for the 128 centre pixels -- taken from LDS into registers
+    // there, x is then read from memory ONCE for those channels (the blocks that are not held are read a second time in phase 3)
+    uint4 held[NHELD > 0 ? NHELD : 1][NPB][2];
+
+    // the folded BatchNorm constants of this wave's channels, requested FIRST (the oldest entries of the in-order load queue) and kept in
+    // 8 registers, one float4 per lane and table; an epilogue fetches value f of a table with v_readlane (lane f / 4, component f % 4) and
+    // picks the lane's half by h.  As per-element loads in front of each epilogue they were short-latency loads queued behind the residual
+    // requests of the next block -- every epilogue waited for an HBM round trip.
+    //   cst12: [scale1 | shift1 | scale2 | shift2][32 channels of block cb]     (lanes 0..31, mirrored in 32..63)
+    //   cst3 : [q][scale3 | shift3][32 channels of block wave + 4 q]            (NOBW * 64 floats)
+    float4 cst12, cst3;
+    {
+        const int l = lane & 31, arr = l >> 3, i4 = l & 7;
+        const float* t12 = arr == 0 ? a.scale[0] : arr == 1 ? a.shift[0] : arr == 2 ? a.scale[1] : a.shift[1];
+        cst12 = *(const float4*)(t12 + 32 * cb + 4 * i4);
+        const int f = (4 * lane) % (NOBW * 64), q = f >> 6, which = (f >> 5) & 1, c = f & 31;
+        cst3 = *(const float4*)((which ? a.shift[2] : a.scale[2]) + 32 * (wave + 4 * q) + c);
+    }
+    auto cget = [&](const float4& tb, int f) -> float {      // f is a compile-time constant at every call site
+        const float v = (f & 3) == 0 ? tb.x : (f & 3) == 1 ? tb.y : (f & 3) == 2 ? tb.z : tb.w;
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), f >> 2));
+    };
+    // constant e (0..15) of a 32-channel table starting at float `base`: channel 16 (e >> 3) + 8 h + (e & 7)
+    auto csel = [&](const float4& tb, int base, int e) -> float {
+        const float lo = cget(tb, base + 16 * (e >> 3) + (e & 7)), hi = cget(tb, base + 16 * (e >> 3) + 8 + (e & 7));
+        return hk ? hi : lo;
+    };
+
+    BN_STAMP(0);
     // ================================================ phase 1: t1 = relu(bn1(W1 x)) on the halo =======================================
     {
+#ifndef LT_BNECK_ABL_SEG128
         const int prow = lane >> 2;
+#endif
+#ifdef LT_BNECK_ABL_SEG128  /* timing only: eight lanes read 128 contiguous bytes of a row (8 rows per piece) instead of four lanes 64 bytes */
+        const int prow = lane >> 3;
+        const int kvlog = lane & 7;
+#elif defined(LT_BNECK_ABL_NOSWZ)   /* timing only: is the permuted 16-byte order inside a row's 64 bytes what the address path pays for? */
+        const int kvlog = lane & 3;
+#else
         const int kvlog = (lane & 3) ^ swz64_b(prow);
+#endif
         int dbase[3];
         bool dact[3];
 #pragma unroll
@@ -153,14 +233,26 @@ __global__ __launch_bounds__(256, 2) void bneck_kernel(const BneckArgs a) {
         auto issue_piece = [&](int ks, unsigned stage_base, auto ic) {
             constexpr int I = decltype(ic)::value;
             if (dact[I]) {
+#ifdef LT_BNECK_ABL_NODMA   /* timing only: every piece reads the zero page (L2 hit) */
+                const void* src = zero_page;
+#else
+#ifdef LT_BNECK_ABL_SEG128
+                const void* src = dbase[I] >= 0 ? (const void*)(x + (dbase[I] + (ks * 32 < C - 64 ? ks * 32 : C - 64))) : zero_page;
+#else
                 const void* src = dbase[I] >= 0 ? (const void*)(x + (dbase[I] + ks * 32)) : zero_page;
+#endif
+#endif
                 dma16b(src, lds0 + stage_base + (wave + 4 * I) * 1024);
             }
         };
         const int hb0 = NCB == 4 ? 0 : 3 * whalf;          // first halo pixel block of this wave
         const T* w1l = a.w1 + (size_t)cb * 512;            // fragment (g, cb): + g * NCB * 512 elements; lane offset in bytes below
         const unsigned wlane = lane * 16;
-        V16 fa[2][2];
+        // W1 fragments are requested DA K steps ahead: a fragment load is queued behind the ring pieces issued before it and loads return in
+        // order, so at distance 1 every K step lasted as long as a ring piece's round trip to HBM (2.7k cycles per step whatever the ring depth)
+        constexpr int DA = 3, NFA = DA + 1;
+        static_assert(AHEAD > DA && NK1 >= DA, "W1 prefetch distance");
+        V16 fa[NFA][2];
         auto loadA = [&](int ks, V16 (&dst)[2]) {
             const T* p = w1l + (size_t)(2 * ks) * NCB * 512;
             gload16b(dst[0], p, wlane);
@@ -168,6 +260,15 @@ __global__ __launch_bounds__(256, 2) void bneck_kernel(const BneckArgs a) {
         };
         const unsigned fo0 = n31 * 64 + (((0 + hk) ^ swz64_b(n31)) << 4);
         const unsigned fo1 = n31 * 64 + (((2 + hk) ^ swz64_b(n31)) << 4);
+        auto capture = [&](unsigned stage_base, uint4 (&dst)[NPB][2]) {
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+                const int hpc = (2 * pb + prr + 1) * HPI + pcc + 1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    dst[pb][j] = *(const uint4*)((lptr_t)(size_t)(lds0 + stage_base + hpc * 64 + (((2 * j + hk) ^ swz64_b(hpc)) << 4)));
+            }
+        };
 
         f32x16 acc[NPB1];
 #pragma unroll
@@ -175,27 +276,28 @@ __global__ __launch_bounds__(256, 2) void bneck_kernel(const BneckArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-        loadA(0, fa[0]);
+        static_for_b<0, DA>([&](auto kc) { loadA(decltype(kc)::value, fa[decltype(kc)::value]); });
 #pragma unroll
         for (int s = 0; s < AHEAD; ++s)
-            static_for_b<0, 3>([&](auto ic) { issue_piece(s, RING_OFF + s * STAGE, ic); });
+            static_for_b<0, 3>([&](auto ic) { issue_piece(s, s * STAGE, ic); });
 
-        unsigned rbuf = 0, wbuf = AHEAD * STAGE;
-        auto step = [&](int ks, auto rc) {
-            constexpr int R = decltype(rc)::value;
-            const int after = ks == 0 ? (AHEAD - 1) * 3 : (ks + AHEAD - 1 < NK1 ? 3 : 0);
-            wait_vm(after);                                  // A(ks) and, older, this wave's pieces of stage ks
+        // fully unrolled: every K step's wait count, ring stage and fragment register set are compile-time (and every asm load's result is used:
+        // hipcc may give the registers of a dead one to something live, and the data landing later overwrites it)
+        static_for_b<0, NK1>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value, R = ks % NFA;
+            constexpr unsigned rbuf = (ks % NST) * STAGE, wbuf = ((ks + AHEAD) % NST) * STAGE;
+            wait_vm_c<bneck_after<NK1, AHEAD, DA>(ks)>();    // A(ks) and this wave's pieces of stage ks
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             frag_ready_b(fa[R][0]);
             frag_ready_b(fa[R][1]);
-            // no prefetch behind the last step: an asynchronous asm load whose result is never used leaves hipcc free to give its
-            // destination registers to something live (here: an LDS fragment of the fully unrolled C = 256 loop), and the data
-            // landing later overwrites it
-            if (ks + 1 < NK1) loadA(ks + 1, fa[R ^ 1]);
-            if (ks + AHEAD < NK1) static_for_b<0, 3>([&](auto ic) { issue_piece(ks + AHEAD, RING_OFF + wbuf, ic); });
-            const unsigned rb = lds0 + RING_OFF + rbuf + hb0 * 2048;
+            if constexpr (ks + DA < NK1) loadA(ks + DA, fa[(ks + DA) % NFA]);
+            if constexpr (ks + AHEAD < NK1) static_for_b<0, 3>([&](auto ic) { issue_piece(ks + AHEAD, wbuf, ic); });
+            if constexpr (NHELD > 0 && ks < 4) { if (ks == wave) capture(rbuf, held[0]); }
+            if constexpr (NHELD > 1 && ks >= 4 && ks < 8) { if (ks == wave + 4) capture(rbuf, held[NHELD > 1 ? 1 : 0]); }
+            const unsigned rb = lds0 + rbuf + hb0 * 2048;
             // all fragments of one K half are requested before its MFMAs, the second half's under the first half's MFMAs (left to itself
             // hipcc reads every fragment into the same four registers: ds_read -> lgkmcnt(0) -> MFMA, one LDS round trip per MFMA)
+#ifndef LT_BNECK_ABL_NOMMA1   /* timing only: phase 1 without fragment reads and MFMAs */
             V16 b0[NPB1], b1[NPB1];
 #pragma unroll
             for (int i = 0; i < NPB1; ++i) b0[i].u = *(const uint4*)((lptr_t)(size_t)(rb + fo0 + i * 2048));
@@ -208,24 +310,24 @@ __global__ __launch_bounds__(256, 2) void bneck_kernel(const BneckArgs a) {
 #pragma unroll
             for (int i = 0; i < NPB1; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[R][1].h, b1[i].h, acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            rbuf = rbuf + STAGE == NST * STAGE ? 0 : rbuf + STAGE;
-            wbuf = wbuf + STAGE == NST * STAGE ? 0 : wbuf + STAGE;
-        };
-        for (int ks = 0; ks < NK1; ks += 2) {
-            step(ks, std::integral_constant<int, 0>{});
-            step(ks + 1, std::integral_constant<int, 1>{});
-        }
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+            acc[0][0] += fa[R][0].f[0] + fa[R][1].f[0];
+#endif
+        });
+        // the last stages of the ring lie in t1's bytes: every wave is done reading them before t1 is written
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        BN_STAMP(1);
 
         // epilogue: lane (pixel n31, h) holds channels 32 cb + 8 h + e (e < 8) and 32 cb + 16 + 8 h + (e - 8) of halo pixel 32 hb + n31
         float esc[16], esf[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int c = 32 * cb + 16 * (e >> 3) + 8 * hk + (e & 7);
-            const float bi = a.bias[0] ? a.bias[0][c] : 0.f;
-            esc[e] = a.scale[0][c];
-            esf[e] = a.shift[0][c];
-            if (a.bias[0]) esf[e] = bi * esc[e] + esf[e];   // (acc + b) s + f == acc s + (b s + f) up to one rounding; ResNet has no bias
+            esc[e] = csel(cst12, 0, e);
+            esf[e] = csel(cst12, 32, e);
+        }
+        if (a.bias[0]) {                                     // (acc + b) s + f == acc s + (b s + f) up to one rounding; ResNet has no bias
+#pragma unroll
+            for (int e = 0; e < 16; ++e) esf[e] = a.bias[0][32 * cb + 16 * (e >> 3) + 8 * hk + (e & 7)] * esc[e] + esf[e];
         }
 #pragma unroll
         for (int i = 0; i < NPB1; ++i) {
@@ -250,9 +352,32 @@ __global__ __launch_bounds__(256, 2) void bneck_kernel(const BneckArgs a) {
         }
     }
     __syncthreads();
+    BN_STAMP(2);
 
-    // output pixel of (block pb, lane n31): tile row 2 pb + r, column c with the odd row rotated by two columns (bank argument above)
-    const int prr = n31 >> 4, pcc = ((n31 & 15) - 2 * prr) & 15;
+    // ---- phase 3's operands that are requested early: W3 fragments one output-channel block (G2 units) ahead, and the residual of the
+    // blocks that were not held one block ahead of its use (vector-memory loads return in order: a short-latency weight load queued behind a
+    // long-latency residual load waits for it, so the distance between the two has to cover the residual's latency)
+    constexpr int NU3 = NOBW * G2, WD3 = G2 < 6 ? G2 : 6;
+    int poff[NPB];                                           // element offset of this lane's pixel in block pb, channel 8 h
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+        poff[pb] = ((img * a.H + ty * TH + 2 * pb + prr) * a.W + tx * TW + pcc) * C + 8 * hk;
+    const T* wl3 = a.w3 + (size_t)lane * 8;
+    auto load_w3 = [&](int u) -> V16 {                       // unit u = q * G2 + g -> fragment (g, ob = wave + 4 q)
+        const int q = u / G2, g = u - q * G2;
+        V16 v;
+        v.u = *(const uint4*)(wl3 + ((size_t)g * NOB + wave + 4 * q) * 512);
+        return v;
+    };
+    V16 wf3[WD3 + 1];
+    uint4 rq[2][NPB][2];
+    auto load_res = [&](int q, uint4 (&dst)[NPB][2]) {
+        const int ob = wave + 4 * q;
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[pb][j] = *(const uint4*)(x + poff[pb] + 32 * ob + 16 * j);
+    };
 
     // ================================================ phase 2: t2 = relu(bn2(W2 * t1)) ================================================
     {
@@ -267,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void bneck_kernel(const BneckArgs a) {
             v.u = *(const uint4*)(wl + (size_t)u * NCB * 512);
             return v;
         };
-        constexpr int NU = 9 * G2, WD = 4;
+        constexpr int NU = 9 * G2, WD = 6;
         V16 wf[WD + 1];
 #pragma unroll
         for (int u = 0; u < WD; ++u) wf[u] = load_w(u);
@@ -297,14 +422,22 @@ __global__ __launch_bounds__(256, 2) void bneck_kernel(const BneckArgs a) {
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % (WD + 1)].h, xa[u & 1][i].h, acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
+        BN_STAMP(3);
+        // phase 3's first requests go out here, in front of this phase's epilogue and the barrier: weights, then (younger) the residual
+#pragma unroll
+        for (int u = 0; u < WD3; ++u) wf3[u] = load_w3(u);
+        if constexpr (NHELD < NOBW) load_res(NHELD, rq[0]);
+        __builtin_amdgcn_sched_barrier(0);
 
         float esc[16], esf[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int c = 32 * cb + 16 * (e >> 3) + 8 * hk + (e & 7);
-            esc[e] = a.scale[1][c];
-            esf[e] = a.shift[1][c];
-            if (a.bias[1]) esf[e] = a.bias[1][c] * esc[e] + esf[e];
+            esc[e] = csel(cst12, 64, e);
+            esf[e] = csel(cst12, 96, e);
+        }
+        if (a.bias[1]) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) esf[e] = a.bias[1][32 * cb + 16 * (e >> 3) + 8 * hk + (e & 7)] * esc[e] + esf[e];
         }
 #pragma unroll
         for (int i = 0; i < NPB2; ++i) {
@@ -323,85 +456,75 @@ __global__ __launch_bounds__(256, 2) void bneck_kernel(const BneckArgs a) {
         }
     }
     __syncthreads();
+    BN_STAMP(4);
 
     // ================================================ phase 3: y = relu(bn3(W3 t2) + x) ==============================================
     {
-        unsigned a2[G2];
-#pragma unroll
-        for (int g = 0; g < G2; ++g) a2[g] = (lds0 + T2_OFF + n31 * RB + ((hk ^ fsw(n31)) << 4)) ^ (g << 5);
-        int poff[NPB];                                       // element offset of this lane's pixel in block pb, channel 8 h
-#pragma unroll
-        for (int pb = 0; pb < NPB; ++pb)
-            poff[pb] = ((img * a.H + ty * TH + 2 * pb + prr) * a.W + tx * TW + pcc) * C + 8 * hk;
-        const T* wl = a.w3 + (size_t)lane * 8;
-        auto load_w = [&](int u) -> V16 {                    // unit u = q * G2 + g -> fragment (g, ob = wave + 4 q)
-            const int q = u / G2, g = u - q * G2;
-            V16 v;
-            v.u = *(const uint4*)(wl + ((size_t)g * NOB + wave + 4 * q) * 512);
-            return v;
-        };
-        constexpr int NU = NOBW * G2, WD = 3;
-        V16 wf[WD + 1];
-#pragma unroll
-        for (int u = 0; u < WD; ++u) wf[u] = load_w(u);
+        const unsigned a2 = lds0 + T2_OFF + n31 * RB + ((hk ^ fsw(n31)) << 4);   // K block g: ^ (g << 5), pixel block pb: + pb * 32 * RB
         f32x16 acc[NPB];
-        uint4 rq[NPB][2];
-        static_for_b<0, NU>([&](auto uc) {
+        static_for_b<0, NU3>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             constexpr int q = u / G2, g = u % G2;
             const int ob = wave + 4 * q;
             if constexpr (g == 0) {
 #pragma unroll
-                for (int pb = 0; pb < NPB; ++pb) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[pb][e] = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) rq[pb][j] = *(const uint4*)(x + poff[pb] + 32 * ob + 16 * j);
-                }
-            }
-            if constexpr (u + WD < NU) wf[(u + WD) % (WD + 1)] = load_w(u + WD);
-            V16 xb[NPB];
-#pragma unroll
-            for (int pb = 0; pb < NPB; ++pb) xb[pb].u = *(const uint4*)((lptr_t)(size_t)(a2[g] + pb * 32 * RB));
-#pragma unroll
-            for (int pb = 0; pb < NPB; ++pb)
-                acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % (WD + 1)].h, xb[pb].h, acc[pb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (g == G2 - 1) {
-                float esc[16], esf[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int c = 32 * ob + 16 * (e >> 3) + 8 * hk + (e & 7);
-                    esc[e] = a.scale[2][c];
-                    esf[e] = a.shift[2][c];
-                    if (a.bias[2]) esf[e] = a.bias[2][c] * esc[e] + esf[e];
-                }
-#pragma unroll
                 for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const unsigned rr[4] = {rq[pb][j].x, rq[pb][j].y, rq[pb][j].z, rq[pb][j].w};
+                    for (int e = 0; e < 16; ++e) acc[pb][e] = 0.f;
+            }
+            // the residual of the NEXT block (the first one that is read again went out in front of phase 2's epilogue), placed so that every
+            // weight fragment this block still needs is older than it: the fragments requested from here on belong to the next block
+            if constexpr (g == G2 - WD3 && q + 1 < NOBW && q + 1 > NHELD) load_res(q + 1, rq[(q + 1 - NHELD) & 1]);
+            if constexpr (u + WD3 < NU3) wf3[(u + WD3) % (WD3 + 1)] = load_w3(u + WD3);
+            V16 xb[NPB];
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) xb[pb].u = *(const uint4*)((lptr_t)(size_t)((a2 ^ (g << 5)) + pb * 32 * RB));
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb)
+                acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf3[u % (WD3 + 1)].h, xb[pb].h, acc[pb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (g == G2 - 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {                // one 8-channel run at a time: 16 constants live instead of 32
+                    float esc[8], esf[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        esc[e] = csel(cst3, 64 * q, 8 * j + e);
+                        esf[e] = csel(cst3, 64 * q + 32, 8 * j + e);
+                    }
+                    if (a.bias[2]) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) esf[e] = a.bias[2][32 * ob + 16 * j + 8 * hk + e] * esc[e] + esf[e];
+                    }
+#pragma unroll
+                    for (int pb = 0; pb < NPB; ++pb) {
+                        uint4 rv;
+                        if constexpr (q < NHELD) rv = held[q < NHELD ? q : 0][pb][j];
+                        else rv = rq[(q - NHELD) & 1][pb][j];
+                        const unsigned rr[4] = {rv.x, rv.y, rv.z, rv.w};
                         unsigned o[4];
 #pragma unroll
                         for (int d = 0; d < 4; ++d) {
-                            const int e = 8 * j + 2 * d;
-                            const float v0 = fmaxf(acc[pb][e] * esc[e] + esf[e] + __uint_as_float(rr[d] << 16), 0.f);
-                            const float v1 = fmaxf(acc[pb][e + 1] * esc[e + 1] + esf[e + 1] + __uint_as_float(rr[d] & 0xffff0000u), 0.f);
+                            const int e = 2 * d;
+                            const float v0 = fmaxf(acc[pb][8 * j + e] * esc[e] + esf[e] + __uint_as_float(rr[d] << 16), 0.f);
+                            const float v1 = fmaxf(acc[pb][8 * j + e + 1] * esc[e + 1] + esf[e + 1] + __uint_as_float(rr[d] & 0xffff0000u), 0.f);
                             o[d] = pack_bf16x2(v0, v1);
                         }
                         *(uint4*)(a.y + poff[pb] + 32 * ob + 16 * j) = make_uint4(o[0], o[1], o[2], o[3]);
                     }
+                }
             }
         });
     }
+    BN_STAMP(5);
 }
 
-template <int C, int P, int NST>
+template <int C, int P, int NSTR, int NHELD>
 int launch_bneck(const BneckArgs& a, hipStream_t s) {
     constexpr int RB = 2 * P;
-    constexpr int lds = 180 * RB + (NST - 1) * 180 * 64 + 192 * 64;
+    constexpr int lds = 180 * RB + (NSTR - 1) * 180 * 64 + 192 * 64;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    auto kern = bneck_kernel<C, P, NST>;
+    auto kern = bneck_kernel<C, P, NSTR, NHELD>;
     LT_OPT_IN_LDS(kern, lds);
     const long long nblk = (long long)a.N * a.tiles_x * a.tiles_y;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, a);
@@ -410,6 +533,12 @@ int launch_bneck(const BneckArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef LT_BNECK_TRACE
+extern "C" int lt_bneck_trace_read(void* host, int nbytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bneck_trace), nbytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int lt_bottleneck_fwd(const lt_bneck_desc* d, const void* x, void* y, void* stream) {
     LT_REQUIRE(d && x && y, LT_ERR_INVALID, "lt_bottleneck_fwd: null argument");
@@ -435,9 +564,12 @@ extern "C" int lt_bottleneck_fwd(const lt_bneck_desc* d, const void* x, void* y,
     a.N = d->N; a.H = d->H; a.W = d->W;
     a.tiles_x = d->W / 16; a.tiles_y = d->H / 8;
     hipStream_t s = (hipStream_t)stream;
-#ifndef LT_BNECK_NST64
-#define LT_BNECK_NST64 4
+#ifndef LT_BNECK_HELD64
+#define LT_BNECK_HELD64 2
 #endif
-    if (d->P == 64) return launch_bneck<256, 64, LT_BNECK_NST64>(a, s);
-    return launch_bneck<512, 128, 3>(a, s);
+#ifndef LT_BNECK_HELD128
+#define LT_BNECK_HELD128 1
+#endif
+    if (d->P == 64) return launch_bneck<256, 64, 4, LT_BNECK_HELD64>(a, s);
+    return launch_bneck<512, 128, 3, LT_BNECK_HELD128>(a, s);
 }

@@ -111,6 +111,9 @@ class TrainTape:
     def can_chain_pointwise(self, *a, **k):
         return False
 
+    def can_bottleneck(self, *a, **k):     # the training tape records every layer on its own (its backward needs the inner activations)
+        return False
+
     def global_avgpool(self, x):
         """Mean over the map of every sample (GlobalAveragePoolingHead, pose_resnet.py:166-168): x Act [N,1,H,W,C] -> Act [1,1,1,N,C]; backward
         spreads dy / HW over the map (accumulating when the input already has a gradient)."""

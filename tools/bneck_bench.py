@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=128)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--trace", action="store_true", help="library built with -DLT_BNECK_TRACE (LT_HIP_LIB=...): print the phase durations of the last fused launch")
     args = ap.parse_args()
     dev = "cuda:0"
     st = torch.cuda.current_stream().cuda_stream
@@ -43,6 +44,8 @@ def main():
                 y = b.conv(t2, ws[2], None, bns[2], relu=True, residual=xa)
                 os.environ.pop("LT_NO_BNECK")
             plan = b.finish()
+            if fused:
+                plan_f = plan
             for _ in range(3):
                 plan.run_eager(st)
             torch.cuda.synchronize()
@@ -56,6 +59,20 @@ def main():
                 best = min(best, e0.elapsed_ms(e1) / 10)
             res[fused] = (best, y.t.float())
         fl = plan.flops
+        if args.trace:
+            import ctypes
+            import numpy as np
+            lib = H.lib()
+            plan_f.run_eager(st); torch.cuda.synchronize()
+            nwg = min(4096, args.images * (S // 8) * (S // 16))
+            buf = np.zeros(4096 * 4 * 8, dtype=np.uint64)
+            rc = lib.lt_bneck_trace_read(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
+            assert rc == 0, rc
+            tr = buf.reshape(4096, 4, 8)[:nwg].astype(np.int64)
+            d = np.diff(tr[:, :, :6], axis=2).astype(np.float64)          # phase durations per wave
+            names = ["p1 loop", "p1 epi+bar", "p2 loop", "p2 epi+bar", "p3"]
+            print("   trace (%d workgroups, cycles, mean over waves): " % nwg + ", ".join("%s %.0f" % (n, d[:, :, i].mean()) for i, n in enumerate(names)) +
+                  " | total %.0f; kernel span %.0f cycles" % ((tr[:, :, 5] - tr[:, :, 0]).mean(), float(tr[:, :, 5].max() - tr[:, :, 0].min())), flush=True)
         d = float((res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max())
         print("bneck %d/%d @%dx%dx%d: fused %.1f us (%.0f TFLOP/s, %.2f TB/s of x+y) | three launches %.1f us | max rel diff %.2e" % (
             C, P, args.images, S, S, 1e3 * res[True][0], fl / res[True][0] / 1e9, 2 * x.numel() * 2 / res[True][0] / 1e9, 1e3 * res[False][0], d), flush=True)
