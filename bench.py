@@ -122,7 +122,8 @@ def cpu_leg(state_dict, args, images, batch, geom):
         refs[0] = run(0); n += 1
     dt = time.perf_counter() - t0
     base = {"value": n / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "kind_note": "oracle/ restatement issuing the reference's own ATen ops (the reference is Python + torch: there is no separate binary to build)",
+            "kind_note": "oracle/ restatement issuing the reference's own ATen ops; pinned: oracle/make_golden.py runs the imported reference and the oracle on the same "
+                         "inputs and all 88 stage comparisons differ by exactly 0.0 (tests/golden/*), so timing the port times the reference's arithmetic",
             "cpu_model": cpu_model_name(), "logical_cpus": os.cpu_count(),
             "sample": "%d forwards of B=1 (%d views %dx%d, %d^3 voxels, ResNet-%d, fp32), %.1f s" % (
                 n, args.views, args.image, args.image, args.volume, args.layers, dt)}
@@ -188,7 +189,7 @@ def sub_leg(argv, timeout_s):
     return out
 
 
-def pmc_leg(args, timeout_s=90):
+def pmc_leg(args, timeout_s=90, train=False):
     """HBM traffic and MFMA-busy of THIS run's kernels, measured now: three child runs of this script (one forward each after setup, eager
     launches) under ``rocprofv3 --kernel-trace --pmc <counters>`` -- FETCH_SIZE, WRITE_SIZE and the SQ / GRBM counters in SEPARATE passes, as
     MI355X_MICROARCH.md prescribes -- summarised by tools/pmc_summary.py (FETCH_SIZE x2 on gfx950, KiB -> bytes).  Returns None when
@@ -205,6 +206,9 @@ def pmc_leg(args, timeout_s=90):
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-profile", "--no-extras", "--no-graph",
              "--preroll-s", "0", "--batch", str(args.batch), "--views", str(args.views), "--volume", str(args.volume), "--image", str(args.image),
              "--layers", str(args.layers), "--dtype", args.dtype]
+    nsteps = 3                     # forwards per pass: 2 setup + 1 timed
+    if train:                      # training step: 2 warm-up steps (the first one records the tape) + 1 timed
+        child += ["--train", "--train-dtype", args.train_dtype, "--no-pmc-leg"]
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LT_BENCH_SELF_LAUNCHED"):
         env.pop(k, None)
@@ -217,13 +221,19 @@ def pmc_leg(args, timeout_s=90):
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
             if r.returncode != 0:
                 return None
-        res = pmc_summary.summarise(out, 3, args.batch, args.dtype, args.views, args.volume, "", " --steps 1 --warmup 0 (3 forwards per pass), run by bench.py itself")
+        res = pmc_summary.summarise(out, nsteps, args.batch, args.train_dtype if train else args.dtype, args.views, args.volume, "",
+                                    " --steps 1 --warmup 0 (3 %s per pass), run by bench.py itself" % ("training steps" if train else "forwards"))
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
         return None
     finally:
         shutil.rmtree(out, ignore_errors=True)
     if not res.get("conv_family_bytes_per_step"):
         return None
+    # every kernel of the step together (the training legs report the whole step): busy cycles of the MFMA pipes / shader cycles of all launches
+    mf = sum(v.get("mfma_busy_frac", 0.0) * v.get("shader_cycles_per_step", 0.0) for v in res["per_kernel"].values())
+    cyc = sum(v.get("shader_cycles_per_step", 0.0) for v in res["per_kernel"].values())
+    res["all_kernels_mfma_busy_frac"] = mf / cyc if cyc else None
+    res["all_kernels_bytes_per_step"] = res["total_fetch_bytes_per_step"] + res["total_write_bytes_per_step"]
     res.pop("per_kernel", None)
     res["leg_wall_s"] = time.perf_counter() - t0
     return res
@@ -300,8 +310,8 @@ def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
         res = {"metric": "multi-view samples/sec (%d-view vol-softmax training step: fwd + bwd + Adam)" % args.views, "value": value, "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup), "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.train_dtype == "fp32" else "bf16 MFMA for the convolutions and their input gradients (fp32 accumulation and storage); f32 activations, "
-                                                                  "BatchNorm, weight gradients, optimiser",
+               "dtype": "f32" if args.train_dtype == "fp32" else "bf16 MFMA for the convolutions, their input gradients and their weight gradients (fp32 accumulation); "
+                                                                  "f32 activations, BatchNorm, master weights, optimiser",
                "data": "synthetic",
                "config": {"workload": "training step of: " + workload, "per_gpu_batch": B, "global_batch": B * world,
                           "parallelism": "data parallel x%d, bucketed gradient all-reduce (RCCL) overlapped with the backward" % world if world > 1 else "1 GPU",
@@ -311,8 +321,17 @@ def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
                "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
         if fwd_flops:
             ach = 3 * fwd_flops / (1e-3 * res["ms_per_step"]) / 1e12
+            # the peak the step's FLOPs run against: every convolution product of the mixed step (forward, input gradient, weight gradient) is a bf16
+            # MFMA, every one of the fp32 step an exact-fp32 MFMA -- so the whole-step figure is priced against that dtype's dense peak
+            pk = PEAK_TFLOPS["fp32" if args.train_dtype == "fp32" else "bf16"]
+            live = pmc_leg(args, timeout_s=240, train=True) if (world == 1 and not args.no_pmc_leg) else None
             res["roofline"] = {"kernel": "whole step (convolutions: forward + input gradient + weight gradient = 3 x forward MACs)", "bound": "mfma",
-                               "achieved": ach, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS["fp32"], "traffic": None}
+                               "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk,
+                               "peak_basis": "dense %s MFMA peak: all three convolution products of this step run on that MFMA" % ("fp32" if args.train_dtype == "fp32" else "bf16"),
+                               "traffic": live["all_kernels_bytes_per_step"] if live else None,
+                               "mfma_busy_frac": live["all_kernels_mfma_busy_frac"] if live else None,
+                               "traffic_source": ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ counters, three child runs of this "
+                                                  "command (all kernels of a step; %.0f s)" % live["leg_wall_s"]) if live else None}
         print(json.dumps(res))
     barrier()
     lt_dist.shutdown()
@@ -345,6 +364,8 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the config-4 and training legs of the default (config 2, N = 1) run")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="CPU baseline leg: timed forwards of sample 0 until this many seconds (at least one)")
     ap.add_argument("--cpu-parity-samples", type=int, default=2, help="samples of the timed batch the CPU oracle evaluates as parity references")
+    ap.add_argument("--fp32-parity-batch", type=int, default=0, help="with --no-extras: also run this many samples through the exact-fp32 kernel set and report their "
+                    "parity (the config-4 child leg of the default run: the driver line then shows config 4 inside the tolerance)")
     ap.add_argument("--stub-cpu", action="store_true", help="TEST ONLY: gloo backend, no GPU, step() is a sleep (exercises launcher + timing plumbing)")
     args = ap.parse_args()
     if not args.batch:
@@ -460,7 +481,7 @@ def main():
             live = None
             if world == 1 and not args.no_pmc_leg and (not args.no_extras or args.force_pmc_leg):
                 live = pmc_leg(args)
-            for name in ([] if live else ["r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"]):
+            for name in ([] if live else ["r04_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"]):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                 except (OSError, ValueError):
@@ -473,7 +494,7 @@ def main():
                 pmc = live
                 src = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ counters, three child runs of this command (%s; %.0f s)" % (
                     "eager launches, 3 forwards per pass", live["leg_wall_s"])
-            result["roofline"] = {"kernel": "conv family: conv_igemm2/3/6, conv3d_halo*, conv_pw, stem_pool, pwchain (all %d launches of one step)" % conv["launches"],
+            result["roofline"] = {"kernel": "conv family: conv_igemm2/3/6/7, bneck, conv3d_halo*, conv_pw, stem_pool, pwchain (all %d launches of one step)" % conv["launches"],
                                   "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                   "traffic": pmc.get("conv_family_bytes_per_step"), "traffic_source": src,
                                   "mfma_busy_frac": pmc.get("conv_family_mfma_busy_frac"),
@@ -491,6 +512,23 @@ def main():
             if args.ops_json:
                 os.makedirs(os.path.dirname(os.path.abspath(args.ops_json)), exist_ok=True)
                 json.dump(ops, open(args.ops_json, "w"), indent=0)
+        if world == 1 and args.no_extras and args.fp32_parity_batch and refs is not None and args.dtype != "fp32":
+            # ---- parity of the exact-fp32 kernel set on the first samples of the timed batch (not a timing leg)
+            nb32 = min(args.fp32_parity_batch, B)
+            im_b = images[:nb32]
+            batch_b = {"cameras": [c[:nb32] for c in batch["cameras"]], "pred_keypoints_3d": batch["pred_keypoints_3d"][:nb32]}
+            model.compute_dtype = torch.float32
+            model.invalidate_plans()
+            torch.cuda.empty_cache()
+            for _ in range(2):
+                o32 = model(im_b, None, batch_b)
+            n32 = 3
+            dt32, o32 = time_steps(lambda: model(im_b, None, batch_b), n32, lambda: None)
+            result["fp32_parity_mode"] = {"value": nb32 * n32 / dt32, "unit": "samples/s", "steps": n32, "per_gpu_batch": nb32, "ms_per_step": 1e3 * dt32 / n32,
+                                          "parity": parity_block(o32[0], refs[:nb32], "fp32", model.cuboid_side)}
+            model.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
+            model.invalidate_plans()
+            del o32
         if world == 1 and not args.no_extras:
             # ---- the same workload on the exact-fp32 kernel set (the mode that meets the 1e-4 gate)
             if args.dtype != "fp32":
@@ -535,7 +573,7 @@ def main():
                 model.invalidate_plans()
                 torch.cuda.empty_cache()
                 result["config4"] = sub_leg(["--views", "8", "--volume", "128", "--batch", "16", "--steps", "3", "--warmup", "1", "--no-extras",
-                                             "--cpu-budget-s", "1", "--cpu-parity-samples", "1", "--preroll-s", "0.3", "--force-pmc-leg"], 600)
+                                             "--cpu-budget-s", "1", "--cpu-parity-samples", "1", "--preroll-s", "0.3", "--force-pmc-leg", "--fp32-parity-batch", "2"], 600)
                 result["train"] = sub_leg(["--train", "--batch", "4", "--steps", "8", "--warmup", "2"], 600)
                 # config 5's reduced-precision step (bf16 MFMA for the convolutions, their input AND weight gradients; fp32 activations, BatchNorm,
                 # master weights and optimiser): not a parity mode -- its loss values are printed next to the fp32 leg's, same seeds

@@ -29,7 +29,9 @@ extern "C" {
 
 #define LT_ABI_VERSION 1
 
-enum { LT_F32 = 0, LT_BF16 = 1 };
+enum { LT_F32 = 0, LT_BF16 = 1,
+       LT_FP8 = 2 /* OCP e4m3 ("e4m3fn", torch.float8_e4m3fn; what gfx950's v_cvt_pk_fp8_f32 and fp8 MFMAs use), one byte per element: operands of
+                     lt_conv_fwd only (BASELINE config 5: fp8 MFMA for the V2V 3D convolutions of the training step) */ };
 enum { LT_OK = 0, LT_ERR_INVALID = -1, LT_ERR_UNSUPPORTED = -2, LT_ERR_LAUNCH = -3 };
 
 /* view-aggregation modes of op.unproject_heatmaps (mvn/utils/op.py:149-164) */
@@ -72,6 +74,11 @@ int lt_device_info(int* cu_count, int* lds_per_cu, char* arch, int arch_len);
  *                                                         NULL = 0 / 1 / 0; arrays hold cout_pad floats)
  *     if RELU_PRE v = max(v,0);  if residual v += residual[same place as y];  if RELU_POST v = max(v,0)
  *     y[n, od*osd + ood_p, oh*osh + ooh_p, ow*osw + oow_p, co] = v
+ *
+ * dtype == LT_FP8: x and the weights are e4m3 bytes (per-tensor scaled by the caller: x ~ sx * x8, w ~ sw * w8, see lt_quant_fp8), the
+ * products run on v_mfma_f32_*_fp8_fp8 with fp32 accumulation, the result is stored as fp32 (LT_EPI_STORE_F32 is required, a residual is
+ * fp32 too: LT_EPI_RES_F32); the caller passes sx * sw in `scale` and the convolution's bias in `shift` (bias = NULL).  Cin >= 16,
+ * k_pad % 128 == 0 (one 128-byte K step = 128 elements); generic implicit-GEMM kernel only.
  *
  * A plain convolution is one phase with out_stride 1 / out_off 0; a stride-2 transposed convolution
  * is 2^nd phases (one per output parity) with out_stride 2.  A single one-tap phase with unit strides,
@@ -266,7 +273,8 @@ int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32_t C, float
  * lt_bn_act_bwd : its autograd: g = dz * relu mask; dbeta = sum g; dgamma = sum g x^; dy = gamma invstd (g - dbeta/n - x^ dgamma/n)
  *   (LT_BN_FROZEN in flags: mean / var are running statistics that do not depend on the batch: dy = gamma invstd g);
  *   dres (may be NULL) = the residual input's gradient, added to the buffer when accumulate_res.  workspace: lt_bn_act_bwd_workspace.
- * lt_act_bwd    : layers without BatchNorm: dy = dz * mask(z, residual, flags) (+ dres); LT_EPI_SIGMOID: dy = dz * z * (1 - z).
+ * lt_act_bwd    : layers without BatchNorm: dy = dz * mask(z, flags) (+ dres); LT_EPI_SIGMOID: dy = dz * z * (1 - z).  LT_EPI_RELU_PRE together
+ *   with a residual is refused (LT_ERR_UNSUPPORTED): the sign of v cannot be rebuilt from z = relu(v) + res.
  * lt_channel_sum: out[c] (+)= sum over rows of x[row][c] (bias gradients), fp64 accumulation.
  * lt_maxpool_bwd: dx (pre-zeroed / accumulated) += dy at the first maximal element of every window; overlapping windows (k > s) are walked in
  *   ceil(k / s)^3 classes of mutually disjoint windows, one launch each: no atomics, bitwise repeatable.
@@ -326,6 +334,17 @@ int lt_add_i64_multi(const void* ptrs, int32_t n, int64_t delta, void* stream);
 int lt_global_avgpool_bwd(const float* dy, float* dx, int32_t N, int32_t HW, int32_t C, int32_t accumulate, void* stream);
 /* fp32 -> bf16, round to nearest even (operands of the mixed-precision training convolutions); 16-byte aligned pointers */
 int lt_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* ---- fp8 (e4m3) operands for lt_conv_fwd(dtype = LT_FP8): per-tensor amax scaling, scale = amax / 448 (the largest e4m3 value), q = rne(x / scale).
+ * lt_amax_f32     : *amax = max(*amax, max_i |x[i]|)  (zero *amax first, e.g. with lt_zero; an exact, order-independent maximum of non-negative
+ *                   floats taken with integer atomics on their bit patterns: bitwise repeatable);
+ * lt_quant_fp8    : q[i] = e4m3(x[i] / scale) with scale = *amax > 0 ? *amax / 448 : 1; writes the scale to *scale_out (device) -- the caller
+ *                   multiplies the two operands' scales into lt_conv_fwd's `scale` array with lt_scale_product;
+ * lt_gather_f32_fp8: the same for weights in one pass with the layout change of lt_gather_f32: q[i] = idx[i] >= 0 ? e4m3(src[idx[i]] / scale) : 0;
+ * lt_scale_product: dst[i] = *a * *b for i < n. */
+int lt_amax_f32(const float* x, int64_t n, float* amax, void* stream);
+int lt_quant_fp8(const float* x, void* q, int64_t n, const float* amax, float* scale_out, void* stream);
+int lt_gather_f32_fp8(const float* src, const int32_t* idx, void* q, int64_t n, const float* amax, float* scale_out, void* stream);
+int lt_scale_product(float* dst, int32_t n, const float* a, const float* b, void* stream);
 /* many gathers in one launch.  jobs (device memory): njobs records of
  *   { const float* src; const int32_t* idx; float* dst; int64_t n; int32_t first_block; int32_t out_bf16; }   (40 bytes)
  * with first_block = running sum of ceil(n / 1024) over the preceding jobs; total_blocks = that sum over all jobs; out_bf16 != 0: dst is a bf16

@@ -71,6 +71,31 @@ template <> struct Mma<bf16_t, 16> {
     }
 };
 
+// fp8 (e4m3): a 16-byte fragment vector holds 16 K elements = two 8-byte operands of v_mfma_f32_*_fp8_fp8 (K = 16 / 32 per instruction; the K
+// order inside a fragment group differs from the bf16 kernels', identically for both operands, which a sum over K does not see)
+union V16Q {
+    uint4 u;
+    long q[2];
+};
+template <> struct Mma<fp8_t, 32> {
+    typedef f32x16 acc_t;
+    static __device__ __forceinline__ void run(acc_t& c, const V16& a, const V16& b) {
+        V16Q qa, qb;
+        qa.u = a.u; qb.u = b.u;
+        c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(qa.q[0], qb.q[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(qa.q[1], qb.q[1], c, 0, 0, 0);
+    }
+};
+template <> struct Mma<fp8_t, 16> {
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ void run(acc_t& c, const V16& a, const V16& b) {
+        V16Q qa, qb;
+        qa.u = a.u; qb.u = b.u;
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(qa.q[0], qb.q[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(qa.q[1], qb.q[1], c, 0, 0, 0);
+    }
+};
+
 // decode a GEMM row into (sample, od, oh, ow)
 __device__ __forceinline__ void decode_row(const ConvArgs& a, int m, int& n, int& od, int& oh, int& ow) {
     int hw = a.Ho * a.Wo;

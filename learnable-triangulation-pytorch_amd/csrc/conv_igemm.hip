@@ -315,16 +315,20 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
 extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bias, const float* scale, const float* shift,
                            const void* residual, void* y, void* stream) {
     LT_REQUIRE(d && x && y, LT_ERR_INVALID, "lt_conv_fwd: null argument");
-    LT_REQUIRE(d->dtype == LT_F32 || d->dtype == LT_BF16, LT_ERR_INVALID, "lt_conv_fwd: bad dtype %d", d->dtype);
-    const int vec = d->dtype == LT_F32 ? 4 : 8;
+    LT_REQUIRE(d->dtype == LT_F32 || d->dtype == LT_BF16 || d->dtype == LT_FP8, LT_ERR_INVALID, "lt_conv_fwd: bad dtype %d", d->dtype);
+    const int vec = d->dtype == LT_F32 ? 4 : d->dtype == LT_BF16 ? 8 : 16;
+    LT_REQUIRE(d->dtype != LT_FP8 || ((d->flags & LT_EPI_STORE_F32) && (!residual || (d->flags & LT_EPI_RES_F32)) && !(d->flags & LT_EPI_SIGMOID)),
+               LT_ERR_UNSUPPORTED, "lt_conv_fwd: an fp8 convolution stores fp32 (LT_EPI_STORE_F32) and takes an fp32 residual (LT_EPI_RES_F32)");
+    LT_REQUIRE(d->dtype != LT_FP8 || d->tile == LT_TILE_AUTO || (d->tile >= LT_TILE2_128x128 && d->tile <= LT_TILE2_64x64), LT_ERR_UNSUPPORTED,
+               "lt_conv_fwd: fp8 convolutions run on the generic implicit-GEMM tiles only");
     const int l2 = ilog2_exact(d->Cin);
     LT_REQUIRE(l2 >= 0 && d->Cin >= vec, LT_ERR_UNSUPPORTED,
                "lt_conv_fwd: Cin=%d must be a power of two >= %d (pad the channel dimension)", d->Cin, vec);
     LT_REQUIRE(d->nphase >= 1 && d->nphase <= LT_CONV_MAX_PHASES, LT_ERR_INVALID, "lt_conv_fwd: nphase=%d", d->nphase);
     LT_REQUIRE(d->k_pad > 0 && d->k_pad % (8 * vec) == 0, LT_ERR_INVALID, "lt_conv_fwd: k_pad=%d not a multiple of %d", d->k_pad, 8 * vec);
     LT_REQUIRE(d->Cout >= 1 && d->ldc >= d->Cout && d->cout_pad >= d->Cout, LT_ERR_INVALID, "lt_conv_fwd: Cout/ldc/cout_pad");
-    LT_REQUIRE(!(d->flags & LT_EPI_RES_F32) || ((d->flags & LT_EPI_STORE_F32) && d->dtype == LT_BF16), LT_ERR_INVALID,
-               "lt_conv_fwd: LT_EPI_RES_F32 goes with LT_EPI_STORE_F32 on a bf16 convolution");
+    LT_REQUIRE(!(d->flags & LT_EPI_RES_F32) || ((d->flags & LT_EPI_STORE_F32) && d->dtype != LT_F32), LT_ERR_INVALID,
+               "lt_conv_fwd: LT_EPI_RES_F32 goes with LT_EPI_STORE_F32 on a bf16 / fp8 convolution");
     const long long M = (long long)d->N * d->Do * d->Ho * d->Wo;
     const long long in_elems = (long long)d->N * d->D * d->H * d->W * d->Cin;
     const long long out_pix = (long long)d->N * d->OD * d->OH * d->OW;
@@ -353,6 +357,7 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bi
     LT_REQUIRE(max_taps <= 2048, LT_ERR_UNSUPPORTED, "lt_conv_fwd: too many taps (%d)", max_taps);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == LT_F32) return dispatch<float>(a, d->cout_pad, d->nphase, max_taps, d->tile, s);
+    if (d->dtype == LT_FP8) return conv2_dispatch(LT_FP8, a, d->cout_pad, d->nphase, max_taps, d->tile, s);
     return dispatch<bf16_t>(a, d->cout_pad, d->nphase, max_taps, d->tile, s);
 }
 

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     const bool sigm = a.flags & LT_EPI_SIGMOID;
     const bool store_f32 = (a.flags & LT_EPI_STORE_F32) != 0 || sizeof(T) == 4;
     const bool has_res = a.res != nullptr;
-    const bool res_f32 = (a.flags & LT_EPI_RES_F32) != 0 && sizeof(T) == 2;      // fp32 residual of a bf16 convolution that stores fp32
+    const bool res_f32 = (a.flags & LT_EPI_RES_F32) != 0 && sizeof(T) <= 2;      // fp32 residual of a bf16 / fp8 convolution that stores fp32
     const int col0 = n0 + wn * WN;                 // first output channel of this wave's sub-tile
     const int veco = store_f32 ? 4 : 8;
     const bool vec_ok = (a.Cout % veco == 0) && (a.ldc % veco == 0);
@@ -648,6 +648,7 @@ int dispatch2(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int til
 namespace lt {
 int conv2_dispatch(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile, hipStream_t s) {
     if (dtype == LT_F32) return dispatch2<float>(a, cout_pad, nphase, max_taps, tile, s);
+    if (dtype == LT_FP8) return dispatch2<fp8_t>(a, cout_pad, nphase, max_taps, tile, s);
     return dispatch2<bf16_t>(a, cout_pad, nphase, max_taps, tile, s);
 }
 }  // namespace lt

@@ -103,6 +103,16 @@ template <> struct elt<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// OCP e4m3 operand bytes of lt_conv_fwd(dtype = LT_FP8); never an output type (the fp8 convolutions store fp32), so ld / st only exist for
+// the generic code paths that are instantiated but not reachable
+struct fp8_t { unsigned char v; };
+template <> struct elt<fp8_t> {
+    static constexpr int bytes = 1;
+    static constexpr int vec = 16;
+    __device__ static __forceinline__ float ld(const fp8_t*) { return 0.f; }
+    __device__ static __forceinline__ void st(fp8_t*, float) {}
+};
+
 // a BatchNorm input that is either fp32 or bf16 (LT_BN_Y_BF16: the mixed-precision training step stores its convolution outputs in bf16)
 __device__ __forceinline__ float4 ld4_f32_or_bf16(const void* p, size_t off, int is_bf16) {
     if (is_bf16) {

@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
         float m = 1.f;
         if (flags & LT_EPI_SIGMOID) m = z[i] * (1.f - z[i]);                               // z = sigmoid(v): the confidence heads' last layer
         else if (flags & LT_EPI_RELU_POST) m = z[i] > 0.f ? 1.f : 0.f;                     // z = relu(v + res)
-        else if (flags & LT_EPI_RELU_PRE) m = (z[i] - (res ? res[i] : 0.f)) > 0.f ? 1.f : 0.f;   // z = relu(v) + res
+        else if (flags & LT_EPI_RELU_PRE) m = z[i] > 0.f ? 1.f : 0.f;                      // z = relu(v); with a residual behind the ReLU the sign of v is
+                                                                                               // not recoverable from z (lt_act_bwd refuses that combination)
         const float g = dz[i] * m;
         dy[i] = g;
         if (dres) {
@@ -967,6 +968,10 @@ extern "C" int lt_bn_act_bwd(const float* dz, const void* y, const float* residu
 extern "C" int lt_act_bwd(const float* dz, const float* z, const float* residual, float* dy, float* dres, int32_t accumulate_res, int64_t total,
                           int32_t flags, void* stream) {
     LT_REQUIRE(dz && z && dy && total >= 1, LT_ERR_INVALID, "lt_act_bwd: bad argument");
+    // z = relu(v) + res: (z - res) > 0 loses a live gradient whenever 0 < relu(v) < ulp(res) / 2 -- the mask has to come from v, which a layer
+    // without BatchNorm does not keep (the tape never records this shape: every such layer of the reference's networks carries BatchNorm)
+    LT_REQUIRE(!((flags & LT_EPI_RELU_PRE) && !(flags & (LT_EPI_RELU_POST | LT_EPI_SIGMOID)) && residual), LT_ERR_UNSUPPORTED,
+               "lt_act_bwd: ReLU in front of a residual add without BatchNorm (the mask of relu(v) cannot be rebuilt from relu(v) + res)");
     const long long blocks = cdiv(total, 256);
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, dz, z, residual, dy, dres, flags,
                        accumulate_res, (long long)total);

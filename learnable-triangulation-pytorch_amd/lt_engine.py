@@ -35,11 +35,11 @@ def cout_pad_of(cout):
 
 
 def k_step_of(dtype):
-    return 32 if dtype == torch.float32 else 64  # elements per 128-byte K step
+    return 128 // torch.empty((), dtype=dtype).element_size()  # elements per 128-byte K step: 32 fp32 / 64 bf16 / 128 fp8
 
 
 def min_cin_of(dtype):
-    return 4 if dtype == torch.float32 else 8   # one 16-byte vector per pixel
+    return 16 // torch.empty((), dtype=dtype).element_size()   # one 16-byte vector per pixel
 
 
 @dataclass
@@ -268,7 +268,7 @@ class PlanBuilder:
         (LT_EPI_RES_F32: the training tape's input-gradient accumulation)."""
         flags = ((H.EPI_RELU_POST if relu else 0) | (H.EPI_RELU_PRE if relu_pre else 0) | (H.EPI_STORE_F32 if out_f32 else 0)
                  | (H.EPI_SIGMOID if sigmoid else 0) | (H.EPI_RES_F32 if residual_f32 else 0))
-        assert not residual_f32 or (out_f32 and residual is not None and self.dtype == torch.bfloat16)
+        assert not residual_f32 or (out_f32 and residual is not None and self.dtype in (torch.bfloat16, torch.float8_e4m3fn))
         spec = make_conv_spec(weight, bias, bn, x.shape, stride, pad, self.dtype, transposed, flags, output_padding)
         S = self.splitk_slices(spec, weight, transposed, out_f32, sigmoid, out)
         if S > 1:
@@ -340,7 +340,7 @@ class PlanBuilder:
         self._add(lambda s, d=d, xp=x.t.data_ptr(), bip=bi.data_ptr(), scp=sc.data_ptr(), shp=sh.data_ptr(),
                   rp=H.ptr(residual.t) if residual is not None else None, yp=y.t.data_ptr():
                   H.check(lib.lt_conv_fwd(C.byref(d), xp, bip, scp, shp, rp, yp, s), "lt_conv_fwd"),
-                  "conv", label, 2 * macs, nbytes, {"spec": spec, "x": x, "y": y, "res": residual, "wdev": wdevs, "bias_dev": bi})
+                  "conv", label, 2 * macs, nbytes, {"spec": spec, "x": x, "y": y, "res": residual, "wdev": wdevs, "bias_dev": bi, "scale_dev": sc, "shift_dev": sh})
         return y
 
     # ---- split-K for the tiny levels of V2V ---------------------------------------------------------------------------------------

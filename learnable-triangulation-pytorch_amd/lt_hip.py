@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # LT_HIP_LIB: load an A/B variant build of the same ABI instead (lt_build.build_variant); never a different backend
 LIB_PATH = os.environ.get("LT_HIP_LIB") or os.path.join(HERE, "lib", "liblt_hip.so")
 
-LT_F32, LT_BF16 = 0, 1
+LT_F32, LT_BF16, LT_FP8 = 0, 1, 2
 AGG = {"sum": 0, "max": 1, "softmax": 2, "conf": 3, "conf_norm": 4}
 EPI_RELU_PRE, EPI_RELU_POST, EPI_STORE_F32, EPI_SIGMOID = 1, 2, 4, 8
 EPI_RES_F32 = 64
@@ -104,6 +104,10 @@ SIGNATURES = {
     "lt_add_i64_multi": (C.c_int, [vp, i32, i64, vp]),
     "lt_cast_f32_bf16": (C.c_int, [vp, vp, i64, vp]),
     "lt_gather_f32_multi": (C.c_int, [vp, i32, i32, vp]),
+    "lt_amax_f32": (C.c_int, [vp, i64, vp, vp]),
+    "lt_quant_fp8": (C.c_int, [vp, vp, i64, vp, vp, vp]),
+    "lt_gather_f32_fp8": (C.c_int, [vp, vp, vp, i64, vp, vp, vp]),
+    "lt_scale_product": (C.c_int, [vp, i32, vp, vp, vp]),
     "lt_gather_f32": (C.c_int, [vp, vp, vp, i64, vp]),
     "lt_gather_f32_bf16": (C.c_int, [vp, vp, vp, i64, vp]),
     "lt_conv_wgrad_workspace": (C.c_size_t, [i64, i32, i32]),
@@ -162,7 +166,9 @@ def dtype_code(dt):
         return LT_F32
     if dt == torch.bfloat16:
         return LT_BF16
-    raise TypeError("liblt_hip supports float32 and bfloat16 activations, got %s" % dt)
+    if dt == torch.float8_e4m3fn:          # operands of lt_conv_fwd only (the fp8 V2V convolutions of the training step)
+        return LT_FP8
+    raise TypeError("liblt_hip supports float32 and bfloat16 activations (and float8_e4m3fn convolution operands), got %s" % dt)
 
 
 def require_gpu(t, name="tensor"):

@@ -87,16 +87,26 @@ def test_act_bwd_and_channel_sum(flags_name):
     pd, rd = pre.double().requires_grad_(True), res.double().requires_grad_(True)
     n = pd
     if flags_name == "relu_pre":
+        # z = relu(v) alone: the mask is z > 0.  With a residual BEHIND the ReLU the sign of v cannot be rebuilt from relu(v) + res
+        # ((z - res) > 0 loses live gradients below half an ulp of res): the entry point refuses that combination
         n = F.relu(n)
-    n = n + rd
-    if flags_name == "relu":
-        n = F.relu(n)
-    (n * dz.double()).sum().backward()
-    zg, dzg, resg = n.detach().float().to(DEV), dz.to(DEV), res.to(DEV)
-    dy, dres = torch.empty_like(zg), torch.empty_like(zg)
-    H.check(lib.lt_act_bwd(dzg.data_ptr(), zg.data_ptr(), resg.data_ptr(), dy.data_ptr(), dres.data_ptr(), 0, rows * C, flags, _st()), "lt_act_bwd")
-    check("train/act_bwd %s dy" % flags_name, dy.cpu(), pd.grad, 1e-6)
-    check("train/act_bwd %s dres" % flags_name, dres.cpu(), rd.grad, 1e-6)
+        (n * dz.double()).sum().backward()
+        zg, dzg, resg = n.detach().float().to(DEV), dz.to(DEV), res.to(DEV)
+        dy, dres = torch.empty_like(zg), torch.empty_like(zg)
+        H.check(lib.lt_act_bwd(dzg.data_ptr(), zg.data_ptr(), None, dy.data_ptr(), None, 0, rows * C, flags, _st()), "lt_act_bwd")
+        check("train/act_bwd relu_pre dy", dy.cpu(), pd.grad, 1e-6)
+        assert lib.lt_act_bwd(dzg.data_ptr(), zg.data_ptr(), resg.data_ptr(), dy.data_ptr(), dres.data_ptr(), 0, rows * C, flags, _st()) == -2
+        assert b"residual" in lib.lt_last_error()
+    else:
+        n = n + rd
+        if flags_name == "relu":
+            n = F.relu(n)
+        (n * dz.double()).sum().backward()
+        zg, dzg, resg = n.detach().float().to(DEV), dz.to(DEV), res.to(DEV)
+        dy, dres = torch.empty_like(zg), torch.empty_like(zg)
+        H.check(lib.lt_act_bwd(dzg.data_ptr(), zg.data_ptr(), resg.data_ptr(), dy.data_ptr(), dres.data_ptr(), 0, rows * C, flags, _st()), "lt_act_bwd")
+        check("train/act_bwd %s dy" % flags_name, dy.cpu(), pd.grad, 1e-6)
+        check("train/act_bwd %s dres" % flags_name, dres.cpu(), rd.grad, 1e-6)
     out = torch.empty(C, device=DEV)
     ws = torch.empty(max(1, lib.lt_channel_sum_workspace(rows, C)), dtype=torch.uint8, device=DEV)
     H.check(lib.lt_channel_sum(dzg.data_ptr(), rows, C, out.data_ptr(), 0, ws.data_ptr(), _st()), "lt_channel_sum")
@@ -853,10 +863,11 @@ def test_mixed_precision_training_step_deviation_and_descent(golden_dir):
         sub = f[::max(1, f.numel() // 129)][:129]
         errs.append(float((sub - torch.from_numpy(G["g/" + n]).double()).abs().max()) / float(G["gn/" + n][1]))
     errs.sort()
-    record("train/mixed precision (bf16 MFMA convolutions) one step vs the reference's fp32 step -- deviation, not gated",
+    record("train/mixed precision (bf16 MFMA convolutions) one step vs the reference's fp32 step -- gated: median <= 8 %, p90 <= 20 %",
            {"joints_max_rel": float(d.max()), "mae": float(mae.detach()), "mae_reference": float(G["mae"]), "ce": float(ce.detach()), "ce_reference": float(G["ce"]),
             "parameter_gradient_err_median": errs[len(errs) // 2], "parameter_gradient_err_p90": errs[int(len(errs) * 0.9)], "parameter_gradient_err_max": errs[-1]})
-    assert float(d.max()) < 5e-2 and errs[len(errs) // 2] < 0.2, (float(d.max()), errs[len(errs) // 2])
+    # gated at the level the mode achieves on this fixture (VERDICT r3 "next" 8): median 6.3 %, p90 15.8 % of each tensor's largest reference gradient
+    assert float(d.max()) < 5e-2 and errs[len(errs) // 2] <= 0.08 and errs[int(len(errs) * 0.9)] <= 0.20, (float(d.max()), errs[len(errs) // 2], errs[int(len(errs) * 0.9)])
     # descent
     opt = lt_train.Adam(list(m.parameters()), lr=1e-4)
     gt2 = torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float().to(DEV)
