@@ -260,6 +260,15 @@ def family_table(ops):
     return fam, conv
 
 
+TRAIN_DTYPE_NOTE = {
+    "fp32": "f32",
+    "bf16": "bf16 MFMA for the convolutions, their input gradients and their weight gradients (fp32 accumulation); f32 activations, BatchNorm, master weights, optimiser",
+    "act16": "bf16 MFMA for the convolutions, their input gradients and their weight gradients (fp32 accumulation); bf16 activations and activation gradients "
+             "(BASELINE config 5's 16-bit activations); f32 BatchNorm statistics, parameter gradients, master weights, optimiser",
+    "fp8v2v": "act16 with V2V's 3x3x3 convolutions and their input gradients on the fp8 (e4m3, per-tensor amax scale) MFMA -- BASELINE config 5 as named",
+}
+
+
 def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
     """--train: BASELINE config 5's step in its present form -- train-mode forward (batch-statistics BatchNorm), MAE + 0.01 x
     VolumetricCELoss (train.py:217-230), backward, gradient all-reduce over RCCL for N > 1 (overlapped with the backward,
@@ -310,8 +319,7 @@ def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
         res = {"metric": "multi-view samples/sec (%d-view vol-softmax training step: fwd + bwd + Adam)" % args.views, "value": value, "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup), "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.train_dtype == "fp32" else "bf16 MFMA for the convolutions, their input gradients and their weight gradients (fp32 accumulation); "
-                                                                  "f32 activations, BatchNorm, master weights, optimiser",
+               "dtype": TRAIN_DTYPE_NOTE[args.train_dtype],
                "data": "synthetic",
                "config": {"workload": "training step of: " + workload, "per_gpu_batch": B, "global_batch": B * world,
                           "parallelism": "data parallel x%d, bucketed gradient all-reduce (RCCL) overlapped with the backward" % world if world > 1 else "1 GPU",
@@ -356,7 +364,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32, help="host threads for the CPU baseline leg")
     ap.add_argument("--tile", type=int, default=0, help="force a conv tile id (LT_TILE_*), 0 = auto")
     ap.add_argument("--preroll-s", type=float, default=1.0, help="untimed steady-state run before the W warm-up steps (clocks settle)")
-    ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="--train: fp32 (the reference's precision, default) or bf16 = the "
+    ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16", "act16", "fp8v2v"], help="--train: act16 = bf16 MFMA + bf16 activations / activation gradients; fp8v2v = act16 + fp8 V2V convolutions; fp32 (the reference's precision, default) or bf16 = the "
                     "convolutions and their input gradients on the bf16 MFMA (bf16 copies of the operands, fp32 accumulation / storage), everything else fp32")
     ap.add_argument("--train", action="store_true", help="time the training step (fwd + bwd + Adam, fp32) instead of the forward; its own JSON line")
     ap.add_argument("--force-pmc-leg", action="store_true", help="measure roofline.traffic live even with --no-extras (the config-4 child leg of the default run)")

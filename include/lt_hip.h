@@ -48,8 +48,12 @@ enum {
                              gradient that is already there in the epilogue of the next input-gradient convolution) */
     LT_BN_FROZEN = 32,    /* lt_bn_act_bwd only: mean / var are FROZEN running statistics (a BatchNorm module in eval() inside a training step):
                              dy = gamma invstd g, without the batch-statistics terms; dgamma / dbeta as usual */
-    LT_BN_Y_BF16 = 128    /* lt_bn_act_fwd / lt_bn_act_bwd: the convolution output y is a bf16 tensor (the mixed-precision training step stores it in
+    LT_BN_Y_BF16 = 128,   /* lt_bn_act_fwd / lt_bn_act_bwd: the convolution output y is a bf16 tensor (the mixed-precision training step stores it in
                              16 bits; lt_bn_stats_fwd takes dtype = LT_BF16 for the same tensor); C % 4 == 0 */
+    LT_ACT_BF16 = 256     /* lt_bn_act_fwd / lt_bn_act_bwd / lt_act_bwd: the 16-bit-activation training step (BASELINE config 5: "fp16 activations" -- bf16 here,
+                             the 16-bit type whose MFMA products need no loss scaling): every activation-shaped tensor of the call other than y -- residual
+                             and z (forward); dz, residual, dy, dres (backward) -- is a bf16 tensor behind the same pointer argument; the separate bf16
+                             copies (z_bf16 / dy_bf16) must be NULL; C % 4 == 0 for the BatchNorm calls.  Statistics, gamma / beta and their gradients stay fp32. */
 };
 
 const char* lt_last_error(void);
@@ -285,19 +289,24 @@ int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32_t C, float
  *   stride 2): dw[ci][tap * Cout + co].
  * lt_adam_step  : torch.optim.Adam's single-tensor update (bias-corrected, eps outside the sqrt).
  * -------------------------------------------------------------------------------------------*/
-int lt_bn_act_fwd(const void* y /* fp32, or bf16 with LT_BN_Y_BF16 */, const float* mean, const float* var, const float* gamma, const float* beta, const float* residual, float* z,
+int lt_bn_act_fwd(const void* y /* fp32, or bf16 with LT_BN_Y_BF16 */, const float* mean, const float* var, const float* gamma, const float* beta, const void* residual, void* z,
                   void* z_bf16 /* optional: a bf16 copy of z on the way (mixed-precision training), or NULL */, int64_t rows, int32_t C, float eps,
                   int32_t flags, void* stream);
 size_t lt_bn_act_bwd_workspace(int64_t rows, int32_t C);
-int lt_bn_act_bwd(const float* dz, const void* y /* fp32, or bf16 with LT_BN_Y_BF16 */, const float* residual, const float* mean, const float* var, const float* gamma, const float* beta,
-                  float* dy, void* dy_bf16 /* optional bf16 copy of dy, or NULL */, float* dgamma, float* dbeta, float* dres, int32_t accumulate_res,
+int lt_bn_act_bwd(const void* dz, const void* y /* fp32, or bf16 with LT_BN_Y_BF16 */, const void* residual, const float* mean, const float* var, const float* gamma, const float* beta,
+                  void* dy, void* dy_bf16 /* optional bf16 copy of dy, or NULL */, float* dgamma, float* dbeta, void* dres, int32_t accumulate_res,
                   int64_t rows, int32_t C, float eps, int32_t flags, void* workspace, void* stream);
-int lt_act_bwd(const float* dz, const float* z, const float* residual, float* dy, float* dres, int32_t accumulate_res, int64_t total, int32_t flags,
+int lt_act_bwd(const void* dz, const void* z, const void* residual, void* dy, void* dres, int32_t accumulate_res, int64_t total, int32_t flags,
                void* stream);
 size_t lt_channel_sum_workspace(int64_t rows, int32_t C);
 int lt_channel_sum(const float* x, int64_t rows, int32_t C, float* out, int32_t accumulate, void* workspace, void* stream);
+/* the same over a tensor of element type `dtype` (LT_F32 | LT_BF16: the 16-bit-activation training step); same workspace */
+int lt_channel_sum_dt(int32_t dtype, const void* x, int64_t rows, int32_t C, float* out, int32_t accumulate, void* workspace, void* stream);
 int lt_maxpool_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, const int32_t k[3],
                    const int32_t s[3], const int32_t p[3], void* stream);
+/* x, dy, dx of element type `dtype` (LT_F32 | LT_BF16); the (up to ceil(k / s)^3) contributions an input collects are added in the class order, in `dtype` */
+int lt_maxpool_bwd_dt(int32_t dtype, const void* x, const void* dy, void* dx, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, const int32_t k[3],
+                      const int32_t s[3], const int32_t p[3], void* stream);
 size_t lt_conv_wgrad_workspace(int64_t rows, int32_t cout_pad, int32_t k_pad);
 int lt_conv_wgrad(const float* dy, const float* x, const int32_t* taps, float* dw, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin, int32_t Do,
                   int32_t Ho, int32_t Wo, const int32_t stride[3], const int32_t pad[3], int32_t Cout, int32_t ldy, int32_t cout_pad, int32_t k_pad,
@@ -326,6 +335,9 @@ int lt_gather_f32_bf16(const float* src, const int32_t* idx, void* dst_bf16, int
  * the 17-joint layer widened to the power-of-two channel count lt_conv_fwd wants on its input); zero fill (scatter targets) */
 int lt_add_f32(float* y, const float* x, int64_t n, void* stream);
 int lt_pad_channels_f32(const float* src, float* dst, int64_t rows, int32_t C, int32_t c_pad, void* stream);
+/* the same with a change of element type on the way (src_dtype / dst_dtype: LT_F32 | LT_BF16, round to nearest even; c_pad == C: a plain cast): the fp32 <-> bf16
+ * boundaries of the 16-bit-activation training step (loss gradient in, unprojection backward in / out); 16-byte aligned pointers */
+int lt_convert_pad(int32_t src_dtype, const void* src, int32_t dst_dtype, void* dst, int64_t rows, int32_t C, int32_t c_pad, void* stream);
 int lt_zero(void* p, int64_t nbytes, void* stream);
 /* *ptrs[i] += delta for n int64 scalars in device memory (ptrs: device array of n pointers): BatchNorm's num_batches_tracked counters of a
  * whole network in one launch (torch: one `num_batches_tracked += 1` kernel per layer, pose_resnet.py / v2v.py BatchNorm modules in train()) */

@@ -125,6 +125,16 @@ __device__ __forceinline__ float ld1_f32_or_bf16(const void* p, size_t off, int 
     return is_bf16 ? __uint_as_float((unsigned)((const unsigned short*)p)[off] << 16) : ((const float*)p)[off];
 }
 
+// stores of the same kind (LT_ACT_BF16: the activations and activation gradients of the 16-bit training step are bf16 tensors)
+__device__ __forceinline__ void st4_f32_or_bf16(void* p, size_t off, int is_bf16, float a, float b, float c, float d) {
+    if (is_bf16) *(uint2*)((bf16_t*)p + off) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+    else *(float4*)((float*)p + off) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void st1_f32_or_bf16(void* p, size_t off, int is_bf16, float v) {
+    if (is_bf16) ((bf16_t*)p)[off] = (bf16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+    else ((float*)p)[off] = v;
+}
+
 static inline int ilog2_exact(int v) {  // -1 when v is not a power of two
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;

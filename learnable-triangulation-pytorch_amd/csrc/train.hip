@@ -32,11 +32,11 @@ __device__ __forceinline__ float relu_mask_post(float v) { return v > 0.f ? 1.f 
 struct BnActArgs {
     const void* y;         // rows x C: convolution output (bias included), fp32 or (y16) bf16
     const float* mean; const float* var; const float* gamma; const float* beta;
-    const float* res;      // rows x C or null
-    float* z;
+    const void* res;       // rows x C or null (a16: bf16)
+    void* z;               // fp32, or (a16) bf16
     bf16_t* z16;           // optional bf16 copy of z (mixed-precision training: the next convolution's operand), or null
     float eps;
-    int flags, C, y16;
+    int flags, C, y16, a16;
     long long rows;
 };
 
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActArgs a) {
         const float4 y4 = ld4_f32_or_bf16(a.y, off, a.y16);
         const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
         float rr[4] = {-0.0f, -0.0f, -0.0f, -0.0f};
-        if (a.res) { const float4 r4 = *(const float4*)(a.res + off); rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w; }
+        if (a.res) { const float4 r4 = ld4_f32_or_bf16(a.res, off, a.a16); rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w; }
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -59,21 +59,21 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActArgs a) {
             const float v = (yy[e] - a.mean[c + e]) * invstd * a.gamma[c + e] + a.beta[c + e];
             o[e] = epi_apply(v, fl, rr[e]);
         }
-        *(float4*)(a.z + off) = make_float4(o[0], o[1], o[2], o[3]);
+        st4_f32_or_bf16(a.z, off, a.a16, o[0], o[1], o[2], o[3]);
         if (a.z16) *(uint2*)(a.z16 + off) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
     }
 }
 
 struct BnBwdArgs {
-    const float* dz; const void* y; const float* res;      // rows x C (y: fp32 or, with y16, bf16)
+    const void* dz; const void* y; const void* res;        // rows x C (y: fp32 or, with y16, bf16; dz / res / dy / dres: fp32 or, with a16, bf16)
     const float* mean; const float* var; const float* gamma; const float* beta;
     double* part;            // [nslab][C][2]: sum g, sum g x^
     float* dgamma; float* dbeta;
-    float* dy;               // rows x C
+    void* dy;                // rows x C
     bf16_t* dy16;            // optional bf16 copy of dy (mixed-precision training: the input-gradient convolution's operand), or null
-    float* dres;             // rows x C or null: gradient of the residual input (accumulated when accumulate_res)
+    void* dres;              // rows x C or null: gradient of the residual input (accumulated when accumulate_res)
     float eps;
-    int flags, C, nslab, accumulate_res, y16;
+    int flags, C, nslab, accumulate_res, y16, a16;
     long long rows;
 };
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
             for (long long r = r0 + rl; r < r1; r += RL) {
                 const size_t off = (size_t)r * a.C + c;
                 float xh;
-                const float g = bn_g(a, a.dz[off], ld1_f32_or_bf16(a.y, off, a.y16), a.res ? a.res[off] : 0.f, c, xh);
+                const float g = bn_g(a, ld1_f32_or_bf16(a.dz, off, a.a16), ld1_f32_or_bf16(a.y, off, a.y16), a.res ? ld1_f32_or_bf16(a.res, off, a.a16) : 0.f, c, xh);
                 s += (double)g; q += (double)g * (double)xh;
             }
         ss[threadIdx.x] = s; sq[threadIdx.x] = q;
@@ -130,14 +130,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % a.C);
         float xh;
-        const float r = a.res ? a.res[i] : 0.f;
-        const float dzv = a.dz[i];
+        const float r = a.res ? ld1_f32_or_bf16(a.res, (size_t)i, a.a16) : 0.f;
+        const float dzv = ld1_f32_or_bf16(a.dz, (size_t)i, a.a16);
         const float g = bn_g(a, dzv, ld1_f32_or_bf16(a.y, (size_t)i, a.y16), r, c, xh);
         const float invstd = 1.0f / sqrtf(a.var[c] + a.eps);
-        a.dy[i] = a.gamma[c] * invstd * (g - a.dbeta[c] * inv_n - xh * a.dgamma[c] * inv_n);
+        st1_f32_or_bf16(a.dy, (size_t)i, a.a16, a.gamma[c] * invstd * (g - a.dbeta[c] * inv_n - xh * a.dgamma[c] * inv_n));
         if (a.dres) {
             const float dr = (a.flags & LT_EPI_RELU_POST) ? g : dzv;     // RELU_PRE / none: the residual is added after the activation
-            a.dres[i] = a.accumulate_res ? a.dres[i] + dr : dr;
+            st1_f32_or_bf16(a.dres, (size_t)i, a.a16, a.accumulate_res ? ld1_f32_or_bf16(a.dres, (size_t)i, a.a16) + dr : dr);
         }
     }
 }
@@ -147,9 +147,9 @@ struct BnBwdLoad {
     BnBwdArgs a;
     __device__ __forceinline__ void operator()(long long row, int c, float (&q)[2][4]) const {
         const size_t off = (size_t)row * a.C + c;
-        const float4 dz4 = *(const float4*)(a.dz + off), y4 = ld4_f32_or_bf16(a.y, off, a.y16);
+        const float4 dz4 = ld4_f32_or_bf16(a.dz, off, a.a16), y4 = ld4_f32_or_bf16(a.y, off, a.y16);
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.res) r4 = *(const float4*)(a.res + off);
+        if (a.res) r4 = ld4_f32_or_bf16(a.res, off, a.a16);
         const float dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -188,9 +188,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdArgs a
     const bool post = a.flags & LT_EPI_RELU_POST, pre = a.flags & LT_EPI_RELU_PRE;
     for (long long r = r0 + rl; r < r1; r += rl_n) {
         const size_t off = (size_t)r * a.C + c;
-        const float4 dz4 = *(const float4*)(a.dz + off), y4 = ld4_f32_or_bf16(a.y, off, a.y16);
+        const float4 dz4 = ld4_f32_or_bf16(a.dz, off, a.a16), y4 = ld4_f32_or_bf16(a.y, off, a.y16);
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.res) r4 = *(const float4*)(a.res + off);
+        if (a.res) r4 = ld4_f32_or_bf16(a.res, off, a.a16);
         const float dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
         float o[4], dr[4];
 #pragma unroll
@@ -204,27 +204,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdArgs a
             o[e] = k1[e] * (g - kb[e] - xh * kg[e]);
             dr[e] = post ? g : dzv[e];     // RELU_PRE / none: the residual is added after the activation
         }
-        *(float4*)(a.dy + off) = make_float4(o[0], o[1], o[2], o[3]);
+        st4_f32_or_bf16(a.dy, off, a.a16, o[0], o[1], o[2], o[3]);
         if (a.dy16) *(uint2*)(a.dy16 + off) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
         if (a.dres) {
             if (a.accumulate_res) {
-                const float4 d0 = *(const float4*)(a.dres + off);
+                const float4 d0 = ld4_f32_or_bf16(a.dres, off, a.a16);
                 dr[0] += d0.x; dr[1] += d0.y; dr[2] += d0.z; dr[3] += d0.w;
             }
-            *(float4*)(a.dres + off) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+            st4_f32_or_bf16(a.dres, off, a.a16, dr[0], dr[1], dr[2], dr[3]);
         }
     }
 }
 
 struct ChanSumLoad {
-    const float* x; int C;
+    const void* x; int C, x16;
     __device__ __forceinline__ void operator()(long long row, int c, float (&q)[1][4]) const {
-        const float4 v = *(const float4*)(x + (size_t)row * C + c);
+        const float4 v = ld4_f32_or_bf16(x, (size_t)row * C + c, x16);
         q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w;
     }
 };
-__global__ __launch_bounds__(256) void channel_sum_vec_kernel(const float* __restrict__ x, long long rows, int C, int nslab, int cw4, int rl, double* __restrict__ part) {
-    colsum_partial<1>(rows, C, nslab, cw4, rl, part, ChanSumLoad{x, C});
+__global__ __launch_bounds__(256) void channel_sum_vec_kernel(const void* __restrict__ x, int x16, long long rows, int C, int nslab, int cw4, int rl, double* __restrict__ part) {
+    colsum_partial<1>(rows, C, nslab, cw4, rl, part, ChanSumLoad{x, C, x16});
 }
 struct ChanSumFin {
     float* out; int accumulate;
@@ -235,24 +235,27 @@ __global__ __launch_bounds__(256) void channel_sum_finalize_vec_kernel(const dou
 }
 
 // layers without BatchNorm: z = act(y, res) with y = conv + bias: dy = dz * mask, dres likewise
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ res,
-                                                      float* __restrict__ dy, float* __restrict__ dres, int flags, int accumulate_res, long long total) {
+__global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ dz, const void* __restrict__ z, const void* __restrict__ res,
+                                                      void* __restrict__ dy, void* __restrict__ dres, int flags, int accumulate_res, long long total) {
+    const int a16 = (flags & LT_ACT_BF16) ? 1 : 0, z16 = a16;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         float m = 1.f;
-        if (flags & LT_EPI_SIGMOID) m = z[i] * (1.f - z[i]);                               // z = sigmoid(v): the confidence heads' last layer
-        else if (flags & LT_EPI_RELU_POST) m = z[i] > 0.f ? 1.f : 0.f;                     // z = relu(v + res)
-        else if (flags & LT_EPI_RELU_PRE) m = z[i] > 0.f ? 1.f : 0.f;                      // z = relu(v); with a residual behind the ReLU the sign of v is
+        const float zi = (flags & (LT_EPI_SIGMOID | LT_EPI_RELU_POST | LT_EPI_RELU_PRE)) ? ld1_f32_or_bf16(z, (size_t)i, z16) : 0.f;
+        if (flags & LT_EPI_SIGMOID) m = zi * (1.f - zi);                                   // z = sigmoid(v): the confidence heads' last layer
+        else if (flags & LT_EPI_RELU_POST) m = zi > 0.f ? 1.f : 0.f;                       // z = relu(v + res)
+        else if (flags & LT_EPI_RELU_PRE) m = zi > 0.f ? 1.f : 0.f;                        // z = relu(v); with a residual behind the ReLU the sign of v is
                                                                                                // not recoverable from z (lt_act_bwd refuses that combination)
-        const float g = dz[i] * m;
-        dy[i] = g;
+        const float dzi = ld1_f32_or_bf16(dz, (size_t)i, a16);
+        const float g = dzi * m;
+        st1_f32_or_bf16(dy, (size_t)i, a16, g);
         if (dres) {
-            const float dr = (flags & LT_EPI_RELU_POST) ? g : dz[i];
-            dres[i] = accumulate_res ? dres[i] + dr : dr;
+            const float dr = (flags & LT_EPI_RELU_POST) ? g : dzi;
+            st1_f32_or_bf16(dres, (size_t)i, a16, accumulate_res ? ld1_f32_or_bf16(dres, (size_t)i, a16) + dr : dr);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x, long long rows, int C, int nslab, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const void* __restrict__ x, int x16, long long rows, int C, int nslab, double* __restrict__ part) {
     __shared__ double ss[256];
     const int slab = blockIdx.x;
     const long long r0 = rows * slab / nslab, r1 = rows * (slab + 1) / nslab;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* _
         const int c = c0 + cl;
         double s = 0.0;
         if (rl < RL && c < C)
-            for (long long r = r0 + rl; r < r1; r += RL) s += (double)x[(size_t)r * C + c];
+            for (long long r = r0 + rl; r < r1; r += RL) s += (double)ld1_f32_or_bf16(x, (size_t)r * C + c, x16);
         ss[threadIdx.x] = s;
         __syncthreads();
         if (rl == 0 && c < C) {
@@ -287,7 +290,7 @@ __global__ void channel_sum_finalize_kernel(const double* __restrict__ part, int
 // order -- bitwise repeatable (round 2: float atomics in arbitrary order)
 struct PoolClass { int cd, ch, cw, md, mh, mw, nd, nh, nw; };      // class offset, class stride, outputs of the class per dimension
 
-__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int N, int D, int H, int W, int C,
+__global__ void maxpool_bwd_kernel(const void* __restrict__ x, const void* __restrict__ dy, void* __restrict__ dx, int a16, int N, int D, int H, int W, int C,
                                    int Do, int Ho, int Wo, int kd, int kh, int kw, int sd, int sh, int sw, int pd, int ph, int pw, PoolClass pc) {
     const long long total = (long long)N * pc.nd * pc.nh * pc.nw * C;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
@@ -309,12 +312,13 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
                     const int iw = ow * sw - pw + cc;
                     if ((unsigned)iw >= (unsigned)W) continue;
                     const long long idx = ((((long long)n * D + id) * H + ih) * W + iw) * C + c;
-                    const float v = x[idx];
+                    const float v = ld1_f32_or_bf16(x, (size_t)idx, a16);
                     if (v > best || bi < 0) { best = v; bi = idx; }
                 }
             }
         }
-        if (bi >= 0) dx[bi] += dy[((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + c];
+        if (bi >= 0)
+            st1_f32_or_bf16(dx, (size_t)bi, a16, ld1_f32_or_bf16(dx, (size_t)bi, a16) + ld1_f32_or_bf16(dy, (size_t)(((((long long)n * Do + od) * Ho + oh) * Wo + ow) * C + c), a16));
     }
 }
 
@@ -910,13 +914,15 @@ int slabs_for(long long rows) { return (int)(rows < 1024 ? 1 : (rows / 256 < 102
 
 }  // namespace
 
-extern "C" int lt_bn_act_fwd(const void* y, const float* mean, const float* var, const float* gamma, const float* beta, const float* residual,
-                             float* z, void* z_bf16, int64_t rows, int32_t C, float eps, int32_t flags, void* stream) {
+extern "C" int lt_bn_act_fwd(const void* y, const float* mean, const float* var, const float* gamma, const float* beta, const void* residual,
+                             void* z, void* z_bf16, int64_t rows, int32_t C, float eps, int32_t flags, void* stream) {
     LT_REQUIRE(y && mean && var && gamma && beta && z, LT_ERR_INVALID, "lt_bn_act_fwd: null argument");
+    LT_REQUIRE(!(flags & LT_ACT_BF16) || !z_bf16, LT_ERR_INVALID, "lt_bn_act_fwd: with LT_ACT_BF16 z itself is the bf16 tensor (z_bf16 must be NULL)");
     LT_REQUIRE(rows >= 1 && C >= 4 && C % 4 == 0, LT_ERR_UNSUPPORTED, "lt_bn_act_fwd: C %% 4 == 0 required (C=%d)", C);
     BnActArgs a;
     a.y = y; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.res = residual; a.z = z; a.z16 = (bf16_t*)z_bf16; a.eps = eps; a.flags = flags; a.C = C; a.rows = rows;
     a.y16 = (flags & LT_BN_Y_BF16) ? 1 : 0;
+    a.a16 = (flags & LT_ACT_BF16) ? 1 : 0;
     const long long blocks = cdiv(rows * (C / 4), 256);
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, a);
     LT_CHECK_LAUNCH("lt_bn_act_fwd");
@@ -928,8 +934,8 @@ extern "C" size_t lt_bn_act_bwd_workspace(int64_t rows, int32_t C) {
     return generic > fast ? generic : fast;
 }
 
-extern "C" int lt_bn_act_bwd(const float* dz, const void* y, const float* residual, const float* mean, const float* var, const float* gamma,
-                             const float* beta, float* dy, void* dy_bf16, float* dgamma, float* dbeta, float* dres, int32_t accumulate_res, int64_t rows,
+extern "C" int lt_bn_act_bwd(const void* dz, const void* y, const void* residual, const float* mean, const float* var, const float* gamma,
+                             const float* beta, void* dy, void* dy_bf16, float* dgamma, float* dbeta, void* dres, int32_t accumulate_res, int64_t rows,
                              int32_t C, float eps, int32_t flags, void* workspace, void* stream) {
     LT_REQUIRE(dz && y && mean && var && gamma && beta && dy && dgamma && dbeta && workspace, LT_ERR_INVALID, "lt_bn_act_bwd: null argument");
     LT_REQUIRE(rows >= 1 && C >= 1 && C <= 4096, LT_ERR_INVALID, "lt_bn_act_bwd: bad shape");
@@ -939,7 +945,9 @@ extern "C" int lt_bn_act_bwd(const float* dz, const void* y, const float* residu
     a.dgamma = dgamma; a.dbeta = dbeta; a.dy = dy; a.dy16 = (bf16_t*)dy_bf16; a.dres = dres; a.eps = eps; a.flags = flags; a.C = C; a.nslab = slabs_for(rows);
     a.accumulate_res = accumulate_res; a.rows = rows;
     a.y16 = (flags & LT_BN_Y_BF16) ? 1 : 0;
+    a.a16 = (flags & LT_ACT_BF16) ? 1 : 0;
     LT_REQUIRE(!a.y16 || C % 4 == 0, LT_ERR_UNSUPPORTED, "lt_bn_act_bwd: a bf16 y needs C %% 4 == 0 (C=%d)", C);
+    LT_REQUIRE(!a.a16 || (C % 4 == 0 && !dy_bf16), LT_ERR_UNSUPPORTED, "lt_bn_act_bwd: LT_ACT_BF16 needs C %% 4 == 0 and no separate bf16 copy of dy (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
     if (colsum_fast(C)) {
         const ColsumPlan p = colsum_plan(rows, C);
@@ -965,7 +973,7 @@ extern "C" int lt_bn_act_bwd(const float* dz, const void* y, const float* residu
     return LT_OK;
 }
 
-extern "C" int lt_act_bwd(const float* dz, const float* z, const float* residual, float* dy, float* dres, int32_t accumulate_res, int64_t total,
+extern "C" int lt_act_bwd(const void* dz, const void* z, const void* residual, void* dy, void* dres, int32_t accumulate_res, int64_t total,
                           int32_t flags, void* stream) {
     LT_REQUIRE(dz && z && dy && total >= 1, LT_ERR_INVALID, "lt_act_bwd: bad argument");
     // z = relu(v) + res: (z - res) > 0 loses a live gradient whenever 0 < relu(v) < ulp(res) / 2 -- the mask has to come from v, which a layer
@@ -985,18 +993,24 @@ extern "C" size_t lt_channel_sum_workspace(int64_t rows, int32_t C) {
 }
 
 extern "C" int lt_channel_sum(const float* x, int64_t rows, int32_t C, float* out, int32_t accumulate, void* workspace, void* stream) {
+    return lt_channel_sum_dt(LT_F32, x, rows, C, out, accumulate, workspace, stream);
+}
+
+extern "C" int lt_channel_sum_dt(int32_t dtype, const void* x, int64_t rows, int32_t C, float* out, int32_t accumulate, void* workspace, void* stream) {
     LT_REQUIRE(x && out && workspace && rows >= 1 && C >= 1, LT_ERR_INVALID, "lt_channel_sum: bad argument");
+    LT_REQUIRE(dtype == LT_F32 || dtype == LT_BF16, LT_ERR_INVALID, "lt_channel_sum_dt: bad dtype %d", dtype);
+    const int x16 = dtype == LT_BF16 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (colsum_fast(C)) {
         const ColsumPlan p = colsum_plan(rows, C);
-        hipLaunchKernelGGL(channel_sum_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
+        hipLaunchKernelGGL(channel_sum_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, x, x16, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
         LT_CHECK_LAUNCH("lt_channel_sum(partial)");
         hipLaunchKernelGGL(channel_sum_finalize_vec_kernel, dim3((unsigned)cdiv(C, COLSUM_FIN_C)), dim3(256), 0, st, (const double*)workspace, C, p.nslab, ChanSumFin{out, accumulate});
         LT_CHECK_LAUNCH("lt_channel_sum(finalize)");
         return LT_OK;
     }
     const int ns = slabs_for(rows);
-    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(ns), dim3(256), 0, st, x, (long long)rows, C, ns, (double*)workspace);
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(ns), dim3(256), 0, st, x, x16, (long long)rows, C, ns, (double*)workspace);
     LT_CHECK_LAUNCH("lt_channel_sum(partial)");
     hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, C, ns, out, accumulate);
     LT_CHECK_LAUNCH("lt_channel_sum(finalize)");
@@ -1005,7 +1019,14 @@ extern "C" int lt_channel_sum(const float* x, int64_t rows, int32_t C, float* ou
 
 extern "C" int lt_maxpool_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, const int32_t k[3],
                               const int32_t s[3], const int32_t p[3], void* stream) {
+    return lt_maxpool_bwd_dt(LT_F32, x, dy, dx, N, D, H, W, C, k, s, p, stream);
+}
+
+extern "C" int lt_maxpool_bwd_dt(int32_t dtype, const void* x, const void* dy, void* dx, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C, const int32_t k[3],
+                                 const int32_t s[3], const int32_t p[3], void* stream) {
     LT_REQUIRE(x && dy && dx && k && s && p, LT_ERR_INVALID, "lt_maxpool_bwd: null argument");
+    LT_REQUIRE(dtype == LT_F32 || dtype == LT_BF16, LT_ERR_INVALID, "lt_maxpool_bwd_dt: bad dtype %d", dtype);
+    const int a16 = dtype == LT_BF16 ? 1 : 0;
     const int Do = (D + 2 * p[0] - k[0]) / s[0] + 1, Ho = (H + 2 * p[1] - k[1]) / s[1] + 1, Wo = (W + 2 * p[2] - k[2]) / s[2] + 1;
     LT_REQUIRE(N >= 1 && C >= 1 && Do >= 1 && Ho >= 1 && Wo >= 1, LT_ERR_INVALID, "lt_maxpool_bwd: bad shape");
     const int md = (int)cdiv(k[0], s[0]), mh = (int)cdiv(k[1], s[1]), mw = (int)cdiv(k[2], s[2]);
@@ -1017,7 +1038,7 @@ extern "C" int lt_maxpool_bwd(const float* x, const float* dy, float* dx, int32_
                 pc.nd = (Do - cd + md - 1) / md; pc.nh = (Ho - ch + mh - 1) / mh; pc.nw = (Wo - cw + mw - 1) / mw;
                 const long long total = (long long)N * pc.nd * pc.nh * pc.nw * C;
                 const long long blocks = cdiv(total, 256);
-                hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, D, H, W, C,
+                hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, a16, N, D, H, W, C,
                                    Do, Ho, Wo, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2], pc);
                 LT_CHECK_LAUNCH("lt_maxpool_bwd");
             }
@@ -1191,6 +1212,36 @@ extern "C" int lt_add_f32(float* y, const float* x, int64_t n, void* stream) {
     const long long blocks = cdiv(n >> 2, 256);
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, y, x, (long long)n);
     LT_CHECK_LAUNCH("lt_add_f32");
+    return LT_OK;
+}
+
+namespace {
+// dst[r][c] = c < C ? src[r][c] : 0 with a change of element type on the way (fp32 <-> bf16, round to nearest even)
+__global__ __launch_bounds__(256) void convert_pad_kernel(const void* __restrict__ src, int s16, void* __restrict__ dst, int d16, long long rows, int C, int Cpad) {
+    const long long total = rows * Cpad;
+    if (C == Cpad && (total & 3) == 0) {          // plain casts: four elements per thread
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (total >> 2); i += (long long)gridDim.x * 256) {
+            const float4 v = ld4_f32_or_bf16(src, (size_t)i * 4, s16);
+            st4_f32_or_bf16(dst, (size_t)i * 4, d16, v.x, v.y, v.z, v.w);
+        }
+        return;
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / Cpad;
+        const int c = (int)(i - r * Cpad);
+        st1_f32_or_bf16(dst, (size_t)i, d16, c < C ? ld1_f32_or_bf16(src, (size_t)(r * C + c), s16) : 0.f);
+    }
+}
+}  // namespace
+
+extern "C" int lt_convert_pad(int32_t src_dtype, const void* src, int32_t dst_dtype, void* dst, int64_t rows, int32_t C, int32_t c_pad, void* stream) {
+    LT_REQUIRE(src && dst && rows >= 1 && C >= 1 && c_pad >= C, LT_ERR_INVALID, "lt_convert_pad: bad argument");
+    LT_REQUIRE((src_dtype == LT_F32 || src_dtype == LT_BF16) && (dst_dtype == LT_F32 || dst_dtype == LT_BF16), LT_ERR_INVALID, "lt_convert_pad: bad dtype");
+    LT_REQUIRE(((size_t)src % 16 == 0) && ((size_t)dst % 16 == 0), LT_ERR_INVALID, "lt_convert_pad: 16-byte aligned pointers");
+    const long long blocks = cdiv(rows * c_pad, 1024);
+    hipLaunchKernelGGL(convert_pad_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, src,
+                       src_dtype == LT_BF16 ? 1 : 0, dst, dst_dtype == LT_BF16 ? 1 : 0, (long long)rows, C, c_pad);
+    LT_CHECK_LAUNCH("lt_convert_pad");
     return LT_OK;
 }
 

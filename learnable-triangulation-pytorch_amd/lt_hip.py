@@ -18,6 +18,7 @@ EPI_RELU_PRE, EPI_RELU_POST, EPI_STORE_F32, EPI_SIGMOID = 1, 2, 4, 8
 EPI_RES_F32 = 64
 BN_FROZEN = 32
 BN_Y_BF16 = 128
+ACT_BF16 = 256
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_256x32, TILE_256x16, TILE_64x64, TILE_DIRECT = 0, 1, 2, 3, 4, 5, 99
 TILE2_128x128, TILE2_128x64, TILE2_256x32, TILE2_256x16, TILE2_64x64 = 11, 12, 13, 14, 15
 TILE_HALO = 20
@@ -93,6 +94,9 @@ SIGNATURES = {
     "lt_act_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i64, i32, vp]),
     "lt_channel_sum_workspace": (C.c_size_t, [i64, i32]),
     "lt_channel_sum": (C.c_int, [vp, i64, i32, vp, i32, vp, vp]),
+    "lt_channel_sum_dt": (C.c_int, [i32, vp, i64, i32, vp, i32, vp, vp]),
+    "lt_maxpool_bwd_dt": (C.c_int, [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32 * 3, vp]),
+    "lt_convert_pad": (C.c_int, [i32, vp, i32, vp, i64, i32, i32, vp]),
     "lt_maxpool_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32 * 3, vp]),
     "lt_adam_step_multi": (C.c_int, [vp, i32, i32, f32, f32, f32, f32, i32, vp]),
     "lt_add_f32": (C.c_int, [vp, vp, i64, vp]),

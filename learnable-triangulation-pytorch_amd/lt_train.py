@@ -41,7 +41,7 @@ class TrainTape:
     an ``lt_gather_f32`` from the Parameter (wherever the optimiser has left it) into the layer's GEMM layout, with an index map built
     at record time by pushing a tensor of indices through the very host code that lays out inference weights."""
 
-    def __init__(self, device, params=(), momentum=0.1, reducer=None, bucket_bytes=64 << 20, mixed=False):
+    def __init__(self, device, params=(), momentum=0.1, reducer=None, bucket_bytes=64 << 20, mixed=False, act16=False, fp8_3d=False):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("training runs on the GPU only (device=%s); there is no CPU fallback" % device)
@@ -49,7 +49,16 @@ class TrainTape:
         self.pb = E.PlanBuilder(device, torch.float32)          # builds the lt_conv_fwd descriptors
         # mixed precision: the convolutions (forward and input gradients) take bf16 COPIES of their operands to the bf16 MFMA and store
         # fp32 (LT_EPI_STORE_F32); activations, BatchNorm, weight gradients, optimiser stay fp32 (the master weights are the Parameters)
-        self.mixed = bool(mixed)
+        # act16 (train_precision "act16", BASELINE config 5's "fp16 activations" -- bf16 here): on top of ``mixed``, every activation and every
+        # activation gradient is STORED in bf16 only -- the convolutions read and write bf16 through their ordinary (inference) epilogues, so every
+        # bf16 kernel of the forward applies to the forward and to the input gradients; BatchNorm reads / writes 2 bytes per element (its
+        # statistics, gamma / beta, their gradients, the weight gradients, the master weights and the optimiser stay fp32)
+        self.act16 = bool(act16)
+        self.fp8_3d = bool(fp8_3d) and self.act16          # 'fp8v2v': the 3x3x3 convolutions (V2V) and their input gradients on the fp8 MFMA
+        self.mixed = bool(mixed) or self.act16
+        self.adt = torch.bfloat16 if self.act16 else torch.float32          # storage type of activations and activation gradients
+        self.acode = H.LT_BF16 if self.act16 else H.LT_F32
+        self.aflag = H.ACT_BF16 if self.act16 else 0
         self.pbh = E.PlanBuilder(device, torch.bfloat16) if self.mixed else None
         if self.pbh is not None:
             self.pbh.live_weights = True
@@ -57,7 +66,7 @@ class TrainTape:
         # normalisation and the BatchNorm backward read 2 bytes instead of 4, and every bf16 kernel of the forward applies (fp32 stores are
         # restricted to the generic one and the column walk); BatchNorm's output, the gradients and everything else stay fp32.  Measured: the
         # step at 8 samples 87.5 -> 83.9 ms, the deviation from the fp32 step on the small fixture 3.8e-2 -> 5.5e-2 of the joints: off by default.
-        self.y16 = self.mixed and os.environ.get("LT_TRAIN_Y16") == "1"
+        self.y16 = self.mixed and (self.act16 or os.environ.get("LT_TRAIN_Y16") == "1")
         self._bf16 = {}                                         # id(Act) -> (Act, bf16 copy); cast op recorded with the first consumer
         self.fwd_ops, self.bwd_ops = [], []                     # fn(stream) closures, in launch order
         self._cur = self.fwd_ops
@@ -79,7 +88,7 @@ class TrainTape:
         # mixed precision: the weight gradients run on the bf16 MFMA too (lt_conv_wgrad_bf16 over image-octet packed operands, packed by
         # lt_pack_n8_bf16 into scratch buffers right in front of the kernel, on the stream the kernel runs on).  LT_TRAIN_WGRAD_FP32=1 keeps
         # them on the exact-fp32 MFMA (then every sixth one stays on the main stream: the side stream would be the longer one).
-        self.wgrad16 = self.mixed and os.environ.get("LT_TRAIN_WGRAD_FP32") is None
+        self.wgrad16 = self.mixed and (self.act16 or os.environ.get("LT_TRAIN_WGRAD_FP32") is None)
         self.wgrad_main_every = int(os.environ.get("LT_TRAIN_WGRAD_MAIN_EVERY", "6" if (mixed and not self.wgrad16) else "0"))
         self._pk_main = [torch.empty(16, dtype=torch.uint8, device=self.device) for _ in range(2)]          # octet-packed dY / X of the layer in flight
         self._pk_side = [torch.empty(16, dtype=torch.uint8, device=self.device) for _ in range(2)]
@@ -97,7 +106,7 @@ class TrainTape:
 
     # ---- PlanBuilder surface -------------------------------------------------------------------------------------------------
     def alloc(self, shape, dtype=None):
-        return E.Act(torch.empty(shape, dtype=dtype or torch.float32, device=self.device))
+        return E.Act(torch.empty(shape, dtype=dtype or self.adt, device=self.device))
 
     def release(self, act):            # activations are needed again by the backward: nothing is recycled
         pass
@@ -117,6 +126,9 @@ class TrainTape:
     def global_avgpool(self, x):
         """Mean over the map of every sample (GlobalAveragePoolingHead, pose_resnet.py:166-168): x Act [N,1,H,W,C] -> Act [1,1,1,N,C]; backward
         spreads dy / HW over the map (accumulating when the input already has a gradient)."""
+        if self.act16:
+            raise NotImplementedError("train_precision 'act16': the confidence heads (global average pool + linear layers) are not built for bf16 "
+                                      "activations; use 'bf16' or 'fp32' for conf / conf_norm aggregation and for AlgebraicTriangulationNet's confidences")
         N, D, Hh, W, Cc = x.shape
         HW = D * Hh * W
         y = self.alloc((1, 1, 1, N, Cc))
@@ -193,6 +205,8 @@ class TrainTape:
         self.do(lambda st: H.check(H.lib().lt_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), n, st), "lt_cast_f32_bf16"), "cast")
 
     def _bf16_of(self, act):
+        if act.t.dtype == torch.bfloat16:          # act16: the activation IS the bf16 operand
+            return act
         e = self._bf16.get(id(act))
         if e is None:
             t16 = torch.empty(act.t.shape, dtype=torch.bfloat16, device=self.device)
@@ -201,13 +215,33 @@ class TrainTape:
             return E.Act(t16)
         return E.Act(e[1])
 
-    def _live_conv(self, x, wparam, wt=None, bias=None, out_f32=True, **kw):
+    def _live_conv(self, x, wparam, wt=None, bias=None, out_f32=None, **kw):
         """lt_conv_fwd over the CURRENT values of ``wparam`` (optionally seen through the view transform ``wt``: the transposed / flipped
         filter of an input gradient) and of ``bias``."""
         assert wparam.numel() < (1 << 24)
+        if out_f32 is None:          # fp32 storage unless the tape keeps its activations in bf16
+            out_f32 = not self.act16
         idx = torch.arange(1, wparam.numel() + 1, dtype=torch.float32).reshape(wparam.shape)      # 1 + flat index; 0 = padding
         if wt is not None:
             idx = wt(idx).contiguous()
+        if self.act16:
+            # bf16 in, bf16 out (fp32 for the logits layer, ``out_f32``) through the ordinary epilogue of whichever bf16 kernel lt_conv_fwd picks:
+            # activation flags and a bf16 residual (the input gradient that is already there) apply in the reference's order inside the kernel
+            y = self.pbh.conv(x, torch.zeros(idx.shape), bias, None, out_f32=out_f32, **kw)
+            fn, info = self.pbh.ops[-1][0], self.pbh.last_info
+            spec_idx = E.make_conv_spec(idx, None, None, x.shape, kw.get("stride", 1), kw.get("pad", 0), torch.bfloat16, kw.get("transposed", False), 0,
+                                        kw.get("output_padding", 0))
+            assert len(spec_idx.phases) == len(info["wdev"])
+            for ph, wdev in zip(spec_idx.phases, info["wdev"]):
+                assert tuple(ph.weight.shape) == tuple(wdev.shape)
+                self._gather(wparam, (ph.weight.round().to(torch.int32) - 1).contiguous().to(self.device), wdev, "w")      # fp32 Parameter -> bf16 GEMM layout
+            if bias is not None:
+                bi = info["bias_dev"]
+                bmap = torch.full((bi.numel(),), -1, dtype=torch.int32)
+                bmap[:bias.numel()] = torch.arange(bias.numel(), dtype=torch.int32)
+                self._gather(bias, bmap.to(self.device), bi, "w")
+            self.do(fn, ("dgrad " if self._cur is self.bwd_ops else "conv ") + self.pbh.ops[-1][1]["label"])
+            return y
         if self.mixed:
             residual = kw.pop("residual", None)
             if residual is not None and (kw.get("relu") or kw.get("relu_pre")):
@@ -266,11 +300,15 @@ class TrainTape:
                 raise NotImplementedError("a BatchNorm-less layer with ReLU before a residual add")
             kw = dict(stride=stride, pad=pad, transposed=transposed, relu=relu, relu_pre=relu_pre, residual=residual)
             if sigmoid:
+                if self.act16:
+                    raise NotImplementedError("train_precision 'act16': sigmoid heads are not built for bf16 activations")
                 kw["sigmoid"] = True
-            z = self._live_conv(x, weight, None, bias, **kw)
+            z = self._live_conv(x, weight, None, bias, out_f32=True if (out_f32 or not self.act16) else False, **kw)
             y_raw = stats = None
         else:
             y16 = self.y16 and weight.shape[1 if transposed else 0] % 8 == 0
+            if self.act16 and not y16:
+                raise NotImplementedError("train_precision 'act16': a BatchNorm layer whose channel count is no multiple of 8")
             y_raw = self._live_conv(x, weight, None, bias, out_f32=not y16, stride=stride, pad=pad, transposed=transposed)
             gamma, beta, rmean, rvar = bn
             Cc = y_raw.shape[-1]
@@ -294,7 +332,8 @@ class TrainTape:
             z = self.alloc(y_raw.shape)
             rp = residual.t if residual is not None else None
             z16 = None
-            if self.mixed and Cc % 4 == 0:          # the next convolution's bf16 operand is written on the way (no separate cast pass)
+            flags |= self.aflag          # act16: z and the residual are bf16 tensors
+            if self.mixed and not self.act16 and Cc % 4 == 0:          # the next convolution's bf16 operand is written on the way (no separate cast pass)
                 z16 = torch.empty(z.t.shape, dtype=torch.bfloat16, device=self.device)
                 self._bf16[id(z)] = (z, z16)
             self.do(lambda st: H.check(lib.lt_bn_act_fwd(y_raw.t.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), H.ptr(rp),
@@ -305,8 +344,9 @@ class TrainTape:
         return z
 
     def maxpool(self, x, k, s, p, nd):
-        y = self.pb.maxpool(x, k, s, p, nd)
-        self.do(self.pb.ops[-1][0])
+        pb = self.pbh if self.act16 else self.pb
+        y = pb.maxpool(x, k, s, p, nd)
+        self.do(pb.ops[-1][0])
         kk = (1, k, k) if nd == 2 else (k, k, k)
         ss = (1, s, s) if nd == 2 else (s, s, s)
         pp = (0, p, p) if nd == 2 else (p, p, p)
@@ -319,10 +359,11 @@ class TrainTape:
             if dx is None:
                 dx = torch.empty_like(x.t)
                 self._add_grad(x, dx)
-                nb = dx.numel() * 4
+                nb = dx.numel() * dx.element_size()
                 self.do(lambda st: H.check(H.lib().lt_zero(dx.data_ptr(), nb, st), "lt_zero"), "zero")
             N, D, Hh, W, Cc = x.shape
-            self.do(lambda st: H.check(H.lib().lt_maxpool_bwd(x.t.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, D, Hh, W, Cc, H.i3(kk), H.i3(ss), H.i3(pp), st),
+            ac = self.acode
+            self.do(lambda st: H.check(H.lib().lt_maxpool_bwd_dt(ac, x.t.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, D, Hh, W, Cc, H.i3(kk), H.i3(ss), H.i3(pp), st),
                                        "lt_maxpool_bwd"))
         self.recorders.append(bwd)
         return y
@@ -372,7 +413,7 @@ class TrainTape:
             return
         Cout = z.shape[-1]
         rows = z.t.numel() // Cout
-        dy = torch.empty_like(z.t)
+        dy = torch.empty(z.t.shape, dtype=self.adt, device=self.device)
         dres, acc_res = None, 0
         rp = residual.t if residual is not None else None
         if residual is not None:
@@ -387,18 +428,21 @@ class TrainTape:
             dgamma, dbeta = self._grad_view(gamma), self._grad_view(beta)
             self._ws_need(lib.lt_bn_act_bwd_workspace(rows, Cout))
             dy16 = None
-            if self.mixed and id(x) not in self.no_grad_ids and Cout >= 4 and Cout & (Cout - 1) == 0:      # the input gradient's bf16 operand on the way
+            if self.mixed and not self.act16 and id(x) not in self.no_grad_ids and Cout >= 4 and Cout & (Cout - 1) == 0:      # the input gradient's bf16 operand on the way
                 dy16 = torch.empty(dy.shape, dtype=torch.bfloat16, device=self.device)
             self.do(lambda st: H.check(lib.lt_bn_act_bwd(dz.data_ptr(), y_raw.t.data_ptr(), H.ptr(rp), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
                                                          beta.data_ptr(), dy.data_ptr(), H.ptr(dy16), dgamma.data_ptr(), dbeta.data_ptr(), H.ptr(dres), acc_res, rows,
                                                          Cout, BN_EPS, flags, self._ws.data_ptr(), st), "lt_bn_act_bwd"), "bn_bwd %dx%d" % (rows, Cout))
         else:
             total = z.t.numel()
-            self.do(lambda st: H.check(lib.lt_act_bwd(dz.data_ptr(), z.t.data_ptr(), H.ptr(rp), dy.data_ptr(), H.ptr(dres), acc_res, total, flags, st), "lt_act_bwd"))
+            if self.act16 and z.t.dtype != torch.bfloat16 and (flags & (H.EPI_RELU_POST | H.EPI_RELU_PRE | H.EPI_SIGMOID)):
+                raise NotImplementedError("train_precision 'act16': an activation on a layer that stores fp32 (only the logits layer does, and it has none)")
+            self.do(lambda st: H.check(lib.lt_act_bwd(dz.data_ptr(), z.t.data_ptr(), H.ptr(rp), dy.data_ptr(), H.ptr(dres), acc_res, total, flags | self.aflag, st), "lt_act_bwd"))
         if bias is not None and bias.requires_grad:
             db = self._grad_view(bias)
             self._ws_need(lib.lt_channel_sum_workspace(rows, Cout))
-            self.do(lambda st: H.check(lib.lt_channel_sum(dy.data_ptr(), rows, Cout, db.data_ptr(), 0, self._ws.data_ptr(), st), "lt_channel_sum"))
+            ac = self.acode
+            self.do(lambda st: H.check(lib.lt_channel_sum_dt(ac, dy.data_ptr(), rows, Cout, db.data_ptr(), 0, self._ws.data_ptr(), st), "lt_channel_sum"))
         nd = weight.dim() - 2
         st3 = ((1,) + (stride,) * 2) if nd == 2 else (stride,) * 3
         pd3 = ((0,) + (pad,) * 2) if nd == 2 else (pad,) * 3
@@ -407,6 +451,17 @@ class TrainTape:
         taps_all = torch.tensor([(a, b, c, 0) for a in range(ks3[0]) for b in range(ks3[1]) for c in range(ks3[2])], dtype=torch.int32, device=self.device)
         ntaps = taps_all.shape[0]
         N, D, Hh, W, cin_buf = x.shape
+        # lt_conv_fwd wants a power-of-two channel count on its input: dY widened with zero channels (17 joints -> 32) for the input gradient
+        # (and, in the 16-bit step, for the octet pack of the weight gradient)
+        dy_in, cpad = dy, Cout
+        if (Cout & (Cout - 1) or Cout < 4) and (self.act16 or id(x) not in self.no_grad_ids):
+            cpad = max(4, 1 << (Cout - 1).bit_length())
+            if self.act16:
+                cpad = max(8, cpad)
+            dyp = torch.empty(*dy.shape[:-1], cpad, dtype=self.adt, device=self.device)
+            ac_ = self.acode
+            self.do(lambda st: H.check(lib.lt_convert_pad(ac_, dy.data_ptr(), ac_, dyp.data_ptr(), rows, Cout, cpad, st), "lt_convert_pad"), "pad")
+            dy_in = dyp                     # (dy itself must keep its name: the closures above read it when they are replayed)
         if weight.requires_grad:
             # ---- weight gradient: dw[co][tap * Cin + ci] over the GEMM rows of the forward convolution, then into the Parameter's layout
             if not transposed:
@@ -436,9 +491,18 @@ class TrainTape:
                 need = lib.lt_conv_wgrad_bf16_workspace((n_img + 7) // 8 * pa_px, cop, kp)
                 pk_need = (lib.lt_pack_n8_bf16_bytes(n_img, pa_px, geo[9]), lib.lt_pack_n8_bf16_bytes(n_img, pb_px, geo[4]))
                 # where the bf16 copy the convolutions read exists already (same layout), the pack reads that: 2 instead of 4 bytes per element
-                x16e = self._bf16.get(id(x))
-                x16 = x16e[1] if x16e is not None and x16e[1].shape == x.t.shape and cin_buf % 8 == 0 else None
-                d16 = dy16 if (bn is not None and dy16 is not None and Cout % 8 == 0) else None
+                if self.act16:          # the activations / gradients are the bf16 operands (dY through its zero-padded copy when Cout % 8)
+                    if cin_buf % 8 or (transposed and Cout % 8):
+                        raise NotImplementedError("train_precision 'act16': a weight gradient over %d input channels" % cin_buf)
+                    x16, d16 = x.t, dy_in
+                    if not transposed and dy_in is not dy:
+                        geo = geo[:8] + (cpad, cpad)          # Cout, ldy of the widened dY (cout_pad_of(Cout) == cpad rows of dw, the extra ones zero)
+                        assert cop >= cpad
+                    pk_need = (lib.lt_pack_n8_bf16_bytes(n_img, pa_px, geo[9]), lib.lt_pack_n8_bf16_bytes(n_img, pb_px, geo[4]))
+                else:
+                    x16e = self._bf16.get(id(x))
+                    x16 = x16e[1] if x16e is not None and x16e[1].shape == x.t.shape and cin_buf % 8 == 0 else None
+                    d16 = dy16 if (bn is not None and dy16 is not None and Cout % 8 == 0) else None
                 a16, b16 = (d16, x16) if not transposed else (x16, d16)
                 self.keep += [t for t in (a16, b16) if t is not None]
             else:
@@ -490,15 +554,8 @@ class TrainTape:
         if id(x) in self.no_grad_ids:
             return
         prev = self.grad_of(x)
-        if Cout & (Cout - 1) or Cout < 4:       # lt_conv_fwd wants a power-of-two channel count on its input: pad dY with zero channels (17 joints -> 32)
-            cpad = max(4, 1 << (Cout - 1).bit_length())
-            dyp = torch.empty(*dy.shape[:-1], cpad, dtype=torch.float32, device=self.device)
-            self.do(lambda st: H.check(lib.lt_pad_channels_f32(dy.data_ptr(), dyp.data_ptr(), rows, Cout, cpad, st), "lt_pad_channels_f32"), "pad")
-            dy_in = dyp                     # (dy itself must keep its name: the closures above read it when they are replayed)
-        else:
-            dy_in = dy
         dya = E.Act(dy_in)
-        if bn is not None and dy16 is not None:
+        if bn is not None and not self.act16 and dy16 is not None:
             self._bf16[id(dya)] = (dya, dy16)
         res = E.Act(prev) if prev is not None else None
         if not transposed and stride == 1:

@@ -58,12 +58,15 @@ class _VolTrainPlan:
             x = x.float().contiguous()
         first = self.tape is None
         if first:
-            mixed = getattr(model, "train_precision", "fp32") == "bf16"
-            self.tape = tape = lt_train.TrainTape(device, params=list(model.parameters()), reducer=getattr(model, "grad_reducer", None), mixed=mixed)
+            prec = getattr(model, "train_precision", "fp32")
+            mixed, act16 = prec != "fp32", prec in ("act16", "fp8v2v")
+            self.tape = tape = lt_train.TrainTape(device, params=list(model.parameters()), reducer=getattr(model, "grad_reducer", None), mixed=mixed, act16=act16,
+                                                  fp8_3d=prec == "fp8v2v")
             self.x_in = tape.alloc((B * NV, 1, Hh, W, E.min_cin_of(torch.bfloat16 if mixed else torch.float32)))
             tape.no_grad_ids.add(id(self.x_in))
         tape = self.tape
-        H.check(lib.lt_nchw_to_nhwc(H.LT_F32, x.data_ptr(), self.x_in.t.data_ptr(), B * NV, 3, Hh * W, self.x_in.t.shape[-1], st), "lt_nchw_to_nhwc")
+        ac = tape.acode          # element type of the activations: fp32, or bf16 in the 16-bit-activation step
+        H.check(lib.lt_nchw_to_nhwc(ac, x.data_ptr(), self.x_in.t.data_ptr(), B * NV, 3, Hh * W, self.x_in.t.shape[-1], st), "lt_nchw_to_nhwc")
         if first:
             # layers in front of the unprojection (its launch needs the map size, the geometry block the launch reads needs the maps' size too)
             _, feats256, _, volc = model.backbone.record(tape, self.x_in, want_heatmaps=False)
@@ -98,7 +101,7 @@ class _VolTrainPlan:
             cmu = int(bool(model.transfer_cmu_to_human36m))
             volc = self.volc
             conf_p = None if volc is None else volc.t.data_ptr()          # (B, NV, 32) raw confidences; 'conf_norm' is normalised inside the kernels
-            tape.do(lambda s_: H.check(lib.lt_unproject_grid_fwd(H.LT_F32, feats.t.data_ptr(), gp, gp + 4 * o_pos, gp + 4 * o_cen, gp + 4 * o_rot, step, cmu,
+            tape.do(lambda s_: H.check(lib.lt_unproject_grid_fwd(ac, feats.t.data_ptr(), gp, gp + 4 * o_pos, gp + 4 * o_cen, gp + 4 * o_rot, step, cmu,
                                                                  coords.data_ptr(), conf_p, vol.t.data_ptr(), B, NV, 32, h, w, V, agg, s_), "lt_unproject_grid_fwd"),
                     "unproject")
 
@@ -106,14 +109,27 @@ class _VolTrainPlan:
                 dvol = tape.grad_of(vol)
                 if dvol is None:
                     return
-                gfe = torch.empty_like(feats.t)                    # written completely by the gather (no zero fill)
+                gfe32 = torch.empty(feats.t.shape, dtype=torch.float32, device=device)                    # written completely by the gather (no zero fill)
                 gconf = None if volc is None else torch.empty_like(volc.t)
+                if tape.act16:
+                    # lt_unproject_bwd takes and gives fp32 gradients: the volume's bf16 gradient is widened in front of it, the maps' gradient rounded behind it
+                    dvol16 = dvol
+                    dvol32 = torch.empty(dvol16.shape, dtype=torch.float32, device=device)
+                    nvol = dvol16.numel()
+                    tape.do(lambda s_: H.check(lib.lt_convert_pad(H.LT_BF16, dvol16.data_ptr(), H.LT_F32, dvol32.data_ptr(), nvol // 32, 32, 32, s_), "lt_convert_pad"), "cast")
+                else:
+                    dvol32 = dvol
                 per_sample = lib.lt_unproject_bwd_workspace(1, NV, 32, V, V, V)
                 ws = torch.empty(max(16, min(per_sample * B, max(per_sample, 4 << 30))), dtype=torch.uint8, device=device)
                 nws = ws.numel()
-                tape.do(lambda s_: H.check(lib.lt_unproject_bwd(H.LT_F32, feats.t.data_ptr(), gp, coords.data_ptr(), conf_p, dvol.data_ptr(), gfe.data_ptr(),
+                tape.do(lambda s_: H.check(lib.lt_unproject_bwd(ac, feats.t.data_ptr(), gp, coords.data_ptr(), conf_p, dvol32.data_ptr(), gfe32.data_ptr(),
                                                                 H.ptr(gconf), B, NV, 32, h, w, V, V, V, agg, ws.data_ptr(), nws, s_), "lt_unproject_bwd"),
                         "unproject_bwd")
+                gfe = gfe32
+                if tape.act16:
+                    gfe = torch.empty(feats.t.shape, dtype=torch.bfloat16, device=device)
+                    nfe = gfe.numel()
+                    tape.do(lambda s_: H.check(lib.lt_convert_pad(H.LT_F32, gfe32.data_ptr(), H.LT_BF16, gfe.data_ptr(), nfe // 32, 32, 32, s_), "lt_convert_pad"), "cast")
                 tape.seed(feats, gfe)
                 if volc is not None:
                     tape.seed(volc, gconf)            # the head's backward (recorded earlier, so replayed later) starts from here
@@ -126,8 +142,18 @@ class _VolTrainPlan:
             mult, sm = self.mult, self.sm
             tape.do(lambda s_: H.check(lib.lt_softargmax3d_fwd(logits.t.data_ptr(), coords.data_ptr(), mult, sm, 1, J, kp.data_ptr(), probs.data_ptr(), B, J, V ** 3,
                                                                ws.data_ptr(), s_), "lt_softargmax3d_fwd"))
-            self.gl = torch.empty(B, V ** 3, J, dtype=torch.float32, device=device)         # d loss / d logits, channels-last like the logits
-            tape.seed(logits, self.gl.view(logits.t.shape))
+            self.gl = gl = torch.empty(B, V ** 3, J, dtype=torch.float32, device=device)         # d loss / d logits, channels-last like the logits
+            if tape.act16:          # the backward's first op rounds the loss gradient to bf16 (recorders run in reverse order: this one first)
+                gl16 = torch.empty(B * V ** 3 * J + 8, dtype=torch.bfloat16, device=device)
+                gl16v = gl16[:B * V ** 3 * J].view(logits.t.shape)
+                nrow = B * V ** 3
+
+                def seed_cast():
+                    tape.do(lambda s_: H.check(lib.lt_convert_pad(H.LT_F32, gl.data_ptr(), H.LT_BF16, gl16.data_ptr(), nrow, J, J, s_), "lt_convert_pad"), "cast")
+                tape.seed(logits, gl16v)
+                tape.add_backward(seed_cast)
+            else:
+                tape.seed(logits, self.gl.view(logits.t.shape))
         else:
             tape.replay(tape.fwd_ops, self.n_front)
         self.step_id += 1
@@ -138,7 +164,7 @@ class _VolTrainPlan:
                 conf_out = conf_out / conf_out.sum(dim=1, keepdim=True)
         self.conf_out = conf_out
         feats_out = torch.empty(B, NV, 32, h, w, dtype=torch.float32, device=device)          # the returned features, contiguous like the reference's
-        H.check(lib.lt_nhwc_to_nchw_f32(H.LT_F32, self.feats.t.data_ptr(), feats_out.data_ptr(), B * NV, 32, h * w, 32, st), "lt_nhwc_to_nchw_f32")
+        H.check(lib.lt_nhwc_to_nchw_f32(ac, self.feats.t.data_ptr(), feats_out.data_ptr(), B * NV, 32, h * w, 32, st), "lt_nhwc_to_nchw_f32")
         base_points = self.geo[o_cen:o_rot].reshape(B, 3).clone()
         return self.kp.clone(), self.probs.clone(), feats_out, self.coords.clone(), base_points, position, sides
 
@@ -498,8 +524,11 @@ class VolumetricTriangulationNet(_PlannedNet):
                bool(self.volume_softmax), self.volume_aggregation_method, bool(self.transfer_cmu_to_human36m), self.num_joints,
                tuple(p.requires_grad for p in params), id(getattr(self, "grad_reducer", None)), getattr(self, "train_precision", "fp32"),
                tuple(c.training for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm)))
-        if getattr(self, "train_precision", "fp32") not in ("fp32", "bf16"):
-            raise ValueError("train_precision must be 'fp32' (the reference's precision) or 'bf16' (bf16 MFMA convolutions, fp32 everything else)")
+        if getattr(self, "train_precision", "fp32") not in ("fp32", "bf16", "act16", "fp8v2v"):
+            raise ValueError("train_precision must be 'fp32' (the reference's precision), 'bf16' (bf16 MFMA convolutions, fp32 storage), 'act16' (bf16 MFMA "
+                             "convolutions AND bf16 activations / activation gradients) or 'fp8v2v' (act16 with V2V's 3x3x3 convolutions on the fp8 MFMA)")
+        if getattr(self, "train_precision", "fp32") in ("act16", "fp8v2v") and self.volume_aggregation_method.startswith("conf"):
+            raise NotImplementedError("train_precision '%s' with the confidence heads (conf / conf_norm): use 'bf16' or 'fp32'" % self.train_precision)
         red = getattr(self, "grad_reducer", None)
         if red is not None:
             # DistributedDataParallel's semantics (reference train.py:453): rank 0's parameters and buffers at "construction" (here: the

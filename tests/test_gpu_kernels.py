@@ -360,6 +360,63 @@ def test_conv_fp32_residual_on_a_bf16_convolution():
             check("conv bf16 + fp32 residual nd%d %d->%d k%d%s tile%d" % (nd, cin, cout, k, " T" if tr else "", tile), out - res, ref0, 1e-4)
 
 
+FP8_CASES = [  # nd, N, cin, cout, k, stride, pad, spatial
+    (3, 2, 32, 32, 3, 1, 1, (8, 8, 8)),        # V2V 3^3 32 -> 32
+    (3, 1, 16, 32, 3, 1, 1, (6, 8, 10)),       # 16 input channels: one 16-byte vector per voxel
+    (3, 2, 64, 64, 3, 1, 1, (4, 8, 8)),
+    (3, 1, 128, 128, 3, 1, 1, (4, 4, 4)),
+    (2, 2, 256, 64, 1, 1, 0, (9, 7)),          # pointwise fast path
+]
+
+
+@pytest.mark.parametrize("case", FP8_CASES, ids=lambda c: "nd%d_%dto%d_k%d" % (c[0], c[2], c[3], c[4]))
+def test_conv_fp8_operands(case):
+    """lt_conv_fwd(dtype = LT_FP8): e4m3 operands (per-tensor amax scaling by lt_amax_f32 / lt_quant_fp8, the scale product in the epilogue's
+    ``scale``, the bias in ``shift``), fp32 accumulation and storage, an fp32 residual -- against torch's conv over the SAME quantised operands
+    (torch.float8_e4m3fn is the OCP format gfx950 converts to): products of two e4m3 values are exact in fp32, so only the summation
+    order differs.  Also checks the quantisation kernels bit for bit against torch's cast."""
+    nd, N, cin, cout, k, s_, p_, sp = case
+    lib = H.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(cin * 3 + cout + k)
+    x = torch.randn(N, cin, *sp, generator=g) * 1.7
+    w = torch.randn(cout, cin, *([k] * nd), generator=g) * (1.0 / (cin * k ** nd) ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    # ---- quantisation on the device: amax -> scale -> e4m3 bytes
+    xcl = to_cl(x)                                       # N,D,H,W,C fp32
+    amax = torch.zeros(2, dtype=torch.float32, device=DEV)
+    scales = torch.zeros(2, dtype=torch.float32, device=DEV)
+    x8 = torch.empty(xcl.shape, dtype=torch.uint8, device=DEV)
+    H.check(lib.lt_amax_f32(xcl.data_ptr(), xcl.numel(), amax.data_ptr(), st), "lt_amax_f32")
+    H.check(lib.lt_quant_fp8(xcl.data_ptr(), x8.data_ptr(), xcl.numel(), amax.data_ptr(), scales.data_ptr(), st), "lt_quant_fp8")
+    torch.cuda.synchronize()
+    sx = float(x.abs().max()) / 448.0
+    assert abs(float(amax[0]) - float(x.abs().max())) == 0.0 and abs(float(scales[0]) - np.float32(np.float32(x.abs().max()) / np.float32(448.0))) <= 1e-12
+    sx = float(scales[0])
+    xq_ref = (xcl.cpu() * np.float32(1.0 / np.float32(sx))).to(torch.float8_e4m3fn)
+    mism = (x8.cpu() != xq_ref.view(torch.uint8)).float().mean()
+    record("fp8/quantisation bytes differing from torch's e4m3fn cast (nd%d %d->%d)" % (nd, cin, cout), float(mism))
+    assert float(mism) == 0.0, float(mism)
+    sw = float(w.abs().max()) / 448.0
+    wq = (w / sw).to(torch.float8_e4m3fn)
+    conv = F.conv2d if nd == 2 else F.conv3d
+    xq_nc = xq_ref.float().permute(0, 4, 1, 2, 3)
+    xq_nc = xq_nc[:, :, 0] if nd == 2 else xq_nc
+    ref0 = conv(xq_nc, wq.float(), None, stride=s_, padding=p_) * (sx * sw) + bias.reshape([1, -1] + [1] * nd)
+    res = torch.randn(ref0.shape, generator=g)
+    for with_res in (False, True):
+        for tile in (0, TILES["v2_256x32"] if E.cout_pad_of(cout) == 32 else TILES["v2_128x64"]):
+            b = E.PlanBuilder(DEV, torch.float8_e4m3fn, tile_override=tile)
+            # the epilogue is (acc + bias) * scale + shift: scale = sx * sw and shift = the convolution's bias, through the BatchNorm slot
+            bn = (torch.full((cout,), sx * sw), bias, torch.zeros(cout), torch.ones(cout) - 1e-5)          # invstd = 1 / sqrt(var + 1e-5) = 1
+            xa = E.Act(x8.view(torch.float8_e4m3fn))
+            ra = E.Act(to_cl(res)) if with_res else None
+            y = b.conv(xa, wq.float(), None, bn, stride=s_, pad=p_, residual=ra, out_f32=True, residual_f32=with_res, relu=with_res)
+            b.finish().run_eager(st); torch.cuda.synchronize()
+            ref = torch.relu(ref0 + res) if with_res else ref0
+            check("conv fp8 nd%d %d->%d k%d tile%d%s" % (nd, cin, cout, k, tile, " +res" if with_res else ""), from_cl(y.t, nd), ref, 1e-4)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_conv_epilogue_variants(dtype):
     """fp32 store from bf16 compute (V2V logits), sigmoid head (linear as 1x1 conv over an N-pixel row), ragged Cout."""

@@ -136,6 +136,115 @@ def test_maxpool_bwd(nd, k, s, p, shape):
     assert abs(float(ours.double().sum()) - float(ref.sum())) <= 1e-3 * float(ref.abs().sum())
 
 
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("flags_name,with_res", [("none", False), ("relu", True), ("relu_pre", True)])
+@pytest.mark.parametrize("rows,C", [(1000, 64), (70000, 32), (37, 16)])
+def test_bn_act_fwd_bwd_bf16_activations(rows, C, flags_name, with_res):
+    """LT_ACT_BF16 (+ LT_BN_Y_BF16): the 16-bit-activation step's BatchNorm passes -- y, residual, z, dz, dy, dres are bf16 tensors.  Reference: fp64
+    autograd over the bf16-ROUNDED inputs; outputs compared after their own rounding to bf16 (2^-8 relative), the fp32 sums at fp32 tolerances."""
+    H, lib = _lib()
+    g = torch.Generator().manual_seed(rows + C + 1)
+    y = _bf(torch.randn(rows, C, generator=g) * 2 + 0.5)
+    res = _bf(torch.randn(rows, C, generator=g)) if with_res else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    dz = _bf(torch.randn(rows, C, generator=g))
+    flags = {"none": 0, "relu": H.EPI_RELU_POST, "relu_pre": H.EPI_RELU_PRE}[flags_name]
+    yd = y.double().requires_grad_(True); gd = gamma.double().requires_grad_(True); bd = beta.double().requires_grad_(True)
+    rd = res.double().requires_grad_(True) if with_res else None
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    n = (yd - mean) / torch.sqrt(var + 1e-5) * gd + bd
+    if flags_name == "relu_pre":
+        dz = dz * (n.detach().abs() > 1e-4).float()
+        n = F.relu(n)
+    if with_res:
+        n = n + rd
+    if flags_name == "relu":
+        dz = dz * (n.detach().abs() > 1e-4).float()
+        n = F.relu(n)
+    (n * dz.double()).sum().backward()
+    bf = torch.bfloat16
+    yg, dzg = y.to(DEV, bf), dz.to(DEV, bf)
+    resg = res.to(DEV, bf) if with_res else None
+    mg, vg = mean.detach().float().to(DEV), var.detach().float().to(DEV)
+    gg, bg = gamma.to(DEV), beta.to(DEV)
+    fl = flags | H.BN_Y_BF16 | H.ACT_BF16
+    # the statistics kernel over the bf16 tensor
+    m2, v2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ws0 = torch.empty(max(1, lib.lt_bn_stats_workspace(rows, C)), dtype=torch.uint8, device=DEV)
+    H.check(lib.lt_bn_stats_fwd(H.LT_BF16, yg.data_ptr(), rows, C, m2.data_ptr(), v2.data_ptr(), None, None, 0.1, ws0.data_ptr(), _st()), "stats")
+    tag = "train/bn_act bf16 activations %dx%d %s%s" % (rows, C, flags_name, "+res" if with_res else "")
+    check(tag + " mean", m2.cpu(), mean.detach(), 1e-5)
+    check(tag + " var", v2.cpu(), var.detach(), 1e-5)
+    z = torch.empty(rows, C, dtype=bf, device=DEV)
+    H.check(lib.lt_bn_act_fwd(yg.data_ptr(), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), H.ptr(resg), z.data_ptr(), None, rows, C, 1e-5, fl, _st()), "fwd")
+    check(tag + " fwd", z.float().cpu(), n.detach(), 5e-3)
+    assert lib.lt_bn_act_fwd(yg.data_ptr(), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), H.ptr(resg), z.data_ptr(), z.data_ptr(), rows, C, 1e-5, fl, _st()) == -1
+    dy, dga, dbe = torch.empty(rows, C, dtype=bf, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dres = torch.full((rows, C), 3.0, dtype=bf, device=DEV) if with_res else None
+    ws = torch.empty(max(1, lib.lt_bn_act_bwd_workspace(rows, C)), dtype=torch.uint8, device=DEV)
+    H.check(lib.lt_bn_act_bwd(dzg.data_ptr(), yg.data_ptr(), H.ptr(resg), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), dy.data_ptr(), None,
+                              dga.data_ptr(), dbe.data_ptr(), H.ptr(dres), 1 if with_res else 0, rows, C, 1e-5, fl, ws.data_ptr(), _st()), "bwd")
+    check(tag + " dy", dy.float().cpu(), yd.grad, 5e-3)
+    check(tag + " dgamma", dga.cpu(), gd.grad, 2e-5)
+    check(tag + " dbeta", dbe.cpu(), bd.grad, 2e-5)
+    if with_res:
+        check(tag + " dres (accumulated onto 3)", dres.float().cpu(), rd.grad + 3.0, 5e-3)
+
+
+def test_bf16_activation_helpers():
+    """lt_convert_pad (casts and channel padding between fp32 and bf16), lt_channel_sum_dt / lt_act_bwd / lt_maxpool_bwd_dt on bf16 tensors."""
+    H, lib = _lib()
+    g = torch.Generator().manual_seed(77)
+    bf = torch.bfloat16
+    rows, C = 4099, 17
+    x = torch.randn(rows, C, generator=g)
+    xg = x.to(DEV)
+    # fp32 -> bf16 with padding 17 -> 32, bf16 -> fp32 plain cast, fp32 -> bf16 plain cast (vector path: rows * C % 4 == 0 needs an even count)
+    o16 = torch.empty(rows, 32, dtype=bf, device=DEV)
+    H.check(lib.lt_convert_pad(H.LT_F32, xg.data_ptr(), H.LT_BF16, o16.data_ptr(), rows, C, 32, _st()), "pad")
+    assert torch.equal(o16[:, :C].cpu(), x.to(bf)) and float(o16[:, C:].float().abs().max()) == 0.0
+    x4 = torch.randn(4096, 32, generator=g)
+    a16 = torch.empty(4096, 32, dtype=bf, device=DEV)
+    H.check(lib.lt_convert_pad(H.LT_F32, x4.to(DEV).data_ptr(), H.LT_BF16, a16.data_ptr(), 4096, 32, 32, _st()), "cast")
+    assert torch.equal(a16.cpu(), x4.to(bf))
+    b32 = torch.empty(4096, 32, device=DEV)
+    H.check(lib.lt_convert_pad(H.LT_BF16, a16.data_ptr(), H.LT_F32, b32.data_ptr(), 4096, 32, 32, _st()), "cast back")
+    assert torch.equal(b32.cpu(), x4.to(bf).float())
+    o17 = torch.empty(rows, C, dtype=bf, device=DEV)          # 17 columns, same width: the scalar tail path
+    H.check(lib.lt_convert_pad(H.LT_F32, xg.data_ptr(), H.LT_BF16, o17.data_ptr(), rows, C, C, _st()), "cast 17")
+    assert torch.equal(o17.cpu(), x.to(bf))
+    # channel sums of a bf16 tensor (vector and scalar column paths)
+    for cc in (17, 64):
+        t = torch.randn(rows, cc, generator=g).to(bf)
+        out = torch.empty(cc, device=DEV)
+        ws = torch.empty(max(1, lib.lt_channel_sum_workspace(rows, cc)), dtype=torch.uint8, device=DEV)
+        H.check(lib.lt_channel_sum_dt(H.LT_BF16, t.to(DEV).data_ptr(), rows, cc, out.data_ptr(), 0, ws.data_ptr(), _st()), "lt_channel_sum_dt")
+        check("train/channel_sum bf16 C=%d" % cc, out.cpu(), t.double().sum(0), 1e-6)
+    # activation backward on bf16 tensors: z = relu(v + res)
+    pre, res, dz = (torch.randn(rows, C, generator=g).to(bf) for _ in range(3))
+    zz = F.relu(pre.float() + res.float()).to(bf)
+    dy, dres = torch.empty(rows, C, dtype=bf, device=DEV), torch.full((rows, C), 2.0, dtype=bf, device=DEV)
+    H.check(lib.lt_act_bwd(dz.to(DEV).data_ptr(), zz.to(DEV).data_ptr(), res.to(DEV).data_ptr(), dy.data_ptr(), dres.data_ptr(), 1, rows * C, H.EPI_RELU_POST | H.ACT_BF16, _st()),
+            "lt_act_bwd")
+    gref = dz.float() * (zz.float() > 0).float()
+    assert torch.equal(dy.cpu(), gref.to(bf)) and torch.equal(dres.cpu(), (gref + 2.0).to(bf))
+    # max pool backward on bf16 tensors (V2V's 2^3 / stride 2 pool: one contribution per input, exact)
+    xs = F.relu(torch.randn(2, 32, 8, 8, 8, generator=g)).to(bf).float()
+    xd = xs.double().requires_grad_(True)
+    y = F.max_pool3d(xd, 2, 2, 0)
+    dyy = torch.randn(y.shape, generator=g).to(bf).float()
+    (y * dyy.double()).sum().backward()
+    xcl, dycl = to_cl(xs, None, bf), to_cl(dyy, None, bf)
+    dx = torch.zeros_like(xcl)
+    N, D, Hh, W, Cc = xcl.shape
+    H.check(lib.lt_maxpool_bwd_dt(H.LT_BF16, xcl.data_ptr(), dycl.data_ptr(), dx.data_ptr(), N, D, Hh, W, Cc, H.i3((2, 2, 2)), H.i3((2, 2, 2)), H.i3((0, 0, 0)), _st()), "lt_maxpool_bwd_dt")
+    m = xs > 0
+    check("train/maxpool_bwd bf16 (x > 0)", from_cl(dx, 3) * m, xd.grad * m, 1e-6)
+
+
 CONV_CASES = [  # nd, Cin, Cout, k, stride, pad, transposed, spatial
     (2, 16, 32, 3, 1, 1, False, (10, 12)),
     (2, 64, 64, 1, 1, 0, False, (9, 7)),
@@ -158,7 +267,7 @@ CONV_CASES = [  # nd, Cin, Cout, k, stride, pad, transposed, spatial
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "nd%d_%dto%d_k%ds%dp%d%s" % (c[0], c[1], c[2], c[3], c[4], c[5], "_T" if c[6] else ""))
 @pytest.mark.parametrize("mode", ["bn_relu_res", "bias_only"])
-@pytest.mark.parametrize("mixed", [False, True], ids=["fp32", "bf16mma"])
+@pytest.mark.parametrize("mixed", [False, True, "act16"], ids=["fp32", "bf16mma", "act16"])
 def test_tape_layer_gradients(case, mode, mixed):
     """One layer through TrainTape: z = act(BN_train(conv(x) + b) [+ res]); all gradients vs torch-CPU fp64 autograd.  ``mixed``: the
     convolution and its input gradient on the bf16 MFMA (bf16 copies of the operands, fp32 accumulation and storage), everything else
@@ -196,15 +305,18 @@ def test_tape_layer_gradients(case, mode, mixed):
 
     wp, bp = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
     gp, btp = torch.nn.Parameter(gamma.to(DEV)), torch.nn.Parameter(beta.to(DEV))
-    tape = lt_train.TrainTape(DEV, params=[wp, bp, gp, btp], mixed=mixed)
+    act16 = mixed == "act16"          # bf16 activations and activation gradients on top of the bf16 MFMA (train_precision "act16")
+    adt = torch.bfloat16 if act16 else torch.float32
+    tape = lt_train.TrainTape(DEV, params=[wp, bp, gp, btp], mixed=bool(mixed), act16=act16)
     T1, T2, T3 = (2e-5, 5e-5, 1e-6) if not mixed else (2e-2, 2e-2, 2e-2)
     rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
-    xa = E.Act(to_cl(x))
-    ra = E.Act(to_cl(res)) if use_bn else None
+    xa = E.Act(to_cl(x, None, adt))
+    ra = E.Act(to_cl(res, None, adt)) if use_bn else None
     z = tape.conv(xa, wp, bp, (gp, btp, rm, rv) if use_bn else None, stride=s, pad=p, transposed=tr, relu=use_bn, residual=ra)
-    tag = "train/layer%s nd%d %d->%d k%d s%d p%d%s %s" % (" bf16mma" if mixed else "", nd, Cin, Cout, k, s, p, " T" if tr else "", mode)
+    tag = "train/layer%s nd%d %d->%d k%d s%d p%d%s %s" % (" act16" if act16 else " bf16mma" if mixed else "", nd, Cin, Cout, k, s, p, " T" if tr else "", mode)
+    assert z.t.dtype == adt
     check(tag + " z", from_cl(z.t, nd), y.detach(), T1)
-    dzb = to_cl(dz)
+    dzb = to_cl(dz, None, adt)
     tape.seed(z, dzb)
     pg = tape.run_backward()          # records the backward while running it
     first = {k: v.clone() for k, v in pg.items()}
@@ -639,7 +751,7 @@ def _check_two_rank_gradients(got, single, tag):
     assert worst <= 1e-5, worst
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "act16"])
 def test_training_step_is_bitwise_repeatable(precision):
     """Two independent recordings (fresh models, same weights / inputs / rotations) and their replays give BITWISE identical parameter
     gradients: every reduction of the step has a fixed order (column sums in fp64 slabs, weight gradients by slab partials -- on the fp32
@@ -830,7 +942,8 @@ def test_training_api_semantics_accumulation_stale_backward_torch_optimizer():
     assert len(m._train_plans) == 2 and torch.isfinite(kp1).all()
 
 
-def test_mixed_precision_training_step_deviation_and_descent(golden_dir):
+@pytest.mark.parametrize("precision", ["bf16", "act16"])
+def test_mixed_precision_training_step_deviation_and_descent(golden_dir, precision):
     """train_precision = "bf16": the convolutions and their input gradients on the bf16 MFMA, everything else fp32.  Outside the fp32
     tolerance by construction (like the bf16 inference mode): the deviation of one whole step from the reference's step is RECORDED
     (joints, loss, parameter gradients), loosely bounded, and ten Adam steps must lower the loss."""
@@ -844,7 +957,7 @@ def test_mixed_precision_training_step_deviation_and_descent(golden_dir):
     m.load_state_dict(sd, strict=True)
     m.to(DEV)
     m.train()
-    m.train_precision = "bf16"
+    m.train_precision = precision
     batch = {"cameras": _cameras(inp, c["B"]), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
     np.random.seed(c["seed"] + 100)
     kp, feats, vols, conf, cuboids, cvs, bps = m(inp["images"].to(DEV), None, batch)
@@ -863,11 +976,12 @@ def test_mixed_precision_training_step_deviation_and_descent(golden_dir):
         sub = f[::max(1, f.numel() // 129)][:129]
         errs.append(float((sub - torch.from_numpy(G["g/" + n]).double()).abs().max()) / float(G["gn/" + n][1]))
     errs.sort()
-    record("train/mixed precision (bf16 MFMA convolutions) one step vs the reference's fp32 step -- gated: median <= 8 %, p90 <= 20 %",
+    record("train/mixed precision (%s) one step vs the reference's fp32 step -- gated: median <= 8 %%, p90 <= 20 %%" % ("bf16 MFMA convolutions" if precision == "bf16" else precision),
            {"joints_max_rel": float(d.max()), "mae": float(mae.detach()), "mae_reference": float(G["mae"]), "ce": float(ce.detach()), "ce_reference": float(G["ce"]),
             "parameter_gradient_err_median": errs[len(errs) // 2], "parameter_gradient_err_p90": errs[int(len(errs) * 0.9)], "parameter_gradient_err_max": errs[-1]})
     # gated at the level the mode achieves on this fixture (VERDICT r3 "next" 8): median 6.3 %, p90 15.8 % of each tensor's largest reference gradient
-    assert float(d.max()) < 5e-2 and errs[len(errs) // 2] <= 0.08 and errs[int(len(errs) * 0.9)] <= 0.20, (float(d.max()), errs[len(errs) // 2], errs[int(len(errs) * 0.9)])
+    g_med, g_p90 = (0.08, 0.20) if precision == "bf16" else (0.15, 0.35)          # act16 rounds every activation and activation gradient to bf16 as well
+    assert float(d.max()) < 5e-2 and errs[len(errs) // 2] <= g_med and errs[int(len(errs) * 0.9)] <= g_p90, (float(d.max()), errs[len(errs) // 2], errs[int(len(errs) * 0.9)])
     # descent
     opt = lt_train.Adam(list(m.parameters()), lr=1e-4)
     gt2 = torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float().to(DEV)
@@ -881,7 +995,7 @@ def test_mixed_precision_training_step_deviation_and_descent(golden_dir):
         loss.backward()
         opt.step()
         losses.append(float(loss.detach()))
-    record("train/mixed precision loss over 10 Adam steps", losses)
+    record("train/mixed precision (%s) loss over 10 Adam steps" % precision, losses)
     assert losses[-1] < losses[0], losses
 
 
@@ -997,7 +1111,7 @@ def test_whole_algebraic_training_step_vs_reference(golden_dir, use_conf):
     assert torch.isfinite(kp3b).all() and float(loss2.detach()) != float(loss.detach())
 
 
-@pytest.mark.parametrize("y16", [False, True], ids=["fp32_conv_outputs", "bf16_conv_outputs"])
+@pytest.mark.parametrize("y16", [False, True, "act16"], ids=["fp32_conv_outputs", "bf16_conv_outputs", "act16"])
 def test_mixed_precision_step_tracks_fp32_on_a_bottleneck_backbone(y16, monkeypatch):
     """(``y16``: the opt-in LT_TRAIN_Y16=1 variant -- bf16 convolution outputs in front of BatchNorm, hence the whole set of bf16 forward kernels
     over LIVE weights at real layer shapes -- against the same gates.)
@@ -1040,12 +1154,12 @@ def test_mixed_precision_step_tracks_fp32_on_a_bottleneck_backbone(y16, monkeypa
             losses.append(float(loss.detach()))
         return losses, g0
 
-    if y16:
+    if y16 is True:
         monkeypatch.setenv("LT_TRAIN_Y16", "1")
     else:
         monkeypatch.delenv("LT_TRAIN_Y16", raising=False)
     l32, g32 = run("fp32")
-    l16, g16 = run("bf16")
+    l16, g16 = run("act16" if y16 == "act16" else "bf16")          # act16: bf16 activations and activation gradients as well (train_precision "act16")
     gtot = float(torch.cat(list(g32.values())).norm())
 
     def group(n):
@@ -1061,7 +1175,7 @@ def test_mixed_precision_step_tracks_fp32_on_a_bottleneck_backbone(y16, monkeypa
             continue
         groups.setdefault(group(n), []).append(float((a @ g16[n]) / (a.norm() * g16[n].norm() + 1e-300)))
     stats = {k: {"tensors": len(v), "median_cosine": sorted(v)[len(v) // 2], "worst_cosine": min(v)} for k, v in groups.items()}
-    record("train/mixed%s vs fp32 on a bottleneck backbone (ResNet-50, 64^3): losses and gradient cosines per group" % (" (bf16 conv outputs)" if y16 else ""),
+    record("train/mixed%s vs fp32 on a bottleneck backbone (ResNet-50, 64^3): losses and gradient cosines per group" % (" (act16: bf16 activations and gradients)" if y16 == "act16" else " (bf16 conv outputs)" if y16 else ""),
            {"losses_fp32": l32, "losses_bf16": l16, "groups": stats})
     print(stats, l32, l16)
     assert abs(l16[0] - l32[0]) <= 0.01 * abs(l32[0]), (l16, l32)
