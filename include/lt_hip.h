@@ -80,9 +80,10 @@ int lt_device_info(int* cu_count, int* lds_per_cu, char* arch, int arch_len);
  *     y[n, od*osd + ood_p, oh*osh + ooh_p, ow*osw + oow_p, co] = v
  *
  * dtype == LT_FP8: x and the weights are e4m3 bytes (per-tensor scaled by the caller: x ~ sx * x8, w ~ sw * w8, see lt_quant_fp8), the
- * products run on v_mfma_f32_*_fp8_fp8 with fp32 accumulation, the result is stored as fp32 (LT_EPI_STORE_F32 is required, a residual is
- * fp32 too: LT_EPI_RES_F32); the caller passes sx * sw in `scale` and the convolution's bias in `shift` (bias = NULL).  Cin >= 16,
- * k_pad % 128 == 0 (one 128-byte K step = 128 elements); generic implicit-GEMM kernel only.
+ * products run on v_mfma_f32_*_fp8_fp8 with fp32 accumulation, the result is stored as fp32 (LT_EPI_STORE_F32, a residual is fp32 too:
+ * LT_EPI_RES_F32) or -- without LT_EPI_STORE_F32, Cout % 8 == 0 -- as bf16 (y and the residual are bf16 tensors: the 16-bit-activation training
+ * step); the caller passes sx * sw in `scale` and the convolution's bias in `shift` (bias = NULL).  Cin >= 16, k_pad % 128 == 0 (one 128-byte
+ * K step = 128 elements); generic implicit-GEMM kernel only.
  *
  * A plain convolution is one phase with out_stride 1 / out_off 0; a stride-2 transposed convolution
  * is 2^nd phases (one per output parity) with out_stride 2.  A single one-tap phase with unit strides,
@@ -355,6 +356,9 @@ int lt_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
  * lt_scale_product: dst[i] = *a * *b for i < n. */
 int lt_amax_f32(const float* x, int64_t n, float* amax, void* stream);
 int lt_quant_fp8(const float* x, void* q, int64_t n, const float* amax, float* scale_out, void* stream);
+/* the same two over a tensor of element type `dtype` (LT_F32 | LT_BF16: the bf16 activations / gradients of the 16-bit-activation training step) */
+int lt_amax_dt(int32_t dtype, const void* x, int64_t n, float* amax, void* stream);
+int lt_quant_fp8_dt(int32_t dtype, const void* x, void* q, int64_t n, const float* amax, float* scale_out, void* stream);
 int lt_gather_f32_fp8(const float* src, const int32_t* idx, void* q, int64_t n, const float* amax, float* scale_out, void* stream);
 int lt_scale_product(float* dst, int32_t n, const float* a, const float* b, void* stream);
 /* many gathers in one launch.  jobs (device memory): njobs records of

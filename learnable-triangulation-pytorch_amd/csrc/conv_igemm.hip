@@ -317,8 +317,10 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bi
     LT_REQUIRE(d && x && y, LT_ERR_INVALID, "lt_conv_fwd: null argument");
     LT_REQUIRE(d->dtype == LT_F32 || d->dtype == LT_BF16 || d->dtype == LT_FP8, LT_ERR_INVALID, "lt_conv_fwd: bad dtype %d", d->dtype);
     const int vec = d->dtype == LT_F32 ? 4 : d->dtype == LT_BF16 ? 8 : 16;
-    LT_REQUIRE(d->dtype != LT_FP8 || ((d->flags & LT_EPI_STORE_F32) && (!residual || (d->flags & LT_EPI_RES_F32)) && !(d->flags & LT_EPI_SIGMOID)),
-               LT_ERR_UNSUPPORTED, "lt_conv_fwd: an fp8 convolution stores fp32 (LT_EPI_STORE_F32) and takes an fp32 residual (LT_EPI_RES_F32)");
+    LT_REQUIRE(d->dtype != LT_FP8 || (!(d->flags & LT_EPI_SIGMOID) &&
+                                      (((d->flags & LT_EPI_STORE_F32) && (!residual || (d->flags & LT_EPI_RES_F32))) ||
+                                       (!(d->flags & LT_EPI_STORE_F32) && d->Cout % 8 == 0 && d->ldc % 8 == 0))),
+               LT_ERR_UNSUPPORTED, "lt_conv_fwd: an fp8 convolution stores fp32 (LT_EPI_STORE_F32, fp32 residual: LT_EPI_RES_F32) or, with Cout %% 8 == 0, bf16 (bf16 residual)");
     LT_REQUIRE(d->dtype != LT_FP8 || d->tile == LT_TILE_AUTO || (d->tile >= LT_TILE2_128x128 && d->tile <= LT_TILE2_64x64), LT_ERR_UNSUPPORTED,
                "lt_conv_fwd: fp8 convolutions run on the generic implicit-GEMM tiles only");
     const int l2 = ilog2_exact(d->Cin);

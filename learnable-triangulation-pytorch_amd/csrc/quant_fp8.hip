@@ -12,14 +12,14 @@ namespace {
 constexpr float FP8_MAX = 448.f;
 
 // max |x| of non-negative floats == max of their bit patterns as unsigned integers: an integer atomic, exact and independent of the order
-__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ amax) {
+__global__ __launch_bounds__(256) void amax_kernel(const void* __restrict__ x, int x16, long long n, unsigned* __restrict__ amax) {
     float m = 0.f;
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const float4 v = ((const float4*)x)[i];
+        const float4 v = ld4_f32_or_bf16(x, (size_t)i * 4, x16);
         m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
     }
-    for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(ld1_f32_or_bf16(x, (size_t)i, x16)));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));   // NaN never compares greater: a NaN input leaves the maximum of the rest
@@ -38,19 +38,20 @@ __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d
     return (unsigned)w;
 }
 
-__global__ __launch_bounds__(256) void quant_fp8_kernel(const float* __restrict__ x, unsigned char* __restrict__ q, long long n, const float* __restrict__ amax,
+__global__ __launch_bounds__(256) void quant_fp8_kernel(const void* __restrict__ x, int x16, unsigned char* __restrict__ q, long long n, const float* __restrict__ amax,
                                                         float* __restrict__ scale_out) {
     float scale;
     const float inv = inv_scale_of(*amax, scale);
     if (blockIdx.x == 0 && threadIdx.x == 0 && scale_out) *scale_out = scale;
     const long long n16 = n >> 4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
-        const float4 v0 = ((const float4*)x)[4 * i], v1 = ((const float4*)x)[4 * i + 1], v2 = ((const float4*)x)[4 * i + 2], v3 = ((const float4*)x)[4 * i + 3];
+        const float4 v0 = ld4_f32_or_bf16(x, (size_t)i * 16, x16), v1 = ld4_f32_or_bf16(x, (size_t)i * 16 + 4, x16), v2 = ld4_f32_or_bf16(x, (size_t)i * 16 + 8, x16),
+                     v3 = ld4_f32_or_bf16(x, (size_t)i * 16 + 12, x16);
         ((uint4*)q)[i] = make_uint4(pack4_fp8(v0.x * inv, v0.y * inv, v0.z * inv, v0.w * inv), pack4_fp8(v1.x * inv, v1.y * inv, v1.z * inv, v1.w * inv),
                                     pack4_fp8(v2.x * inv, v2.y * inv, v2.z * inv, v2.w * inv), pack4_fp8(v3.x * inv, v3.y * inv, v3.z * inv, v3.w * inv));
     }
     for (long long i = (n16 << 4) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        q[i] = (unsigned char)(pack4_fp8(x[i] * inv, 0.f, 0.f, 0.f) & 0xff);
+        q[i] = (unsigned char)(pack4_fp8(ld1_f32_or_bf16(x, (size_t)i, x16) * inv, 0.f, 0.f, 0.f) & 0xff);
 }
 
 __global__ __launch_bounds__(256) void gather_fp8_kernel(const float* __restrict__ src, const int* __restrict__ idx, unsigned char* __restrict__ q, long long n,
@@ -80,16 +81,24 @@ unsigned grid_for(long long work_items) {
 
 }  // namespace
 
-extern "C" int lt_amax_f32(const float* x, int64_t n, float* amax, void* stream) {
-    LT_REQUIRE(x && amax && n >= 1 && ((size_t)x % 16 == 0), LT_ERR_INVALID, "lt_amax_f32: bad argument (16-byte aligned x)");
-    hipLaunchKernelGGL(amax_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, (unsigned*)amax);
-    LT_CHECK_LAUNCH("lt_amax_f32");
+extern "C" int lt_amax_f32(const float* x, int64_t n, float* amax, void* stream) { return lt_amax_dt(LT_F32, x, n, amax, stream); }
+
+extern "C" int lt_amax_dt(int32_t dtype, const void* x, int64_t n, float* amax, void* stream) {
+    LT_REQUIRE(x && amax && n >= 1 && ((size_t)x % 16 == 0) && (dtype == LT_F32 || dtype == LT_BF16), LT_ERR_INVALID, "lt_amax: bad argument (16-byte aligned x, fp32 or bf16)");
+    hipLaunchKernelGGL(amax_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, dtype == LT_BF16 ? 1 : 0, (long long)n, (unsigned*)amax);
+    LT_CHECK_LAUNCH("lt_amax");
     return LT_OK;
 }
 
 extern "C" int lt_quant_fp8(const float* x, void* q, int64_t n, const float* amax, float* scale_out, void* stream) {
-    LT_REQUIRE(x && q && amax && n >= 1 && ((size_t)x % 16 == 0) && ((size_t)q % 16 == 0), LT_ERR_INVALID, "lt_quant_fp8: bad argument (16-byte aligned pointers)");
-    hipLaunchKernelGGL(quant_fp8_kernel, dim3(grid_for(n / 16 + 1)), dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)q, (long long)n, amax, scale_out);
+    return lt_quant_fp8_dt(LT_F32, x, q, n, amax, scale_out, stream);
+}
+
+extern "C" int lt_quant_fp8_dt(int32_t dtype, const void* x, void* q, int64_t n, const float* amax, float* scale_out, void* stream) {
+    LT_REQUIRE(x && q && amax && n >= 1 && ((size_t)x % 16 == 0) && ((size_t)q % 16 == 0) && (dtype == LT_F32 || dtype == LT_BF16), LT_ERR_INVALID,
+               "lt_quant_fp8: bad argument (16-byte aligned pointers, fp32 or bf16 source)");
+    hipLaunchKernelGGL(quant_fp8_kernel, dim3(grid_for(n / 16 + 1)), dim3(256), 0, (hipStream_t)stream, x, dtype == LT_BF16 ? 1 : 0, (unsigned char*)q, (long long)n, amax,
+                       scale_out);
     LT_CHECK_LAUNCH("lt_quant_fp8");
     return LT_OK;
 }

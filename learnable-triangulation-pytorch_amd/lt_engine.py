@@ -214,6 +214,8 @@ class PlanBuilder:
             H.lib()
         self.dtype = dtype
         self.code = H.dtype_code(dtype)
+        # element type of outputs / residuals that are not fp32: the plan's own, except that fp8 (an OPERAND type of lt_conv_fwd only) stores bf16
+        self.out_dtype = torch.bfloat16 if dtype == torch.float8_e4m3fn else dtype
         self.ops = []          # (callable, args)
         self.keep = []         # tensors / ctypes objects that must outlive the plan
         self.pool = {}         # nbytes -> [tensor]
@@ -273,12 +275,12 @@ class PlanBuilder:
         S = self.splitk_slices(spec, weight, transposed, out_f32, sigmoid, out)
         if S > 1:
             return self._conv_splitk(x, weight, spec, S, residual)
-        y = out or self.alloc((spec.N, spec.OD, spec.OH, spec.OW, spec.Cout), torch.float32 if out_f32 else self.dtype)
+        y = out or self.alloc((spec.N, spec.OD, spec.OH, spec.OW, spec.Cout), torch.float32 if out_f32 else self.out_dtype)
         self.keep.append(x.t)   # the launch closure holds raw pointers only
         if residual is not None:
             self.keep.append(residual.t)
         if residual is not None:
-            assert residual.shape == y.shape and residual.t.dtype == (torch.float32 if residual_f32 else self.dtype), (residual.shape, y.shape)
+            assert residual.shape == y.shape and residual.t.dtype == (torch.float32 if residual_f32 else self.out_dtype), (residual.shape, y.shape)
         d = H.ConvDesc()
         d.dtype = self.code
         d.N, d.D, d.H, d.W, d.Cin = spec.N, spec.D, spec.H, spec.W, spec.Cin

@@ -109,6 +109,8 @@ SIGNATURES = {
     "lt_cast_f32_bf16": (C.c_int, [vp, vp, i64, vp]),
     "lt_gather_f32_multi": (C.c_int, [vp, i32, i32, vp]),
     "lt_amax_f32": (C.c_int, [vp, i64, vp, vp]),
+    "lt_amax_dt": (C.c_int, [i32, vp, i64, vp, vp]),
+    "lt_quant_fp8_dt": (C.c_int, [i32, vp, vp, i64, vp, vp, vp]),
     "lt_quant_fp8": (C.c_int, [vp, vp, i64, vp, vp, vp]),
     "lt_gather_f32_fp8": (C.c_int, [vp, vp, vp, i64, vp, vp, vp]),
     "lt_scale_product": (C.c_int, [vp, i32, vp, vp, vp]),

@@ -103,6 +103,69 @@ class TrainTape:
         self.param_grads = {}                                   # Parameter -> view of the arena
         self.reducer, self.bucket_elems = reducer, max(1, int(bucket_bytes) // 4)
         self.bwd_recorded = False
+        if self.fp8_3d:
+            # 'fp8v2v' (BASELINE config 5: "fp8 MFMA for V2V 3D convs"): e4m3 operands with per-tensor amax scaling, everything on the device -- the
+            # maxima live in one pool that the forward's first op zeroes (lt_amax_* takes the maximum INTO its slot), the scales next to them
+            self.pb8 = E.PlanBuilder(device, torch.float8_e4m3fn)
+            self.pb8.live_weights = True
+            self._fp8 = {}                                      # id(Act) -> (Act, e4m3 copy, scale slot)
+            self._q_pool = torch.zeros(8192, dtype=torch.float32, device=self.device)
+            self._q_used = 0
+            pool, nb = self._q_pool, self._q_pool.numel() * 4
+            self.do(lambda st: H.check(H.lib().lt_zero(pool.data_ptr(), nb, st), "lt_zero"), "zero")
+
+    # ---- fp8 operands ------------------------------------------------------------------------------------------------------------
+    def _q_slot(self):
+        if self._q_used >= self._q_pool.numel():
+            raise RuntimeError("fp8 scale pool exhausted")
+        self._q_used += 1
+        return self._q_pool[self._q_used - 1:self._q_used]
+
+    def _fp8_of(self, act):
+        """(e4m3 copy of ``act``, device scalar with its scale): amax over the tensor, then one quantisation pass; recorded with the first
+        consumer (the producer has written ``act`` by then), shared by the later ones."""
+        e = self._fp8.get(id(act))
+        if e is None:
+            lib = H.lib()
+            t = act.t
+            n, dt = t.numel(), H.dtype_code(t.dtype)
+            q = torch.empty(t.shape, dtype=torch.float8_e4m3fn, device=self.device)
+            am, sc = self._q_slot(), self._q_slot()
+            self.keep += [t, q]
+            self.do(lambda st: H.check(lib.lt_amax_dt(dt, t.data_ptr(), n, am.data_ptr(), st), "lt_amax_dt"), "amax")
+            self.do(lambda st: H.check(lib.lt_quant_fp8_dt(dt, t.data_ptr(), q.data_ptr(), n, am.data_ptr(), sc.data_ptr(), st), "lt_quant_fp8_dt"), "quant fp8")
+            e = self._fp8[id(act)] = (act, q, sc)
+        return E.Act(e[1]), e[2]
+
+    def _fp8_conv(self, x, wparam, idx, bias, kw):
+        """A 3x3x3 / stride-1 convolution (forward, or an input gradient = the same shape over dY with the flipped filter) on the fp8 MFMA:
+        x and the live weights quantised to e4m3 with per-tensor scales, the product of the two scales in the epilogue's ``scale``, the bias in its
+        ``shift``; bf16 output (and bf16 residual) like every other convolution of the 16-bit-activation step."""
+        lib = H.lib()
+        x8, sx = self._fp8_of(x)
+        y = self.pb8.conv(x8, torch.zeros(idx.shape), None, None, **kw)
+        fn, info = self.pb8.ops[-1][0], self.pb8.last_info
+        spec_idx = E.make_conv_spec(idx, None, None, x.shape, kw.get("stride", 1), kw.get("pad", 0), torch.float8_e4m3fn)
+        assert len(spec_idx.phases) == len(info["wdev"]) == 1
+        wam, sw = self._q_slot(), self._q_slot()
+        wn = wparam.numel()
+        self.do(lambda st: H.check(lib.lt_amax_dt(H.LT_F32, wparam.data_ptr(), wn, wam.data_ptr(), st), "lt_amax_dt"), "amax")
+        ph, wdev = spec_idx.phases[0], info["wdev"][0]
+        assert tuple(ph.weight.shape) == tuple(wdev.shape)
+        imap = (ph.weight.round().to(torch.int32) - 1).contiguous().to(self.device)
+        n8 = wdev.numel()
+        self.keep += [imap, wdev]
+        self.do(lambda st: H.check(lib.lt_gather_f32_fp8(wparam.data_ptr(), imap.data_ptr(), wdev.data_ptr(), n8, wam.data_ptr(), sw.data_ptr(), st), "lt_gather_f32_fp8"),
+                "gather fp8")
+        sc, sh = info["scale_dev"], info["shift_dev"]
+        nsc = sc.numel()
+        self.do(lambda st: H.check(lib.lt_scale_product(sc.data_ptr(), nsc, sx.data_ptr(), sw.data_ptr(), st), "lt_scale_product"), "scale")
+        if bias is not None:          # (acc * sx sw) + bias: the bias rides in the epilogue's shift
+            bmap = torch.full((sh.numel(),), -1, dtype=torch.int32)
+            bmap[:bias.numel()] = torch.arange(bias.numel(), dtype=torch.int32)
+            self._gather(bias, bmap.to(self.device), sh, "w")
+        self.do(fn, ("dgrad fp8 " if self._cur is self.bwd_ops else "conv fp8 ") + self.pb8.ops[-1][1]["label"])
+        return y
 
     # ---- PlanBuilder surface -------------------------------------------------------------------------------------------------
     def alloc(self, shape, dtype=None):
@@ -225,6 +288,9 @@ class TrainTape:
         if wt is not None:
             idx = wt(idx).contiguous()
         if self.act16:
+            if (self.fp8_3d and idx.dim() == 5 and tuple(idx.shape[2:]) == (3, 3, 3) and kw.get("stride", 1) == 1 and not kw.get("transposed", False)
+                    and not out_f32 and x.shape[-1] >= 16 and x.shape[-1] & (x.shape[-1] - 1) == 0 and idx.shape[0] % 8 == 0):
+                return self._fp8_conv(x, wparam, idx, bias, kw)
             # bf16 in, bf16 out (fp32 for the logits layer, ``out_f32``) through the ordinary epilogue of whichever bf16 kernel lt_conv_fwd picks:
             # activation flags and a bf16 residual (the input gradient that is already there) apply in the reference's order inside the kernel
             y = self.pbh.conv(x, torch.zeros(idx.shape), bias, None, out_f32=out_f32, **kw)

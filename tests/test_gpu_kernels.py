@@ -415,6 +415,13 @@ def test_conv_fp8_operands(case):
             b.finish().run_eager(st); torch.cuda.synchronize()
             ref = torch.relu(ref0 + res) if with_res else ref0
             check("conv fp8 nd%d %d->%d k%d tile%d%s" % (nd, cin, cout, k, tile, " +res" if with_res else ""), from_cl(y.t, nd), ref, 1e-4)
+    # bf16 store with a bf16 residual (the 16-bit-activation training step: train_precision "fp8v2v")
+    b = E.PlanBuilder(DEV, torch.float8_e4m3fn)
+    bn = (torch.full((cout,), sx * sw), bias, torch.zeros(cout), torch.ones(cout) - 1e-5)
+    y = b.conv(E.Act(x8.view(torch.float8_e4m3fn)), wq.float(), None, bn, stride=s_, pad=p_, residual=E.Act(to_cl(res, None, torch.bfloat16)), relu=True)
+    b.finish().run_eager(st); torch.cuda.synchronize()
+    assert y.t.dtype == torch.bfloat16
+    check("conv fp8 nd%d %d->%d k%d bf16 store + bf16 residual" % (nd, cin, cout, k), from_cl(y.t, nd), torch.relu(ref0 + bf16_round(res)), 1.5e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -811,7 +818,8 @@ def test_unproject_grid_fused_vs_separate(NV, V, dtype, method, cmu):
     coords = torch.full((B, V, V, V, 3), float("nan"), device=DEV)
     out = torch.empty(B, V, V, V, C, dtype=dtype, device=DEV)
     step = float(np.float32(side / (V - 1)))
-    H.check(H.lib().lt_unproject_grid_fwd(H.dtype_code(dtype), feats.data_ptr(), P.to(DEV).data_ptr(), pos.data_ptr(), cen.data_ptr(), rot.data_ptr(), step,
+    Pg = P.to(DEV)
+    H.check(H.lib().lt_unproject_grid_fwd(H.dtype_code(dtype), feats.data_ptr(), Pg.data_ptr(), pos.data_ptr(), cen.data_ptr(), rot.data_ptr(), step,
                                           int(cmu), coords.data_ptr(), None, out.data_ptr(), B, NV, C, hw, hw, V, H.AGG[method], H.cur_stream()),
             "lt_unproject_grid_fwd")
     assert torch.equal(coords, cv_ref), "coordinates written by the fused kernel differ from lt_coord_volumes"

@@ -180,18 +180,18 @@ def test_bn_act_fwd_bwd_bf16_activations(rows, C, flags_name, with_res):
     check(tag + " var", v2.cpu(), var.detach(), 1e-5)
     z = torch.empty(rows, C, dtype=bf, device=DEV)
     H.check(lib.lt_bn_act_fwd(yg.data_ptr(), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), H.ptr(resg), z.data_ptr(), None, rows, C, 1e-5, fl, _st()), "fwd")
-    check(tag + " fwd", z.float().cpu(), n.detach(), 5e-3)
+    check(tag + " fwd", z.float().cpu(), n.detach(), 8e-3)          # one rounding to bf16: <= 2^-8 of each element, ~1.7e-3 rms
     assert lib.lt_bn_act_fwd(yg.data_ptr(), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), H.ptr(resg), z.data_ptr(), z.data_ptr(), rows, C, 1e-5, fl, _st()) == -1
     dy, dga, dbe = torch.empty(rows, C, dtype=bf, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     dres = torch.full((rows, C), 3.0, dtype=bf, device=DEV) if with_res else None
     ws = torch.empty(max(1, lib.lt_bn_act_bwd_workspace(rows, C)), dtype=torch.uint8, device=DEV)
     H.check(lib.lt_bn_act_bwd(dzg.data_ptr(), yg.data_ptr(), H.ptr(resg), mg.data_ptr(), vg.data_ptr(), gg.data_ptr(), bg.data_ptr(), dy.data_ptr(), None,
                               dga.data_ptr(), dbe.data_ptr(), H.ptr(dres), 1 if with_res else 0, rows, C, 1e-5, fl, ws.data_ptr(), _st()), "bwd")
-    check(tag + " dy", dy.float().cpu(), yd.grad, 5e-3)
+    check(tag + " dy", dy.float().cpu(), yd.grad, 8e-3)
     check(tag + " dgamma", dga.cpu(), gd.grad, 2e-5)
     check(tag + " dbeta", dbe.cpu(), bd.grad, 2e-5)
     if with_res:
-        check(tag + " dres (accumulated onto 3)", dres.float().cpu(), rd.grad + 3.0, 5e-3)
+        check(tag + " dres (accumulated onto 3)", dres.float().cpu(), rd.grad + 3.0, 8e-3)
 
 
 def test_bf16_activation_helpers():
@@ -208,7 +208,8 @@ def test_bf16_activation_helpers():
     assert torch.equal(o16[:, :C].cpu(), x.to(bf)) and float(o16[:, C:].float().abs().max()) == 0.0
     x4 = torch.randn(4096, 32, generator=g)
     a16 = torch.empty(4096, 32, dtype=bf, device=DEV)
-    H.check(lib.lt_convert_pad(H.LT_F32, x4.to(DEV).data_ptr(), H.LT_BF16, a16.data_ptr(), 4096, 32, 32, _st()), "cast")
+    x4g = x4.to(DEV)
+    H.check(lib.lt_convert_pad(H.LT_F32, x4g.data_ptr(), H.LT_BF16, a16.data_ptr(), 4096, 32, 32, _st()), "cast")
     assert torch.equal(a16.cpu(), x4.to(bf))
     b32 = torch.empty(4096, 32, device=DEV)
     H.check(lib.lt_convert_pad(H.LT_BF16, a16.data_ptr(), H.LT_F32, b32.data_ptr(), 4096, 32, 32, _st()), "cast back")
@@ -219,16 +220,17 @@ def test_bf16_activation_helpers():
     # channel sums of a bf16 tensor (vector and scalar column paths)
     for cc in (17, 64):
         t = torch.randn(rows, cc, generator=g).to(bf)
+        tg = t.to(DEV)
         out = torch.empty(cc, device=DEV)
         ws = torch.empty(max(1, lib.lt_channel_sum_workspace(rows, cc)), dtype=torch.uint8, device=DEV)
-        H.check(lib.lt_channel_sum_dt(H.LT_BF16, t.to(DEV).data_ptr(), rows, cc, out.data_ptr(), 0, ws.data_ptr(), _st()), "lt_channel_sum_dt")
+        H.check(lib.lt_channel_sum_dt(H.LT_BF16, tg.data_ptr(), rows, cc, out.data_ptr(), 0, ws.data_ptr(), _st()), "lt_channel_sum_dt")
         check("train/channel_sum bf16 C=%d" % cc, out.cpu(), t.double().sum(0), 1e-6)
     # activation backward on bf16 tensors: z = relu(v + res)
     pre, res, dz = (torch.randn(rows, C, generator=g).to(bf) for _ in range(3))
     zz = F.relu(pre.float() + res.float()).to(bf)
     dy, dres = torch.empty(rows, C, dtype=bf, device=DEV), torch.full((rows, C), 2.0, dtype=bf, device=DEV)
-    H.check(lib.lt_act_bwd(dz.to(DEV).data_ptr(), zz.to(DEV).data_ptr(), res.to(DEV).data_ptr(), dy.data_ptr(), dres.data_ptr(), 1, rows * C, H.EPI_RELU_POST | H.ACT_BF16, _st()),
-            "lt_act_bwd")
+    dzg, zzg, resg = dz.to(DEV), zz.to(DEV), res.to(DEV)
+    H.check(lib.lt_act_bwd(dzg.data_ptr(), zzg.data_ptr(), resg.data_ptr(), dy.data_ptr(), dres.data_ptr(), 1, rows * C, H.EPI_RELU_POST | H.ACT_BF16, _st()), "lt_act_bwd")
     gref = dz.float() * (zz.float() > 0).float()
     assert torch.equal(dy.cpu(), gref.to(bf)) and torch.equal(dres.cpu(), (gref + 2.0).to(bf))
     # max pool backward on bf16 tensors (V2V's 2^3 / stride 2 pool: one contribution per input, exact)
@@ -300,20 +302,25 @@ def test_tape_layer_gradients(case, mode, mixed):
         y = F.relu(y + rd)
     dz = torch.randn(y.shape, generator=g)
     if use_bn:
-        dz = dz * (pre.abs() > (1e-4 if not mixed else 5e-2)).float()      # no upstream gradient where rounding (fp32 / bf16 operands) could flip the ReLU mask
+        dz = dz * (pre.abs() > (1e-4 if not mixed else 0.6 if mixed == "fp8v2v" else 5e-2)).float()      # no upstream gradient where rounding (fp32 / bf16 / e4m3 operands) could flip the ReLU mask
     (y * dz.double()).sum().backward()
 
     wp, bp = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
     gp, btp = torch.nn.Parameter(gamma.to(DEV)), torch.nn.Parameter(beta.to(DEV))
-    act16 = mixed == "act16"          # bf16 activations and activation gradients on top of the bf16 MFMA (train_precision "act16")
+    act16 = mixed in ("act16", "fp8v2v")          # bf16 activations and activation gradients on top of the bf16 MFMA (train_precision "act16")
+    fp8 = mixed == "fp8v2v"                       # ... and the 3x3x3 convolutions + their input gradients on the fp8 MFMA (e4m3: 3 mantissa bits)
     adt = torch.bfloat16 if act16 else torch.float32
-    tape = lt_train.TrainTape(DEV, params=[wp, bp, gp, btp], mixed=bool(mixed), act16=act16)
+    tape = lt_train.TrainTape(DEV, params=[wp, bp, gp, btp], mixed=bool(mixed), act16=act16, fp8_3d=fp8)
     T1, T2, T3 = (2e-5, 5e-5, 1e-6) if not mixed else (2e-2, 2e-2, 2e-2)
+    if fp8:
+        T1, T2 = 0.25, 0.25
     rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
     xa = E.Act(to_cl(x, None, adt))
     ra = E.Act(to_cl(res, None, adt)) if use_bn else None
     z = tape.conv(xa, wp, bp, (gp, btp, rm, rv) if use_bn else None, stride=s, pad=p, transposed=tr, relu=use_bn, residual=ra)
-    tag = "train/layer%s nd%d %d->%d k%d s%d p%d%s %s" % (" act16" if act16 else " bf16mma" if mixed else "", nd, Cin, Cout, k, s, p, " T" if tr else "", mode)
+    tag = "train/layer%s nd%d %d->%d k%d s%d p%d%s %s" % (" fp8v2v" if fp8 else " act16" if act16 else " bf16mma" if mixed else "", nd, Cin, Cout, k, s, p, " T" if tr else "", mode)
+    if fp8:
+        assert any("fp8" in (tape.labels.get(id(f)) or "") for f in tape.fwd_ops), "the fp8 path was not taken"
     assert z.t.dtype == adt
     check(tag + " z", from_cl(z.t, nd), y.detach(), T1)
     dzb = to_cl(dz, None, adt)
@@ -343,7 +350,8 @@ def test_tape_layer_gradients(case, mode, mixed):
         check(tag + " dbeta", pg[btp].cpu(), btd.grad, T2)
         check(tag + " dres", from_cl(tape.grad_of(ra), nd), rd.grad, T3)
         # the bias in front of a training-mode BatchNorm has an exactly zero gradient; ours is rounding noise of the channel sums
-        assert float(pg[bp].abs().max()) <= 1e-4 * float(dz.abs().sum() / Cout)
+        # (bf16 activation gradients: the sum of dy's rounding errors, ~2^-9 sqrt(n) of its magnitude)
+        assert float(pg[bp].abs().max()) <= (3e-3 if act16 else 1e-4) * float(dz.abs().sum() / Cout)
         n_el = y.numel() // Cout
         yb = conv(x.double(), w.double(), b.double(), stride=s, padding=p)
         dims = [0] + list(range(2, 2 + nd))
@@ -434,6 +442,15 @@ def test_tape_layer_gradients_with_bf16_conv_outputs(case, monkeypatch):
     dtype = LT_BF16 in lt_bn_stats_fwd, live weights without fragment-order copies) -- the same gates as the mixed mode."""
     monkeypatch.setenv("LT_TRAIN_Y16", "1")
     test_tape_layer_gradients(case, "bn_relu_res", True)
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[0] == 3 and c[3] == 3 and c[4] == 1 and not c[6]],
+                         ids=lambda c: "nd%d_%dto%d_k%ds%dp%d" % (c[0], c[1], c[2], c[3], c[4], c[5]))
+def test_tape_layer_gradients_fp8_3d(case):
+    """train_precision "fp8v2v" (BASELINE config 5: "fp8 MFMA for V2V 3D convs"): the 3x3x3 layer and its input gradient on the fp8 MFMA -- e4m3
+    operands with per-tensor amax scales computed on the device every step (activations, gradients and the live weights) -- inside the
+    16-bit-activation tape; the weight gradient stays on the bf16 MFMA.  Gated at e4m3's resolution (3 mantissa bits: ~4 % rms per sum)."""
+    test_tape_layer_gradients(case, "bn_relu_res", "fp8v2v")
 
 
 def test_adam_step_vs_torch():
@@ -980,8 +997,8 @@ def test_mixed_precision_training_step_deviation_and_descent(golden_dir, precisi
            {"joints_max_rel": float(d.max()), "mae": float(mae.detach()), "mae_reference": float(G["mae"]), "ce": float(ce.detach()), "ce_reference": float(G["ce"]),
             "parameter_gradient_err_median": errs[len(errs) // 2], "parameter_gradient_err_p90": errs[int(len(errs) * 0.9)], "parameter_gradient_err_max": errs[-1]})
     # gated at the level the mode achieves on this fixture (VERDICT r3 "next" 8): median 6.3 %, p90 15.8 % of each tensor's largest reference gradient
-    g_med, g_p90 = (0.08, 0.20) if precision == "bf16" else (0.15, 0.35)          # act16 rounds every activation and activation gradient to bf16 as well
-    assert float(d.max()) < 5e-2 and errs[len(errs) // 2] <= g_med and errs[int(len(errs) * 0.9)] <= g_p90, (float(d.max()), errs[len(errs) // 2], errs[int(len(errs) * 0.9)])
+    g_med, g_p90 = (0.08, 0.20) if precision == "bf16" else (0.10, 0.28)          # act16 rounds every activation and activation gradient to bf16 as well: 7.7 % / 21.4 %
+    assert float(d.max()) < (5e-2 if precision == "bf16" else 8e-2) and errs[len(errs) // 2] <= g_med and errs[int(len(errs) * 0.9)] <= g_p90, (float(d.max()), errs[len(errs) // 2], errs[int(len(errs) * 0.9)])
     # descent
     opt = lt_train.Adam(list(m.parameters()), lr=1e-4)
     gt2 = torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float().to(DEV)
