@@ -158,6 +158,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, long long ro
 
 struct BnStatLoad {
     const void* x; int C, is_bf16;
+    __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void operator()(long long row, int c, float (&q)[2][4]) const {
         const float4 v = ld4_f32_or_bf16(x, (size_t)row * C + c, is_bf16);
         q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w;

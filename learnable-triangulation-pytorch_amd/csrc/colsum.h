@@ -5,7 +5,7 @@
 //                    four rows in flight, accumulates in fp64, the row lanes are combined through LDS, one fp64 partial per
 //                    (slab, channel, quantity) goes to the workspace;
 //   colsum_finalize  64 slab lanes x 4 channels per workgroup add the partials in a fixed order and hand the NQ totals to a functor.
-// The slab count keeps >= 4 rows per thread, <= 1024 workgroups and <= 4 MB of partials.
+// The slab count keeps >= 8 rows per thread, <= 2048 workgroups and <= 8 MB of partials per quantity pair.
 #pragma once
 #include "lt_common.h"
 
@@ -19,8 +19,10 @@ inline ColsumPlan colsum_plan(long long rows, int C) {
     p.cw4 = c4 < 256 ? c4 : 256;
     p.rl = 256 / p.cw4;
     p.ncb = (c4 + 255) / 256;
-    long long n = rows / ((long long)p.rl * 4);
-    const long long cap_blocks = 1024 / p.ncb, cap_part = (256ll << 10) / C;
+    long long n = rows / ((long long)p.rl * 8);
+    // (round 4: 512K / C slabs -- 256 workgroups of four waves with four 8-byte loads per lane in flight gave the 18432 x 1024 bf16 layers
+    //  1.2 TB/s: the pass is bound by bytes in flight, not by bytes)
+    const long long cap_blocks = 2048 / p.ncb, cap_part = (512ll << 10) / C;
     if (n > cap_blocks) n = cap_blocks;
     if (n > cap_part) n = cap_part;
     if (n < 1) n = 1;
@@ -39,9 +41,10 @@ inline size_t colsum_workspace(long long rows, int C, int nq) {
     return colsum_fast(C) ? (size_t)colsum_plan(rows, C).nslab * C * nq * sizeof(double) : 0;
 }
 
-// Load: void operator()(long long row, int c /* multiple of 4 */, float (&q)[NQ][4]) -- the NQ quantities of four consecutive channels
+// Load: void prepare(int c) -- once per thread, c = the first of its four channels (per-channel constants into registers);
+//       void operator()(long long row, int c /* multiple of 4 */, float (&q)[NQ][4]) -- the NQ quantities of four consecutive channels
 template <int NQ, class Load>
-__device__ __forceinline__ void colsum_partial(long long rows, int C, int nslab, int cw4, int rl_n, double* __restrict__ part, const Load& load) {
+__device__ __forceinline__ void colsum_partial(long long rows, int C, int nslab, int cw4, int rl_n, double* __restrict__ part, const Load& load_in) {
     __shared__ double red[256][NQ * 4 + 1];
     const int slab = blockIdx.x;
     const long long r0 = rows * slab / nslab, r1 = rows * (slab + 1) / nslab;
@@ -52,14 +55,16 @@ __device__ __forceinline__ void colsum_partial(long long rows, int C, int nslab,
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[q][e] = 0.0;
+    Load load = load_in;
     if (c < C) {
+        load.prepare(c);
         long long r = r0 + rl;
-        for (; r + 3ll * rl_n < r1; r += 4ll * rl_n) {          // four rows in flight
-            float v[4][NQ][4];
+        for (; r + 7ll * rl_n < r1; r += 8ll * rl_n) {          // eight rows in flight (four left the pass latency-bound at ~1.2 TB/s)
+            float v[8][NQ][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) load(r + (long long)u * rl_n, c, v[u]);
+            for (int u = 0; u < 8; ++u) load(r + (long long)u * rl_n, c, v[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
 #pragma unroll

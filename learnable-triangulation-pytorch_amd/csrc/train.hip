@@ -41,12 +41,21 @@ struct BnActArgs {
 };
 
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActArgs a) {
-    const long long total = a.rows * (a.C >> 2);
+    const int c4n = a.C >> 2;
+    const long long total = a.rows * c4n;
     const EpiFloors fl = epi_floors(a.flags);
-    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
-        const long long row = g / (a.C >> 2);
-        const int c = (int)(g - row * (a.C >> 2)) * 4;
-        const size_t off = (size_t)row * a.C + c;
+    // the grid's stride is a multiple of C / 4 (launch): a thread keeps its four channels, whose constants -- the sqrt and the division of
+    // invstd above all, which cost more than the rest of an element's work -- are computed once
+    const long long g0 = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    const int c = (int)(g0 % c4n) * 4;
+    float invstd[4], mean[4], gam[4], bet[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        invstd[e] = 1.0f / sqrtf(a.var[c + e] + a.eps);          // ATen's batch_norm (training): invstd = 1 / sqrt(var + eps) in fp32
+        mean[e] = a.mean[c + e]; gam[e] = a.gamma[c + e]; bet[e] = a.beta[c + e];
+    }
+    for (long long g = g0; g < total; g += stride) {
+        const size_t off = (size_t)g * 4;          // row * C + c
         const float4 y4 = ld4_f32_or_bf16(a.y, off, a.y16);
         const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
         float rr[4] = {-0.0f, -0.0f, -0.0f, -0.0f};
@@ -54,9 +63,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnActArgs a) {
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            // ATen's batch_norm (training): (x - mean) * invstd * weight + bias with invstd = 1 / sqrt(var + eps) in fp32
-            const float invstd = 1.0f / sqrtf(a.var[c + e] + a.eps);
-            const float v = (yy[e] - a.mean[c + e]) * invstd * a.gamma[c + e] + a.beta[c + e];
+            const float v = (yy[e] - mean[e]) * invstd[e] * gam[e] + bet[e];          // (x - mean) * invstd * weight + bias
             o[e] = epi_apply(v, fl, rr[e]);
         }
         st4_f32_or_bf16(a.z, off, a.a16, o[0], o[1], o[2], o[3]);
@@ -145,23 +152,38 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
 // the same three stages on float4 lanes (colsum.h); every BatchNorm layer of these networks takes this path
 struct BnBwdLoad {
     BnBwdArgs a;
+    float invstd[4], mean[4], gam[4], bet[4];          // of the thread's four channels (prepare): bn_g's expressions with the constants hoisted
+    __device__ __forceinline__ void prepare(int c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            invstd[e] = 1.0f / sqrtf(a.var[c + e] + a.eps);
+            mean[e] = a.mean[c + e]; gam[e] = a.gamma[c + e]; bet[e] = a.beta[c + e];
+        }
+    }
     __device__ __forceinline__ void operator()(long long row, int c, float (&q)[2][4]) const {
         const size_t off = (size_t)row * a.C + c;
         const float4 dz4 = ld4_f32_or_bf16(a.dz, off, a.a16), y4 = ld4_f32_or_bf16(a.y, off, a.y16);
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.res) r4 = ld4_f32_or_bf16(a.res, off, a.a16);
         const float dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+        const bool post = a.flags & LT_EPI_RELU_POST, pre = a.flags & LT_EPI_RELU_PRE;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float xh;
-            const float g = bn_g(a, dzv[e], yv[e], rv[e], c + e, xh);
+            const float xh = (yv[e] - mean[e]) * invstd[e];          // the same expressions as bn_g / the apply kernel: the masks must agree
+            const float v = xh * gam[e] + bet[e];
+            float mk = 1.f;
+            if (post) mk = (v + rv[e]) > 0.f ? 1.f : 0.f;
+            else if (pre) mk = v > 0.f ? 1.f : 0.f;
+            const float g = dzv[e] * mk;
             q[0][e] = g; q[1][e] = g * xh;
         }
     }
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BnBwdArgs a, int cw4, int rl) {
-    colsum_partial<2>(a.rows, a.C, a.nslab, cw4, rl, a.part, BnBwdLoad{a});
+    BnBwdLoad ld;
+    ld.a = a;
+    colsum_partial<2>(a.rows, a.C, a.nslab, cw4, rl, a.part, ld);
 }
 
 struct BnBwdFin {
@@ -218,6 +240,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdArgs a
 
 struct ChanSumLoad {
     const void* x; int C, x16;
+    __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void operator()(long long row, int c, float (&q)[1][4]) const {
         const float4 v = ld4_f32_or_bf16(x, (size_t)row * C + c, x16);
         q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w;
@@ -923,8 +946,15 @@ extern "C" int lt_bn_act_fwd(const void* y, const float* mean, const float* var,
     a.y = y; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.res = residual; a.z = z; a.z16 = (bf16_t*)z_bf16; a.eps = eps; a.flags = flags; a.C = C; a.rows = rows;
     a.y16 = (flags & LT_BN_Y_BF16) ? 1 : 0;
     a.a16 = (flags & LT_ACT_BF16) ? 1 : 0;
-    const long long blocks = cdiv(rows * (C / 4), 256);
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, a);
+    long long blocks = cdiv(rows * (C / 4), 256);
+    if (blocks > 8192) blocks = 8192;
+    {          // blocks * 256 a multiple of C / 4: every thread of the grid-stride loop stays on its four channels
+        long long c4n = C / 4, gg = c4n, hh = 256;
+        while (hh) { const long long t = gg % hh; gg = hh; hh = t; }          // gcd(C / 4, 256)
+        const long long m = c4n / gg;
+        blocks = cdiv(blocks, m) * m;
+    }
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     LT_CHECK_LAUNCH("lt_bn_act_fwd");
     return LT_OK;
 }

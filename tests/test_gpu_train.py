@@ -355,8 +355,9 @@ def test_tape_layer_gradients(case, mode, mixed):
         n_el = y.numel() // Cout
         yb = conv(x.double(), w.double(), b.double(), stride=s, padding=p)
         dims = [0] + list(range(2, 2 + nd))
-        check(tag + " running_mean", rm.cpu(), 0.1 * yb.mean(dims), 1e-5 if not mixed else 1e-2)
-        check(tag + " running_var", rv.cpu(), 0.9 + 0.1 * yb.var(dims, unbiased=True), 1e-5 if not mixed else 1e-2)
+        ts = 1e-5 if not mixed else 0.1 if fp8 else 1e-2          # (the statistics of an e4m3 convolution's output carry its ~4 % noise)
+        check(tag + " running_mean", rm.cpu(), 0.1 * yb.mean(dims), ts)
+        check(tag + " running_var", rv.cpu(), 0.9 + 0.1 * yb.var(dims, unbiased=True), ts)
     else:
         check(tag + " db", pg[bp].cpu(), bd.grad, T2)
 
