@@ -309,9 +309,16 @@ def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
     lv = [float(l) for l in losses]
     assert all(np.isfinite(lv)), lv
     comm = lt_dist.comm_info(dev)          # from the communicator: ranks that took part in an all-reduce, backend, RCCL version, devices
+    # self-diagnosis of the N-GPU step (every rank takes part in the collectives inside; rank 0 prints): are the replicas still identical, how many
+    # buckets / bytes went through the all-reduce per step, how long the exchange window was next to the backward, what it left exposed
+    plan = next(iter(model.__dict__.get("_train_plans", {}).values()), None)
+    bt = plan.tape.backward_timing() if plan is not None and plan.tape is not None else None
+    if bt:
+        comm.update(bt)
     if world > 1:
         comm["replicas_identical_after_training"] = model.grad_reducer.replicas_identical(model, buffers=False)
-        comm["gradient_buckets_per_step"] = model.grad_reducer.buckets_sent // max(1, len(lv))
+        comm.update(model.grad_reducer.stats())
+        comm["per_rank_samples_per_s"] = per_rank
     if rank == 0:
         # algorithmic flops: forward 2*MAC of every convolution, backward twice that (input + weight gradients)
         P = model._build_plan(1, args.views, args.image, args.image, dev, dry_run=True)
@@ -335,7 +342,9 @@ def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
             live = pmc_leg(args, timeout_s=240, train=True) if (world == 1 and not args.no_pmc_leg) else None
             res["roofline"] = {"kernel": "whole step (convolutions: forward + input gradient + weight gradient = 3 x forward MACs)", "bound": "mfma",
                                "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk,
-                               "peak_basis": "dense %s MFMA peak: all three convolution products of this step run on that MFMA" % ("fp32" if args.train_dtype == "fp32" else "bf16"),
+                               "peak_basis": "dense %s MFMA peak: all three convolution products of this step run on that MFMA%s" % (
+                                   "fp32" if args.train_dtype == "fp32" else "bf16",
+                                   " (the non-scaled fp8 MFMA of the V2V convolutions issues at the bf16 rate, MI355X_MICROARCH.md)" if args.train_dtype == "fp8v2v" else ""),
                                "traffic": live["all_kernels_bytes_per_step"] if live else None,
                                "mfma_busy_frac": live["all_kernels_mfma_busy_frac"] if live else None,
                                "traffic_source": ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ counters, three child runs of this "
@@ -394,14 +403,34 @@ def main():
 
     if args.stub_cpu:       # launcher / collective plumbing without a GPU (tests/test_distributed_cpu.py)
         dev = torch.device("cpu")
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+        # the exchange of a training step as well, on a stand-in model: attach (rank 0's weights everywhere), a gradient arena that goes through
+        # GradReducer in buckets every "step", an SGD update -- so that the line carries the keys an N-GPU --train line diagnoses itself with
+        torch.manual_seed(100 + rank)
+        net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.BatchNorm1d(256), torch.nn.Linear(256, 64))
+        red = lt_dist.GradReducer(bucket_bytes=32 << 10).attach(net) if world > 1 else None
+        arena = torch.zeros(sum(p.numel() for p in net.parameters()))
+        el = 0.0
+        for it in range(args.steps):
+            t0 = time.perf_counter()
             time.sleep(0.002 * (1 + rank))
-        el = time.perf_counter() - t0
+            el += time.perf_counter() - t0          # this rank's own "compute" (the exchange below synchronises the ranks step by step)
+            if red is not None:
+                arena.copy_(torch.randn(arena.numel(), generator=torch.Generator().manual_seed(1000 * it + rank)))
+                for o in range(0, arena.numel(), 8192):
+                    red.reduce_inplace(arena[o:o + 8192])
+                red.wait_all()
+                o = 0
+                with torch.no_grad():
+                    for p in net.parameters():
+                        p.sub_(1e-3 * arena[o:o + p.numel()].view(p.shape)); o += p.numel()
         barrier()
         value, total, dt = lt_dist.job_throughput(B * args.steps, el, dev)
         per_rank = lt_dist.gather_floats(B * args.steps / el, dev)
         comm = lt_dist.comm_info(dev)          # the same communicator facts the GPU lines carry (backend gloo here)
+        if red is not None:
+            comm["replicas_identical_after_training"] = red.replicas_identical(net, buffers=False)
+            comm.update(red.stats())
+            comm["per_rank_samples_per_s"] = per_rank
         if rank == 0:
             print(json.dumps({"metric": "stub", "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": 1e3 * dt / args.steps, "total_samples": total, "per_rank_samples_per_s": per_rank,
@@ -583,9 +612,13 @@ def main():
                 result["config4"] = sub_leg(["--views", "8", "--volume", "128", "--batch", "16", "--steps", "3", "--warmup", "1", "--no-extras",
                                              "--cpu-budget-s", "1", "--cpu-parity-samples", "1", "--preroll-s", "0.3", "--force-pmc-leg", "--fp32-parity-batch", "2"], 600)
                 result["train"] = sub_leg(["--train", "--batch", "4", "--steps", "8", "--warmup", "2"], 600)
-                # config 5's reduced-precision step (bf16 MFMA for the convolutions, their input AND weight gradients; fp32 activations, BatchNorm,
-                # master weights and optimiser): not a parity mode -- its loss values are printed next to the fp32 leg's, same seeds
-                result["train_mixed"] = sub_leg(["--train", "--train-dtype", "bf16", "--batch", "8", "--steps", "6", "--warmup", "2"], 600)
+                # config 5's reduced-precision step as BASELINE names it: 16-bit activations (bf16) + bf16 MFMA for every convolution product (train_precision
+                # "act16"), and the same with V2V's 3x3x3 convolutions on the fp8 MFMA ("fp8v2v"); fp32 BatchNorm statistics, master weights, optimiser.
+                # Not parity modes -- their loss values are printed next to the fp32 leg's, same seeds.  (Round 3's "bf16" mode -- bf16 MFMA over fp32
+                # activations -- is still selectable: --train-dtype bf16.)
+                result["train_mixed"] = sub_leg(["--train", "--train-dtype", "act16", "--batch", "8", "--steps", "6", "--warmup", "2"], 600)
+                result["train_mixed_b16"] = sub_leg(["--train", "--train-dtype", "act16", "--batch", "16", "--steps", "5", "--warmup", "2", "--no-pmc-leg"], 600)
+                result["train_fp8v2v"] = sub_leg(["--train", "--train-dtype", "fp8v2v", "--batch", "8", "--steps", "5", "--warmup", "2", "--no-pmc-leg"], 600)
         if cpu_base is not None:
             result["cpu_baseline"] = cpu_base
     barrier()

@@ -683,6 +683,10 @@ class TrainTape:
         """First call: records (= runs) the backward; later calls replay it.  Returns {Parameter: gradient view of the arena} (averaged
         over the ranks when a reducer is attached)."""
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        main = torch.cuda.current_stream(self.device)
+        self._collect_bwd_times()
+        ev = self._bwd_events = [torch.cuda.Event(enable_timing=True) for _ in range(3)]          # start, main stream's kernels issued, side stream joined
+        ev[0].record(main)
         if not self.bwd_recorded:
             self._cur = self.bwd_ops
             for rec in reversed(self.recorders):
@@ -692,6 +696,7 @@ class TrainTape:
         else:
             self._gather_all("bwd", self.bwd_jobs)
             self.replay(self.bwd_ops)
+        ev[1].record(main)
         if self.side is not None:
             if self.reducer is not None:
                 with torch.cuda.stream(self.side):
@@ -699,7 +704,26 @@ class TrainTape:
             torch.cuda.current_stream(self.device).wait_stream(self.side)          # the gradients are complete for whoever reads them next
         elif self.reducer is not None:
             self.reducer.wait_all()
+        ev[2].record(main)
         return self.param_grads
+
+    def _collect_bwd_times(self):
+        ev = getattr(self, "_bwd_events", None)
+        if ev is not None:
+            ev[2].synchronize()
+            t = self.__dict__.setdefault("_bwd_times", [0.0, 0.0, 0])
+            t[0] += ev[0].elapsed_time(ev[1]); t[1] += ev[0].elapsed_time(ev[2]); t[2] += 1
+            self._bwd_events = None
+
+    def backward_timing(self):
+        """Average GPU time of the recorded backward: on the main stream alone (input gradients, BatchNorm, ...) and until the side stream -- the
+        weight gradients and, with a reducer, the gradient all-reduce -- has joined: the difference is what the exchange (and the weight
+        gradients) leave EXPOSED behind the backward."""
+        self._collect_bwd_times()
+        t = self.__dict__.get("_bwd_times")
+        if not t or not t[2]:
+            return None
+        return {"backward_main_stream_ms": t[0] / t[2], "backward_until_gradients_complete_ms": t[1] / t[2], "exposed_behind_main_stream_ms": (t[1] - t[0]) / t[2]}
 
 
 def adam_groups(model, config_opt):

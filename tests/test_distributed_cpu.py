@@ -90,6 +90,15 @@ def test_bench_self_launches_n_ranks():
     # rank 1 sleeps twice as long per step: the job is judged on the slowest rank
     assert res["per_rank_samples_per_s"][0] > res["per_rank_samples_per_s"][1]
     assert res["value"] <= 2 * res["per_rank_samples_per_s"][1] * 1.05
+    # the self-diagnosis keys of an N-rank training line (the stub pushes a stand-in gradient arena through lt_dist.GradReducer every step):
+    # the replicas end identical, the buckets / bytes per step are what was handed over, the host-side issue / wait times are there
+    c = res["rccl"]
+    assert c["replicas_identical_after_training"] is True
+    nparam = 64 * 256 + 256 + 256 + 256 + 256 * 64 + 64
+    assert c["gradient_buckets_per_step"] == -(-nparam // 8192) and c["gradient_bytes_per_step"] == 4 * nparam and c["steps_with_exchange"] == 5
+    assert c["world"] == 2 and c["backend"] == "gloo" and c["mean_inside_collective"] is False
+    assert c["allreduce_host_issue_ms_per_step"] >= 0 and c["allreduce_host_wait_ms_per_step"] >= 0 and len(c["per_rank_samples_per_s"]) == 2
+    assert c["allreduce_window_ms_per_step"] is None          # a GPU-stream measurement (events around the first / last bucket): absent on CPU
 
 
 def test_bench_under_torchrun_env_does_not_relaunch():
