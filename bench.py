@@ -359,7 +359,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=0, help="samples per GPU per step (default 32; 16 for 128^3 volumes: 128 images fill the 256 CUs with 288-row tiles)")
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU per step (default 64; 16 for 128^3 volumes: 128 images fill the 256 CUs with 288-row tiles; 8 for --train)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--image", type=int, default=384)
@@ -386,7 +386,9 @@ def main():
     ap.add_argument("--stub-cpu", action="store_true", help="TEST ONLY: gloo backend, no GPU, step() is a sleep (exercises launcher + timing plumbing)")
     args = ap.parse_args()
     if not args.batch:
-        args.batch = 8 if args.train else 16 if args.volume >= 128 else 32
+        # 64 samples (256 images) per GPU per step from round 4 on: two full rounds of 288-row tiles on the 256 CUs and half the per-sample share of the
+        # ~220 launches' fixed cost (+3 % over 32 samples; 48 samples = 1.5 rounds is slower than either); rounds 1-3 timed 32, which stays in batch_sweep
+        args.batch = 8 if args.train else 16 if args.volume >= 128 else 64
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)       # does not return
@@ -591,7 +593,7 @@ def main():
                 torch.cuda.empty_cache()
             # ---- the reference's own batch sizes (train 5, val 10) and single-sample latency
             sweep = {}
-            for bs in (1, 5, 10):
+            for bs in (1, 5, 10, 32):
                 if bs >= B:
                     continue
                 im_b = images[:bs]

@@ -608,12 +608,13 @@ int dispatch2(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int til
                     a.osd == 1 && a.osh == 1 && a.osw == 1 && p0.ood == 0 && p0.ooh == 0 && p0.oow == 0 && a.OD == a.Do && a.OH == a.Ho &&
                     a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
     if (tile == LT_TILE_AUTO) {
+        static const int minblk = getenv("LT_CONV2_MINBLK") ? atoi(getenv("LT_CONV2_MINBLK")) : 480;          // tuning knob
         if (cout_pad <= 16) tile = LT_TILE2_256x16;
         else if (cout_pad <= 32) tile = LT_TILE2_256x32;
-        else if (cout_pad <= 64) tile = blocks(128, 64) >= 480 ? LT_TILE2_128x64 : LT_TILE2_64x64;
-        else if (pw && a.k_pad <= 256 && blocks(128, 64) >= 480) tile = LT_TILE2_128x64;   // short-K expand convs: epilogue-bound,
+        else if (cout_pad <= 64) tile = blocks(128, 64) >= minblk ? LT_TILE2_128x64 : LT_TILE2_64x64;
+        else if (pw && a.k_pad <= 256 && blocks(128, 64) >= minblk) tile = LT_TILE2_128x64;   // short-K expand convs: epilogue-bound,
         // more and smaller workgroups overlap stores with loads (measured 171 vs 204 us on 64->256 at 96^2, 111 vs 120 on 128->512)
-        else tile = blocks(128, 128) >= 480 ? LT_TILE2_128x128 : (blocks(128, 64) >= 480 ? LT_TILE2_128x64 : LT_TILE2_64x64);
+        else tile = blocks(128, 128) >= minblk ? LT_TILE2_128x128 : (blocks(128, 64) >= minblk ? LT_TILE2_128x64 : LT_TILE2_64x64);
     }
     // uniform-tap path: every 128-byte K step lies inside one tap
     static const bool no_ut = getenv("LT_CONV_NO_UT") != nullptr;   // A/B switch

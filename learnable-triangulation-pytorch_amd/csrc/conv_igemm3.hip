@@ -1180,13 +1180,18 @@ int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_ta
         const char* v5e = getenv("LT_CONV_V5");
         const long long tiles_m5 = cdiv(a.M, BM3), nblk5 = tiles_m5 * (cout_pad / 256);
         const bool fits5 = cout_pad % 256 == 0 && a.k_pad % 32 == 0 && max_taps <= 64;
-        const bool want5 = v5e ? v5e[0] == '1' : (nblk5 >= 200 && tiles_m5 * BM3 - a.M <= a.M / 16 && a.k_pad >= 64);
+        const PhaseArg& q0 = a.phase[0];
+        const bool pw5 = q0.ntaps == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.pd == 0 && a.ph == 0 && a.pw == 0 && a.osd == 1 &&
+                         a.osh == 1 && a.osw == 1 && q0.ood == 0 && q0.ooh == 0 && q0.oow == 0 && a.OD == a.Do && a.OH == a.Ho &&
+                         a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
+        const char* no6 = getenv("LT_CONV_NO_V6");   // A/B, read per call
+        // small batches (the reference trains at 5 samples = 20 images): the short-K expand layers still fill the chip with the 144-row variant of
+        // conv_igemm6 (two workgroups per CU) when the 288-row count says no -- 256 -> 1024 at 20 images: 320 tiles of 144 x 256 instead of
+        // 1440 L2-stream-bound 128 x 64 tiles of the generic kernel (LT_CONV_NO_SMALL144=1: off)
+        const bool small144 = pw5 && q0.wfrag && !no6 && a.k_pad % 64 == 0 && a.k_pad <= 256 && a.M % 144 == 0 && (a.M / 144) * (cout_pad / 256) >= 200 &&
+                              getenv("LT_CONV_NO_SMALL144") == nullptr;
+        const bool want5 = v5e ? v5e[0] == '1' : ((nblk5 >= 200 && tiles_m5 * BM3 - a.M <= a.M / 16 && a.k_pad >= 64) || small144);
         if (fits5 && want5) {
-            const PhaseArg& q0 = a.phase[0];
-            const bool pw5 = q0.ntaps == 1 && a.sd == 1 && a.sh == 1 && a.sw == 1 && a.pd == 0 && a.ph == 0 && a.pw == 0 && a.osd == 1 &&
-                             a.osh == 1 && a.osw == 1 && q0.ood == 0 && q0.ooh == 0 && q0.oow == 0 && a.OD == a.Do && a.OH == a.Ho &&
-                             a.OW == a.Wo && a.D == a.Do && a.H == a.Ho && a.W == a.Wo && a.k_pad == a.Cin;
-            const char* no6 = getenv("LT_CONV_NO_V6");   // A/B, read per call
             if (q0.wfrag32 && a.k_pad % 64 == 0) {       // weights packed for the 32x32x16 MFMA (plan built with LT_CONV_V7=1): conv_igemm7
                 const int rc7 = conv7_try(a, cout_pad, max_taps, pw5, s);
                 if (rc7 != 0) return rc7;
