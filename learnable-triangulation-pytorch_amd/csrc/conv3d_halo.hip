@@ -30,6 +30,10 @@
 
 #include "conv_common.h"
 
+#ifndef LT_ACC64_MASK
+#define LT_ACC64_MASK 3          // fp32 (parity) kernels: fp64 flush of the MFMA accumulators every LT_ACC64_MASK + 1 taps / K steps
+#endif
+
 using namespace lt;
 
 namespace {
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
             else if constexpr (!LAST_) load_ring(coff_n, wb_n, std::integral_constant<int, (tj + PD) % TPC>{});         \
             lgkm_wait<ahead * RPT>();                                                                                   \
             mma_tap(tjc);                                                                                               \
-            if (ACC64 && (((ch * TPC + tj) & 1) == 1 || ch * TPC + tj + 1 == C::NTAPS)) {                               \
+            if (ACC64 && (((ch * TPC + tj) & LT_ACC64_MASK) == LT_ACC64_MASK || ch * TPC + tj + 1 == C::NTAPS)) {                               \
                 _Pragma("unroll") for (int i = 0; i < SM; ++i)                                                          \
                     _Pragma("unroll") for (int j = 0; j < SN; ++j)                                                      \
                         _Pragma("unroll") for (int e = 0; e < NACC; ++e) {                                              \
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
     #pragma unroll
                             for (int j = 0; j < SN; ++j) LT_HMMA(acc[i][j], fa[tj & 1][g][i], fb[tj & 1][g][j]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (ACC64 && ((tap & 1) == 1 || tap + 1 == C::NTAPS)) {
+                    if (ACC64 && ((tap & LT_ACC64_MASK) == LT_ACC64_MASK || tap + 1 == C::NTAPS)) {
     #pragma unroll
                         for (int i = 0; i < SM; ++i)
     #pragma unroll

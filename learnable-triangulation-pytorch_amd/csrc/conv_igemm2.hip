@@ -22,6 +22,11 @@
 
 #include "conv_common.h"
 
+// fp32 (parity) kernels: the MFMA accumulators are added into fp64 registers every LT_ACC64_MASK + 1 K steps of 32 products
+#ifndef LT_ACC64_MASK
+#define LT_ACC64_MASK 3
+#endif
+
 using namespace lt;
 
 namespace {
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);                                                                   \
             }                                                                                                        \
         }                                                                                                            \
-        if (ACC64 && ((ks & 1) == 1 || ks + 1 == nk)) {                                                              \
+        if (ACC64 && ((ks & LT_ACC64_MASK) == LT_ACC64_MASK || ks + 1 == nk)) {                                                              \
             _Pragma("unroll") for (int i = 0; i < SM; ++i)                                                           \
                 _Pragma("unroll") for (int j = 0; j < SN; ++j)                                                       \
                     _Pragma("unroll") for (int e = 0; e < NACC; ++e) {                                               \
