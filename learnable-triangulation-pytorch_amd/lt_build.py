@@ -63,7 +63,9 @@ def _build(LIB, objsub, extra, verbose, only=None):
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "lt_hip.h")]
-    force_all = bool(extra) and only is None and False or os.environ.get("LT_BUILD_FORCE") == "1"
+    force_all = os.environ.get("LT_BUILD_FORCE") == "1"
+    # the flags an object was compiled with travel next to it: a variant rebuilt under the same name with other -D switches recompiles
+    stamp = " ".join(FLAGS)
 
     def compile_one(src):
         if only is not None and os.path.basename(src) not in only:
@@ -73,12 +75,16 @@ def _build(LIB, objsub, extra, verbose, only=None):
             return base_obj
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         # incremental: an object newer than its source, every header and this script (the flags) is kept
-        if not force_all and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in [src, __file__] + headers):
+        fl = obj + ".flags"
+        same_flags = os.path.exists(fl) and open(fl).read() == stamp
+        if not force_all and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in [src, __file__] + headers):
             return obj
         cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr))
+        with open(fl, "w") as f:
+            f.write(stamp)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:

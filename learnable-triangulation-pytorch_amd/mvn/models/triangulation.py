@@ -35,6 +35,17 @@ def _bn_in_train_mode(m):
     return any(isinstance(c, nn.modules.batchnorm._BatchNorm) and c.training for c in m.modules())
 
 
+def _sync_buffers_before_eval(model):
+    """DistributedDataParallel(broadcast_buffers=True) hands rank 0's buffers to every rank at EVERY forward, evaluation included (the reference
+    validates through the wrapped model, train.py:450-460).  The training forward does it through its reducer; here the first evaluation forward
+    after a training step does (the BatchNorm statistics of the ranks differ by their last momentum update until then; buffers do not change in
+    eval(), so once is enough).  A collective: like under DDP, every rank has to run the evaluation forward."""
+    red = getattr(model, "grad_reducer", None)
+    if red is not None and red.attached and model.__dict__.get("_buffers_stale"):
+        red.sync_buffers()
+        model.__dict__["_buffers_stale"] = False
+
+
 class _VolTrainPlan:
     """The training step of VolumetricTriangulationNet for one input shape, recorded once and replayed (lt_train.TrainTape): the first
     forward / backward run the layers while recording them; later steps re-launch the recorded closures over the same buffers.  What
@@ -120,10 +131,13 @@ class _VolTrainPlan:
                 else:
                     dvol32 = dvol
                 per_sample = lib.lt_unproject_bwd_workspace(1, NV, 32, V, V, V)
-                ws = torch.empty(max(16, min(per_sample * B, max(per_sample, 4 << 30))), dtype=torch.uint8, device=device)
-                nws = ws.numel()
+                # the gather's workspace comes out of the tape's shared main-stream scratch (it is only live during this one op; a private buffer per
+                # cached plan was up to 4 GiB each), capped like op.unproject_heatmaps' autograd path: below the whole batch's worth the
+                # entry point walks the batch in chunks
+                nws = int(max(16, min(per_sample * B, max(per_sample, op.UNPROJECT_BWD_WORKSPACE_CAP))))
+                tape._ws_need(nws)
                 tape.do(lambda s_: H.check(lib.lt_unproject_bwd(ac, feats.t.data_ptr(), gp, coords.data_ptr(), conf_p, dvol32.data_ptr(), gfe32.data_ptr(),
-                                                                H.ptr(gconf), B, NV, 32, h, w, V, V, V, agg, ws.data_ptr(), nws, s_), "lt_unproject_bwd"),
+                                                                H.ptr(gconf), B, NV, 32, h, w, V, V, V, agg, tape._ws.data_ptr(), nws, s_), "lt_unproject_bwd"),
                         "unproject_bwd")
                 gfe = gfe32
                 if tape.act16:
@@ -483,6 +497,7 @@ class VolumetricTriangulationNet(_PlannedNet):
         H.require_gpu(images, "images")
         if _bn_in_train_mode(self):          # any BatchNorm module in train(): the training step (modules left in eval() keep frozen statistics)
             return self._forward_train(images, batch)
+        _sync_buffers_before_eval(self)
         B, NV = images.shape[:2]
         cap = self.max_samples_per_launch(NV, images.shape[3], images.shape[4])
         if B <= cap:
@@ -537,6 +552,7 @@ class VolumetricTriangulationNet(_PlannedNet):
                 red.attach(self)
             else:
                 red.sync_buffers()
+            self.__dict__["_buffers_stale"] = True          # this step updates the running statistics per rank: the next eval forward re-syncs
         plans = self.__dict__.setdefault("_train_plans", OrderedDict())
         plan = plans.get(key)
         if plan is None:
@@ -661,6 +677,7 @@ class AlgebraicTriangulationNet(_PlannedNet):
         H.require_gpu(images, "images")
         if _bn_in_train_mode(self):
             return self._forward_train(images, proj_matricies)
+        _sync_buffers_before_eval(self)
         device = images.device
         B, NV = images.shape[:2]
         Hh, W = images.shape[3:]
@@ -693,6 +710,7 @@ class AlgebraicTriangulationNet(_PlannedNet):
                 red.attach(self)
             else:
                 red.sync_buffers()
+            self.__dict__["_buffers_stale"] = True          # this step updates the running statistics per rank: the next eval forward re-syncs
         key = (B * NV, Hh, W, device, tuple(p.requires_grad for p in params), id(red), getattr(self, "train_precision", "fp32"),
                tuple(c.training for c in self.modules() if isinstance(c, nn.modules.batchnorm._BatchNorm)))
         plans = self.__dict__.setdefault("_train_plans", OrderedDict())

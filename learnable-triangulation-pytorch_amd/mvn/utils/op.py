@@ -9,6 +9,10 @@ import torch
 
 import lt_hip as H
 
+# workspace of lt_unproject_bwd's deterministic gather: at most this much (or one sample's share, if that is more); with less than the whole
+# batch's worth the entry point walks the batch in chunks.  One constant for the autograd path here and the recorded training step.
+UNPROJECT_BWD_WORKSPACE_CAP = 2 << 30
+
 _METHODS = ("sum", "max", "softmax", "conf", "conf_norm")
 
 
@@ -76,7 +80,7 @@ class _UnprojectFn(torch.autograd.Function):
         lib = H.lib()
         # deterministic gather: workspace for as many samples as fit 2 GiB at a time (the entry walks the batch in chunks)
         per_sample = lib.lt_unproject_bwd_workspace(1, NV, Cc, v0, v1, v2)
-        ws = torch.empty(max(16, min(per_sample * B, max(per_sample, 2 << 30))), dtype=torch.uint8, device=feats.device)
+        ws = torch.empty(max(16, min(per_sample * B, max(per_sample, UNPROJECT_BWD_WORKSPACE_CAP))), dtype=torch.uint8, device=feats.device)
         H.check(lib.lt_unproject_bwd(H.dtype_code(feats.dtype), feats.data_ptr(), P.data_ptr(), cv.data_ptr(), H.ptr(conf), g.data_ptr(),
                                      gfeats.data_ptr(), H.ptr(gconf), B, NV, Cc, h, w, v0, v1, v2,
                                      H.AGG["conf"] if conf is not None else H.AGG[ctx.method], ws.data_ptr(), ws.numel(), H.cur_stream()), "lt_unproject_bwd")

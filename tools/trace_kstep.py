@@ -30,13 +30,14 @@ def main():
     ap.add_argument("--only", default="rn l3,rn l2 3x3,rn l1 3x3")
     ap.add_argument("--tiles", default="auto", help="comma list: auto,128x128,128x64,64x64,...")
     ap.add_argument("--stages", default="0", help="comma list of ring depths (0 = auto)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="fp32: the exact-fp32 (parity) kernels")
     args = ap.parse_args()
     lib = H.lib()
     lib.lt_trace_read.restype = C.c_int
     lib.lt_trace_read.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.lt_trace_read3.restype = C.c_int
     lib.lt_trace_read3.argtypes = [C.c_void_p, C.c_int, C.c_int]
-    dev, dt = "cuda:0", torch.bfloat16
+    dev, dt = "cuda:0", {"bf16": torch.bfloat16, "fp32": torch.float32}[args.dtype]
     st = torch.cuda.current_stream().cuda_stream
     buf = np.zeros(8 * 1024, dtype=np.int64)
     print("%-26s %-10s %3s | %6s %7s | %6s %6s %6s %6s | %5s %5s" % ("layer", "tile", "nst", "blocks", "cyc/ks", "vmwait", "barr", "issue", "mfma", "MHz", "us"))
