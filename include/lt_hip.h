@@ -345,6 +345,8 @@ int lt_zero(void* p, int64_t nbytes, void* stream);
 int lt_add_i64_multi(const void* ptrs, int32_t n, int64_t delta, void* stream);
 /* backward of lt_global_avgpool (GlobalAveragePoolingHead's mean over the map, pose_resnet.py:166-168): dx[n][p][c] (=|+=) dy[n][c] / HW */
 int lt_global_avgpool_bwd(const float* dy, float* dx, int32_t N, int32_t HW, int32_t C, int32_t accumulate, void* stream);
+/* dy / dx of element type `dtype` (LT_F32 | LT_BF16: the 16-bit-activation training step) */
+int lt_global_avgpool_bwd_dt(int32_t dtype, const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, int32_t accumulate, void* stream);
 /* fp32 -> bf16, round to nearest even (operands of the mixed-precision training convolutions); 16-byte aligned pointers */
 int lt_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* ---- fp8 (e4m3) operands for lt_conv_fwd(dtype = LT_FP8): per-tensor amax scaling, scale = amax / 448 (the largest e4m3 value), q = rne(x / scale).

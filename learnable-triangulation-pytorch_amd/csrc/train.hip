@@ -1284,13 +1284,13 @@ extern "C" int lt_pad_channels_f32(const float* src, float* dst, int64_t rows, i
 }
 
 // d mean-over-the-map / d x: every pixel of sample n gets dy[n][c] / HW
-__global__ __launch_bounds__(256) void global_avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int HW, int C, int accumulate, long long total) {
+__global__ __launch_bounds__(256) void global_avgpool_bwd_kernel(const void* __restrict__ dy, void* __restrict__ dx, int a16, int HW, int C, int accumulate, long long total) {
     const float inv = 1.f / (float)HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long np = i / C;
         const int c = (int)(i - np * C);
-        const float g = dy[(np / HW) * C + c] * inv;
-        dx[i] = accumulate ? dx[i] + g : g;
+        const float g = ld1_f32_or_bf16(dy, (size_t)((np / HW) * C + c), a16) * inv;
+        st1_f32_or_bf16(dx, (size_t)i, a16, accumulate ? ld1_f32_or_bf16(dx, (size_t)i, a16) + g : g);
     }
 }
 
@@ -1301,9 +1301,14 @@ __global__ void add_i64_multi_kernel(long long* const* __restrict__ ptrs, int n,
 }
 
 extern "C" int lt_global_avgpool_bwd(const float* dy, float* dx, int32_t N, int32_t HW, int32_t C, int32_t accumulate, void* stream) {
-    LT_REQUIRE(dy && dx && N >= 1 && HW >= 1 && C >= 1, LT_ERR_INVALID, "lt_global_avgpool_bwd: bad argument");
+    return lt_global_avgpool_bwd_dt(LT_F32, dy, dx, N, HW, C, accumulate, stream);
+}
+
+extern "C" int lt_global_avgpool_bwd_dt(int32_t dtype, const void* dy, void* dx, int32_t N, int32_t HW, int32_t C, int32_t accumulate, void* stream) {
+    LT_REQUIRE(dy && dx && N >= 1 && HW >= 1 && C >= 1 && (dtype == LT_F32 || dtype == LT_BF16), LT_ERR_INVALID, "lt_global_avgpool_bwd: bad argument");
     const long long total = (long long)N * HW * C, blocks = cdiv(total, 256);
-    hipLaunchKernelGGL(global_avgpool_bwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, dy, dx, HW, C, accumulate, total);
+    hipLaunchKernelGGL(global_avgpool_bwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, dy, dx, dtype == LT_BF16 ? 1 : 0, HW, C,
+                       accumulate, total);
     LT_CHECK_LAUNCH("lt_global_avgpool_bwd");
     return LT_OK;
 }

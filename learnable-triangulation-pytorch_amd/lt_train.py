@@ -189,13 +189,11 @@ class TrainTape:
     def global_avgpool(self, x):
         """Mean over the map of every sample (GlobalAveragePoolingHead, pose_resnet.py:166-168): x Act [N,1,H,W,C] -> Act [1,1,1,N,C]; backward
         spreads dy / HW over the map (accumulating when the input already has a gradient)."""
-        if self.act16:
-            raise NotImplementedError("train_precision 'act16': the confidence heads (global average pool + linear layers) are not built for bf16 "
-                                      "activations; use 'bf16' or 'fp32' for conf / conf_norm aggregation and for AlgebraicTriangulationNet's confidences")
         N, D, Hh, W, Cc = x.shape
         HW = D * Hh * W
         y = self.alloc((1, 1, 1, N, Cc))
-        self.do(lambda st: H.check(H.lib().lt_global_avgpool(H.LT_F32, x.t.data_ptr(), y.t.data_ptr(), N, HW, Cc, st), "lt_global_avgpool"), "avgpool")
+        ac = self.acode
+        self.do(lambda st: H.check(H.lib().lt_global_avgpool(ac, x.t.data_ptr(), y.t.data_ptr(), N, HW, Cc, st), "lt_global_avgpool"), "avgpool")
 
         def bwd():
             dy = self.grad_of(y)
@@ -206,7 +204,7 @@ class TrainTape:
             if dx is None:
                 dx = torch.empty_like(x.t)
                 self._add_grad(x, dx)
-            self.do(lambda st: H.check(H.lib().lt_global_avgpool_bwd(dy.data_ptr(), dx.data_ptr(), N, HW, Cc, acc, st), "lt_global_avgpool_bwd"), "avgpool_bwd")
+            self.do(lambda st: H.check(H.lib().lt_global_avgpool_bwd_dt(ac, dy.data_ptr(), dx.data_ptr(), N, HW, Cc, acc, st), "lt_global_avgpool_bwd"), "avgpool_bwd")
         self.recorders.append(bwd)
         return y
 
@@ -366,8 +364,8 @@ class TrainTape:
                 raise NotImplementedError("a BatchNorm-less layer with ReLU before a residual add")
             kw = dict(stride=stride, pad=pad, transposed=transposed, relu=relu, relu_pre=relu_pre, residual=residual)
             if sigmoid:
-                if self.act16:
-                    raise NotImplementedError("train_precision 'act16': sigmoid heads are not built for bf16 activations")
+                if self.act16 and not out_f32:
+                    raise NotImplementedError("train_precision 'act16': a sigmoid layer that stores bf16 (the confidence heads store fp32)")
                 kw["sigmoid"] = True
             z = self._live_conv(x, weight, None, bias, out_f32=True if (out_f32 or not self.act16) else False, **kw)
             y_raw = stats = None
@@ -501,9 +499,16 @@ class TrainTape:
                                                          Cout, BN_EPS, flags, self._ws.data_ptr(), st), "lt_bn_act_bwd"), "bn_bwd %dx%d" % (rows, Cout))
         else:
             total = z.t.numel()
-            if self.act16 and z.t.dtype != torch.bfloat16 and (flags & (H.EPI_RELU_POST | H.EPI_RELU_PRE | H.EPI_SIGMOID)):
-                raise NotImplementedError("train_precision 'act16': an activation on a layer that stores fp32 (only the logits layer does, and it has none)")
-            self.do(lambda st: H.check(lib.lt_act_bwd(dz.data_ptr(), z.t.data_ptr(), H.ptr(rp), dy.data_ptr(), H.ptr(dres), acc_res, total, flags | self.aflag, st), "lt_act_bwd"))
+            if self.act16 and z.t.dtype != torch.bfloat16:
+                # a layer of the 16-bit step that STORES fp32 (the logits / heatmap layers, the confidence heads' sigmoid outputs: their consumers -- soft-argmax,
+                # unprojection, the autograd tail -- are fp32): its upstream gradient arrives in fp32 too; activation backward in fp32, then ONE rounding of dy
+                if residual is not None or dz.dtype != torch.float32:
+                    raise NotImplementedError("train_precision 'act16': an fp32-storing layer with a residual / a bf16 upstream gradient")
+                dy32 = torch.empty(z.t.shape, dtype=torch.float32, device=self.device)
+                self.do(lambda st: H.check(lib.lt_act_bwd(dz.data_ptr(), z.t.data_ptr(), None, dy32.data_ptr(), None, 0, total, flags, st), "lt_act_bwd"))
+                self.do(lambda st: H.check(lib.lt_convert_pad(H.LT_F32, dy32.data_ptr(), H.LT_BF16, dy.data_ptr(), rows, Cout, Cout, st), "lt_convert_pad"), "cast")
+            else:
+                self.do(lambda st: H.check(lib.lt_act_bwd(dz.data_ptr(), z.t.data_ptr(), H.ptr(rp), dy.data_ptr(), H.ptr(dres), acc_res, total, flags | self.aflag, st), "lt_act_bwd"))
         if bias is not None and bias.requires_grad:
             db = self._grad_view(bias)
             self._ws_need(lib.lt_channel_sum_workspace(rows, Cout))

@@ -156,18 +156,8 @@ class _VolTrainPlan:
             mult, sm = self.mult, self.sm
             tape.do(lambda s_: H.check(lib.lt_softargmax3d_fwd(logits.t.data_ptr(), coords.data_ptr(), mult, sm, 1, J, kp.data_ptr(), probs.data_ptr(), B, J, V ** 3,
                                                                ws.data_ptr(), s_), "lt_softargmax3d_fwd"))
-            self.gl = gl = torch.empty(B, V ** 3, J, dtype=torch.float32, device=device)         # d loss / d logits, channels-last like the logits
-            if tape.act16:          # the backward's first op rounds the loss gradient to bf16 (recorders run in reverse order: this one first)
-                gl16 = torch.empty(B * V ** 3 * J + 8, dtype=torch.bfloat16, device=device)
-                gl16v = gl16[:B * V ** 3 * J].view(logits.t.shape)
-                nrow = B * V ** 3
-
-                def seed_cast():
-                    tape.do(lambda s_: H.check(lib.lt_convert_pad(H.LT_F32, gl.data_ptr(), H.LT_BF16, gl16.data_ptr(), nrow, J, J, s_), "lt_convert_pad"), "cast")
-                tape.seed(logits, gl16v)
-                tape.add_backward(seed_cast)
-            else:
-                tape.seed(logits, self.gl.view(logits.t.shape))
+            self.gl = torch.empty(B, V ** 3, J, dtype=torch.float32, device=device)         # d loss / d logits, channels-last like the logits (fp32 in every
+            tape.seed(logits, self.gl.view(logits.t.shape))                                  # precision: the logits layer stores fp32, TrainTape._conv_bwd rounds its dY once)
         else:
             tape.replay(tape.fwd_ops, self.n_front)
         self.step_id += 1
@@ -247,12 +237,15 @@ class _AlgTrainPlan:
         st = torch.cuda.current_stream(device).cuda_stream
         first = self.tape is None
         if first:
-            mixed = getattr(model, "train_precision", "fp32") == "bf16"
-            self.tape = tape = lt_train.TrainTape(device, params=list(model.parameters()), reducer=getattr(model, "grad_reducer", None), mixed=mixed)
+            prec = getattr(model, "train_precision", "fp32")
+            if prec not in ("fp32", "bf16", "act16"):
+                raise ValueError("AlgebraicTriangulationNet.train_precision must be 'fp32', 'bf16' or 'act16' (there is no 3D convolution for 'fp8v2v')")
+            mixed = prec != "fp32"
+            self.tape = tape = lt_train.TrainTape(device, params=list(model.parameters()), reducer=getattr(model, "grad_reducer", None), mixed=mixed, act16=prec == "act16")
             self.x_in = tape.alloc((N, 1, Hh, W, E.min_cin_of(torch.bfloat16 if mixed else torch.float32)))
             tape.no_grad_ids.add(id(self.x_in))
         tape = self.tape
-        H.check(lib.lt_nchw_to_nhwc(H.LT_F32, x.data_ptr(), self.x_in.t.data_ptr(), N, 3, Hh * W, self.x_in.t.shape[-1], st), "lt_nchw_to_nhwc")
+        H.check(lib.lt_nchw_to_nhwc(tape.acode, x.data_ptr(), self.x_in.t.data_ptr(), N, 3, Hh * W, self.x_in.t.shape[-1], st), "lt_nchw_to_nhwc")
         if first:
             hm, _, algc, _ = model.backbone.record(tape, self.x_in, want_heatmaps=True)
             self.hm, self.algc = hm, algc
@@ -542,8 +535,6 @@ class VolumetricTriangulationNet(_PlannedNet):
         if getattr(self, "train_precision", "fp32") not in ("fp32", "bf16", "act16", "fp8v2v"):
             raise ValueError("train_precision must be 'fp32' (the reference's precision), 'bf16' (bf16 MFMA convolutions, fp32 storage), 'act16' (bf16 MFMA "
                              "convolutions AND bf16 activations / activation gradients) or 'fp8v2v' (act16 with V2V's 3x3x3 convolutions on the fp8 MFMA)")
-        if getattr(self, "train_precision", "fp32") in ("act16", "fp8v2v") and self.volume_aggregation_method.startswith("conf"):
-            raise NotImplementedError("train_precision '%s' with the confidence heads (conf / conf_norm): use 'bf16' or 'fp32'" % self.train_precision)
         red = getattr(self, "grad_reducer", None)
         if red is not None:
             # DistributedDataParallel's semantics (reference train.py:453): rank 0's parameters and buffers at "construction" (here: the
