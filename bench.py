@@ -611,7 +611,7 @@ def main():
                 del out
                 model.invalidate_plans()
                 torch.cuda.empty_cache()
-                result["config4"] = sub_leg(["--views", "8", "--volume", "128", "--batch", "16", "--steps", "3", "--warmup", "1", "--no-extras",
+                result["config4"] = sub_leg(["--views", "8", "--volume", "128", "--batch", "16", "--steps", "8", "--warmup", "3", "--no-extras",
                                              "--cpu-budget-s", "1", "--cpu-parity-samples", "1", "--preroll-s", "0.3", "--force-pmc-leg", "--fp32-parity-batch", "2"], 600)
                 result["train"] = sub_leg(["--train", "--batch", "4", "--steps", "8", "--warmup", "2"], 600)
                 # config 5's reduced-precision step as BASELINE names it: 16-bit activations (bf16) + bf16 MFMA for every convolution product (train_precision
