@@ -264,6 +264,11 @@ int lt_unproject_bwd(int32_t dtype, const void* feats, const float* proj, const 
 int lt_softargmax3d_bwd(const float* probs, const float* coords, const float* kp, const float* grad_kp, const int32_t* gp_idx,
                         const float* gp_val, float multiplier, int32_t softmax, int32_t channels_last, float* grad_logits, int32_t B,
                         int32_t J, int64_t nvox, void* stream);
+/* the same with a DENSE gradient on the returned probabilities as well (gp_dense: B,J,nvox fp32 or NULL -- any loss on the volumes, what the reference's
+ * autograd accepts at train.py:222-230): a_i += gp_dense_i; workspace_bj: B * J floats (sum_i p_i gp_dense_i per joint, softmax mode). */
+int lt_softargmax3d_bwd_dense(const float* probs, const float* coords, const float* kp, const float* grad_kp, const int32_t* gp_idx,
+                              const float* gp_val, const float* gp_dense, float* workspace_bj, float multiplier, int32_t softmax,
+                              int32_t channels_last, float* grad_logits, int32_t B, int32_t J, int64_t nvox, void* stream);
 int lt_volumetric_ce_fwd(const float* coords, const float* probs, const float* keypoints_gt, const float* validity, float* terms,
                          int32_t* idx, float* grad_val, int32_t B, int32_t J, int64_t nvox, void* stream);
 size_t lt_bn_stats_workspace(int64_t rows, int32_t C);

@@ -24,6 +24,8 @@ struct SA3BwdArgs {
     const float* gkp;        // (B, J, 3)
     const int* gp_idx;       // (B, J) voxel index, or null
     const float* gp_val;     // (B, J) gradient on probs[b, j, idx]
+    const float* gp_dense;   // (B, J, nvox) DENSE gradient on the returned probabilities (any loss on the volumes, train.py:222-230), or null
+    const float* pgsum;      // (B, J): sum_i p_i gp_dense_i (sa3_pg_kernel), softmax mode with gp_dense
     float* glogits;
     float mult;
     int softmax, J, channels_last;
@@ -42,17 +44,35 @@ __global__ __launch_bounds__(256) void sa3_bwd_kernel(const SA3BwdArgs a) {
     if (a.softmax) {
         sub = g0 * a.kp[bj * 3] + g1 * a.kp[bj * 3 + 1] + g2 * a.kp[bj * 3 + 2];
         if (idx >= 0) sub += p[idx] * gv;
+        if (a.gp_dense) sub += a.pgsum[bj];
     }
+    const float* gd = a.gp_dense ? a.gp_dense + (long long)bj * a.nvox : nullptr;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.nvox; i += (long long)gridDim.x * 256) {
         const float pi = p[i];
         float ai = g0 * cd[i * 3] + g1 * cd[i * 3 + 1] + g2 * cd[i * 3 + 2];
         if (i == idx) ai += gv;
+        if (gd) ai += gd[i];
         float gl;
         if (a.softmax) gl = a.mult * pi * (ai - sub);
         else gl = pi > 0.f ? a.mult * ai : 0.f;
         if (a.channels_last) a.glogits[((long long)b * a.nvox + i) * a.J + j] = gl;
         else a.glogits[(long long)bj * a.nvox + i] = gl;
     }
+}
+
+// sum_i p_i g_i per (b, j), fp64 accumulation in a fixed order (one workgroup per (b, j): lanes stride the voxels, LDS tree)
+__global__ __launch_bounds__(256) void sa3_pg_kernel(const float* __restrict__ probs, const float* __restrict__ gp, long long nvox, float* __restrict__ out) {
+    __shared__ double red[256];
+    const long long base = (long long)blockIdx.x * nvox;
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < nvox; i += 256) s += (double)probs[base + i] * (double)gp[base + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k >= 1; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)red[0];
 }
 
 // ---- VolumetricCELoss, fused (loss.py:52-80) -----------------------------------------------------------------------------------
@@ -195,11 +215,23 @@ __global__ __launch_bounds__(256) void bn_finalize_vec_kernel(const double* __re
 extern "C" int lt_softargmax3d_bwd(const float* probs, const float* coords, const float* kp, const float* grad_kp, const int32_t* gp_idx,
                                    const float* gp_val, float multiplier, int32_t softmax, int32_t channels_last, float* grad_logits, int32_t B,
                                    int32_t J, int64_t nvox, void* stream) {
+    return lt_softargmax3d_bwd_dense(probs, coords, kp, grad_kp, gp_idx, gp_val, nullptr, nullptr, multiplier, softmax, channels_last, grad_logits, B, J, nvox, stream);
+}
+
+extern "C" int lt_softargmax3d_bwd_dense(const float* probs, const float* coords, const float* kp, const float* grad_kp, const int32_t* gp_idx,
+                                         const float* gp_val, const float* gp_dense, float* workspace_bj, float multiplier, int32_t softmax,
+                                         int32_t channels_last, float* grad_logits, int32_t B, int32_t J, int64_t nvox, void* stream) {
     LT_REQUIRE(probs && coords && kp && grad_kp && grad_logits, LT_ERR_INVALID, "lt_softargmax3d_bwd: null argument");
+    LT_REQUIRE(!gp_dense || !softmax || workspace_bj, LT_ERR_INVALID, "lt_softargmax3d_bwd_dense: the softmax mode needs B * J floats of workspace");
     LT_REQUIRE((gp_idx == nullptr) == (gp_val == nullptr), LT_ERR_INVALID, "lt_softargmax3d_bwd: gp_idx and gp_val come together");
     LT_REQUIRE(B >= 1 && J >= 1 && nvox >= 1 && (long long)B * J < 65536, LT_ERR_INVALID, "lt_softargmax3d_bwd: bad shape");
     SA3BwdArgs a;
     a.probs = probs; a.coords = coords; a.kp = kp; a.gkp = grad_kp; a.gp_idx = gp_idx; a.gp_val = gp_val; a.glogits = grad_logits;
+    a.gp_dense = gp_dense; a.pgsum = workspace_bj;
+    if (gp_dense && softmax) {
+        hipLaunchKernelGGL(sa3_pg_kernel, dim3((unsigned)(B * J)), dim3(256), 0, (hipStream_t)stream, probs, gp_dense, (long long)nvox, workspace_bj);
+        LT_CHECK_LAUNCH("lt_softargmax3d_bwd_dense(sum)");
+    }
     a.mult = multiplier; a.softmax = softmax; a.J = J; a.channels_last = channels_last; a.nvox = nvox;
     const long long blocks = cdiv(nvox, 256 * 8);
     hipLaunchKernelGGL(sa3_bwd_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096), (unsigned)(B * J)), dim3(256), 0, (hipStream_t)stream, a);

@@ -129,6 +129,7 @@ SIGNATURES = {
     "lt_global_avgpool_bwd": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "lt_global_avgpool_bwd_dt": (C.c_int, [i32, vp, vp, i32, i32, i32, i32, vp]),
     "lt_softargmax3d_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, i32, i32, i64, vp]),
+    "lt_softargmax3d_bwd_dense": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, vp, i32, i32, i64, vp]),
     "lt_volumetric_ce_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp]),
     "lt_bn_stats_workspace": (C.c_size_t, [i64, i32]),
     "lt_bn_stats_fwd": (C.c_int, [i32, vp, i64, i32, vp, vp, vp, vp, f32, vp, vp]),

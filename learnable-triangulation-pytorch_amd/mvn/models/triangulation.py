@@ -172,12 +172,15 @@ class _VolTrainPlan:
         base_points = self.geo[o_cen:o_rot].reshape(B, 3).clone()
         return self.kp.clone(), self.probs.clone(), feats_out, self.coords.clone(), base_points, position, sides
 
-    def backward(self, g_kp, idx, val):
+    def backward(self, g_kp, idx, val, g_dense=None):
         B, J = self.probs.shape[:2]
         nvox = self.probs[0, 0].numel()
         st = torch.cuda.current_stream(self.device).cuda_stream
-        H.check(H.lib().lt_softargmax3d_bwd(self.probs.data_ptr(), self.coords.data_ptr(), self.kp.data_ptr(), g_kp.data_ptr(), H.ptr(idx), H.ptr(val), self.mult, self.sm, 1,
-                                            self.gl.data_ptr(), B, J, nvox, st), "lt_softargmax3d_bwd")
+        ws = None
+        if g_dense is not None:          # a dense gradient on the returned volumes (any loss on them, as the reference's autograd accepts)
+            ws = self.__dict__.setdefault("_pg_ws", torch.empty(B * J, dtype=torch.float32, device=self.device))
+        H.check(H.lib().lt_softargmax3d_bwd_dense(self.probs.data_ptr(), self.coords.data_ptr(), self.kp.data_ptr(), g_kp.data_ptr(), H.ptr(idx), H.ptr(val), H.ptr(g_dense),
+                                                  H.ptr(ws), self.mult, self.sm, 1, self.gl.data_ptr(), B, J, nvox, st), "lt_softargmax3d_bwd")
         pg = self.tape.run_backward()
         flat = self.tape.arena.clone()          # autograd gets its own copy: the arena is overwritten by the next step
         off = self.tape.arena.data_ptr()
@@ -210,12 +213,16 @@ class _VolTrainFn(torch.autograd.Function):
         with torch.cuda.device(plan.device):
             g_kp = torch.zeros_like(plan.kp) if g_kp is None else g_kp.float().contiguous()
             sparse = getattr(ctx, "_lt_sparse_prob_grads", [])
-            idx = val = None
+            idx = val = g_dense = None
             if len(sparse) == 1:
                 idx, val = sparse[0]
-            elif len(sparse) > 1 or (g_probs is not None and g_probs.stride() != (0,) * g_probs.dim()):
-                raise NotImplementedError("a dense gradient on the returned volumes in training (only VolumetricCELoss's sparse one is built)")
-            pg = plan.backward(g_kp, idx, val)
+            elif len(sparse) > 1:
+                raise NotImplementedError("more than one sparse (VolumetricCELoss) gradient on the returned volumes of one forward")
+            if g_probs is not None and g_probs.stride() != (0,) * g_probs.dim():
+                # any other loss on the volumes: a dense (B, J, V, V, V) gradient, added to the soft-argmax backward's a_i (round 4; the all-zero-stride
+                # tensor autograd hands over next to VolumetricCELoss's sparse gradient is that loss's placeholder, not a gradient)
+                g_dense = g_probs.float().contiguous()
+            pg = plan.backward(g_kp, idx, val, g_dense)
         grads = tuple(pg.get(p) if p.requires_grad else None for p in ctx.params)
         return (None, None, None) + grads
 

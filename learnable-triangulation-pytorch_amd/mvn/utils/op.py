@@ -121,7 +121,7 @@ def _softargmax3d_launch(volumes, cv, softmax):
 
 class _SoftArgmax3dFn(torch.autograd.Function):
     """lt_softargmax3d_fwd / _bwd as one node with TWO outputs (coordinates, probabilities): a dense gradient on the
-    probabilities is folded in through its inner product with them; VolumetricCELoss (mvn/models/loss.py) instead hands over its
+    probabilities goes into the same kernel (lt_softargmax3d_bwd_dense); VolumetricCELoss (mvn/models/loss.py) instead hands over its
     one-voxel-per-joint gradient in sparse form (``sparse_prob_grad``), so no (B,J,V^3) gradient tensor is ever materialised."""
 
     @staticmethod
@@ -142,9 +142,6 @@ class _SoftArgmax3dFn(torch.autograd.Function):
         idx = val = None
         if len(sparse) == 1:
             idx, val = sparse[0]
-        gl = torch.empty_like(probs)
-        H.check(H.lib().lt_softargmax3d_bwd(probs.data_ptr(), cv.data_ptr(), kp.data_ptr(), g_kp.data_ptr(), H.ptr(idx), H.ptr(val), 1.0,
-                                            int(ctx.softmax), 0, gl.data_ptr(), B, J, nvox, H.cur_stream()), "lt_softargmax3d_bwd")
         dense = None
         if len(sparse) > 1:       # several sparse consumers: scatter them into one dense gradient (rare)
             dense = torch.zeros(B, J, nvox, dtype=torch.float32, device=probs.device)
@@ -153,11 +150,13 @@ class _SoftArgmax3dFn(torch.autograd.Function):
             dense = dense.reshape(probs.shape)
         if g_probs is not None and g_probs.stride() != (0,) * g_probs.dim():   # a real dense gradient on the returned volumes
             dense = g_probs.float() if dense is None else dense + g_probs.float()
-        if dense is not None:     # d/dl_i += p_i (gp_i - <p, gp>) (softmax) / gp_i [l_i > 0] (ReLU): small torch glue on a rare path
-            if ctx.softmax:
-                gl = gl + probs * (dense - (probs * dense).flatten(2).sum(-1)[..., None, None, None])
-            else:
-                gl = gl + dense * (probs > 0)
+        ws = None
+        if dense is not None:     # a_i += gp_i inside the kernel (softmax: minus <p, gp>, reduced per joint into the workspace first)
+            dense = dense.contiguous()
+            ws = torch.empty(B * J, dtype=torch.float32, device=probs.device)
+        gl = torch.empty_like(probs)
+        H.check(H.lib().lt_softargmax3d_bwd_dense(probs.data_ptr(), cv.data_ptr(), kp.data_ptr(), g_kp.data_ptr(), H.ptr(idx), H.ptr(val), H.ptr(dense), H.ptr(ws), 1.0,
+                                                  int(ctx.softmax), 0, gl.data_ptr(), B, J, nvox, H.cur_stream()), "lt_softargmax3d_bwd")
         return gl.to(ctx.in_dtype), None, None
 
 

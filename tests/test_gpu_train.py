@@ -1001,6 +1001,47 @@ def test_training_api_semantics_accumulation_stale_backward_torch_optimizer():
     assert len(m._train_plans) == 2 and torch.isfinite(kp1).all()
 
 
+def test_dense_gradient_on_the_returned_volumes_in_training():
+    """Any loss on the returned volumes trains (the reference's autograd accepts one, train.py:222-230; round 3 refused everything but
+    VolumetricCELoss's sparse gradient): the SAME gradient handed over once in CE's sparse form and once as a dense (B, J, V, V, V) tensor --
+    (volumes * D).sum() with D = d CE / d volumes -- must give the same parameter gradients (lt_softargmax3d_bwd_dense)."""
+    from mvn.models import loss as L
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    from test_gpu_models import _cameras
+    cfg = synth.vol_config(18, 32, "softmax", 1.0, "mpii")
+    sd = synth.make_state_dict(spec.vol_net_spec(18, 17, False), seed=12, sharpen=60.0, basic_block=True)
+    inp = synth.make_inputs(2, 3, 128, seed=30, inside=False)
+    batch = {"cameras": _cameras(inp, 2), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+    gt = (torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float() + 15.0).to(DEV)
+    val = torch.ones(2, 17, 1, device=DEV)
+    m = VolumetricTriangulationNet(cfg, device=DEV)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV).train()
+    grads = []
+    for dense in (False, True):
+        np.random.seed(3)
+        kp, _, vols, _, _, cvs, _ = m(inp["images"].to(DEV), None, batch)
+        mae = L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val)
+        if dense:
+            v2 = vols.detach().clone().requires_grad_(True)
+            L.VolumetricCELoss()(cvs, v2, gt, val).backward()          # volumes that are no output of our node: the dense scatter of CE's gradient
+            loss = mae + 0.01 * (vols * v2.grad).sum()
+        else:
+            loss = mae + 0.01 * L.VolumetricCELoss()(cvs, vols, gt, val)
+        for p in m.parameters():
+            p.grad = None
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.detach().double().cpu() for n, p in m.named_parameters() if p.grad is not None})
+        for c in m.modules():          # the same running statistics in front of both steps
+            if isinstance(c, torch.nn.modules.batchnorm._BatchNorm):
+                c.reset_running_stats()
+    assert set(grads[0]) == set(grads[1]) and len(grads[0]) > 50
+    worst = max(float((grads[0][n] - grads[1][n]).abs().max() / max(float(grads[0][n].abs().max()), 1e-30)) for n in grads[0] if not ZERO_GRAD.search(n))
+    record("train/dense vs sparse gradient on the returned volumes: worst parameter-gradient difference (of each tensor's max)", worst)
+    assert worst < 1e-4, worst
+
+
 @pytest.mark.parametrize("precision", ["bf16", "act16"])
 def test_mixed_precision_training_step_deviation_and_descent(golden_dir, precision):
     """train_precision = "bf16": the convolutions and their input gradients on the bf16 MFMA, everything else fp32.  Outside the fp32
