@@ -103,6 +103,9 @@ template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, 
 struct HaloCfg {
     static constexpr int ES = sizeof(T);
     static constexpr int VEC = 16 / ES;
+    // outputs / residuals are the operand type, except that fp8 (an operand type only: the 'fp8v2v' training step) stores bf16
+    typedef typename std::conditional<sizeof(T) == 1, bf16_t, T>::type OT;
+    static constexpr int OVEC = 16 / (int)sizeof(OT);
     static constexpr int CINB = CIN * ES;
     static constexpr int NVV = CINB / 16;          // 16-byte vectors per voxel
     static constexpr int VPR = 16 / NVV;           // voxels per 256-byte bank row
@@ -198,7 +201,8 @@ __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArg
                                               ACC& acc, DACC& dacc, bool pre_res, uint4 rp0, uint4 rp1, uint4 rp2, uint4 rp3, uint4 rp4,
                                               uint4 rp5, uint4 rp6, uint4 rp7, const HaloCst<SN>& cst) {
     constexpr int EP_LD = CP + 4;
-    constexpr int VEC_ = 16 / (int)sizeof(T);
+    typedef typename std::conditional<sizeof(T) == 1, bf16_t, T>::type OT;          // fp8 operands: bf16 outputs and residuals
+    constexpr int VEC_ = 16 / (int)sizeof(OT);
     // ---- epilogue (same scheme as conv_igemm2: per-wave fp32 LDS tile -> 16-byte vectors) ----
     float* ep = (float*)(smem + wave * (64 * EP_LD * 4));
 #pragma unroll
@@ -241,7 +245,7 @@ __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArg
                 const size_t off = off0 + it * step;
                 const float* src = ep + (lr + it * RPP) * EP_LD + cq;
                 uint4 ov;
-                if constexpr (sizeof(T) == 4) {
+                if constexpr (sizeof(OT) == 4) {
                     const float4 q = *(const float4*)src;
                     const float nr = has_res ? 0.f : -0.0f;
                     float4 o;
@@ -264,7 +268,7 @@ __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArg
 #ifdef LT_ABL_NO_STORE
                 if (a.N < 0)
 #endif
-                *(uint4*)((T*)a.y + off) = ov;
+                *(uint4*)((OT*)a.y + off) = ov;
             };
             if (pre_res || !has_res) {
                 if (NIT > 0) row(0, rp0);
@@ -283,7 +287,7 @@ __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArg
                 uint4 rv[NIT];
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)      // all residual loads first: independent HBM round trips
-                    rv[it] = *(const uint4*)((const T*)a.res + off0 + it * step);
+                    rv[it] = *(const uint4*)((const OT*)a.res + off0 + it * step);
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) row(it, rv[it]);
             }
@@ -293,8 +297,8 @@ __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArg
             const int r = idx / CP, cc = idx - r * CP;
             if (cc >= a.Cout) continue;
             const size_t off = row_pix(64 * wave + r) * a.ldc + cc;
-            const float rr = has_res ? elt<T>::ld((const T*)a.res + off) : -0.0f;
-            elt<T>::st((T*)a.y + off, epi_apply(ep[r * EP_LD + cc], fl, rr));
+            const float rr = has_res ? elt<OT>::ld((const OT*)a.res + off) : -0.0f;
+            elt<OT>::st((OT*)a.y + off, epi_apply(ep[r * EP_LD + cc], fl, rr));
         }
     }
 }
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
     cst.load(a, lane, MF);
     // ---- residual prefetch: the lane's 16-byte residual vectors (up to 8) are requested before the tap loop, in named
     // registers (see conv_igemm2.hip for why not an array); they are consumed in the epilogue ----
-    constexpr int E_VECO = C::VEC, E_LPR = CP / E_VECO, E_RPP = 64 / E_LPR, E_NIT = 64 / E_RPP;
+    constexpr int E_VECO = C::OVEC, E_LPR = CP / E_VECO, E_RPP = 64 / E_LPR, E_NIT = 64 / E_RPP;
     static_assert(E_NIT <= 16, "epilogue rows per lane");
     // (the 64-channel loader-wave configuration is at its 256-VGPR budget: it loads the residual in the epilogue instead)
     constexpr bool PRE_OK = E_NIT <= 8 && !(LDR && CINB == 128);
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
             const int r = 64 * wave + lane / E_LPR + it * E_RPP;
             const int tw = r % TW, th = (r / TW) % TH, td = r / (TW * TH);
             const size_t pixv = (((size_t)n * a.D + d0 + td) * a.H + h0 + th) * a.W + w0 + tw;
-            const void* src = cqp < a.Cout ? (const void*)((const T*)a.res + pixv * a.ldc + cqp) : zero_page;
+            const void* src = cqp < a.Cout ? (const void*)((const typename C::OT*)a.res + pixv * a.ldc + cqp) : zero_page;
             return *(const uint4*)src;
         };
         if (E_NIT > 0) rp0 = pf(0);
@@ -1830,7 +1834,7 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     a.N = c.N; a.D = c.D; a.H = c.H; a.W = c.W; a.Cout = c.Cout; a.ldc = c.ldc; a.k_pad = c.k_pad; a.flags = c.flags;
     a.tiles_d = c.D / 4; a.tiles_h = c.H / 8; a.tiles_w = c.W / 8;
     a.xcd_pin = (c.N % 8 == 0) ? 1 : 0;
-    const bool bf = dtype == LT_BF16;
+    const bool bf = dtype == LT_BF16, f8 = dtype == LT_FP8;
 #define HALO_CASE_L(T_, KS_, CIN_, CP_, TPC_, NBUF_, PD_, LDR_)                                  \
     if (ks == KS_ && c.Cin == CIN_ && cout_pad == CP_) {                                        \
         int rc = launch_halo<T_, KS_, CIN_, CP_, 4, 8, 8, TPC_, NBUF_, PD_, LDR_>(a, s);        \
@@ -1865,6 +1869,15 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
         if (rc != 1) return rc == LT_OK ? 1 : rc;
     }
     static const bool row_chunks = getenv("LT_HALO_ROW") != nullptr;   // A/B: 3-tap weight chunks -> 51 KB of LDS -> 3 workgroups per CU
+    if (f8) {
+        // e4m3 operands (train_precision 'fp8v2v'): the one-tile loader-wave kernel at half the bytes per voxel / per weight slab; bf16 stores.  The byte
+        // geometries are the bf16 ones of half the channel count: (64, 64) = bf16 (32 -> 64), (32, 32) = bf16 (16 -> 32)
+        if (c.Cout % 8 || c.ldc % 8 || getenv("LT_HALO_NO_FP8")) return 0;
+        HALO_CASE_L(fp8_t, 3, 64, 64, 9, 2, 1, true)
+        HALO_CASE_L(fp8_t, 3, 32, 32, 9, 2, 1, true)
+        HALO_CASE_L(fp8_t, 3, 32, 64, 9, 2, 1, true)
+        return 0;
+    }
     if (bf) {
         static const bool no_ldr = getenv("LT_HALO_NO_LDR") != nullptr;   // A/B: no loader waves in the one-tile kernel
         if (!no_ldr) {

@@ -321,8 +321,8 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bi
                                       (((d->flags & LT_EPI_STORE_F32) && (!residual || (d->flags & LT_EPI_RES_F32))) ||
                                        (!(d->flags & LT_EPI_STORE_F32) && d->Cout % 8 == 0 && d->ldc % 8 == 0))),
                LT_ERR_UNSUPPORTED, "lt_conv_fwd: an fp8 convolution stores fp32 (LT_EPI_STORE_F32, fp32 residual: LT_EPI_RES_F32) or, with Cout %% 8 == 0, bf16 (bf16 residual)");
-    LT_REQUIRE(d->dtype != LT_FP8 || d->tile == LT_TILE_AUTO || (d->tile >= LT_TILE2_128x128 && d->tile <= LT_TILE2_64x64), LT_ERR_UNSUPPORTED,
-               "lt_conv_fwd: fp8 convolutions run on the generic implicit-GEMM tiles only");
+    LT_REQUIRE(d->dtype != LT_FP8 || d->tile == LT_TILE_AUTO || d->tile == LT_TILE_HALO || (d->tile >= LT_TILE2_128x128 && d->tile <= LT_TILE2_64x64), LT_ERR_UNSUPPORTED,
+               "lt_conv_fwd: fp8 convolutions run on the generic implicit-GEMM tiles and the halo kernel only");
     const int l2 = ilog2_exact(d->Cin);
     LT_REQUIRE(l2 >= 0 && d->Cin >= vec, LT_ERR_UNSUPPORTED,
                "lt_conv_fwd: Cin=%d must be a power of two >= %d (pad the channel dimension)", d->Cin, vec);
@@ -359,7 +359,16 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bi
     LT_REQUIRE(max_taps <= 2048, LT_ERR_UNSUPPORTED, "lt_conv_fwd: too many taps (%d)", max_taps);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == LT_F32) return dispatch<float>(a, d->cout_pad, d->nphase, max_taps, d->tile, s);
-    if (d->dtype == LT_FP8) return conv2_dispatch(LT_FP8, a, d->cout_pad, d->nphase, max_taps, d->tile, s);
+    if (d->dtype == LT_FP8) {
+        // the 3^3 layers of the 64^3 / 32^3 levels: input halo in LDS (conv3d_halo.hip); bf16 stores only
+        if ((d->tile == LT_TILE_AUTO || d->tile == LT_TILE_HALO) && !(d->flags & LT_EPI_STORE_F32)) {
+            const int rc = conv3d_halo_try(LT_FP8, a, d->cout_pad, d->nphase, d->tile == LT_TILE_HALO, s);
+            if (rc == 1) return LT_OK;
+            if (rc < 0) return rc;
+        }
+        LT_REQUIRE(d->tile != LT_TILE_HALO, LT_ERR_UNSUPPORTED, "lt_conv_fwd: LT_TILE_HALO requested but this fp8 problem has no halo kernel");
+        return conv2_dispatch(LT_FP8, a, d->cout_pad, d->nphase, max_taps, d->tile, s);
+    }
     return dispatch<bf16_t>(a, d->cout_pad, d->nphase, max_taps, d->tile, s);
 }
 

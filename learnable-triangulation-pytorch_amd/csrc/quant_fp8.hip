@@ -22,7 +22,14 @@ __global__ __launch_bounds__(256) void amax_kernel(const void* __restrict__ x, i
     for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(ld1_f32_or_bf16(x, (size_t)i, x16)));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));   // NaN never compares greater: a NaN input leaves the maximum of the rest
+    // ONE atomic per workgroup (round 4: one per wave from up to 4096 workgroups serialised 16 K atomics on one address -- 64 us per call, 10 ms per step)
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax(amax, __float_as_uint(m));   // NaN never compares greater: a NaN input leaves the maximum of the rest
+    }
 }
 
 __device__ __forceinline__ float inv_scale_of(float amax, float& scale) {
@@ -78,6 +85,10 @@ unsigned grid_for(long long work_items) {
     const long long b = cdiv(work_items, 256);
     return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
+unsigned amax_grid(long long work_items) {          // a few workgroups per CU, each with a long grid-stride loop and ONE atomic at its end
+    const long long b = cdiv(work_items, 256 * 8);
+    return (unsigned)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
 
 }  // namespace
 
@@ -85,7 +96,7 @@ extern "C" int lt_amax_f32(const float* x, int64_t n, float* amax, void* stream)
 
 extern "C" int lt_amax_dt(int32_t dtype, const void* x, int64_t n, float* amax, void* stream) {
     LT_REQUIRE(x && amax && n >= 1 && ((size_t)x % 16 == 0) && (dtype == LT_F32 || dtype == LT_BF16), LT_ERR_INVALID, "lt_amax: bad argument (16-byte aligned x, fp32 or bf16)");
-    hipLaunchKernelGGL(amax_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, dtype == LT_BF16 ? 1 : 0, (long long)n, (unsigned*)amax);
+    hipLaunchKernelGGL(amax_kernel, dim3(amax_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, dtype == LT_BF16 ? 1 : 0, (long long)n, (unsigned*)amax);
     LT_CHECK_LAUNCH("lt_amax");
     return LT_OK;
 }

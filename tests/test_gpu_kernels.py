@@ -366,6 +366,8 @@ FP8_CASES = [  # nd, N, cin, cout, k, stride, pad, spatial
     (3, 2, 64, 64, 3, 1, 1, (4, 8, 8)),
     (3, 1, 128, 128, 3, 1, 1, (4, 4, 4)),
     (2, 2, 256, 64, 1, 1, 0, (9, 7)),          # pointwise fast path
+    (3, 2, 32, 64, 3, 1, 1, (4, 8, 16)),       # halo kernel shapes (with the two above: 32 -> 32 at 8^3, 64 -> 64 at 4 x 8 x 8)
+    (3, 1, 64, 64, 3, 1, 1, (8, 16, 8)),
 ]
 
 
@@ -422,6 +424,15 @@ def test_conv_fp8_operands(case):
     b.finish().run_eager(st); torch.cuda.synchronize()
     assert y.t.dtype == torch.bfloat16
     check("conv fp8 nd%d %d->%d k%d bf16 store + bf16 residual" % (nd, cin, cout, k), from_cl(y.t, nd), torch.relu(ref0 + bf16_round(res)), 1.5e-2)
+    # the halo kernel on e4m3 operands (input halo of the 4 x 8 x 8 tile in LDS, bf16 stores): forced, with and without the residual / ReLU epilogue
+    if nd == 3 and k == 3 and (cin, cout) in ((32, 32), (32, 64), (64, 64)) and sp[0] % 4 == 0 and sp[1] % 8 == 0 and sp[2] % 8 == 0:
+        for with_res in (False, True):
+            b = E.PlanBuilder(DEV, torch.float8_e4m3fn, tile_override=H.TILE_HALO)
+            y = b.conv(E.Act(x8.view(torch.float8_e4m3fn)), wq.float(), None, bn, stride=s_, pad=p_,
+                       residual=E.Act(to_cl(res, None, torch.bfloat16)) if with_res else None, relu=with_res)
+            b.finish().run_eager(st); torch.cuda.synchronize()
+            refh = torch.relu(ref0 + bf16_round(res)) if with_res else ref0
+            check("conv fp8 halo kernel %d->%d @%s%s" % (cin, cout, "x".join(map(str, sp)), " +res" if with_res else ""), from_cl(y.t, nd), refh, 1.5e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
