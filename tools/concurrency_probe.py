@@ -54,6 +54,13 @@ def main():
             models[0](images, None, batch)
 
         t_seq, t_conc, t_whole = timed(seq), timed(conc), timed(whole)
+        # host time of one forward call (returns before the GPU is done unless something in it waits)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        models[0](*[halves[0][0], None, halves[0][1]])
+        t_host = (time.perf_counter() - t0) * 1e3
+        torch.cuda.synchronize()
+        print("host time of one forward call: %.2f ms" % t_host)
     print("B = %d per forward: two forwards one after the other %.2f ms, on two streams %.2f ms, one forward of %d samples %.2f ms" % (B, t_seq, t_conc, 2 * B, t_whole))
     print("samples/s: sequential %.0f, concurrent %.0f, one plan %.0f" % (2e3 * B / t_seq, 2e3 * B / t_conc, 2e3 * B / t_whole))
 
