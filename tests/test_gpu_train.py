@@ -445,6 +445,50 @@ def test_tape_layer_gradients_with_bf16_conv_outputs(case, monkeypatch):
     test_tape_layer_gradients(case, "bn_relu_res", True)
 
 
+def test_act16_step_with_a_frozen_backbone_batchnorm(golden_dir):
+    """train_precision "act16" with the backbone's BatchNorm modules left in eval() (LT_BN_FROZEN | LT_ACT_BF16: frozen running statistics in the
+    normalisation and its backward, bf16 tensors): against the reference's own fp32 step of that setting (tests/golden/train_step_frozen_bn.npz)."""
+    from mvn.models import loss as L
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    from test_gpu_models import _cameras
+    G = np.load(os.path.join(golden_dir, "train_step_frozen_bn.npz"))
+    c, cfg, sd, inp = _train_case()
+    m = VolumetricTriangulationNet(cfg, device=DEV)
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV).train()
+    for mod in m.backbone.modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            mod.eval()
+    m.train_precision = "act16"
+    batch = {"cameras": _cameras(inp, c["B"]), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+    np.random.seed(c["seed"] + 100)
+    kp, feats, vols, conf, cuboids, cvs, bps = m(inp["images"].to(DEV), None, batch)
+    gt, val = torch.from_numpy(G["gt"]).to(DEV), torch.from_numpy(G["val"]).to(DEV)
+    mae = L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val)
+    ce = L.VolumetricCELoss()(cvs, vols, gt, val)
+    (mae + 0.01 * ce).backward()
+    named = dict(m.named_parameters())
+    errs = []
+    for n in G["names"]:
+        n = str(n)
+        if ZERO_GRAD.search(n):
+            continue
+        f = named[n].grad.detach().double().cpu().reshape(-1)
+        sub = f[::max(1, f.numel() // 129)][:129]
+        errs.append(float((sub - torch.from_numpy(G["g/" + n]).double()).abs().max()) / float(G["gn/" + n][1]))
+    errs.sort()
+    d = float(((kp.detach().cpu().double() - torch.from_numpy(G["kp"]).double()).abs() / torch.from_numpy(G["kp"]).double().abs().clamp(min=1.0)).max())
+    st = {"joints_max_rel": d, "mae": float(mae.detach()), "mae_reference": float(G["mae"]), "parameter_gradient_err_median": errs[len(errs) // 2],
+          "parameter_gradient_err_p90": errs[int(len(errs) * 0.9)]}
+    record("train/act16 with frozen backbone BatchNorm, one step vs the reference's fp32 step", st)
+    print(st)
+    # a running-statistics BatchNorm has none of the batch-statistics sensitivity: tighter than the plain act16 gate
+    assert d < 6e-2 and errs[len(errs) // 2] <= 0.07 and errs[int(len(errs) * 0.9)] <= 0.22, st          # achieved: 3.2e-2, 4.3 %, 15.5 %
+    # the frozen modules' running statistics are untouched
+    bn1 = m.backbone.bn1
+    assert torch.equal(bn1.running_mean.cpu(), sd["backbone.bn1.running_mean"]) and int(bn1.num_batches_tracked) == int(sd["backbone.bn1.num_batches_tracked"])
+
+
 def test_act16_step_with_the_confidence_heads_tracks_the_fp32_storage_mode(golden_dir):
     """train_precision "act16" with ``conf_norm`` aggregation: the vol_confidences head (conv + BN + max pool twice, global average pool, three linears,
     sigmoid -- the last layer stores fp32, the unprojection reads and differentiates fp32 confidences) through the 16-bit-activation tape, against
