@@ -690,7 +690,8 @@ class TrainTape:
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         main = torch.cuda.current_stream(self.device)
         self._collect_bwd_times()
-        ev = self._bwd_events = [torch.cuda.Event(enable_timing=True) for _ in range(3)]          # start, main stream's kernels issued, side stream joined
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]          # start, main stream's kernels issued, side stream joined
+        self._bwd_events = ev if self.bwd_recorded else None          # (the recording backward -- index maps, allocations, host work -- is not a sample)
         ev[0].record(main)
         if not self.bwd_recorded:
             self._cur = self.bwd_ops
