@@ -332,6 +332,18 @@ size_t lt_conv_wgrad_bf16_workspace(int64_t octet_rows, int32_t cout_pad, int32_
 int lt_conv_wgrad_bf16(const void* dy16, const void* x16, const int32_t* taps, float* dw, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin, int32_t Do,
                        int32_t Ho, int32_t Wo, const int32_t stride[3], const int32_t pad[3], int32_t Cout, int32_t ldy, int32_t cout_pad, int32_t k_pad,
                        int32_t ntaps, int32_t accumulate, void* workspace, void* stream);
+/* The same GEMM straight from the channels-last bf16 tensors, without the packs (the 16-bit-activation step: the activations and their gradients
+ * ARE the bf16 operands): dy16 [N][Do*Ho*Wo][ldy], x16 [N][D][H][W][ldx], 16-byte aligned; every lane of the 16x16x32 MFMA reads 4 or 8 consecutive
+ * channels of the eight images of its pixel and transposes them in registers (v_perm_b32) into that many operands.  lt_conv_wgrad_bf16_nhwc_ok
+ * -> 1 when the shape is covered: Cin a power of two, Cout / ldy multiples of 8 (4 when cout_pad <= 64), Cin / ldx multiples of 4 (8 when
+ * cout_pad <= 64), k_pad a multiple of 4, 32-bit element offsets -- and NOT one of the V2V shapes lt_conv_wgrad_bf16 has LDS kernels for (3^3 / stride 1
+ * / pad 1 bricks, the 7^3 front layer): those stay on the packed path.  Same result contract, same workspace as lt_conv_wgrad_bf16
+ * (reference: autograd of nn.Conv2d / nn.ConvTranspose2d in pose_resnet.py inside train.py:217-243's backward). */
+int lt_conv_wgrad_bf16_nhwc_ok(int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Do, int32_t Ho, int32_t Wo, const int32_t stride[3],
+                               const int32_t pad[3], int32_t Cout, int32_t ldy, int32_t cout_pad, int32_t k_pad, int32_t ntaps);
+int lt_conv_wgrad_bf16_nhwc(const void* dy16, const void* x16, const int32_t* taps, float* dw, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin, int32_t ldx,
+                            int32_t Do, int32_t Ho, int32_t Wo, const int32_t stride[3], const int32_t pad[3], int32_t Cout, int32_t ldy, int32_t cout_pad,
+                            int32_t k_pad, int32_t ntaps, int32_t accumulate, void* workspace, void* stream);
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0 -- the layout changes between a Parameter's own layout and the GEMM layouts of its layer
  * (forward weights, input-gradient weights, weight-gradient blocks), with index maps built once when a training plan is recorded */
 int lt_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, void* stream);

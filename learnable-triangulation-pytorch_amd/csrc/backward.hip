@@ -5,6 +5,8 @@
 //   VolumetricCELoss (mvn/models/loss.py:52-80)                -> lt_volumetric_ce_fwd (+ its sparse gradient, consumed by lt_softargmax3d_bwd)
 //   nn.BatchNorm{2,3}d in training mode (batch statistics)     -> lt_bn_stats_fwd
 // Gradients are fp32.  Layouts are the forward's: channels-last feature maps / volumes, planar probabilities (B, J, V^3).
+#include <type_traits>
+
 #include "colsum.h"
 
 using namespace lt;
@@ -176,18 +178,25 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, long long ro
     }
 }
 
+template <bool BF16>
 struct BnStatLoad {
-    const void* x; int C, is_bf16;
+    typedef typename std::conditional<BF16, uint2, float4>::type Raw;
+    static constexpr int ROWS = 8;
+    const void* x; int C;
     __device__ __forceinline__ void prepare(int) {}
-    __device__ __forceinline__ void operator()(long long row, int c, float (&q)[2][4]) const {
-        const float4 v = ld4_f32_or_bf16(x, (size_t)row * C + c, is_bf16);
+    __device__ __forceinline__ Raw fetch(long long row, int c) const { return *(const Raw*)((const char*)x + ((size_t)row * C + c) * (BF16 ? 2 : 4)); }
+    __device__ __forceinline__ void eval(const Raw& r, int, float (&q)[2][4]) const {
+        float4 v;
+        if constexpr (BF16) v = bf16x4_to_f32(r);
+        else v = r;
         q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w;
         q[1][0] = v.x * v.x; q[1][1] = v.y * v.y; q[1][2] = v.z * v.z; q[1][3] = v.w * v.w;
     }
 };
 
-__global__ __launch_bounds__(256) void bn_partial_vec_kernel(const void* __restrict__ x, int is_bf16, long long rows, int C, int nslab, int cw4, int rl, double* __restrict__ part) {
-    colsum_partial<2>(rows, C, nslab, cw4, rl, part, BnStatLoad{x, C, is_bf16});
+template <bool BF16>
+__global__ __launch_bounds__(256) void bn_partial_vec_kernel(const void* __restrict__ x, long long rows, int C, int nslab, int cw4, int rl, double* __restrict__ part) {
+    colsum_partial<2>(rows, C, nslab, cw4, rl, part, BnStatLoad<BF16>{x, C});
 }
 
 struct BnStatFin {
@@ -266,8 +275,8 @@ extern "C" int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32
     hipStream_t st = (hipStream_t)stream;
     if (colsum_fast(C)) {       // the training path: four-channel lanes, four rows in flight, parallel finalize (colsum.h); fp32 or bf16 input
         const ColsumPlan p = colsum_plan(rows, C);
-        hipLaunchKernelGGL(bn_partial_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, x, dtype == LT_BF16 ? 1 : 0, (long long)rows, C, p.nslab, p.cw4, p.rl,
-                           (double*)workspace);
+        if (dtype == LT_BF16) hipLaunchKernelGGL(bn_partial_vec_kernel<true>, dim3(p.nslab, p.ncb), dim3(256), 0, st, x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
+        else hipLaunchKernelGGL(bn_partial_vec_kernel<false>, dim3(p.nslab, p.ncb), dim3(256), 0, st, x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
         LT_CHECK_LAUNCH("lt_bn_stats_fwd(partial)");
         hipLaunchKernelGGL(bn_finalize_vec_kernel, dim3((unsigned)cdiv(C, COLSUM_FIN_C)), dim3(256), 0, st, (const double*)workspace, C, p.nslab,
                            BnStatFin{(long long)rows, mean, var, running_mean, running_var, momentum});

@@ -42,7 +42,11 @@ inline size_t colsum_workspace(long long rows, int C, int nq) {
 }
 
 // Load: void prepare(int c) -- once per thread, c = the first of its four channels (per-channel constants into registers);
-//       void operator()(long long row, int c /* multiple of 4 */, float (&q)[NQ][4]) -- the NQ quantities of four consecutive channels
+//       typedef Raw; Raw fetch(long long row, int c) -- the MEMORY READS of one row's four channels, raw bits (8 bytes per bf16 tensor, 16 per fp32 one);
+//       void eval(const Raw&, int c, float (&q)[NQ][4]) -- the NQ quantities of the four channels from them;  static constexpr int ROWS -- rows in flight.
+// fetch / eval are separate so that ROWS rows of raw bits are in flight and evaluated one at a time: holding the EVALUATED quantities of eight
+// rows (round 4's first version) cost the BatchNorm-backward reduction 211 VGPRs = two waves per SIMD, and it ran at a third of the bytes per second of
+// the apply pass next to it (53 vs 26 us per layer for 6 vs 10 bytes per element).
 template <int NQ, class Load>
 __device__ __forceinline__ void colsum_partial(long long rows, int C, int nslab, int cw4, int rl_n, double* __restrict__ part, const Load& load_in) {
     __shared__ double red[256][NQ * 4 + 1];
@@ -59,20 +63,24 @@ __device__ __forceinline__ void colsum_partial(long long rows, int C, int nslab,
     if (c < C) {
         load.prepare(c);
         long long r = r0 + rl;
-        for (; r + 7ll * rl_n < r1; r += 8ll * rl_n) {          // eight rows in flight (four left the pass latency-bound at ~1.2 TB/s)
-            float v[8][NQ][4];
+        constexpr int ROWS = Load::ROWS;
+        for (; r + (long long)(ROWS - 1) * rl_n < r1; r += (long long)ROWS * rl_n) {          // ROWS rows in flight (four left the pass latency-bound at ~1.2 TB/s)
+            typename Load::Raw raw[ROWS];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) load(r + (long long)u * rl_n, c, v[u]);
+            for (int u = 0; u < ROWS; ++u) raw[u] = load.fetch(r + (long long)u * rl_n, c);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < ROWS; ++u) {
+                float v[NQ][4];
+                load.eval(raw[u], c, v);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[q][e] += (double)v[u][q][e];
+                    for (int e = 0; e < 4; ++e) acc[q][e] += (double)v[q][e];
+            }
         }
         for (; r < r1; r += rl_n) {
             float v[NQ][4];
-            load(r, c, v);
+            load.eval(load.fetch(r, c), c, v);
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
 #pragma unroll

@@ -125,6 +125,10 @@ __device__ __forceinline__ float ld1_f32_or_bf16(const void* p, size_t off, int 
     return is_bf16 ? __uint_as_float((unsigned)((const unsigned short*)p)[off] << 16) : ((const float*)p)[off];
 }
 
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
 // stores of the same kind (LT_ACT_BF16: the activations and activation gradients of the 16-bit training step are bf16 tensors)
 __device__ __forceinline__ void st4_f32_or_bf16(void* p, size_t off, int is_bf16, float a, float b, float c, float d) {
     if (is_bf16) *(uint2*)((bf16_t*)p + off) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));

@@ -19,6 +19,8 @@
 //   lt_adam_step(_multi)  torch.optim.Adam's update (train.py:430-437): one launch per tensor / one launch per parameter group
 // The convolution dgrad needs no kernel of its own: it is lt_conv_fwd over dY with the weights transposed / flipped (stride 1), as a
 // parity-phase transposed convolution (stride-2 layers) or as a strided convolution (the transposed layers) -- see lt_train.py.
+#include <type_traits>
+
 #include "colsum.h"
 #include "conv_common.h"
 #include "wgrad_reduce.h"
@@ -150,7 +152,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
 }
 
 // the same three stages on float4 lanes (colsum.h); every BatchNorm layer of these networks takes this path
+// ALL16: dz, y and the residual are bf16 tensors (the 16-bit-activation step: 8 bytes per tensor and row in flight); else the element types are the
+// runtime flags' (fp32 step, and round 3's mixed step with its optional bf16 y): four rows in flight of 16-byte slots
+template <bool ALL16, int NROWS>
 struct BnBwdLoad {
+    struct Raw16 { uint2 dz, y, r; };
+    struct Raw32 { uint4 dz, y, r; };
+    typedef typename std::conditional<ALL16, Raw16, Raw32>::type Raw;
+    static constexpr int ROWS = NROWS;
     BnBwdArgs a;
     float invstd[4], mean[4], gam[4], bet[4];          // of the thread's four channels (prepare): bn_g's expressions with the constants hoisted
     __device__ __forceinline__ void prepare(int c) {
@@ -160,11 +169,34 @@ struct BnBwdLoad {
             mean[e] = a.mean[c + e]; gam[e] = a.gamma[c + e]; bet[e] = a.beta[c + e];
         }
     }
-    __device__ __forceinline__ void operator()(long long row, int c, float (&q)[2][4]) const {
+    __device__ __forceinline__ Raw fetch(long long row, int c) const {
         const size_t off = (size_t)row * a.C + c;
-        const float4 dz4 = ld4_f32_or_bf16(a.dz, off, a.a16), y4 = ld4_f32_or_bf16(a.y, off, a.y16);
-        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.res) r4 = ld4_f32_or_bf16(a.res, off, a.a16);
+        Raw w;
+        if constexpr (ALL16) {
+            w.dz = *(const uint2*)((const bf16_t*)a.dz + off);
+            w.y = *(const uint2*)((const bf16_t*)a.y + off);
+            w.r = a.res ? *(const uint2*)((const bf16_t*)a.res + off) : make_uint2(0u, 0u);
+        } else {
+            w.dz = w.y = w.r = make_uint4(0u, 0u, 0u, 0u);
+            if (a.a16) { const uint2 t = *(const uint2*)((const bf16_t*)a.dz + off); w.dz.x = t.x; w.dz.y = t.y; }
+            else w.dz = *(const uint4*)((const float*)a.dz + off);
+            if (a.y16) { const uint2 t = *(const uint2*)((const bf16_t*)a.y + off); w.y.x = t.x; w.y.y = t.y; }
+            else w.y = *(const uint4*)((const float*)a.y + off);
+            if (a.res) {
+                if (a.a16) { const uint2 t = *(const uint2*)((const bf16_t*)a.res + off); w.r.x = t.x; w.r.y = t.y; }
+                else w.r = *(const uint4*)((const float*)a.res + off);
+            }
+        }
+        return w;
+    }
+    __device__ __forceinline__ void eval(const Raw& w, int, float (&q)[2][4]) const {
+        float4 dz4, y4, r4;
+        if constexpr (ALL16) { dz4 = bf16x4_to_f32(w.dz); y4 = bf16x4_to_f32(w.y); r4 = bf16x4_to_f32(w.r); }
+        else {
+            dz4 = a.a16 ? bf16x4_to_f32(make_uint2(w.dz.x, w.dz.y)) : make_float4(__uint_as_float(w.dz.x), __uint_as_float(w.dz.y), __uint_as_float(w.dz.z), __uint_as_float(w.dz.w));
+            y4 = a.y16 ? bf16x4_to_f32(make_uint2(w.y.x, w.y.y)) : make_float4(__uint_as_float(w.y.x), __uint_as_float(w.y.y), __uint_as_float(w.y.z), __uint_as_float(w.y.w));
+            r4 = a.a16 ? bf16x4_to_f32(make_uint2(w.r.x, w.r.y)) : make_float4(__uint_as_float(w.r.x), __uint_as_float(w.r.y), __uint_as_float(w.r.z), __uint_as_float(w.r.w));
+        }
         const float dzv[4] = {dz4.x, dz4.y, dz4.z, dz4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
         const bool post = a.flags & LT_EPI_RELU_POST, pre = a.flags & LT_EPI_RELU_PRE;
 #pragma unroll
@@ -180,8 +212,9 @@ struct BnBwdLoad {
     }
 };
 
+template <bool ALL16, int NROWS>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BnBwdArgs a, int cw4, int rl) {
-    BnBwdLoad ld;
+    BnBwdLoad<ALL16, NROWS> ld;
     ld.a = a;
     colsum_partial<2>(a.rows, a.C, a.nslab, cw4, rl, a.part, ld);
 }
@@ -239,12 +272,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BnBwdArgs a
 }
 
 struct ChanSumLoad {
+    typedef float4 Raw;
+    static constexpr int ROWS = 8;
     const void* x; int C, x16;
     __device__ __forceinline__ void prepare(int) {}
-    __device__ __forceinline__ void operator()(long long row, int c, float (&q)[1][4]) const {
-        const float4 v = ld4_f32_or_bf16(x, (size_t)row * C + c, x16);
-        q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w;
-    }
+    __device__ __forceinline__ Raw fetch(long long row, int c) const { return ld4_f32_or_bf16(x, (size_t)row * C + c, x16); }
+    __device__ __forceinline__ void eval(const Raw& v, int, float (&q)[1][4]) const { q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w; }
 };
 __global__ __launch_bounds__(256) void channel_sum_vec_kernel(const void* __restrict__ x, int x16, long long rows, int C, int nslab, int cw4, int rl, double* __restrict__ part) {
     colsum_partial<1>(rows, C, nslab, cw4, rl, part, ChanSumLoad{x, C, x16});
@@ -982,7 +1015,13 @@ extern "C" int lt_bn_act_bwd(const void* dz, const void* y, const void* residual
     if (colsum_fast(C)) {
         const ColsumPlan p = colsum_plan(rows, C);
         a.nslab = p.nslab;
-        hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(p.nslab, p.ncb), dim3(256), 0, st, a, p.cw4, p.rl);
+        // rows in flight per thread: 4 / 8 / 2 measured 130.9 / 128.9 / 129.5 samples/s on the act16 step at 8 samples (one session); LT_BNBWD_ROWS=8 keeps the wider one
+        static const int nrows = [] { const char* e = getenv("LT_BNBWD_ROWS"); return e ? atoi(e) : 4; }();
+        if (a.a16 && a.y16) {
+            if (nrows == 8) hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<true, 8>), dim3(p.nslab, p.ncb), dim3(256), 0, st, a, p.cw4, p.rl);
+            else hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<true, 4>), dim3(p.nslab, p.ncb), dim3(256), 0, st, a, p.cw4, p.rl);
+        } else
+            hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<false, 4>), dim3(p.nslab, p.ncb), dim3(256), 0, st, a, p.cw4, p.rl);
         LT_CHECK_LAUNCH("lt_bn_act_bwd(reduce)");
         hipLaunchKernelGGL(bn_bwd_finalize_vec_kernel, dim3((unsigned)cdiv(C, COLSUM_FIN_C)), dim3(256), 0, st, a);
         LT_CHECK_LAUNCH("lt_bn_act_bwd(finalize)");

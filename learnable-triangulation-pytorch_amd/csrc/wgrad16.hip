@@ -266,6 +266,181 @@ Plan16 plan16(long long M, int cout_pad, int k_pad) {
     return p;
 }
 
+// ---- the same GEMM straight from the channels-last bf16 tensors (no octet pack) ------------------------------------------------------------------
+// The octet pack is a transpose of (image, channel) per pixel: eight 16-byte loads (one per image of the group, the same pixel, eight channels),
+// v_perm_b32 on the halves, eight 16-byte stores -- and the generic kernel then reads each octet back exactly once per tile column / row.  Here the
+// loads and the v_perm stay, the stores and the second read go: a lane of the 16x16x32 MFMA takes ACH (BCH) CONSECUTIVE CHANNELS of dY (X at its tap)
+// from the eight images of its pixel, and the transpose hands it ACH (BCH) operands at once -- operand a of lane i is channel ACH i + a, so the rows
+// of an accumulator tile are the channels {ACH i + a : i}: a permutation of the output rows that only the epilogue has to know.  K of one MFMA = 4
+// pixels (lane / 16) x 8 images.  Per step and wave: 8 loads of 2 ACH bytes + 8 of 2 BCH bytes (runs of 32 ACH bytes per pixel and image), ACH x BCH
+// MFMAs; the same bytes per MAC as the packed kernel's 64 x 128 wave tile.  Measured on the 16-bit-activation step at 8 samples: the packs were
+// 7.9 ms per step on one stream (12.5 ms beside the main stream's kernels) of 22 ms of weight-gradient work.
+struct W16UArgs {
+    const unsigned short* dy;   // [N][Do*Ho*Wo][ldy] bf16
+    const unsigned short* x;    // [N][D][H][W][ldx] bf16
+    const int4* taps;
+    float* out;
+    int N, D, H, W, Cin, log2Cin, ldx, Do, Ho, Wo, sd, sh, sw, pd, ph, pw;
+    int Cout, ldy, k_pad, ntaps, M, accumulate, cout_pad;
+    int n_k_t, n_tiles, rows_per_slab;
+    unsigned img_a, img_b;      // elements between two images of dY / of X
+};
+
+template <int CH> struct RawCh;
+template <> struct RawCh<8> {
+    unsigned d[4];
+    __device__ __forceinline__ void load(const unsigned short* p) { const uint4 v = *(const uint4*)p; d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+};
+template <> struct RawCh<4> {
+    unsigned d[2];
+    __device__ __forceinline__ void load(const unsigned short* p) { const uint2 v = *(const uint2*)p; d[0] = v.x; d[1] = v.y; }
+};
+
+template <int ACH, int BCH>
+__global__ __launch_bounds__(256) void conv_wgrad16u_kernel(const W16UArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;          // XCD-contiguous (slab, tile group) ranges, slab-major
+    const int lin2 = (total & 7) ? lin : (lin & 7) * (total >> 3) + (lin >> 3);
+    const int slab = lin2 / (int)gridDim.x, tgroup = lin2 - slab * (int)gridDim.x;
+    const int t = tgroup * 4 + wave;
+    if (t >= a.n_tiles) return;
+    const int co0 = (t / a.n_k_t) * (16 * ACH), k0 = (t % a.n_k_t) * (16 * BCH);
+    const int i = lane & 15, q = lane >> 4;
+    const int co = co0 + ACH * i;
+    const bool co_ok = co < a.Cout;          // Cout is a multiple of ACH: all of the lane's channels or none
+    const int kc = k0 + BCH * i, tap = kc >> a.log2Cin;          // Cin is a multiple of BCH: the lane's columns share the tap
+    int tsel, toff;
+    if (tap < a.ntaps) {
+        const int4 tp = a.taps[tap];
+        tsel = (1 << tp.x) | (1 << (8 + tp.y)) | (1 << (16 + tp.z));
+        toff = ((tp.x * a.H + tp.y) * a.W + tp.z) * a.ldx + (kc & (a.Cin - 1));
+    } else {
+        tsel = (int)0x80000000; toff = 0;
+    }
+    f32x4 acc[ACH][BCH];
+#pragma unroll
+    for (int c = 0; c < ACH; ++c)
+#pragma unroll
+        for (int j = 0; j < BCH; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c][j][e] = 0.f;
+    const int m_begin = slab * a.rows_per_slab;
+    const int m_end = min(a.M, m_begin + a.rows_per_slab);
+    int m = m_begin + q;
+    const int hw = a.Ho * a.Wo, dhw = a.Do * hw;
+    int g = m / dhw, r = m - g * dhw;
+    int od = r / hw; r -= od * hw;
+    int oh = r / a.Wo, ow = r - oh * a.Wo;
+
+    // bits 0-7 of okbits: image e of the lane's dY row is there (row < m_end, channel < Cout, image < N); bit 8: the lane's X tap is inside the volume.
+    // A zero dY operand is enough for rows / images that do not exist (X is then read at a clamped, valid address), a zero X operand for padding.
+    auto load = [&](RawCh<ACH> (&ra)[8], RawCh<BCH> (&rb)[8], unsigned& okbits) {
+        const bool m_ok = m < m_end;
+        const int nv = m_ok ? min(8, a.N - 8 * g) : 0;
+        const bool aok = m_ok & co_ok;
+        const unsigned offa = aok ? (unsigned)(8 * g) * a.img_a + (unsigned)(((od * a.Ho + oh) * a.Wo + ow) * a.ldy + co) : 0u;
+        unsigned bits = aok ? (1u << nv) - 1u : 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ra[e].load(a.dy + offa + (e < nv ? (unsigned)e * a.img_a : 0u));
+        const int id0 = od * a.sd - a.pd, ih0 = oh * a.sh - a.ph, iw0 = ow * a.sw - a.pw;
+        const int pix = ((id0 * a.H + ih0) * a.W + iw0) * a.ldx;          // may point in front of the image (padding): only in-bounds taps are read
+        const int rmask = m_ok ? (range_mask16(id0, a.D) | (range_mask16(ih0, a.H) << 8) | (range_mask16(iw0, a.W) << 16)) : 0;
+        const bool bok = (rmask & tsel) == tsel;
+        const unsigned offb = bok ? (unsigned)(8 * g) * a.img_b + (unsigned)(pix + toff) : 0u;
+        bits |= bok ? 256u : 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rb[e].load(a.x + offb + (bok && e < nv ? (unsigned)e * a.img_b : 0u));
+        okbits = bits;
+        m += 4; ow += 4;
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) { const int w = ow >= a.Wo; ow -= w ? a.Wo : 0; oh += w; }
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) { const int w = oh >= a.Ho; oh -= w ? a.Ho : 0; od += w; }
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) { const int w = od >= a.Do; od -= w ? a.Do : 0; g += w; }
+    };
+    // operand c of the lane = its channel c of the eight images: dword d = (image 2d, image 2d + 1), the image-octet layout of lt_pack_n8_bf16
+    auto mma = [&](const RawCh<ACH> (&ra)[8], const RawCh<BCH> (&rb)[8], unsigned bits) {
+        V16 af[ACH], bf[BCH];
+        const bool bok = bits & 256u;
+#pragma unroll
+        for (int c = 0; c < ACH; ++c) {
+            unsigned w[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned lo = (bits >> (2 * d)) & 1u ? ra[2 * d].d[c >> 1] : 0u, hi = (bits >> (2 * d + 1)) & 1u ? ra[2 * d + 1].d[c >> 1] : 0u;
+                w[d] = __builtin_amdgcn_perm(hi, lo, (c & 1) ? 0x07060302u : 0x05040100u);
+            }
+            af[c].u = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) {
+            unsigned w[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) w[d] = bok ? __builtin_amdgcn_perm(rb[2 * d + 1].d[j >> 1], rb[2 * d].d[j >> 1], (j & 1) ? 0x07060302u : 0x05040100u) : 0u;
+            bf[j].u = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < ACH; ++c)
+#pragma unroll
+            for (int j = 0; j < BCH; ++j) acc[c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c].h, bf[j].h, acc[c][j], 0, 0, 0);
+    };
+    RawCh<ACH> ra0[8], ra1[8];
+    RawCh<BCH> rb0[8], rb1[8];
+    unsigned ok0, ok1;
+    const int nit = (m_end - m_begin + 3) >> 2;
+    load(ra0, rb0, ok0);
+    for (int it = 0; it < nit; it += 2) {          // (rows past m_end load nothing new: a zero dY operand)
+        load(ra1, rb1, ok1); mma(ra0, rb0, ok0);
+        load(ra0, rb0, ok0); mma(ra1, rb1, ok1);
+    }
+    float* out = a.out + (size_t)slab * a.cout_pad * a.k_pad;
+    const bool direct_acc = a.accumulate && gridDim.y == 1;
+    // C of the 16x16 MFMA: row = 4 (lane / 16) + e <-> the A lane of that index, column = lane % 16 <-> the B lane: four (BCH = 4) or eight consecutive
+    // columns of dW per lane and row -- 16-byte stores
+#pragma unroll
+    for (int c = 0; c < ACH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = co0 + ACH * (4 * q + e) + c;
+            if (row >= a.cout_pad) continue;
+#pragma unroll
+            for (int j4 = 0; j4 < BCH; j4 += 4) {
+                const int k = kc + j4;
+                if (k >= a.k_pad) continue;          // (k_pad is a multiple of 4)
+                float4* dst = (float4*)(out + (size_t)row * a.k_pad + k);
+                float4 v = make_float4(acc[c][j4][e], acc[c][j4 + 1][e], acc[c][j4 + 2][e], acc[c][j4 + 3][e]);
+                if (direct_acc) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *dst = v;
+            }
+        }
+}
+
+// wave tile (16 ACH) x (16 BCH): 128 x 64 where there are 128 output channels to fill it, 64 x 128 below
+Plan16 plan16u(long long M, int cout_pad, int k_pad) {
+    Plan16 p;
+    p.variant = cout_pad > 64 ? 0 : 1;
+    const int tco = p.variant == 0 ? 128 : 64, tk = p.variant == 0 ? 64 : 128;
+    p.n_co_t = (int)cdiv(cout_pad, tco); p.n_k_t = (int)cdiv(k_pad, tk);
+    const long long wgs = cdiv((long long)p.n_co_t * p.n_k_t, 4);
+    const double n_bytes = (double)cout_pad * k_pad * 4.0;
+    const long long cap = (long long)(((size_t)48 << 20) / (size_t)n_bytes);
+    long long best = 1;
+    double best_t = 1e30;
+    for (long long S = 1; S <= 512; S = S < 8 ? S + 1 : S + 8) {          // the packed kernel's two-term model: a step is four octet rows and 32 MFMAs of 16 cycles
+        if (S > 1 && (S > cap || S > M / 16)) break;
+        const double rounds = (double)cdiv(wgs * S, 256);
+        const double kernel_us = rounds * (double)cdiv(M, 4 * S) * 0.4;
+        const double reduce_us = S > 1 ? 3.0 + S * n_bytes / 3.0e6 : 0.0;
+        if (kernel_us + reduce_us < best_t) { best_t = kernel_us + reduce_us; best = S; }
+    }
+    long long rps = cdiv(M, best);
+    rps = (rps + 3) & ~3ll;
+    p.rows_per_slab = (int)rps;
+    p.S = (int)best;
+    return p;
+}
+
 // ---- 3^3 / stride 1 / pad 1 from LDS bricks of octets ---------------------------------------------------------------------------------------
 constexpr int B16_D = 2, B16_H = 2, B16_W = 8, B16_VOX = B16_D * B16_H * B16_W;                                   // 32 voxels = 16 MFMA K steps
 constexpr int B16_HD = B16_D + 2, B16_HH = B16_H + 2, B16_HW = B16_W + 2, B16_HVOX = B16_HD * B16_HH * B16_HW;    // 160 halo voxels
@@ -596,6 +771,55 @@ extern "C" int lt_conv_wgrad_bf16(const void* dy16, const void* x16, const int32
     if (p.S > 1) {
         reduce16(workspace, dw, n, p.S, accumulate, st);
         LT_CHECK_LAUNCH("lt_conv_wgrad_bf16(reduce)");
+    }
+    return LT_OK;
+}
+
+extern "C" int lt_conv_wgrad_bf16_nhwc_ok(int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin, int32_t ldx, int32_t Do, int32_t Ho, int32_t Wo, const int32_t stride[3],
+                                          const int32_t pad[3], int32_t Cout, int32_t ldy, int32_t cout_pad, int32_t k_pad, int32_t ntaps) {
+    if (!stride || !pad || N < 1 || ntaps < 1 || Cin < 1) return 0;
+    if (getenv("LT_WGRAD16_PACKED")) return 0;
+    const int G = (int)cdiv(N, 8);
+    const long long M = (long long)G * Do * Ho * Wo;
+    const bool unit = stride[0] == 1 && stride[1] == 1 && stride[2] == 1 && D == Do && H == Ho && W == Wo;
+    // the V2V shapes keep their LDS kernels over packed octets (operands shared by the four waves of a workgroup)
+    if (brick16_ok(D, H, W, Cin, Do, Ho, Wo, stride, pad, Cout, cout_pad, k_pad, ntaps)) return 0;
+    if (unit && ntaps == 343 && Cin == 32 && Cout == 16) return 0;
+    if (ilog2_exact(Cin) < 0 || k_pad % 4 || k_pad < ntaps * Cin || cout_pad < Cout || ldy < Cout || ldx < Cin) return 0;
+    const int ach = cout_pad > 64 ? 8 : 4, bch = cout_pad > 64 ? 4 : 8;
+    if (Cout % ach || ldy % ach || Cin % bch || ldx % bch) return 0;
+    if (M < 1 || M >= (1ll << 31) || (long long)N * D * H * W * ldx >= (1ll << 31) || (long long)N * Do * Ho * Wo * ldy >= (1ll << 31)) return 0;
+    for (int t = 0; t < 3; ++t)
+        if (pad[t] < 0 || stride[t] < 1) return 0;
+    return 1;
+}
+
+extern "C" int lt_conv_wgrad_bf16_nhwc(const void* dy16, const void* x16, const int32_t* taps, float* dw, int32_t N, int32_t D, int32_t H, int32_t W, int32_t Cin,
+                                       int32_t ldx, int32_t Do, int32_t Ho, int32_t Wo, const int32_t stride[3], const int32_t pad[3], int32_t Cout, int32_t ldy,
+                                       int32_t cout_pad, int32_t k_pad, int32_t ntaps, int32_t accumulate, void* workspace, void* stream) {
+    LT_REQUIRE(dy16 && x16 && taps && dw && stride && pad, LT_ERR_INVALID, "lt_conv_wgrad_bf16_nhwc: null argument");
+    LT_REQUIRE(lt_conv_wgrad_bf16_nhwc_ok(N, D, H, W, Cin, ldx, Do, Ho, Wo, stride, pad, Cout, ldy, cout_pad, k_pad, ntaps), LT_ERR_UNSUPPORTED,
+               "lt_conv_wgrad_bf16_nhwc: shape not covered (ask lt_conv_wgrad_bf16_nhwc_ok; pack with lt_pack_n8_from_bf16 and call lt_conv_wgrad_bf16)");
+    LT_REQUIRE((size_t)dy16 % 16 == 0 && (size_t)x16 % 16 == 0, LT_ERR_INVALID, "lt_conv_wgrad_bf16_nhwc: 16-byte aligned tensors");
+    hipStream_t st = (hipStream_t)stream;
+    const int G = (int)cdiv(N, 8);
+    const long long M = (long long)G * Do * Ho * Wo, n = (long long)cout_pad * k_pad;
+    const Plan16 p = plan16u(M, cout_pad, k_pad);
+    LT_REQUIRE(p.S == 1 || workspace, LT_ERR_INVALID, "lt_conv_wgrad_bf16_nhwc: this shape needs a workspace of lt_conv_wgrad_bf16_workspace() bytes");
+    W16UArgs a;
+    a.dy = (const unsigned short*)dy16; a.x = (const unsigned short*)x16; a.taps = (const int4*)taps; a.out = p.S > 1 ? (float*)workspace : dw;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.log2Cin = ilog2_exact(Cin); a.ldx = ldx; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+    a.sd = stride[0]; a.sh = stride[1]; a.sw = stride[2]; a.pd = pad[0]; a.ph = pad[1]; a.pw = pad[2];
+    a.Cout = Cout; a.ldy = ldy; a.k_pad = k_pad; a.ntaps = ntaps; a.M = (int)M; a.accumulate = accumulate; a.cout_pad = cout_pad;
+    a.n_k_t = p.n_k_t; a.n_tiles = p.n_co_t * p.n_k_t; a.rows_per_slab = p.rows_per_slab;
+    a.img_a = (unsigned)((long long)Do * Ho * Wo * ldy); a.img_b = (unsigned)((long long)D * H * W * ldx);
+    const dim3 grid((unsigned)cdiv(a.n_tiles, 4), (unsigned)p.S);
+    if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad16u_kernel<8, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad16u_kernel<4, 8>), grid, dim3(256), 0, st, a);
+    LT_CHECK_LAUNCH("lt_conv_wgrad_bf16_nhwc");
+    if (p.S > 1) {
+        reduce16(workspace, dw, n, p.S, accumulate, st);
+        LT_CHECK_LAUNCH("lt_conv_wgrad_bf16_nhwc(reduce)");
     }
     return LT_OK;
 }

@@ -122,6 +122,8 @@ SIGNATURES = {
     "lt_pack_n8_from_bf16": (C.c_int, [vp, vp, i32, i64, i32, i32, vp]),
     "lt_conv_wgrad_bf16_workspace": (C.c_size_t, [i64, i32, i32]),
     "lt_conv_wgrad_bf16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "lt_conv_wgrad_bf16_nhwc_ok": (C.c_int, [i32, i32, i32, i32, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32, i32, i32, i32, i32]),
+    "lt_conv_wgrad_bf16_nhwc": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32, i32, i32, i32, i32, i32, vp, vp]),
     "lt_conv_wgrad": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32 * 3, i32 * 3, i32, i32, i32, i32, i32, i32, vp, vp]),
     "lt_adam_step": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "lt_unproject_bwd_workspace": (C.c_size_t, [i32, i32, i32, i32, i32, i32]),

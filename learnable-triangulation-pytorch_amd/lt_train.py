@@ -555,7 +555,7 @@ class TrainTape:
                 imap = ar[:cin_t].reshape(cin_t, *ks3, Cout).permute(0, 4, 1, 2, 3)
             imap = (imap[:, :, 0] if nd == 2 else imap).contiguous().reshape(-1).to(self.device)
             dw = torch.empty(cop, kp, dtype=torch.float32, device=self.device)
-            use16 = self.wgrad16
+            use16, direct = self.wgrad16, False
             n_img = geo[0]
             pa_px, pb_px = geo[5] * geo[6] * geo[7], geo[1] * geo[2] * geo[3]          # pixels per image of the dY-role / X-role tensor
             if use16:
@@ -576,6 +576,10 @@ class TrainTape:
                     d16 = dy16 if (bn is not None and dy16 is not None and Cout % 8 == 0) else None
                 a16, b16 = (d16, x16) if not transposed else (x16, d16)
                 self.keep += [t for t in (a16, b16) if t is not None]
+                # both operands there as channels-last bf16 tensors (always in the 16-bit step) and a shape of the kernel that transposes in registers:
+                # no octet packs (LT_WGRAD16_PACKED=1: the packed kernels everywhere)
+                direct = bool(a16 is not None and b16 is not None and lib.lt_conv_wgrad_bf16_nhwc_ok(
+                    geo[0], geo[1], geo[2], geo[3], geo[4], geo[4], geo[5], geo[6], geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps))
             else:
                 need = lib.lt_conv_wgrad_workspace(wrows, cop, kp)
             self.keep += [taps_all, a_ptr, b_ptr, imap, dw]
@@ -592,7 +596,7 @@ class TrainTape:
             elif self._ws2.numel() < need:
                 self._ws2.record_stream(self.side)          # a side-stream kernel of the recording step may still be using it: not to be handed out before that
                 self._ws2 = torch.empty(int(need), dtype=torch.uint8, device=self.device)
-            if use16:
+            if use16 and not direct:
                 pk = self._pk_main if ev is None else self._pk_side
                 for i in range(2):
                     if pk[i].numel() < pk_need[i]:
@@ -606,7 +610,10 @@ class TrainTape:
                     self.side.wait_event(ev)
                     st = self.side.cuda_stream
                 ws = (self._ws if ev is None else self._ws2).data_ptr()
-                if use16:
+                if use16 and direct:
+                    H.check(lib.lt_conv_wgrad_bf16_nhwc(a16.data_ptr(), b16.data_ptr(), taps_all.data_ptr(), dw.data_ptr(), geo[0], geo[1], geo[2], geo[3], geo[4], geo[4],
+                                                        geo[5], geo[6], geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, ws, st), "lt_conv_wgrad_bf16_nhwc")
+                elif use16:
                     pk = self._pk_main if ev is None else self._pk_side
                     for src, src16, dst, px, ch in ((a_ptr, a16, pk[0], pa_px, geo[9]), (b_ptr, b16, pk[1], pb_px, geo[4])):
                         if src16 is not None:

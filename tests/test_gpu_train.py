@@ -374,6 +374,9 @@ W16_CASES = [  # N, (D, H, W), Cin, Cout, k (taps per dim), stride, pad
     (4, (4, 2, 8), 16, 32, (3, 3, 3), 1, 1),         # ... 16 input channels: two taps per column block
     (8, (6, 6, 6), 32, 32, (3, 3, 3), 1, 1),         # 3^3 whose volume is no whole number of bricks: generic kernel
     (8, (3, 4, 8), 32, 16, (7, 7, 7), 1, 3),         # the 7^3 front layer: one kd plane per workgroup on the 16x16x32 MFMA
+    (13, (1, 5, 3), 128, 256, (1, 1, 1), 1, 0),      # two 128-channel tiles of the unpacked kernel, rows of 3 pixels (a step of 4 wraps), ragged octet group
+    (8, (1, 2, 1), 64, 128, (1, 3, 3), 1, 1),        # ... a 2 x 1 image: every step wraps in all dimensions, most taps in the padding
+    (24, (1, 12, 12), 256, 64, (1, 1, 1), 1, 0),     # ... the 64 x 128 wave tile (layer1's reduce convolutions), three octet groups
 ]
 
 
@@ -434,6 +437,25 @@ def test_conv_wgrad_bf16_vs_fp32_kernel_on_rounded_operands(case):
     tag = "train/wgrad_bf16 N%d %s %d->%d k%s s%d" % (N, "x".join(map(str, (D, Hh, W))), Cin, Cout, "".join(map(str, ks)), s)
     check(tag + " vs fp32 kernel on rounded operands", ours[:Cout].cpu(), ref_r[:Cout].cpu(), 2e-5)
     check(tag + " vs fp32 kernel", ours[:Cout].cpu(), ref[:Cout].cpu(), 2e-2)
+    # the same GEMM straight from the channels-last bf16 tensors (lt_conv_wgrad_bf16_nhwc: the transpose in registers instead of the packs)
+    covered = lib.lt_conv_wgrad_bf16_nhwc_ok(N, D, Hh, W, Cin, Cin, Do, Ho, Wo, H.i3(st3), H.i3(pd), Cout, Cout, cop, kp, ntaps)
+    assert covered == (0 if (Cout % 4 or (ks == (3, 3, 3) and (D, Hh, W) != (6, 6, 6)) or ks == (7, 7, 7)) else 1)
+    if covered:
+        x16, dy16 = x.bfloat16().contiguous(), dy.bfloat16().contiguous()
+        ws = torch.empty(max(int(lib.lt_conv_wgrad_bf16_workspace((N + 7) // 8 * Do * Ho * Wo, cop, kp)), 16), dtype=torch.uint8, device=DEV)
+
+        def direct():
+            dw = torch.full((cop, kp), float("nan"), device=DEV)
+            H.check(lib.lt_conv_wgrad_bf16_nhwc(dy16.data_ptr(), x16.data_ptr(), taps.data_ptr(), dw.data_ptr(), N, D, Hh, W, Cin, Cin, Do, Ho, Wo, H.i3(st3), H.i3(pd),
+                                                Cout, Cout, cop, kp, ntaps, 0, ws.data_ptr(), _st()), "lt_conv_wgrad_bf16_nhwc")
+            return dw
+
+        d1 = direct()
+        d2 = direct()
+        torch.cuda.synchronize()
+        assert torch.equal(d1[:Cout], d2[:Cout]), "not bitwise repeatable"
+        assert not torch.isnan(d1).any()
+        check(tag + " unpacked vs fp32 kernel on rounded operands", d1[:Cout].cpu(), ref_r[:Cout].cpu(), 2e-5)
 
 
 @pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[2], CONV_CASES[4], CONV_CASES[5], CONV_CASES[14]],
