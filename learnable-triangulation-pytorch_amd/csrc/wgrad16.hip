@@ -296,7 +296,7 @@ template <> struct RawCh<4> {
     __device__ __forceinline__ void load(const unsigned short* p) { const uint2 v = *(const uint2*)p; d[0] = v.x; d[1] = v.y; }
 };
 
-template <int ACH, int BCH>
+template <int ACH, int BCH, int NS>
 __global__ __launch_bounds__(256) void conv_wgrad16u_kernel(const W16UArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;          // XCD-contiguous (slab, tile group) ranges, slab-major
@@ -389,10 +389,22 @@ __global__ __launch_bounds__(256) void conv_wgrad16u_kernel(const W16UArgs a) {
     RawCh<BCH> rb0[8], rb1[8];
     unsigned ok0, ok1;
     const int nit = (m_end - m_begin + 3) >> 2;
-    load(ra0, rb0, ok0);
-    for (int it = 0; it < nit; it += 2) {          // (rows past m_end load nothing new: a zero dY operand)
-        load(ra1, rb1, ok1); mma(ra0, rb0, ok0);
-        load(ra0, rb0, ok0); mma(ra1, rb1, ok1);
+    if constexpr (NS == 3) {          // two steps in flight ahead of the one in the MFMAs (one wave per SIMD: nothing else hides the L2 latency)
+        RawCh<ACH> ra2[8];
+        RawCh<BCH> rb2[8];
+        unsigned ok2;
+        load(ra0, rb0, ok0); load(ra1, rb1, ok1);
+        for (int it = 0; it < nit; it += 3) {          // (rows past m_end load nothing new: a zero dY operand)
+            load(ra2, rb2, ok2); mma(ra0, rb0, ok0);
+            load(ra0, rb0, ok0); mma(ra1, rb1, ok1);
+            load(ra1, rb1, ok1); mma(ra2, rb2, ok2);
+        }
+    } else {
+        load(ra0, rb0, ok0);
+        for (int it = 0; it < nit; it += 2) {
+            load(ra1, rb1, ok1); mma(ra0, rb0, ok0);
+            load(ra0, rb0, ok0); mma(ra1, rb1, ok1);
+        }
     }
     float* out = a.out + (size_t)slab * a.cout_pad * a.k_pad;
     const bool direct_acc = a.accumulate && gridDim.y == 1;
@@ -550,6 +562,151 @@ __global__ __launch_bounds__(256) void conv3d_wgrad16_brick_kernel(const Brick16
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
                 V16 bv; bv.u = xs[hb + toff[i]];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.h, bv.h, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    float* out = a.out + (size_t)blockIdx.z * a.cout_pad * a.k_pad;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        if (kcol[i] < 0) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = co0 + 8 * (e >> 2) + 4 * half + (e & 3);
+            out[(size_t)row * a.k_pad + kcol[i]] = acc[i][e];
+        }
+    }
+}
+
+// The same brick kernel fed from the channels-last bf16 tensors (Cin a multiple of 32): a staging UNIT is (voxel, eight channels) -- eight 16-byte loads,
+// one per image of the octet group, transposed with v_perm_b32 into the eight octets of those channels on their way into LDS.  A thread's unit is a
+// 128-byte chunk of the LDS image, so the eight octets are written ROTATED inside the chunk (slot = (channel + 4 (voxel & 1) + chunk) & 7: eight
+// consecutive lanes = two voxels x four chunks hit eight different slots; unrotated the ds_write_b128 of a lane group would be an 8-way bank conflict);
+// the readers undo it with one XOR per MFMA (X: the voxel's parity flips bit 2 of the slot) or not at all (dY: the parity is the lane half).
+struct Brick16UArgs {
+    const unsigned short* dy;   // [N][D*H*W][ldy] bf16
+    const unsigned short* x;    // [N][D][H][W][Cin] bf16
+    const int4* taps;
+    float* out;
+    int N, D, H, W, Cin, ldy, cout_pad, k_pad;
+    int nbd, nbh, nbw, nbricks, bricks_per_slab;
+};
+
+__global__ __launch_bounds__(256) void conv3d_wgrad16_brick_u_kernel(const Brick16UArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    constexpr int CIB = 32;
+    constexpr int XU = B16_HVOX * 4, NXU = (XU + 255) / 256;          // 640 units of X: two per thread and a third for the first 128
+    uint4* xs = (uint4*)smem16;                           // [B16_HVOX][CIB], rotated inside every 8-octet chunk
+    uint4* ds = xs + B16_HVOX * CIB;                      // [B16_VOX][32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * CIB;
+    int toff[7], kcol[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int b = wave + 4 * i;
+        const int c = 32 * b + col;                       // column of the (tap, ci) space of this workgroup
+        const int tap = c >> 5, cil = c & 31;
+        if (tap < 27) {
+            const int4 tp = a.taps[tap];
+            const int tv = (tp.x * B16_HH + tp.y) * B16_HW + tp.z;
+            toff[i] = tv * CIB + (cil & ~7) + ((((cil & 7) + (cil >> 3)) & 7) ^ (4 * (tv & 1)));
+            kcol[i] = tap * a.Cin + ci0 + cil;
+        } else {
+            toff[i] = 0; kcol[i] = -1;
+        }
+    }
+    const int acol = (col & ~7) + (((col & 7) + (col >> 3) + 4 * half) & 7);          // dY: voxel parity = lane half
+    // staging units of this thread: X unit k = (halo voxel, chunk) (tid + 256 k) / 4, % 4; dY unit (tid < 128) = (voxel tid / 4, chunk tid % 4)
+    int xco[NXU];
+#pragma unroll
+    for (int k = 0; k < NXU; ++k) {
+        const int v = (threadIdx.x + 256 * k) >> 2;
+        const int hw_ = v % B16_HW, t2 = v / B16_HW;
+        xco[k] = (t2 / B16_HH) | ((t2 % B16_HH) << 8) | (hw_ << 16);
+    }
+    const int c8 = threadIdx.x & 3;
+    const bool x2 = threadIdx.x < XU - 512, yu = threadIdx.x < 128;
+    f32x16 acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const int b_begin = blockIdx.z * a.bricks_per_slab, b_end = min(a.nbricks, b_begin + a.bricks_per_slab);
+    const unsigned img_x = (unsigned)(a.D * a.H * a.W) * (unsigned)a.Cin, img_y = (unsigned)(a.D * a.H * a.W) * (unsigned)a.ldy;
+    uint4 rx[NXU][8], ry[8];
+    unsigned okm = 0;          // bits 0-2: the X units' voxels are inside the volume; bits 8-15: image e of the group exists
+    auto issue = [&](int b) {
+        int r = b;
+        const int bw = r % a.nbw; r /= a.nbw;
+        const int bh = r % a.nbh; r /= a.nbh;
+        const int bd = r % a.nbd;
+        const int g = r / a.nbd;
+        const int d0 = bd * B16_D, h0 = bh * B16_H, w0 = bw * B16_W;
+        const int nv = min(8, a.N - 8 * g);
+        const unsigned short* xg = a.x + (size_t)(8 * g) * img_x + ci0 + 8 * c8;
+        unsigned m = ((1u << nv) - 1u) << 8;
+#pragma unroll
+        for (int k = 0; k < NXU; ++k) {
+            if (k == 2 && !x2) break;
+            const int d = d0 + (xco[k] & 255) - 1, h = h0 + ((xco[k] >> 8) & 255) - 1, w = w0 + (xco[k] >> 16) - 1;
+            const bool ok = (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            const unsigned off = ok ? (unsigned)(((d * a.H + h) * a.W + w) * a.Cin) : 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rx[k][e] = *(const uint4*)(xg + off + (e < nv ? (unsigned)e * img_x : 0u));          // (validity applied on the way to LDS)
+            m |= ok ? 1u << k : 0u;
+        }
+        okm = m;
+        if (yu) {
+            const int v = threadIdx.x >> 2;
+            const int w = v % B16_W, t2 = v / B16_W;
+            const int h = t2 % B16_H, d = t2 / B16_H;
+            const unsigned row = (unsigned)(((d0 + d) * a.H + h0 + h) * a.W + w0 + w);
+            const unsigned short* yg = a.dy + (size_t)(8 * g) * img_y + (size_t)row * a.ldy + co0 + 8 * c8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ry[e] = *(const uint4*)(yg + (e < nv ? (unsigned)e * img_y : 0u));
+        }
+    };
+    // the eight octets of a unit (channel c of the eight images: dword d = images 2d, 2d + 1) into the chunk at dst, rotated by rot
+    auto put = [&](uint4* dst, const uint4 (&raw)[8], unsigned imgs, bool ok, int rot) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            unsigned w[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint4 &r0 = raw[2 * d], &r1 = raw[2 * d + 1];
+                const unsigned lo_ = (c >> 1) == 0 ? r0.x : (c >> 1) == 1 ? r0.y : (c >> 1) == 2 ? r0.z : r0.w;
+                const unsigned hi_ = (c >> 1) == 0 ? r1.x : (c >> 1) == 1 ? r1.y : (c >> 1) == 2 ? r1.z : r1.w;
+                const unsigned lo = ok && ((imgs >> (2 * d)) & 1u) ? lo_ : 0u, hi = ok && ((imgs >> (2 * d + 1)) & 1u) ? hi_ : 0u;
+                w[d] = __builtin_amdgcn_perm(hi, lo, (c & 1) ? 0x07060302u : 0x05040100u);
+            }
+            dst[(c + rot) & 7] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    };
+    if (b_begin < b_end) issue(b_begin);
+    for (int b = b_begin; b < b_end; ++b) {
+        __syncthreads();          // the previous brick's reads are done
+        const unsigned imgs = okm >> 8;
+#pragma unroll
+        for (int k = 0; k < NXU; ++k) {
+            if (k == 2 && !x2) break;
+            const int u = threadIdx.x + 256 * k;          // = 4 voxel + chunk: rot = 4 (voxel & 1) + chunk = u & 7
+            put(xs + 8 * u, rx[k], imgs, (okm >> k) & 1u, u & 7);
+        }
+        if (yu) put(ds + 8 * threadIdx.x, ry, imgs, true, threadIdx.x & 7);
+        __syncthreads();
+        if (b + 1 < b_end) issue(b + 1);                  // in flight during the MFMAs below
+#pragma unroll 2
+        for (int p = 0; p < B16_VOX / 2; ++p) {
+            const int v = 2 * p + half;                       // brick-linear voxel (w fastest): a pair never straddles a row
+            const int w = v % B16_W, t2 = v / B16_W;
+            const int h = t2 % B16_H, d = t2 / B16_H;
+            V16 av; av.u = ds[v * 32 + acol];
+            const int hv = (d * B16_HH + h) * B16_HW + w;          // halo voxel of tap (0, 0, 0)
+            const int hb = hv * CIB, x4 = 4 * (hv & 1);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                V16 bv; bv.u = xs[hb + (toff[i] ^ x4)];
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av.h, bv.h, acc[i], 0, 0, 0);
             }
         }
@@ -782,8 +939,10 @@ extern "C" int lt_conv_wgrad_bf16_nhwc_ok(int32_t N, int32_t D, int32_t H, int32
     const int G = (int)cdiv(N, 8);
     const long long M = (long long)G * Do * Ho * Wo;
     const bool unit = stride[0] == 1 && stride[1] == 1 && stride[2] == 1 && D == Do && H == Ho && W == Wo;
-    // the V2V shapes keep their LDS kernels over packed octets (operands shared by the four waves of a workgroup)
-    if (brick16_ok(D, H, W, Cin, Do, Ho, Wo, stride, pad, Cout, cout_pad, k_pad, ntaps)) return 0;
+    // the V2V 3^3 layers: the LDS-brick kernel, staged from the channels-last tensors when a workgroup's 32 input channels are whole 8-channel chunks
+    if (brick16_ok(D, H, W, Cin, Do, Ho, Wo, stride, pad, Cout, cout_pad, k_pad, ntaps))
+        return Cin % 32 == 0 && ldx == Cin && ldy % 8 == 0 && !getenv("LT_WGRAD16_BRICK_PACKED") && (long long)N * D * H * W * Cin < (1ll << 31) &&
+               (long long)N * D * H * W * ldy < (1ll << 31);
     if (unit && ntaps == 343 && Cin == 32 && Cout == 16) return 0;
     if (ilog2_exact(Cin) < 0 || k_pad % 4 || k_pad < ntaps * Cin || cout_pad < Cout || ldy < Cout || ldx < Cin) return 0;
     const int ach = cout_pad > 64 ? 8 : 4, bch = cout_pad > 64 ? 4 : 8;
@@ -804,6 +963,28 @@ extern "C" int lt_conv_wgrad_bf16_nhwc(const void* dy16, const void* x16, const 
     hipStream_t st = (hipStream_t)stream;
     const int G = (int)cdiv(N, 8);
     const long long M = (long long)G * Do * Ho * Wo, n = (long long)cout_pad * k_pad;
+    if (brick16_ok(D, H, W, Cin, Do, Ho, Wo, stride, pad, Cout, cout_pad, k_pad, ntaps)) {
+        LT_REQUIRE(workspace, LT_ERR_INVALID, "lt_conv_wgrad_bf16_nhwc: this shape needs a workspace of lt_conv_wgrad_bf16_workspace() bytes");
+        const size_t ws_bytes = lt_conv_wgrad_bf16_workspace(M, cout_pad, k_pad);
+        Brick16UArgs b;
+        b.dy = (const unsigned short*)dy16; b.x = (const unsigned short*)x16; b.taps = (const int4*)taps; b.out = (float*)workspace;
+        b.N = N; b.D = D; b.H = H; b.W = W; b.Cin = Cin; b.ldy = ldy; b.cout_pad = cout_pad; b.k_pad = k_pad;
+        b.nbd = D / B16_D; b.nbh = H / B16_H; b.nbw = W / B16_W; b.nbricks = G * b.nbd * b.nbh * b.nbw;
+        const long long blocks = (long long)(Cout / 32) * (Cin / 32);
+        long long S = cdiv(256, blocks);                  // one workgroup per CU (96 KB of LDS each): exactly one round
+        const long long cap = (long long)(ws_bytes / ((size_t)n * 4));
+        S = S > cap ? cap : S;
+        S = S > b.nbricks ? b.nbricks : S;
+        S = S < 1 ? 1 : S;
+        b.bricks_per_slab = (int)cdiv(b.nbricks, S);
+        S = cdiv(b.nbricks, b.bricks_per_slab);
+        const size_t lds = (size_t)(B16_HVOX * 32 + B16_VOX * 32) * 16;
+        hipLaunchKernelGGL(conv3d_wgrad16_brick_u_kernel, dim3(Cout / 32, Cin / 32, (unsigned)S), dim3(256), lds, st, b);
+        LT_CHECK_LAUNCH("lt_conv_wgrad_bf16_nhwc(brick)");
+        reduce16(workspace, dw, n, (int)S, accumulate, st);
+        LT_CHECK_LAUNCH("lt_conv_wgrad_bf16_nhwc(reduce)");
+        return LT_OK;
+    }
     const Plan16 p = plan16u(M, cout_pad, k_pad);
     LT_REQUIRE(p.S == 1 || workspace, LT_ERR_INVALID, "lt_conv_wgrad_bf16_nhwc: this shape needs a workspace of lt_conv_wgrad_bf16_workspace() bytes");
     W16UArgs a;
@@ -814,8 +995,14 @@ extern "C" int lt_conv_wgrad_bf16_nhwc(const void* dy16, const void* x16, const 
     a.n_k_t = p.n_k_t; a.n_tiles = p.n_co_t * p.n_k_t; a.rows_per_slab = p.rows_per_slab;
     a.img_a = (unsigned)((long long)Do * Ho * Wo * ldy); a.img_b = (unsigned)((long long)D * H * W * ldx);
     const dim3 grid((unsigned)cdiv(a.n_tiles, 4), (unsigned)p.S);
-    if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad16u_kernel<8, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad16u_kernel<4, 8>), grid, dim3(256), 0, st, a);
+    static const int ns = [] { const char* e = getenv("LT_WGRAD16U_NS"); return e ? atoi(e) : 3; }();
+    if (ns == 2) {
+        if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad16u_kernel<8, 4, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgrad16u_kernel<4, 8, 2>), grid, dim3(256), 0, st, a);
+    } else {
+        if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad16u_kernel<8, 4, 3>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgrad16u_kernel<4, 8, 3>), grid, dim3(256), 0, st, a);
+    }
     LT_CHECK_LAUNCH("lt_conv_wgrad_bf16_nhwc");
     if (p.S > 1) {
         reduce16(workspace, dw, n, p.S, accumulate, st);

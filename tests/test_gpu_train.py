@@ -439,7 +439,8 @@ def test_conv_wgrad_bf16_vs_fp32_kernel_on_rounded_operands(case):
     check(tag + " vs fp32 kernel", ours[:Cout].cpu(), ref[:Cout].cpu(), 2e-2)
     # the same GEMM straight from the channels-last bf16 tensors (lt_conv_wgrad_bf16_nhwc: the transpose in registers instead of the packs)
     covered = lib.lt_conv_wgrad_bf16_nhwc_ok(N, D, Hh, W, Cin, Cin, Do, Ho, Wo, H.i3(st3), H.i3(pd), Cout, Cout, cop, kp, ntaps)
-    assert covered == (0 if (Cout % 4 or (ks == (3, 3, 3) and (D, Hh, W) != (6, 6, 6)) or ks == (7, 7, 7)) else 1)
+    # (not covered: 17 joints, the 7^3 layer, and the LDS-brick shapes with 16 input channels -- those keep the packed kernels)
+    assert covered == (0 if (Cout % 4 or (ks == (3, 3, 3) and Cin % 32 and (D, Hh, W) != (6, 6, 6)) or ks == (7, 7, 7)) else 1)
     if covered:
         x16, dy16 = x.bfloat16().contiguous(), dy.bfloat16().contiguous()
         ws = torch.empty(max(int(lib.lt_conv_wgrad_bf16_workspace((N + 7) // 8 * Do * Ho * Wo, cop, kp)), 16), dtype=torch.uint8, device=DEV)
