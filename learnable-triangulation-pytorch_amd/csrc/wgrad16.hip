@@ -296,14 +296,16 @@ template <> struct RawCh<4> {
     __device__ __forceinline__ void load(const unsigned short* p) { const uint2 v = *(const uint2*)p; d[0] = v.x; d[1] = v.y; }
 };
 
+// The four waves of a workgroup share ONE tile and split the slab's rows four ways (their sums meet in LDS, added in wave order: deterministic): a
+// quarter of the slabs for the same number of waves, i.e. a quarter of the partial sums written and read back -- which at 8 samples per step cost as
+// much as the GEMM (layer3, 1024 x 256 outputs over 2304 octet rows: 32 slabs x 1 MB before, 8 now).
 template <int ACH, int BCH, int NS>
 __global__ __launch_bounds__(256) void conv_wgrad16u_kernel(const W16UArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;          // XCD-contiguous (slab, tile group) ranges, slab-major
+    const int total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;          // XCD-contiguous (slab, tile) ranges, slab-major
     const int lin2 = (total & 7) ? lin : (lin & 7) * (total >> 3) + (lin >> 3);
-    const int slab = lin2 / (int)gridDim.x, tgroup = lin2 - slab * (int)gridDim.x;
-    const int t = tgroup * 4 + wave;
-    if (t >= a.n_tiles) return;
+    const int slab = lin2 / (int)gridDim.x, t = lin2 - slab * (int)gridDim.x;
     const int co0 = (t / a.n_k_t) * (16 * ACH), k0 = (t % a.n_k_t) * (16 * BCH);
     const int i = lane & 15, q = lane >> 4;
     const int co = co0 + ACH * i;
@@ -324,8 +326,9 @@ __global__ __launch_bounds__(256) void conv_wgrad16u_kernel(const W16UArgs a) {
         for (int j = 0; j < BCH; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[c][j][e] = 0.f;
-    const int m_begin = slab * a.rows_per_slab;
-    const int m_end = min(a.M, m_begin + a.rows_per_slab);
+    const int rq = a.rows_per_slab >> 2;          // (a multiple of 4: whole steps)
+    const int m_begin = slab * a.rows_per_slab + wave * rq;
+    const int m_end = min(a.M, m_begin + rq);
     int m = m_begin + q;
     const int hw = a.Ho * a.Wo, dhw = a.Do * hw;
     int g = m / dhw, r = m - g * dhw;
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(256) void conv_wgrad16u_kernel(const W16UArgs a) {
     RawCh<ACH> ra0[8], ra1[8];
     RawCh<BCH> rb0[8], rb1[8];
     unsigned ok0, ok1;
-    const int nit = (m_end - m_begin + 3) >> 2;
+    const int nit = max(0, (m_end - m_begin + 3) >> 2);
     if constexpr (NS == 3) {          // two steps in flight ahead of the one in the MFMAs (one wave per SIMD: nothing else hides the L2 latency)
         RawCh<ACH> ra2[8];
         RawCh<BCH> rb2[8];
@@ -406,6 +409,26 @@ __global__ __launch_bounds__(256) void conv_wgrad16u_kernel(const W16UArgs a) {
             load(ra0, rb0, ok0); mma(ra1, rb1, ok1);
         }
     }
+    // waves 1-3 hand their sums to wave 0 through LDS ([wave - 1][register][lane]: conflict-free both ways)
+    float* red = (float*)smem16;
+    if (wave > 0) {
+#pragma unroll
+        for (int c = 0; c < ACH; ++c)
+#pragma unroll
+            for (int j = 0; j < BCH; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[(((wave - 1) * (ACH * BCH * 4)) + (c * BCH + j) * 4 + e) * 64 + lane] = acc[c][j][e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll 1
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int c = 0; c < ACH; ++c)
+#pragma unroll
+            for (int j = 0; j < BCH; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c][j][e] += red[((w * (ACH * BCH * 4)) + (c * BCH + j) * 4 + e) * 64 + lane];
     float* out = a.out + (size_t)slab * a.cout_pad * a.k_pad;
     const bool direct_acc = a.accumulate && gridDim.y == 1;
     // C of the 16x16 MFMA: row = 4 (lane / 16) + e <-> the A lane of that index, column = lane % 16 <-> the B lane: four (BCH = 4) or eight consecutive
@@ -434,20 +457,20 @@ Plan16 plan16u(long long M, int cout_pad, int k_pad) {
     p.variant = cout_pad > 64 ? 0 : 1;
     const int tco = p.variant == 0 ? 128 : 64, tk = p.variant == 0 ? 64 : 128;
     p.n_co_t = (int)cdiv(cout_pad, tco); p.n_k_t = (int)cdiv(k_pad, tk);
-    const long long wgs = cdiv((long long)p.n_co_t * p.n_k_t, 4);
+    const long long wgs = (long long)p.n_co_t * p.n_k_t;          // one tile per workgroup, its four waves split the slab's rows
     const double n_bytes = (double)cout_pad * k_pad * 4.0;
     const long long cap = (long long)(((size_t)48 << 20) / (size_t)n_bytes);
     long long best = 1;
     double best_t = 1e30;
     for (long long S = 1; S <= 512; S = S < 8 ? S + 1 : S + 8) {          // the packed kernel's two-term model: a step is four octet rows and 32 MFMAs of 16 cycles
-        if (S > 1 && (S > cap || S > M / 16)) break;
+        if (S > 1 && (S > cap || S > M / 64)) break;
         const double rounds = (double)cdiv(wgs * S, 256);
-        const double kernel_us = rounds * (double)cdiv(M, 4 * S) * 0.4;
+        const double kernel_us = rounds * ((double)cdiv(M, 16 * S) * 0.8 + 2.0);          // (measured: ~0.8 us per step -- the operands come from L2 at ~9 TB/s)
         const double reduce_us = S > 1 ? 3.0 + S * n_bytes / 3.0e6 : 0.0;
         if (kernel_us + reduce_us < best_t) { best_t = kernel_us + reduce_us; best = S; }
     }
     long long rps = cdiv(M, best);
-    rps = (rps + 3) & ~3ll;
+    rps = (rps + 15) & ~15ll;
     p.rows_per_slab = (int)rps;
     p.S = (int)best;
     return p;
@@ -994,15 +1017,10 @@ extern "C" int lt_conv_wgrad_bf16_nhwc(const void* dy16, const void* x16, const 
     a.Cout = Cout; a.ldy = ldy; a.k_pad = k_pad; a.ntaps = ntaps; a.M = (int)M; a.accumulate = accumulate; a.cout_pad = cout_pad;
     a.n_k_t = p.n_k_t; a.n_tiles = p.n_co_t * p.n_k_t; a.rows_per_slab = p.rows_per_slab;
     a.img_a = (unsigned)((long long)Do * Ho * Wo * ldy); a.img_b = (unsigned)((long long)D * H * W * ldx);
-    const dim3 grid((unsigned)cdiv(a.n_tiles, 4), (unsigned)p.S);
-    static const int ns = [] { const char* e = getenv("LT_WGRAD16U_NS"); return e ? atoi(e) : 3; }();
-    if (ns == 2) {
-        if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad16u_kernel<8, 4, 2>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv_wgrad16u_kernel<4, 8, 2>), grid, dim3(256), 0, st, a);
-    } else {
-        if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad16u_kernel<8, 4, 3>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv_wgrad16u_kernel<4, 8, 3>), grid, dim3(256), 0, st, a);
-    }
+    const dim3 grid((unsigned)a.n_tiles, (unsigned)p.S);
+    const size_t lds = (size_t)3 * 128 * 64 * sizeof(float);          // the three other waves' 128 accumulator registers
+    if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad16u_kernel<8, 4, 3>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((conv_wgrad16u_kernel<4, 8, 3>), grid, dim3(256), lds, st, a);
     LT_CHECK_LAUNCH("lt_conv_wgrad_bf16_nhwc");
     if (p.S > 1) {
         reduce16(workspace, dw, n, p.S, accumulate, st);

@@ -509,11 +509,16 @@ class TrainTape:
                 self.do(lambda st: H.check(lib.lt_convert_pad(H.LT_F32, dy32.data_ptr(), H.LT_BF16, dy.data_ptr(), rows, Cout, Cout, st), "lt_convert_pad"), "cast")
             else:
                 self.do(lambda st: H.check(lib.lt_act_bwd(dz.data_ptr(), z.t.data_ptr(), H.ptr(rp), dy.data_ptr(), H.ptr(dres), acc_res, total, flags | self.aflag, st), "lt_act_bwd"))
+        bias_sum = None
         if bias is not None and bias.requires_grad:
             db = self._grad_view(bias)
-            self._ws_need(lib.lt_channel_sum_workspace(rows, Cout))
+            cs_need = lib.lt_channel_sum_workspace(rows, Cout)
             ac = self.acode
-            self.do(lambda st: H.check(lib.lt_channel_sum_dt(ac, dy.data_ptr(), rows, Cout, db.data_ptr(), 0, self._ws.data_ptr(), st), "lt_channel_sum"))
+            bias_sum = lambda st, ws: H.check(lib.lt_channel_sum_dt(ac, dy.data_ptr(), rows, Cout, db.data_ptr(), 0, ws, st), "lt_channel_sum")
+            if not (weight.requires_grad and self.overlap):          # (with a side stream: in front of the layer's weight gradient over there -- only Adam reads it)
+                self._ws_need(cs_need)
+                self.do(lambda st: bias_sum(st, self._ws.data_ptr()))
+                bias_sum = None
         nd = weight.dim() - 2
         st3 = ((1,) + (stride,) * 2) if nd == 2 else (stride,) * 3
         pd3 = ((0,) + (pad,) * 2) if nd == 2 else (pad,) * 3
@@ -591,6 +596,8 @@ class TrainTape:
             self._n_wgrad += 1
             on_main = self.wgrad_main_every > 0 and self._n_wgrad % self.wgrad_main_every == 0
             ev = torch.cuda.Event() if (self.overlap and not on_main) else None
+            if bias_sum is not None:
+                need = max(need, cs_need)
             if ev is None:          # on the main stream: the main stream's workspace (the side stream's may be in use by a concurrent weight gradient)
                 self._ws_need(need)
             elif self._ws2.numel() < need:
@@ -610,6 +617,8 @@ class TrainTape:
                     self.side.wait_event(ev)
                     st = self.side.cuda_stream
                 ws = (self._ws if ev is None else self._ws2).data_ptr()
+                if bias_sum is not None:
+                    bias_sum(st, ws)
                 if use16 and direct:
                     H.check(lib.lt_conv_wgrad_bf16_nhwc(a16.data_ptr(), b16.data_ptr(), taps_all.data_ptr(), dw.data_ptr(), geo[0], geo[1], geo[2], geo[3], geo[4], geo[4],
                                                         geo[5], geo[6], geo[7], H.i3(st3), H.i3(pd3), geo[8], geo[9], cop, kp, ntaps, 0, ws, st), "lt_conv_wgrad_bf16_nhwc")
