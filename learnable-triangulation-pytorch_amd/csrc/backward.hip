@@ -178,10 +178,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, long long ro
     }
 }
 
-template <bool BF16>
+template <bool BF16, int NROWS>
 struct BnStatLoad {
     typedef typename std::conditional<BF16, uint2, float4>::type Raw;
-    static constexpr int ROWS = 8;
+    static constexpr int ROWS = NROWS;
     const void* x; int C;
     __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ Raw fetch(long long row, int c) const { return *(const Raw*)((const char*)x + ((size_t)row * C + c) * (BF16 ? 2 : 4)); }
@@ -194,9 +194,9 @@ struct BnStatLoad {
     }
 };
 
-template <bool BF16>
+template <bool BF16, int NROWS>
 __global__ __launch_bounds__(256) void bn_partial_vec_kernel(const void* __restrict__ x, long long rows, int C, int nslab, int cw4, int rl, double* __restrict__ part) {
-    colsum_partial<2>(rows, C, nslab, cw4, rl, part, BnStatLoad<BF16>{x, C});
+    colsum_partial<2>(rows, C, nslab, cw4, rl, part, BnStatLoad<BF16, NROWS>{x, C});
 }
 
 struct BnStatFin {
@@ -275,8 +275,10 @@ extern "C" int lt_bn_stats_fwd(int32_t dtype, const void* x, int64_t rows, int32
     hipStream_t st = (hipStream_t)stream;
     if (colsum_fast(C)) {       // the training path: four-channel lanes, four rows in flight, parallel finalize (colsum.h); fp32 or bf16 input
         const ColsumPlan p = colsum_plan(rows, C);
-        if (dtype == LT_BF16) hipLaunchKernelGGL(bn_partial_vec_kernel<true>, dim3(p.nslab, p.ncb), dim3(256), 0, st, x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
-        else hipLaunchKernelGGL(bn_partial_vec_kernel<false>, dim3(p.nslab, p.ncb), dim3(256), 0, st, x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
+        static const int nrows = [] { const char* e = getenv("LT_BNSTAT_ROWS"); return e ? atoi(e) : 8; }();
+        if (dtype == LT_BF16 && nrows == 4) hipLaunchKernelGGL((bn_partial_vec_kernel<true, 4>), dim3(p.nslab, p.ncb), dim3(256), 0, st, x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
+        else if (dtype == LT_BF16) hipLaunchKernelGGL((bn_partial_vec_kernel<true, 8>), dim3(p.nslab, p.ncb), dim3(256), 0, st, x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
+        else hipLaunchKernelGGL((bn_partial_vec_kernel<false, 8>), dim3(p.nslab, p.ncb), dim3(256), 0, st, x, (long long)rows, C, p.nslab, p.cw4, p.rl, (double*)workspace);
         LT_CHECK_LAUNCH("lt_bn_stats_fwd(partial)");
         hipLaunchKernelGGL(bn_finalize_vec_kernel, dim3((unsigned)cdiv(C, COLSUM_FIN_C)), dim3(256), 0, st, (const double*)workspace, C, p.nslab,
                            BnStatFin{(long long)rows, mean, var, running_mean, running_var, momentum});

@@ -1019,6 +1019,7 @@ extern "C" int lt_bn_act_bwd(const void* dz, const void* y, const void* residual
         static const int nrows = [] { const char* e = getenv("LT_BNBWD_ROWS"); return e ? atoi(e) : 4; }();
         if (a.a16 && a.y16) {
             if (nrows == 8) hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<true, 8>), dim3(p.nslab, p.ncb), dim3(256), 0, st, a, p.cw4, p.rl);
+            else if (nrows == 2) hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<true, 2>), dim3(p.nslab, p.ncb), dim3(256), 0, st, a, p.cw4, p.rl);
             else hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<true, 4>), dim3(p.nslab, p.ncb), dim3(256), 0, st, a, p.cw4, p.rl);
         } else
             hipLaunchKernelGGL((bn_bwd_reduce_vec_kernel<false, 4>), dim3(p.nslab, p.ncb), dim3(256), 0, st, a, p.cw4, p.rl);

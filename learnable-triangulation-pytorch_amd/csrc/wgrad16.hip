@@ -1019,8 +1019,17 @@ extern "C" int lt_conv_wgrad_bf16_nhwc(const void* dy16, const void* x16, const 
     a.img_a = (unsigned)((long long)Do * Ho * Wo * ldy); a.img_b = (unsigned)((long long)D * H * W * ldx);
     const dim3 grid((unsigned)a.n_tiles, (unsigned)p.S);
     const size_t lds = (size_t)3 * 128 * 64 * sizeof(float);          // the three other waves' 128 accumulator registers
-    if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad16u_kernel<8, 4, 3>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((conv_wgrad16u_kernel<4, 8, 3>), grid, dim3(256), lds, st, a);
+    // Register sets in flight: three are 3 % faster on one stream (17.5 vs 18.1 ms of weight gradients per step) and slower in the step: the kernel runs
+    // BESIDE the main stream's BatchNorm passes, one wave per SIMD -- at 448 allocated registers a 96-register wave of the BatchNorm-backward reduction
+    // does not fit next to it (it ran 10.1 instead of 4.2 ms per step), at 400 it does: 140.1 -> 144.2 samples/s, same session.  LT_WGRAD16U_NS=3: the deep one.
+    static const int ns = [] { const char* e = getenv("LT_WGRAD16U_NS"); return e ? atoi(e) : 2; }();
+    if (ns == 2) {
+        if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad16u_kernel<8, 4, 2>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((conv_wgrad16u_kernel<4, 8, 2>), grid, dim3(256), lds, st, a);
+    } else {
+        if (p.variant == 0) hipLaunchKernelGGL((conv_wgrad16u_kernel<8, 4, 3>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((conv_wgrad16u_kernel<4, 8, 3>), grid, dim3(256), lds, st, a);
+    }
     LT_CHECK_LAUNCH("lt_conv_wgrad_bf16_nhwc");
     if (p.S > 1) {
         reduce16(workspace, dw, n, p.S, accumulate, st);
