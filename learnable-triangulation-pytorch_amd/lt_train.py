@@ -517,7 +517,7 @@ class TrainTape:
             bias_sum = lambda st, ws: H.check(lib.lt_channel_sum_dt(ac, dy.data_ptr(), rows, Cout, db.data_ptr(), 0, ws, st), "lt_channel_sum")
             if not (weight.requires_grad and self.overlap):          # (with a side stream: in front of the layer's weight gradient over there -- only Adam reads it)
                 self._ws_need(cs_need)
-                self.do(lambda st: bias_sum(st, self._ws.data_ptr()))
+                self.do(lambda st, fn=bias_sum: fn(st, self._ws.data_ptr()))          # (fn bound now: the name is cleared below and the closure is replayed later)
                 bias_sum = None
         nd = weight.dim() - 2
         st3 = ((1,) + (stride,) * 2) if nd == 2 else (stride,) * 3
