@@ -249,3 +249,101 @@ def test_octet_pack_and_workspace_sizes_through_the_c_abi():
     for rows, cop, kp in ((2304, 256, 2304), (2304, 1024, 256), (262144, 32, 864), (262144, 16, 10976), (8, 128, 3456), (147456, 64, 392)):
         ws = lib.lt_conv_wgrad_bf16_workspace(rows, cop, kp)
         assert cop * kp * 4 <= ws <= (64 << 20), (rows, cop, kp, ws)
+
+
+def _mfma_16x16x32(A, B):
+    """v_mfma_f32_16x16x32_bf16 as the kernels use it: A[lane] / B[lane] = the lane's 8 K values (lane % 16 = row m of A / column n of B, lane // 16 = K
+    group); returns D[lane][r] = D[m = 4 (lane // 16) + r][n = lane % 16] = sum over K groups q and k of A[16 q + m][k] B[16 q + n][k]."""
+    A4, B4 = A.reshape(4, 16, 8), B.reshape(4, 16, 8)          # [q][m or n][k]
+    D = np.einsum("qmk,qnk->mn", A4, B4)
+    out = np.zeros((64, 4))
+    for lane in range(64):
+        for r in range(4):
+            out[lane, r] = D[4 * (lane // 16) + r, lane % 16]
+    return out
+
+
+@pytest.mark.parametrize("shape", [(11, 5, 3, 8, 24, 1, 0), (9, 4, 6, 8, 40, 3, 1), (3, 6, 5, 16, 136, 3, 1)], ids=["1x1_ragged", "3x3_pad", "3x3_two_co_tiles"])
+def test_weight_gradient_with_the_transpose_in_registers(shape):
+    """The formulation behind lt_conv_wgrad_bf16_nhwc (csrc/wgrad16.hip, conv_wgrad16u_kernel<8, 4>), lane by lane: a lane of the 16x16x32 MFMA
+    (i = lane % 16, q = lane // 16) reads 8 consecutive output channels of dY and 4 consecutive (tap, ci) columns of X for the EIGHT IMAGES of its
+    pixel m + q; the 8 x 8 (8 x 4) transpose gives it operand a = channel 8 i + a of the eight images.  So accumulator (a, b), register r of lane l is
+    dW[co0 + 8 (4 (l // 16) + r) + a][k0 + 4 (l % 16) + b]: a row permutation of the tile that only the epilogue knows.  K of one MFMA = 4 pixels x 8
+    images; images past N and padded taps are zero operands.  Against torch.autograd, 2D, stride 1."""
+    N, Hh, W, Cin, Cout, k, p = shape
+    g = torch.Generator().manual_seed(N + Cout + k)
+    x = torch.randn(N, Cin, Hh, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, k, k, generator=g, dtype=torch.float64).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=1, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    (y * dy).sum().backward()
+    Ho, Wo = y.shape[2:]
+    xc, dyc = x.permute(0, 2, 3, 1).numpy(), dy.permute(0, 2, 3, 1).numpy()          # channels-last, as the step holds them
+    ACH, BCH = 8, 4
+    G, ntaps = (N + 7) // 8, k * k
+    kp = ntaps * Cin
+    cop = (Cout + 127) // 128 * 128
+    dw = np.zeros((cop, kp))
+    M = G * Ho * Wo          # octet rows
+    for co0 in range(0, cop, 16 * ACH):
+        for k0 in range(0, kp, 16 * BCH):
+            acc = np.zeros((ACH, BCH, 64, 4))
+            for m0 in range(0, M, 4):          # one step = one MFMA per (a, b): 4 octet rows x 8 images
+                A, B = np.zeros((ACH, 64, 8)), np.zeros((BCH, 64, 8))
+                for lane in range(64):
+                    i, q = lane % 16, lane // 16
+                    m = m0 + q
+                    if m >= M:
+                        continue
+                    gi, r = divmod(m, Ho * Wo)
+                    oh, ow = divmod(r, Wo)
+                    co, kc = co0 + ACH * i, k0 + BCH * i
+                    tap, ci = divmod(kc, Cin)
+                    ih, iw = oh - p + tap // k, ow - p + tap % k
+                    for e in range(8):
+                        n = 8 * gi + e
+                        if n >= N:
+                            continue          # zero operand: the image does not exist
+                        if co < Cout:
+                            A[:, lane, e] = dyc[n, oh, ow, co:co + ACH] if co + ACH <= Cout else 0.0
+                        if tap < ntaps and 0 <= ih < Hh and 0 <= iw < W:
+                            B[:, lane, e] = xc[n, ih, iw, ci:ci + BCH]
+                for a in range(ACH):
+                    for b in range(BCH):
+                        acc[a, b] += _mfma_16x16x32(A[a], B[b])
+            for a in range(ACH):
+                for b in range(BCH):
+                    for lane in range(64):
+                        for r in range(4):
+                            row, col = co0 + ACH * (4 * (lane // 16) + r) + a, k0 + BCH * (lane % 16) + b
+                            if row < cop and col < kp:
+                                dw[row, col] = acc[a, b, lane, r]
+    want = w.grad.permute(0, 2, 3, 1).reshape(Cout, kp).numpy()          # [co][tap * Cin + ci]
+    assert Cout % ACH == 0 and float(np.abs(dw[:Cout] - want).max()) <= 1e-10 * float(np.abs(want).max())
+    assert float(np.abs(dw[Cout:]).max()) == 0.0 if cop > Cout else True
+
+
+def test_unpacked_weight_gradient_coverage_through_the_c_abi(monkeypatch):
+    """lt_conv_wgrad_bf16_nhwc_ok (host-only): the 2D layers of the backbone and the V2V 3^3 bricks with whole 32-channel blocks are covered; the 7^3
+    layer, the 16-channel brick layer, 17 joints and misaligned rows are not (the tape packs octets for those); LT_WGRAD16_PACKED=1 turns it off."""
+    import ctypes as C
+    import lt_hip as H
+    lib = H.lib()
+    i3 = lambda *v: (C.c_int32 * 3)(*v)
+    ok = lambda N, D, Hh, W, Cin, ldx, Do, Ho, Wo, st, pd, Cout, ldy, cop, kp, nt: lib.lt_conv_wgrad_bf16_nhwc_ok(N, D, Hh, W, Cin, ldx, Do, Ho, Wo, i3(*st), i3(*pd), Cout, ldy, cop, kp, nt)
+    u, z = (1, 1, 1), (0, 0, 0)
+    assert ok(32, 1, 24, 24, 256, 256, 1, 24, 24, u, z, 1024, 1024, 1024, 256, 1) == 1                  # layer3 expand
+    assert ok(32, 1, 24, 24, 256, 256, 1, 24, 24, u, (0, 1, 1), 256, 256, 256, 2304, 9) == 1            # layer3 3x3
+    assert ok(32, 1, 96, 96, 256, 256, 1, 96, 96, u, z, 64, 64, 64, 256, 1) == 1                        # layer1 reduce: the 64 x 128 wave tile
+    assert ok(32, 1, 384, 384, 8, 8, 1, 192, 192, (1, 2, 2), (0, 3, 3), 64, 64, 64, 392, 49) == 1       # the stem on its 8-channel input
+    assert ok(8, 64, 64, 64, 32, 32, 64, 64, 64, u, (1, 1, 1), 32, 32, 32, 864, 27) == 1                # V2V 3^3 bricks, staged from the tensors
+    assert ok(8, 64, 64, 64, 16, 16, 64, 64, 64, u, (1, 1, 1), 32, 32, 32, 432, 27) == 0                # ... 16 input channels: packed
+    assert ok(8, 64, 64, 64, 32, 32, 64, 64, 64, u, (3, 3, 3), 16, 16, 16, 10976, 343) == 0             # the 7^3 front layer: packed
+    assert ok(8, 64, 64, 64, 32, 32, 64, 64, 64, u, z, 17, 17, 32, 32, 1) == 0                          # 17 joints
+    assert ok(8, 64, 64, 64, 32, 32, 64, 64, 64, u, z, 32, 32, 32, 32, 1) == 1                          # ... widened to 32 by the tape
+    assert ok(32, 1, 24, 24, 256, 256, 1, 24, 24, u, z, 1024, 1028, 1024, 256, 1) == 0                  # rows of dY not 16-byte aligned
+    assert ok(32, 1, 24, 24, 24, 24, 1, 24, 24, u, z, 128, 128, 128, 24, 1) == 0                        # Cin not a power of two
+    assert ok(64, 128, 128, 128, 32, 32, 128, 128, 128, u, z, 64, 64, 64, 32, 1) == 0                   # 2^31 elements: 32-bit offsets
+    monkeypatch.setenv("LT_WGRAD16_PACKED", "1")
+    assert ok(32, 1, 24, 24, 256, 256, 1, 24, 24, u, z, 1024, 1024, 1024, 256, 1) == 0
+
