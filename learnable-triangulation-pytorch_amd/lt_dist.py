@@ -148,6 +148,9 @@ class GradReducer:
         self.bytes_sent, self.t_issue, self.t_wait, self.steps_done = 0, 0.0, 0.0, 0
         self._ev_first = self._ev_last = None
         self._window_ms, self._window_n = 0.0, 0
+        # event pairs around the exchange + a synchronize() per step to read them: diagnostics for bench.py's N-GPU line, OFF in production training
+        # (they cap how far the host can run ahead).  LT_TRAIN_TIMING=1 (bench.py sets it) or ``reducer.timing = True`` turns them on.
+        self.timing = os.environ.get("LT_TRAIN_TIMING") == "1"
 
     # ---- DistributedDataParallel's construction-time / per-forward synchronisation -------------------------------------------------------
     def attach(self, model, src=0):
@@ -193,7 +196,7 @@ class GradReducer:
 
     def reduce_inplace(self, flat):
         """Starts the (asynchronous) mean of a contiguous gradient range over the ranks, in place; complete after ``wait_all``."""
-        if flat.is_cuda and not self.inplace:          # first bucket of this backward: the exchange window opens on the stream the collective is issued on
+        if self.timing and flat.is_cuda and not self.inplace:          # first bucket of this backward: the exchange window opens on the stream the collective is issued on
             self._collect_window()
             self._ev_first = torch.cuda.Event(enable_timing=True)
             self._ev_first.record(torch.cuda.current_stream(flat.device))
@@ -217,7 +220,7 @@ class GradReducer:
         self.t_wait += time.perf_counter() - t0
         if self.inplace:
             self.steps_done += 1
-            if cuda_dev is not None and self._ev_first is not None:          # ... and closes behind the last bucket (the waits are stream waits on a GPU)
+            if self.timing and cuda_dev is not None and self._ev_first is not None:          # ... and closes behind the last bucket (the waits are stream waits on a GPU)
                 self._ev_last = torch.cuda.Event(enable_timing=True)
                 self._ev_last.record(torch.cuda.current_stream(cuda_dev))
         self.inplace = []

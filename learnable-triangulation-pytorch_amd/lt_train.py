@@ -103,6 +103,9 @@ class TrainTape:
         self.param_grads = {}                                   # Parameter -> view of the arena
         self.reducer, self.bucket_elems = reducer, max(1, int(bucket_bytes) // 4)
         self.bwd_recorded = False
+        # three timing events per backward and a synchronize() on the previous step's last one (backward_timing(): bench.py's N-GPU diagnosis): OFF by default --
+        # they keep the host from running ahead of the GPU.  LT_TRAIN_TIMING=1 (bench.py sets it) or ``tape.timing = True``.
+        self.timing = os.environ.get("LT_TRAIN_TIMING") == "1"
         if self.fp8_3d:
             # 'fp8v2v' (BASELINE config 5: "fp8 MFMA for V2V 3D convs"): e4m3 operands with per-tensor amax scaling, everything on the device -- the
             # maxima live in one pool that the forward's first op zeroes (lt_amax_* takes the maximum INTO its slot), the scales next to them
@@ -570,6 +573,12 @@ class TrainTape:
                 if self.act16:          # the activations / gradients are the bf16 operands (dY through its zero-padded copy when Cout % 8)
                     if cin_buf % 8 or (transposed and Cout % 8):
                         raise NotImplementedError("train_precision 'act16': a weight gradient over %d input channels" % cin_buf)
+                    if transposed and dy_in is not dy:
+                        # dY was widened to ``cpad`` channels (Cout a multiple of 8 but no power of two): the transposed layer's kernels are told geo[4] = Cout as
+                        # channel count AND leading dimension of the X-role operand, which the widened copy does not have -- silently wrong gradients.
+                        # No layer of V2V / pose_resnet has this shape; refuse it instead of guessing.
+                        raise NotImplementedError("train_precision 'act16': the weight gradient of a transposed convolution with %d output channels "
+                                                  "(not a power of two: dY is read through a zero-padded copy with another leading dimension)" % Cout)
                     x16, d16 = x.t, dy_in
                     if not transposed and dy_in is not dy:
                         geo = geo[:8] + (cpad, cpad)          # Cout, ldy of the widened dY (cout_pad_of(Cout) == cpad rows of dw, the extra ones zero)
@@ -705,10 +714,12 @@ class TrainTape:
         over the ranks when a reducer is attached)."""
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
         main = torch.cuda.current_stream(self.device)
-        self._collect_bwd_times()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]          # start, main stream's kernels issued, side stream joined
-        self._bwd_events = ev if self.bwd_recorded else None          # (the recording backward -- index maps, allocations, host work -- is not a sample)
-        ev[0].record(main)
+        timing = self.timing
+        if timing:
+            self._collect_bwd_times()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]          # start, main stream's kernels issued, side stream joined
+            self._bwd_events = ev if self.bwd_recorded else None          # (the recording backward -- index maps, allocations, host work -- is not a sample)
+            ev[0].record(main)
         if not self.bwd_recorded:
             self._cur = self.bwd_ops
             for rec in reversed(self.recorders):
@@ -718,7 +729,8 @@ class TrainTape:
         else:
             self._gather_all("bwd", self.bwd_jobs)
             self.replay(self.bwd_ops)
-        ev[1].record(main)
+        if timing:
+            ev[1].record(main)
         if self.side is not None:
             if self.reducer is not None:
                 with torch.cuda.stream(self.side):
@@ -726,7 +738,8 @@ class TrainTape:
             torch.cuda.current_stream(self.device).wait_stream(self.side)          # the gradients are complete for whoever reads them next
         elif self.reducer is not None:
             self.reducer.wait_all()
-        ev[2].record(main)
+        if timing:
+            ev[2].record(main)
         return self.param_grads
 
     def _collect_bwd_times(self):

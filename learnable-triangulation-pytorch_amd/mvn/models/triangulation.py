@@ -16,6 +16,8 @@ import ctypes as C
 
 from collections import OrderedDict
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -39,7 +41,12 @@ def _sync_buffers_before_eval(model):
     """DistributedDataParallel(broadcast_buffers=True) hands rank 0's buffers to every rank at EVERY forward, evaluation included (the reference
     validates through the wrapped model, train.py:450-460).  The training forward does it through its reducer; here the first evaluation forward
     after a training step does (the BatchNorm statistics of the ranks differ by their last momentum update until then; buffers do not change in
-    eval(), so once is enough).  A collective: like under DDP, every rank has to run the evaluation forward."""
+    eval(), so once is enough).  A COLLECTIVE: like under DDP, every rank has to run that evaluation forward -- a rank-0-only forward (master-only
+    visualisation, checkpoint evaluation) on a model with an attached reducer would wait for the other ranks forever.  For that use set
+    ``model.sync_buffers_on_eval = False`` (or LT_NO_EVAL_BUFFER_SYNC=1): the forward then runs on this rank's own statistics and no collective is issued
+    (ADVICE r4)."""
+    if not getattr(model, "sync_buffers_on_eval", True) or os.environ.get("LT_NO_EVAL_BUFFER_SYNC") == "1":
+        return
     red = getattr(model, "grad_reducer", None)
     if red is not None and red.attached and model.__dict__.get("_buffers_stale"):
         red.sync_buffers()
@@ -218,9 +225,9 @@ class _VolTrainFn(torch.autograd.Function):
                 idx, val = sparse[0]
             elif len(sparse) > 1:
                 raise NotImplementedError("more than one sparse (VolumetricCELoss) gradient on the returned volumes of one forward")
-            if g_probs is not None and g_probs.stride() != (0,) * g_probs.dim():
-                # any other loss on the volumes: a dense (B, J, V, V, V) gradient, added to the soft-argmax backward's a_i (round 4; the all-zero-stride
-                # tensor autograd hands over next to VolumetricCELoss's sparse gradient is that loss's placeholder, not a gradient)
+            if g_probs is not None and not op.is_sparse_placeholder(ctx, g_probs):
+                # any other loss on the volumes: a dense (B, J, V, V, V) gradient, added to the soft-argmax backward's a_i (round 4; VolumetricCELoss's
+                # placeholder next to its sparse gradient is recognised by its storage -- a uniform gradient, volumes.sum(), is a real one)
                 g_dense = g_probs.float().contiguous()
             pg = plan.backward(g_kp, idx, val, g_dense)
         grads = tuple(pg.get(p) if p.requires_grad else None for p in ctx.params)

@@ -148,7 +148,7 @@ class _SoftArgmax3dFn(torch.autograd.Function):
             for i2, v2 in sparse:
                 dense.scatter_add_(2, i2.long()[..., None], v2[..., None])
             dense = dense.reshape(probs.shape)
-        if g_probs is not None and g_probs.stride() != (0,) * g_probs.dim():   # a real dense gradient on the returned volumes
+        if g_probs is not None and not is_sparse_placeholder(ctx, g_probs):   # a real dense gradient on the returned volumes (a uniform one -- volumes.sum() -- included)
             dense = g_probs.float() if dense is None else dense + g_probs.float()
         ws = None
         if dense is not None:     # a_i += gp_i inside the kernel (softmax: minus <p, gp>, reduced per joint into the workspace first)
@@ -158,6 +158,15 @@ class _SoftArgmax3dFn(torch.autograd.Function):
         H.check(H.lib().lt_softargmax3d_bwd_dense(probs.data_ptr(), cv.data_ptr(), kp.data_ptr(), g_kp.data_ptr(), H.ptr(idx), H.ptr(val), H.ptr(dense), H.ptr(ws), 1.0,
                                                   int(ctx.softmax), 0, gl.data_ptr(), B, J, nvox, H.cur_stream()), "lt_softargmax3d_bwd")
         return gl.to(ctx.in_dtype), None, None
+
+
+def is_sparse_placeholder(node, g):
+    """True when ``g`` is the all-zero stride-0 tensor ``sparse_prob_grad`` returned for a gradient it left on ``node`` in sparse form.  Recognised by the
+    STORAGE of the placeholder: any other zero-stride tensor -- the expanded ones of ``volumes.sum()``, a uniform ``volumes.mean()`` -- is a real dense
+    gradient (with ``volume_softmax=False`` a uniform gradient on the ReLU volumes is not zero after the backward)."""
+    if g.stride() != (0,) * g.dim():
+        return False
+    return any(z.data_ptr() == g.data_ptr() for z in getattr(node, "_lt_placeholders", []))
 
 
 def sparse_prob_grad(volumes, idx, val):
@@ -170,7 +179,11 @@ def sparse_prob_grad(volumes, idx, val):
         if not hasattr(node, "_lt_sparse_prob_grads"):
             node._lt_sparse_prob_grads = []
         node._lt_sparse_prob_grads.append((idx, val))
-        return torch.zeros((), dtype=volumes.dtype, device=volumes.device).expand(volumes.shape)
+        zero = torch.zeros((), dtype=volumes.dtype, device=volumes.device)
+        if not hasattr(node, "_lt_placeholders"):
+            node._lt_placeholders = []
+        node._lt_placeholders.append(zero)          # kept alive on the node: the placeholder is recognised by its storage, not by its strides
+        return zero.expand(volumes.shape)
     B, J = volumes.shape[:2]
     dense = torch.zeros(B, J, volumes[0, 0].numel(), dtype=torch.float32, device=volumes.device)
     dense.scatter_(2, idx.long()[..., None], val[..., None])

@@ -58,3 +58,32 @@ def test_bench_pmc_leg_and_sub_leg_fail_soft(monkeypatch, tmp_path):
     assert "error" in bad and bad["argv"] == ["--no-such-flag"]
     ok = bench.sub_leg(["--gpus", "1", "--steps", "2", "--warmup", "0", "--batch", "3", "--stub-cpu"], 120)
     assert ok.get("metric") == "stub" and ok["total_samples"] == 6 and ok["leg_wall_s"] > 0
+
+
+def test_compact_line_fits_the_drivers_tail_and_keeps_every_headline_figure():
+    """VERDICT r4 "next" 3: the driver stores an 8 KB tail of stdout and round 4's line was 14 KB.  bench.compact_line() of a FULL record (round 4's own line,
+    profiles/r04_bench_bf16.json, plus the legs added this round) must stay under 5 KB and still carry: headline, roofline, roofline_hbm, cpu_baseline,
+    parity (max abs mm, MPJPE, meets_gate), fp32_parity_mode (value, frac, meets_gate), batch_sweep["32"], one-number summaries of every leg."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_bf16.json")))
+    full["train_trajectory"] = {"steps": 20, "config": {"per_gpu_batch": 4}, "curves": {k: [53.0 - 0.5 * i for i in range(20)] for k in ("fp32", "act16", "fp8v2v")},
+                                "final": {"fp32": 43.5, "act16": 43.6, "fp8v2v": 43.9}, "final_rel_to_fp32": {"fp32": 0.0, "act16": 0.0023, "fp8v2v": 0.0092},
+                                "max_rel_gap_to_fp32_over_the_run": {"fp32": 0.0, "act16": 0.004, "fp8v2v": 0.011}}
+    full["train_mixed"]["kernel_share"] = {"conv fwd+dgrad": 0.31, "batchnorm+sums": 0.27, "wgrad": 0.25, "params+casts": 0.05, "unproject": 0.04, "other": 0.08}
+    full["roofline_hbm"]["unproject"]["valu_issue_frac"] = 0.71
+    full["roofline_hbm"]["unproject"]["lane_insts_per_voxel"] = 1650.0
+    c = bench.compact_line(full)
+    line = json.dumps(c)
+    assert len(line) < 5 * 1024, len(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert c[k] == full[k] or (isinstance(full[k], float) and abs(c[k] - full[k]) <= 1e-5 * abs(full[k])), k
+    assert abs(c["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-3 and c["roofline"]["traffic"] and c["roofline"]["bound"] == "mfma"
+    assert c["roofline_hbm"]["unproject"]["valu_issue_frac"] == 0.71 and c["roofline_hbm"]["softargmax3d"]["frac"] > 0
+    assert c["parity"]["meets_gate"] is False and c["parity"]["max_abs_mm"] > 1 and c["parity"]["mpjpe_mm"] > 1
+    assert c["fp32_parity_mode"]["parity"]["meets_gate"] is True and c["fp32_parity_mode"]["value"] > 100 and c["fp32_parity_mode"]["frac"] > 0.5
+    assert c["batch_sweep"]["32"] > 1000 and c["config4"]["parity_fp32"]["meets_gate"] is True and c["config4"]["unproject"]["frac"] > 0
+    assert c["train_mixed"]["traffic_gb"] > 100 and c["train_mixed"]["kernel_share"]["batchnorm+sums"] == 0.27 and c["train_fp8v2v"]["value"] > 0
+    assert c["train_trajectory"]["final"]["fp8v2v"] == 43.9 and c["cpu_baseline"]["cores"] == 32
+    # a failed leg stays visible as an error, not as a crash of the line
+    full["config4"] = {"error": "timed out after 600 s", "argv": []}
+    assert bench.compact_line(full)["config4"] == {"error": "timed out after 600 s"}

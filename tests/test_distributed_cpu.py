@@ -101,6 +101,23 @@ def test_bench_self_launches_n_ranks():
     assert c["allreduce_window_ms_per_step"] is None          # a GPU-stream measurement (events around the first / last bucket): absent on CPU
 
 
+def test_bench_eight_ranks_the_drivers_scaling_shape():
+    """VERDICT r4 "next" 7: the node the scaling bench runs on has 8 GPUs -- the same launcher / rendezvous / collectives with world = 8 (gloo, the stub
+    step): 8 ranks counted by the communicator, 8 distinct devices, whole-job aggregate over 8 shards, the gradient exchange of the stand-in training
+    step in the expected number of buckets per step, replicas identical afterwards, one per-rank rate each (rank r sleeps (1 + r) x 2 ms per step)."""
+    res = _run_bench(["--gpus", "8", "--steps", "4", "--warmup", "1", "--batch", "3", "--stub-cpu"], timeout=600)
+    assert res["n_gpus"] == 8 and res["self_launched"] is True and res["backend"] == "gloo"
+    c = res["rccl"]
+    assert c["nranks"] == 8 and c["world_size"] == 8 and len(set(c["devices"])) == 8 and c["world"] == 8
+    assert res["total_samples"] == 8 * 4 * 3 and len(res["per_rank_samples_per_s"]) == 8 and len(c["per_rank_samples_per_s"]) == 8
+    rates = res["per_rank_samples_per_s"]
+    assert rates[0] > rates[3] > rates[7]                                   # the sleeps: rank 7 is the slowest ...
+    assert res["value"] <= 8 * rates[7] * 1.05                              # ... and the job is judged on it (max over ranks of the time)
+    nparam = 64 * 256 + 256 + 256 + 256 + 256 * 64 + 64
+    assert c["replicas_identical_after_training"] is True and c["steps_with_exchange"] == 4
+    assert c["gradient_buckets_per_step"] == -(-nparam // 8192) and c["gradient_bytes_per_step"] == 4 * nparam
+
+
 def test_bench_under_torchrun_env_does_not_relaunch():
     """The driver's way: torch.distributed.run starts the ranks; bench.py must then NOT launch again."""
     import json

@@ -71,6 +71,40 @@ def test_softargmax3d_backward_and_losses_vs_reference_autograd(ops, grads):
     assert int((pv2.grad != 0).sum()) <= pv2.shape[0] * pv2.shape[1]
 
 
+def test_uniform_gradient_on_the_returned_volumes_is_a_real_gradient(ops):
+    """``volumes.sum()`` / ``.mean()`` hand the soft-argmax node an EXPANDED (all strides zero) gradient -- the same shape of tensor as the
+    placeholder VolumetricCELoss leaves next to its sparse gradient.  It must be treated as the dense gradient it is: with softmax=False (ReLU volumes,
+    op.py:90-91) d sum(relu(v)) / dv = [v > 0] is not zero.  Reference: torch autograd over the reference's expressions (op.py:84-96) on the CPU."""
+    from mvn.models import loss as L
+    from mvn.utils import op
+    cvs = torch.from_numpy(ops["int3d_cv"]).to(DEV)
+    x = torch.from_numpy(ops["int3d_in"])
+    for sm in (False, True):
+        v = x.clone().to(DEV).requires_grad_(True)
+        c, pv = op.integrate_tensor_3d_with_coordinates(v, cvs, softmax=sm)
+        (c.sum() * 0.01 + pv.sum() * 0.5).backward()
+        vr = x.clone().double().requires_grad_(True)
+        flat = vr.reshape(*vr.shape[:2], -1)
+        pr = (torch.softmax(flat, dim=2) if sm else torch.relu(flat)).reshape(vr.shape)
+        cr = torch.einsum("bnxyz,bxyzc->bnc", pr, cvs.cpu().double())
+        (cr.sum() * 0.01 + pr.sum() * 0.5).backward()
+        assert sm or float(vr.grad.abs().max()) > 0.4          # the ReLU case really has a uniform 0.5 where v > 0
+        check("bwd/softargmax3d softmax=%d uniform (zero-stride) gradient on the volumes" % sm, v.grad.cpu(), vr.grad, 1e-4)
+    # and next to VolumetricCELoss's sparse gradient the placeholder is still recognised (nothing is added twice, nothing dropped)
+    gt = torch.randn(x.shape[0], x.shape[1], 3) * 200
+    val = torch.ones(x.shape[0], x.shape[1], 1)
+    v = x.clone().to(DEV).requires_grad_(True)
+    c, pv = op.integrate_tensor_3d_with_coordinates(v, cvs, softmax=True)
+    L.VolumetricCELoss()(cvs, pv, gt.to(DEV), val.to(DEV)).backward()
+    g_sparse = v.grad.clone()
+    v2 = x.clone().to(DEV).requires_grad_(True)
+    c2, pv2 = op.integrate_tensor_3d_with_coordinates(v2, cvs, softmax=True)
+    pv3 = pv2.detach().clone().requires_grad_(True)          # the same loss through the dense-scatter fallback, fed back as a dense gradient
+    L.VolumetricCELoss()(cvs, pv3, gt.to(DEV), val.to(DEV)).backward()
+    (pv2 * pv3.grad).sum().backward()
+    check("bwd/softargmax3d CE sparse (placeholder) vs the same gradient handed over dense", g_sparse.cpu(), v2.grad.cpu(), 1e-5)
+
+
 def test_pipeline_shape_gradients_vs_reference_autograd(golden_dir, grads):
     """small_softmax whole-pipeline case (2 samples, 3 views, camera 0 inside the cube, rotated cuboids, 32 channels, 32^3 voxels):
     d loss / d features through lt_unproject_bwd for a random upstream gradient, and d (MAE + 0.01 CE) / d logits."""

@@ -842,6 +842,10 @@ def _two_rank_gradient_mean(backend, own_device, tag):
         assert info["nranks"] == 2 and info["backend"] == backend, info
         if own_device:
             assert len(set(info["devices"])) == 2, info          # two different GPUs took part in the all-reduce
+    # the census the assertions above checked, printed and kept (VERDICT r4 "next" 7): ranks counted by an all-reduce, backend, RCCL version, every rank's device
+    census = {"rank %d" % rank: {"communicator": info, "gradient_buckets_sent": nb} for rank, res, nb, info in got}
+    print(tag, "census:", census)
+    record(tag + " -- communicator census", census)
     return _check_two_rank_gradients(got, single, tag)
 
 
@@ -1123,11 +1127,17 @@ def test_dense_gradient_on_the_returned_volumes_in_training():
     assert worst < 1e-4, worst
 
 
-@pytest.mark.parametrize("precision", ["bf16", "act16"])
+# gates of the whole reduced-precision step against the REFERENCE's fp32 step (tests/golden/train_step.npz): joints (1 mm floor), median / p90 of the
+# parameter-gradient error (of each tensor's largest reference gradient) -- set at what each mode measures on this fixture plus ~25 % headroom
+MIXED_STEP_GATES = {"bf16": (5e-2, 0.08, 0.20), "act16": (8e-2, 0.10, 0.28), "fp8v2v": (8e-2, 0.12, 0.28)}          # measured (round 5): bf16 3.8e-2 / 6.3 % / 15.8 %, act16 5.5e-2 / 7.7 % / 21.4 %, fp8v2v 4.4e-2 / 9.2 % / 22.1 %
+
+
+@pytest.mark.parametrize("precision", ["bf16", "act16", "fp8v2v"])
 def test_mixed_precision_training_step_deviation_and_descent(golden_dir, precision):
-    """train_precision = "bf16": the convolutions and their input gradients on the bf16 MFMA, everything else fp32.  Outside the fp32
-    tolerance by construction (like the bf16 inference mode): the deviation of one whole step from the reference's step is RECORDED
-    (joints, loss, parameter gradients), loosely bounded, and ten Adam steps must lower the loss."""
+    """train_precision = "bf16": the convolutions and their input gradients on the bf16 MFMA, everything else fp32; "act16": bf16 storage of every
+    activation / activation gradient too; "fp8v2v" (BASELINE config 5 as named): act16 with V2V's 3x3x3 convolutions and their input gradients on
+    the fp8 MFMA.  Outside the fp32 tolerance by construction (like the bf16 inference mode): the deviation of one WHOLE step from the reference's
+    own fp32 step is recorded (joints, losses, parameter gradients) and GATED at MIXED_STEP_GATES, and ten Adam steps must lower the loss."""
     import lt_train
     from mvn.models import loss as L
     from mvn.models.triangulation import VolumetricTriangulationNet
@@ -1157,12 +1167,15 @@ def test_mixed_precision_training_step_deviation_and_descent(golden_dir, precisi
         sub = f[::max(1, f.numel() // 129)][:129]
         errs.append(float((sub - torch.from_numpy(G["g/" + n]).double()).abs().max()) / float(G["gn/" + n][1]))
     errs.sort()
-    record("train/mixed precision (%s) one step vs the reference's fp32 step -- gated: median <= 8 %%, p90 <= 20 %%" % ("bf16 MFMA convolutions" if precision == "bf16" else precision),
+    record("train/mixed precision (%s) one step vs the reference's fp32 step -- gated at MIXED_STEP_GATES (joints, median, p90): %s" % (
+        "bf16 MFMA convolutions" if precision == "bf16" else precision, MIXED_STEP_GATES[precision]),
            {"joints_max_rel": float(d.max()), "mae": float(mae.detach()), "mae_reference": float(G["mae"]), "ce": float(ce.detach()), "ce_reference": float(G["ce"]),
             "parameter_gradient_err_median": errs[len(errs) // 2], "parameter_gradient_err_p90": errs[int(len(errs) * 0.9)], "parameter_gradient_err_max": errs[-1]})
     # gated at the level the mode achieves on this fixture (VERDICT r3 "next" 8): median 6.3 %, p90 15.8 % of each tensor's largest reference gradient
-    g_med, g_p90 = (0.08, 0.20) if precision == "bf16" else (0.10, 0.28)          # act16 rounds every activation and activation gradient to bf16 as well: 7.7 % / 21.4 %
-    assert float(d.max()) < (5e-2 if precision == "bf16" else 8e-2) and errs[len(errs) // 2] <= g_med and errs[int(len(errs) * 0.9)] <= g_p90, (float(d.max()), errs[len(errs) // 2], errs[int(len(errs) * 0.9)])
+    # (act16 rounds every activation and activation gradient to bf16 as well: 7.7 % / 21.4 %; fp8v2v adds e4m3 operands in V2V)
+    g_kp, g_med, g_p90 = MIXED_STEP_GATES[precision]
+    assert abs(float(mae.detach()) - float(G["mae"])) <= 0.02 * abs(float(G["mae"])) and abs(float(ce.detach()) - float(G["ce"])) <= 0.02 * abs(float(G["ce"])), (float(mae.detach()), float(ce.detach()))
+    assert float(d.max()) < g_kp and errs[len(errs) // 2] <= g_med and errs[int(len(errs) * 0.9)] <= g_p90, (float(d.max()), errs[len(errs) // 2], errs[int(len(errs) * 0.9)])
     # descent
     opt = lt_train.Adam(list(m.parameters()), lr=1e-4)
     gt2 = torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float().to(DEV)
@@ -1364,19 +1377,24 @@ def test_mixed_precision_step_tracks_fp32_on_a_bottleneck_backbone(y16, monkeypa
     assert stats["backbone"]["median_cosine"] > 0.9, stats
 
 
-def test_act16_step_tracks_fp32_at_the_config2_shape():
-    """VERDICT r3 "next" 2's gate at the BASELINE config-2 SHAPE: ResNet-152, 4 views of 384 x 384, 64^3 volume, 2 samples, the fixtures' conditioned
-    weights (oracle.synth.make_state_dict: variance-preserving filters, small last-BatchNorm gammas, sharpened output layer): the first step of
-    train_precision "act16" against the fp32 step -- same weights, inputs, rotations.  Gated: loss within 1 %, backbone gradient cosine > 0.9."""
+@pytest.mark.parametrize("B", [2, 8])
+def test_act16_step_tracks_fp32_at_the_config2_shape(B):
+    """The first step of train_precision "act16" against the fp32 step at the BASELINE config-2 SHAPE: ResNet-152, 4 views of 384 x 384, 64^3 volume, the
+    fixtures' conditioned weights (oracle.synth.make_state_dict: variance-preserving filters, small last-BatchNorm gammas, sharpened output layer), same
+    weights, inputs, rotations -- at 2 samples per step (8 images per BatchNorm) and at 8 samples per step, the batch bench.py's ``train_mixed`` leg
+    times (VERDICT r4 "next" 1c).  What is ASSERTED (the numbers behind it are recorded in the parity report): loss within 1 % of the fp32 step's,
+    V2V's gradient cosine > 0.99, and the backbone's gradient cosine > (CONTROL - 0.35), where CONTROL is the cosine of the fp32 step with its input
+    images rounded to bf16 ONCE and nothing else changed (0.86 at B = 2: this network amplifies one 2^-9 perturbation that much through ~150
+    batch-statistics BatchNorm layers).  A fixed "backbone cosine > 0.9" is NOT met at this shape (act16: 0.57 at B = 2) and is not what this test claims."""
     from mvn.models import loss as L
     from mvn.models.triangulation import VolumetricTriangulationNet
     from test_gpu_models import _cameras
     cfg = synth.vol_config(152, 64, "softmax", 1.0, "mpii")
     sd = synth.make_state_dict(spec.vol_net_spec(152, 17, False), seed=5, sharpen=60.0)
-    inp = synth.make_inputs(2, 4, 384, seed=41, inside=False)
-    batch = {"cameras": _cameras(inp, 2), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+    inp = synth.make_inputs(B, 4, 384, seed=41, inside=False)
+    batch = {"cameras": _cameras(inp, B), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
     gt = (torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float() + 25.0).to(DEV)
-    val = torch.ones(2, 17, 1, device=DEV)
+    val = torch.ones(B, 17, 1, device=DEV)
     images = inp["images"].to(DEV)
 
     def run(prec, images=images):
@@ -1397,7 +1415,7 @@ def test_act16_step_tracks_fp32_at_the_config2_shape():
 
     k32, l32, g32 = run("fp32")
     k16, l16, g16 = run("act16")
-    kb, lb, gb = run("bf16")          # round 3's mode (bf16 MFMA over fp32 storage): what bf16 OPERANDS alone do to this network
+    kb, lb, gb = run("bf16") if B == 2 else (k16, l16, g16)          # round 3's mode (bf16 MFMA over fp32 storage): what bf16 OPERANDS alone do to this network (B = 2 only)
     # CONTROL: the fp32 step itself with ONE 2^-9 perturbation -- the input images rounded to bf16, everything else exact fp32
     kc, lc, gc = run("fp32", images.bfloat16().float())
     assert set(g16) == set(g32) and all(bool(torch.isfinite(v).all()) for v in g16.values())
@@ -1414,7 +1432,10 @@ def test_act16_step_tracks_fp32_at_the_config2_shape():
              "act16_vs_bf16": {"backbone": cosine(gb, g16, bb), "v2v": cosine(gb, g16, v2v)},
              "CONTROL fp32 with bf16-rounded input images vs fp32": {"backbone": cosine(g32, gc, bb), "backbone layer4 + deconvs": cosine(g32, gc, late),
                                                                      "v2v": cosine(g32, gc, v2v), "loss": lc}}
-    record("train/act16 vs fp32 at the config-2 shape (ResNet-152, 4 x 384^2, 64^3, 2 samples, conditioned weights), first step", stats)
+    if B != 2:
+        stats.pop("bf16_vs_fp32"); stats.pop("act16_vs_bf16"); stats.pop("loss_bf16")
+    stats["asserted"] = "loss within 1 %, v2v cosine > 0.99, backbone cosine > CONTROL backbone cosine - 0.35"
+    record("train/act16 vs fp32 at the config-2 shape (ResNet-152, 4 x 384^2, 64^3, %d samples, conditioned weights), first step" % B, stats)
     print(stats)
     # Gated: the loss (1 %), V2V's gradient direction (> 0.99), and the backbone's direction RELATIVE TO THE CONTROL: through ~150 batch-statistics BatchNorm
     # layers over 8 images this network amplifies ONE 2^-9 rounding of its input images -- everything else exact fp32 -- into a backbone gradient cosine of
@@ -1422,6 +1443,45 @@ def test_act16_step_tracks_fp32_at_the_config2_shape():
     # numbers are recorded in the parity report (DESIGN.md "Training step": the reference's own gradients move by 1e-3 median under a 1e-6 change of the images).
     ctl = stats["CONTROL fp32 with bf16-rounded input images vs fp32"]
     assert abs(l16 - l32) <= 0.01 * abs(l32) and stats["act16_vs_fp32"]["v2v"] > 0.99 and stats["act16_vs_fp32"]["backbone"] > ctl["backbone"] - 0.35, stats
+
+
+# band of the reduced-precision runs' FINAL loss around the fp32 run's after TRAJ_STEPS Adam updates on one fixed batch (relative to the fp32 final loss), and the
+# largest gap allowed anywhere along the run -- set from the measured curves (parity report "train/trajectory ...") with headroom
+TRAJ_STEPS, TRAJ_FINAL_BAND, TRAJ_RUN_BAND = 20, {"act16": 0.05, "fp8v2v": 0.08}, {"act16": 0.08, "fp8v2v": 0.12}
+
+
+def test_training_trajectory_same_batch_fp32_act16_fp8v2v():
+    """VERDICT r4 "next" 1b: does reduced precision change where training goes?  The SAME run three times at the BASELINE config-2 shape (ResNet-152, 4 views
+    of 384 x 384, 64^3 volume): identical conditioned weights, ONE fixed batch of 4 samples, identical cuboid rotations, the reference's loss (train.py:217-230) and
+    three-group Adam (train.py:430-437), 20 updates -- in fp32 (the reference's precision), act16 and fp8v2v (BASELINE config 5 as named).  Gated: every run
+    descends, and the reduced-precision runs end within TRAJ_FINAL_BAND of the fp32 run's final loss and stay within TRAJ_RUN_BAND of it at every step;
+    the three curves go to the parity report (bench.py prints the same comparison on its own weights as ``train_trajectory``)."""
+    import bench
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    from test_gpu_models import _cameras
+    B = 4
+    cfg = synth.vol_config(152, 64, "softmax", 1.0, "mpii")
+    sd = synth.make_state_dict(spec.vol_net_spec(152, 17, False), seed=5, sharpen=60.0)
+    inp = synth.make_inputs(B, 4, 384, seed=43, inside=False)
+    batch = {"cameras": _cameras(inp, B), "pred_keypoints_3d": inp["pred_keypoints_3d"]}
+    gt = (torch.as_tensor(np.asarray(inp["pred_keypoints_3d"]))[:, :, :3].float() + 25.0).to(DEV)
+
+    def make():
+        m = VolumetricTriangulationNet(cfg, device=DEV)
+        m.load_state_dict(sd, strict=True)
+        return m
+    curves = bench.trajectory(make, inp["images"].to(DEV), batch, gt, ["fp32", "act16", "fp8v2v"], TRAJ_STEPS, DEV)
+    ref = curves["fp32"]
+    stats = {"curves": {k: [round(v, 4) for v in c] for k, c in curves.items()},
+             "final_rel_to_fp32": {k: (c[-1] - ref[-1]) / abs(ref[-1]) for k, c in curves.items()},
+             "max_rel_gap_over_the_run": {k: max(abs(a - b) / abs(b) for a, b in zip(c, ref)) for k, c in curves.items()},
+             "asserted": "every run: finite, final < first; act16 / fp8v2v: |final - fp32 final| <= %s, gap at every step <= %s (of the fp32 loss)" % (TRAJ_FINAL_BAND, TRAJ_RUN_BAND)}
+    record("train/trajectory: %d Adam steps on one fixed batch of %d samples at the config-2 shape, fp32 vs act16 vs fp8v2v" % (TRAJ_STEPS, B), stats)
+    print(stats)
+    for k, c in curves.items():
+        assert all(np.isfinite(c)) and c[-1] < c[0], (k, c)
+    for k in ("act16", "fp8v2v"):
+        assert abs(stats["final_rel_to_fp32"][k]) <= TRAJ_FINAL_BAND[k] and stats["max_rel_gap_over_the_run"][k] <= TRAJ_RUN_BAND[k], (k, stats)
 
 
 @pytest.mark.parametrize("precision", ["bf16", "act16"])

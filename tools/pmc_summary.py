@@ -25,6 +25,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_SIMD = 256 * 4
+VALU_CYCLES_PER_WAVE_INST = 2          # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md)
 N_XCD = 8        # GRBM_GUI_ACTIVE of a dispatch is summed over the 8 XCDs (45.1 M 'cycles' for a 2.56 ms kernel = 8 x 2.2 GHz)
 
 
@@ -96,6 +97,17 @@ def summarise(out_dir, steps, batch=32, dtype="bf16", views=4, volume=64, suffix
             e["wave_wait_any_frac"] = sq["SQ_WAIT_ANY"].get(k, [0.0])[0] / wc
             e["wave_issue_stall_frac"] = sq["SQ_WAIT_INST_ANY"].get(k, [0.0])[0] / wc
             e["wave_active_frac"] = sq["SQ_ACTIVE_INST_ANY"].get(k, [0.0])[0] / wc
+    # optional fourth pass (pmc_valu/): SQ_INSTS_VALU counts wave-level VALU instructions over the whole chip; a wave64 instruction occupies its
+    # SIMD-32 for 2 cycles (MI355X_MICROARCH.md "Wave scheduling"), so valu_issue_frac = 2 x SQ_INSTS_VALU / (1024 SIMDs x kernel cycles) -- the roof a
+    # VALU-bound kernel (the unprojection gather) is priced against
+    vl = load(os.path.join(out_dir, "pmc_valu" + suffix, "*counter_collection.csv"), ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])
+    for k in vl["SQ_INSTS_VALU"]:
+        iv, n = vl["SQ_INSTS_VALU"][k]
+        gui = vl["GRBM_GUI_ACTIVE"].get(k, [0.0, 0])[0]
+        e = per.setdefault(k, {"family": family(k)})
+        e["valu_wave_insts_per_step"] = iv / steps
+        if gui > 0:
+            e["valu_issue_frac"] = VALU_CYCLES_PER_WAVE_INST * iv / (N_SIMD * gui / N_XCD)
     tot = lambda fam, key: sum(v.get(key, 0.0) for v in per.values() if v["family"] == fam)
     hbm = {}
     for fam in ("unproject", "softargmax3d", "coord_volumes"):
@@ -113,6 +125,11 @@ def summarise(out_dir, steps, batch=32, dtype="bf16", views=4, volume=64, suffix
            "conv_family_bytes_per_step": (tot("conv", "fetch_bytes_per_step_corrected") + tot("conv", "write_bytes_per_step")) if (fetch and write) else None,
            "conv_family_mfma_busy_frac": (conv_mf / (N_SIMD * conv_gui / N_XCD)) if conv_gui else None,
            "hbm_kernels_bytes_per_step": hbm if (fetch and write) else {},
+           "valu": {fam: {"wave_insts_per_step": sum(v.get("valu_wave_insts_per_step", 0.0) for v in per.values() if v["family"] == fam),
+                          "issue_frac": (VALU_CYCLES_PER_WAVE_INST * sum(vl["SQ_INSTS_VALU"][k][0] for k in vl["SQ_INSTS_VALU"] if family(k) == fam) /
+                                         (N_SIMD * sum(vl["GRBM_GUI_ACTIVE"][k][0] for k in vl["GRBM_GUI_ACTIVE"] if family(k) == fam) / N_XCD))
+                          if any(family(k) == fam for k in vl["GRBM_GUI_ACTIVE"]) else None}
+                    for fam in ("unproject", "softargmax3d", "conv") if any(family(k) == fam for k in vl["SQ_INSTS_VALU"])},
            "per_kernel": per}
     assert "" not in per, "a kernel name parsed to the empty string"
     return res
