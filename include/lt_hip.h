@@ -481,6 +481,32 @@ typedef struct {
 int lt_bottleneck_fwd(const lt_bneck_desc* desc, const void* x, void* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The 1x1 EXPAND of one identity Bottleneck block and the 1x1 REDUCE of the next one in one launch
+ * (mvn/models/pose_resnet.py:75-95, the seam between two consecutive blocks of a ResNet stage):
+ *   y  = relu(bn3(conv1x1_expand(t2)) + residual)          C channels, written once
+ *   t1 = relu(bn1'(conv1x1_reduce'(y)))                    P channels, the next block's first activation
+ * The reduce consumes y from LDS while the tile is there: the C-channel tensor is not read back from memory.
+ * y is rounded to bf16 exactly where the expand's own launch would store it (the reduce sees those values).
+ * t2 [M][P], residual / y [M][C], t1 [M][P]: channels-last bf16, M = N * H * W GEMM rows (any M: 128-row
+ * tiles, the last one masked);  (C, P) = (1024, 256): the identity blocks of ResNet layer3.
+ * weight[0]: lt_conv_pack_weights_t32 of the expand's lt_conv_fwd packing [C][P] (ntaps 1, cin P);
+ * weight[1]: the same of the reduce's [P][C] (ntaps 1, cin C);  scale / shift [i]: the folded BatchNorm of
+ * layer i (C / P floats), applied as acc * scale + shift (ResNet convolutions carry no bias).
+ * Outputs must not alias the inputs.
+ * -------------------------------------------------------------------------------------------*/
+typedef struct {
+    int32_t dtype;                       /* LT_BF16 */
+    int32_t C, P;                        /* block width, bottleneck width (C == 4 P) */
+    int64_t M;                           /* GEMM rows */
+    const void* weight[2];
+    const float* scale[2];
+    const float* shift[2];
+    const float* consts;                 /* optional (may be NULL): scale[0] | shift[0] | scale[1] | shift[1] back to back (2 C + 2 P floats,
+                                            16-byte aligned): the kernel then fetches the four tables with one LDS-DMA instead of four dependent loads */
+} lt_xr_desc;
+int lt_expand_reduce_fwd(const lt_xr_desc* desc, const void* t2, const void* residual, void* y, void* t1_next, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * hipGraph + event helpers (the forward is ~230 launches: replay it as one graph)
  * -------------------------------------------------------------------------------------------*/
 int lt_graph_begin(void* stream);

@@ -203,36 +203,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm7_kernel(const ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    // ---- residual vectors of the epilogue, fetched AHEAD: the first RPF passes' before the K loop (their round trip hides behind it), pass i + RPF's inside pass
-    // i.  Round 5: with one pass's two 16-byte loads per lane in flight the 256 -> 1024 expand layers of ResNet layer3 (K = 256: eight K steps, then nine
-    // epilogue passes that each waited for their own residual) moved 16 KB per CU at a time -- 4.2 MB on the chip, ~4.5 TB/s at HBM latency, which is what they
-    // measured (0.20 of the MFMA roof) at every batch size, Infinity-Cache resident or not: latency-bound, not bandwidth-bound.
-    constexpr int RPF = 3, RQ = RPF + 1;
-    const int colv = n0 + wave * 32 + (lane & 3) * 8;    // this lane's eight output channels
-    const bool has_res = a.res != nullptr;
-    auto out_off = [&](int i, int k) -> long long {
-        const int m = m0 + i * 32 + k * 16 + (lane >> 2);
-        if (m >= a.M || colv >= a.Cout) return -1;
-        long long pix = m;
-        if (!PW) {
-            int n, od, oh, ow;
-            decode_row(a, m, n, od, oh, ow);
-            pix = ((long long)(n * a.OD + od * a.osd + ph.ood) * a.OH + oh * a.osh + ph.ooh) * a.OW + ow * a.osw + ph.oow;
-        }
-        return pix * a.ldc + colv;
-    };
-    long long offq[RQ][2];
-    uint4 rvq[RQ][2];
-    auto res_fetch = [&](int i, int slot) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            offq[slot][k] = out_off(i, k);
-            rvq[slot][k] = (has_res && offq[slot][k] >= 0) ? *(const uint4*)((const T*)a.res + offq[slot][k]) : make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < RPF; ++i) res_fetch(i, i);
-
     V16 fb[2][2];                                         // [register set = ks & 1][kk]
     gload16<0>(fb[0][0], wfrag, wlane);
     gload16<1024>(fb[0][1], wfrag, wlane);
@@ -289,17 +259,32 @@ __global__ __launch_bounds__(512, 2) void conv_igemm7_kernel(const ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring becomes the epilogue staging area
 
     // ---- epilogue: nine passes of one 32 x 32 block through this wave's private fp32 LDS tile -> 16-byte vectors ----
+    const int colv = n0 + wave * 32 + (lane & 3) * 8;    // this lane's eight output channels
     const EpiFloors fl = epi_floors(a.flags);
+    const bool has_res = a.res != nullptr;
     float* ep = (float*)(smem + wave * EP_WAVE);
     const int colj = n0 + wave * 32 + r31;               // < cout_pad: the constant arrays are padded
     const float bi = a.bias ? a.bias[colj] : 0.f, sc = a.scale ? a.scale[colj] : 1.f, sf = a.shift ? a.shift[colj] : 0.f;
+    auto out_off = [&](int i, int k) -> long long {
+        const int m = m0 + i * 32 + k * 16 + (lane >> 2);
+        if (m >= a.M || colv >= a.Cout) return -1;
+        long long pix = m;
+        if (!PW) {
+            int n, od, oh, ow;
+            decode_row(a, m, n, od, oh, ow);
+            pix = ((long long)(n * a.OD + od * a.osd + ph.ood) * a.OH + oh * a.osh + ph.ooh) * a.OW + ow * a.osw + ph.oow;
+        }
+        return pix * a.ldc + colv;
+    };
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
-        if (i + RPF < SM) res_fetch(i + RPF, (i + RPF) % RQ);          // three passes ahead (the slot of pass i - 1, consumed)
         long long off[2];
         uint4 rv[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) { off[k] = offq[i % RQ][k]; rv[k] = rvq[i % RQ][k]; }
+        for (int k = 0; k < 2; ++k) {                    // this pass's residual vectors first: independent round trips
+            off[k] = out_off(i, k);
+            rv[k] = (has_res && off[k] >= 0) ? *(const uint4*)((const T*)a.res + off[k]) : make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e)                     // C layout of the 32x32 MFMA: row 8 (e >> 2) + 4 (lane >> 5) + (e & 3), column lane & 31
             ep[(8 * (e >> 2) + 4 * hk + (e & 3)) * EP_LD + r31] = (acc[i][e] + bi) * sc + sf;

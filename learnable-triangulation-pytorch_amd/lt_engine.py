@@ -533,6 +533,55 @@ class PlanBuilder:
                   "conv", label, flops, nbytes, {"bneck": True, "specs": specs, "x": x, "y": y})
         return y
 
+    # ---- the seam between two identity Bottleneck blocks in one launch (ResNet layer3): expand of block i + reduce of block i + 1 -----------
+    def can_expand_reduce(self, t2, res, w_expand, w_reduce):
+        """True when lt_expand_reduce_fwd covers the seam: bf16 plan over build-time weights, 2D maps, 1x1 P -> C expand with a C-channel residual and
+        1x1 C -> P reduce with (C, P) = (1024, 256) (LT_NO_XR=1: off -- the A/B switch)."""
+        if self.dtype != torch.bfloat16 or self.live_weights or self.tile_override or os.environ.get("LT_NO_XR") == "1":
+            return False
+        if t2.shape[1] != 1 or res.shape[1] != 1 or tuple(t2.shape[:4]) != tuple(res.shape[:4]):
+            return False
+        P, Cc = t2.shape[-1], res.shape[-1]
+        if (Cc, P) != (1024, 256):
+            return False
+        return tuple(w_expand.shape) == (Cc, P, 1, 1) and tuple(w_reduce.shape) == (P, Cc, 1, 1)
+
+    def expand_reduce(self, t2, res, w_expand, bn_expand, w_reduce, bn_reduce):
+        """y = relu(bn3(conv1x1(t2)) + res) and t1' = relu(bn1'(conv1x1'(y))) in ONE launch (lt_expand_reduce_fwd: the reduce consumes y from LDS).
+        Returns (y, t1') as new Acts."""
+        assert self.can_expand_reduce(t2, res, w_expand, w_reduce)
+        N, _, Hh, W, P = t2.shape
+        Cc = res.shape[-1]
+        s3 = make_conv_spec(w_expand, None, bn_expand, t2.shape, 1, 0, self.dtype, False, H.EPI_RELU_POST)
+        s1 = make_conv_spec(w_reduce, None, bn_reduce, res.shape, 1, 0, self.dtype, False, H.EPI_RELU_POST)
+        y = self.alloc((N, 1, Hh, W, Cc))
+        t1 = self.alloc((N, 1, Hh, W, P))
+        d = H.XrDesc()
+        d.dtype, d.C, d.P, d.M = self.code, Cc, P, N * Hh * W
+        lib = None if self.dry_run else H.lib()
+        flops = 0
+        for i, spec in enumerate((s3, s1)):
+            assert spec.cout_pad == spec.Cout and spec.k_pad == spec.Cin and not bool(spec.bias.any()), (spec.cout_pad, spec.k_pad)
+            wdev = self.const(spec.phases[0].weight, self.dtype)
+            sc, sh = self.const(spec.scale), self.const(spec.shift)
+            wfr = torch.empty_like(wdev)
+            if not self.dry_run:
+                H.check(lib.lt_conv_pack_weights_t32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, spec.Cin, 1, wfr.data_ptr(), H.cur_stream()), "lt_conv_pack_weights_t32")
+            self.keep += [wfr, sc, sh]
+            d.weight[i], d.scale[i], d.shift[i] = wfr.data_ptr(), sc.data_ptr(), sh.data_ptr()
+            flops += 2 * N * Hh * W * spec.Cout * spec.Cin
+        packed = self.const(torch.cat([s3.scale, s3.shift, s1.scale, s1.shift]))          # the four tables back to back: one LDS-DMA in the kernel's prologue
+        d.consts = packed.data_ptr()
+        self.keep += [t2.t, res.t, d, packed]
+        self.flops += flops
+        esz = t2.t.element_size()
+        nbytes = (t2.t.numel() + res.t.numel() + y.t.numel() + t1.t.numel() + 2 * Cc * P) * esz
+        label = "xr expand %d->%d + reduce %d->%d @%s" % (P, Cc, Cc, P, "x".join(str(v) for v in (N, 1, Hh, W)))
+        self._add(lambda s, d=d, a=t2.t.data_ptr(), r=res.t.data_ptr(), yp=y.t.data_ptr(), tp=t1.t.data_ptr():
+                  H.check(lib.lt_expand_reduce_fwd(C.byref(d), a, r, yp, tp, s), "lt_expand_reduce_fwd"),
+                  "conv", label, flops, nbytes, {"xr": True, "specs": [s3, s1], "x": t2, "res": res, "y": y, "t1": t1})
+        return y, t1
+
     def can_stem_pool(self, x, weight, stride, pad, pool):
         """True when lt_stem_pool_fwd covers conv -> BN -> ReLU -> max pool: bf16 plan, 2D map with 8 (padded) channels,
         7x7 / stride 2 / pad 3 convolution to 64 channels, 3x3 / stride 2 / pad 1 pool."""

@@ -47,13 +47,33 @@ class ResidualBlock(nn.Module):
 
     expansion = property(lambda self: 4 if self.kind == "bottleneck" else 1)
 
-    def record(self, b, x):
+    def is_identity_bottleneck(self):
+        return self.kind == "bottleneck" and self.downsample is None and all(s == 1 for s in self.strides)
+
+    def record(self, b, x, t1=None, next_block=None):
+        """Records the block over input ``x``.  ``t1``: this block's first activation relu(bn1(conv1(x))) when the PREVIOUS block's seam launch has already
+        produced it (lt_expand_reduce_fwd); ``next_block``: fuse this block's expand with that block's reduce when the plan supports the shape -- the
+        return value is then (y, t1 of the next block) instead of y (ResNet layer3's identity blocks: the 4 P-channel tensor is written once and not read
+        back by the next block's first convolution)."""
         n = len(self.strides)
-        if self.kind == "bottleneck" and self.downsample is None:
+        if self.kind == "bottleneck" and self.downsample is None and t1 is None and next_block is None:
             # identity blocks of layer1 / layer2 in bf16 plans: the whole block in one launch, the two bottleneck-width tensors stay in LDS
             convs = [self.conv1.weight, self.conv2.weight, self.conv3.weight]
             if b.can_bottleneck(x, convs, self.strides):
                 return b.bottleneck(x, convs, [bn_tuple(self.bn1), bn_tuple(self.bn2), bn_tuple(self.bn3)])
+        if t1 is not None or next_block is not None:
+            assert self.is_identity_bottleneck()
+            if t1 is None:
+                t1 = b.conv(x, self.conv1.weight, None, bn_tuple(self.bn1), stride=1, pad=0, relu=True)
+            t2 = b.conv(t1, self.conv2.weight, None, bn_tuple(self.bn2), stride=1, pad=1, relu=True)
+            b.release(t1)
+            if next_block is not None and b.can_expand_reduce(t2, x, self.conv3.weight, next_block.conv1.weight):
+                y, t1n = b.expand_reduce(t2, x, self.conv3.weight, bn_tuple(self.bn3), next_block.conv1.weight, bn_tuple(next_block.bn1))
+                b.release(t2)
+                return y, t1n
+            y = b.conv(t2, self.conv3.weight, None, bn_tuple(self.bn3), stride=1, pad=0, relu=True, residual=x)
+            b.release(t2)
+            return (y, None) if next_block is not None else y
         res = x
         if self.downsample is not None:
             res = b.conv(x, self.downsample[0].weight, None, bn_tuple(self.downsample[1]), stride=self.downsample[0].stride[0], pad=0)
@@ -148,10 +168,22 @@ class PoseResNet(E.PlanCache):
             p = b.maxpool(y, 3, 2, 1, nd=2); b.release(y)
             y = p
         for li in range(1, 5):
-            for blk in getattr(self, "layer%d" % li):
-                z = blk.record(b, y)
+            blocks = list(getattr(self, "layer%d" % li))
+            t1 = None                                         # the next block's first activation, when the seam launch in front of it produced it
+            for bi, blk in enumerate(blocks):
+                nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+                # a run of identity bottleneck blocks whose seams lt_expand_reduce_fwd covers (ResNet layer3, bf16 plans): expand(i) + reduce(i + 1) in one launch
+                chain = (nxt is not None and blk.is_identity_bottleneck() and nxt.is_identity_bottleneck() and hasattr(b, "can_expand_reduce") and
+                         tuple(blk.conv3.weight.shape[:2]) == (1024, 256) and tuple(nxt.conv1.weight.shape[:2]) == (256, 1024) and b.dtype == torch.bfloat16 and
+                         not getattr(b, "live_weights", False))
+                if chain:
+                    z, t1n = blk.record(b, y, t1=t1, next_block=nxt)
+                elif t1 is not None:
+                    z, t1n = blk.record(b, y, t1=t1), None
+                else:
+                    z, t1n = blk.record(b, y), None
                 b.release(y)
-                y = z
+                y, t1 = z, t1n
         alg = self.alg_confidences.record(b, y) if hasattr(self, "alg_confidences") else None
         vol = self.vol_confidences.record(b, y) if hasattr(self, "vol_confidences") else None
         for i in range(0, len(self.deconv_layers), 3):

@@ -81,6 +81,12 @@ def run_plan_on_cpu(plan):
             t1 = emulate_conv(s1, x).to(info["x"].t.dtype).float()
             t2 = emulate_conv(s2, t1).to(info["x"].t.dtype).float()
             info["y"].t.copy_(emulate_conv(s3, t2, x))
+        elif kind == "conv" and info.get("xr"):              # lt_expand_reduce_fwd: expand (+ residual, ReLU) rounded to the plan dtype, then the next block's reduce
+            s3, s1 = info["specs"]
+            dt = info["x"].t.dtype
+            y = emulate_conv(s3, info["x"].t.float().clone(), info["res"].t.float().clone()).to(dt)
+            info["y"].t.copy_(y)
+            info["t1"].t.copy_(emulate_conv(s1, y.float()))
         elif kind == "conv":
             res = None if info["res"] is None else info["res"].t.float().clone()
             out = emulate_conv(info["spec"], info["x"].t.float().clone(), res)

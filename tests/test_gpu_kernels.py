@@ -920,3 +920,51 @@ def test_bottleneck_fused(C, P, N, Hh, W, monkeypatch):
     # the three launches and the fused kernel agree to bf16 rounding noise: a structural mistake (one tap, one halo row) is far above this
     record(name + "/rms_vs_three_launches", float((y.float() - y3.float()).pow(2).mean().sqrt() / y3.float().pow(2).mean().sqrt()))
     assert float((y.float() - y3.float()).pow(2).mean().sqrt() / y3.float().pow(2).mean().sqrt()) < 2e-3
+
+
+@pytest.mark.parametrize("N,Hh,W", [(2, 6, 6), (2, 24, 24), (8, 24, 24), (3, 12, 20)])
+def test_expand_reduce_seam_fused(N, Hh, W, monkeypatch):
+    """lt_expand_reduce_fwd (round 5; pose_resnet.py:75-95, the seam between two identity blocks of layer3: expand + bn3 + residual + ReLU of block i, reduce +
+    bn1 + ReLU of block i + 1) against (a) torch fp32 on bf16-rounded operands with y rounded to bf16 where the expand stores it, (b) the two lt_conv_fwd
+    launches it replaces.  72 rows (one ragged 128-row tile), 1152 and 4608 rows (whole tiles, several per XCD), 720 rows (5.6 tiles: ragged tail, odd count)."""
+    C_, P = 1024, 256
+    g = torch.Generator().manual_seed(N * 1000 + Hh)
+    t2 = torch.relu(torch.randn(N, P, Hh, W, generator=g))
+    res = torch.relu(torch.randn(N, C_, Hh, W, generator=g))
+    w3, w1 = torch.randn(C_, P, 1, 1, generator=g) / P ** 0.5, torch.randn(P, C_, 1, 1, generator=g) / C_ ** 0.5
+    bn3, bn1 = _bn(C_, g), _bn(P, g)
+    t2_cl, res_cl = to_cl(t2, None, torch.bfloat16), to_cl(res, None, torch.bfloat16)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("LT_NO_XR", raising=False)
+        else:
+            monkeypatch.setenv("LT_NO_XR", "1")
+        b = E.PlanBuilder(DEV, torch.bfloat16)
+        ta, ra = E.Act(t2_cl), E.Act(res_cl)
+        if fused:
+            assert b.can_expand_reduce(ta, ra, w3, w1)
+            y, t1 = b.expand_reduce(ta, ra, w3, bn3, w1, bn1)
+        else:
+            assert not b.can_expand_reduce(ta, ra, w3, w1)
+            y = b.conv(ta, w3, None, bn3, relu=True, residual=ra)
+            t1 = b.conv(y, w1, None, bn1, relu=True)
+        plan = b.finish()
+        assert len(plan.ops) == (1 if fused else 2)
+        plan.run_eager(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return y.t, t1.t
+    y, t1 = run(True)
+    rd = bf16_round
+    y_ref = rd(torch.relu(_bn_ref(F.conv2d(rd(t2), rd(w3)), bn3) + rd(res)))
+    t1_ref = torch.relu(_bn_ref(F.conv2d(y_ref, rd(w1)), bn1))
+    name = "xr/%dx%dx%d" % (N, Hh, W)
+    check(name + "/y vs_torch", from_cl(y, 2), y_ref, 1.5e-2)
+    check(name + "/t1 vs_torch", from_cl(t1, 2), t1_ref, 1.5e-2)
+    y2, t12 = run(False)
+    monkeypatch.delenv("LT_NO_XR", raising=False)
+    for nm, a_, b_ in (("y", y, y2), ("t1", t1, t12)):
+        rms = float((a_.float() - b_.float()).pow(2).mean().sqrt() / b_.float().pow(2).mean().sqrt())
+        record(name + "/%s rms_vs_two_launches" % nm, rms)
+        check(name + "/%s vs_two_launches" % nm, from_cl(a_, 2), from_cl(b_, 2), 1.5e-2)
+        assert rms < 2e-3, (nm, rms)          # bf16 rounding noise; a structural mistake (one K block, one channel run) is far above this

@@ -257,3 +257,54 @@ def test_identity_bottlenecks_are_recorded_as_one_launch_in_bf16_plans(monkeypat
     b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
     m.layer2[3].record(b, b.alloc((2, 1, 8, 16, 512)))
     assert [meta["label"] for _, meta in b.finish().ops] == ["bneck 512->128->512 @2x1x8x16"]
+
+
+def test_expand_reduce_seam_fusion_of_layer3_is_recorded_and_equals_the_separate_launches(monkeypatch):
+    """Round 5: bf16 plans run the seam between two identity Bottleneck blocks of ResNet layer3 (1024 / 256 wide) as ONE lt_expand_reduce_fwd -- the
+    expand of block i (+ residual + ReLU) and the reduce of block i + 1.  The recorded chain must be the same function as the separate lt_conv_fwd
+    launches LT_NO_XR=1 records (the interpreter rounds y where the expand would store it), with 2 launches per block instead of 3 inside the run, the
+    first block's reduce and the last block's expand as ordinary convolutions; fp32 plans, other widths and the training tape keep the three launches."""
+    import lt_engine as E
+    from mvn.models.pose_resnet import PoseResNet
+    torch.manual_seed(12)
+    m = PoseResNet("bottleneck", [3, 4, 6, 3], 17).eval()
+    for bn in [mm for mm in m.modules() if isinstance(mm, torch.nn.BatchNorm2d)]:
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.data.uniform_(0.2, 0.6); bn.bias.data.normal_(0, 0.1)
+    x = torch.randn(2, 1, 6, 6, 1024)                      # 72 GEMM rows: one ragged 128-row tile
+
+    def run_layer3_tail(b, inp):
+        y, t1 = inp, None
+        blocks = list(m.layer3)[1:5]                       # four identity blocks
+        for bi, blk in enumerate(blocks):
+            nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+            if nxt is not None:
+                z, t1 = blk.record(b, y, t1=t1, next_block=nxt)
+            else:
+                z, t1 = (blk.record(b, y, t1=t1) if t1 is not None else blk.record(b, y)), None
+            y = z
+        return y
+    outs, counts = {}, {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("LT_NO_XR", "1")
+        b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
+        inp = b.alloc(tuple(x.shape))
+        y = run_layer3_tail(b, inp)
+        plan = b.finish()
+        labels = [meta["label"] for _, meta in plan.ops]
+        counts[fused] = len(labels)
+        inp.t.copy_(x)
+        run_plan_on_cpu(plan)
+        outs[fused] = y.t.float().clone()
+        if fused:
+            assert sum(l.startswith("xr expand 256->1024 + reduce 1024->256") for l in labels) == 3, labels
+            assert labels[0].startswith("conv1x1 1024->256") and labels[-1].startswith("conv1x1 256->1024"), labels
+    monkeypatch.delenv("LT_NO_XR")
+    assert counts == {True: 9, False: 12}, counts          # reduce + 4 x 3x3 + 3 seams + last expand  vs  4 x 3
+    assert torch.equal(outs[True], outs[False])
+    # the whole backbone records the seams through PoseResNet.record; fp32 plans do not
+    for dt, want in ((torch.bfloat16, 4), (torch.float32, 0)):          # layer3 of ResNet-50: six blocks, five identity ones: four seams
+        b = E.PlanBuilder("cpu", dt, dry_run=True)
+        m.record(b, b.alloc((1, 1, 64, 64, E.min_cin_of(dt))), False)
+        labels = [meta["label"] for _, meta in b.finish().ops]
+        assert sum(l.startswith("xr ") for l in labels) == want, (dt, [l for l in labels if l.startswith("xr ")])
