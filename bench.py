@@ -41,6 +41,8 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # before the first HIP call: see lt_hip.py (streams that share a hardware queue serialise)
+
 import numpy as np
 import torch
 
@@ -244,11 +246,16 @@ def pmc_leg(args, timeout_s=90, train=False, keep_per_kernel=False):
         res["per_kernel"] = per
     # kernel families by share of the step's shader cycles (training legs: the BatchNorm passes / weight gradients / convolutions split)
     if train and per and cyc:
+        # shares of the STEP's kernel time: the profiled passes run three steps of which the first records the tape (weight packing, index maps, uploads --
+        # "setup+copies"), so those kernels are left out of the denominator and reported next to the shares as a fraction of everything profiled
+        step_cyc = sum(v.get("shader_cycles_per_step", 0.0) for k, v in per.items() if train_family(k) != "setup+copies")
         share = {}
         for k, v in per.items():
-            share[train_family(k)] = share.get(train_family(k), 0.0) + v.get("shader_cycles_per_step", 0.0) / cyc
+            if train_family(k) != "setup+copies":
+                share[train_family(k)] = share.get(train_family(k), 0.0) + v.get("shader_cycles_per_step", 0.0) / step_cyc
         res["kernel_share"] = {k: round(v, 3) for k, v in sorted(share.items(), key=lambda kv: -kv[1])}
-        res["kernel_share_other_top"] = [[k, round(v.get("shader_cycles_per_step", 0.0) / cyc, 4)] for k, v in
+        res["kernel_share"]["(recording-step setup, of all profiled)"] = round(1.0 - step_cyc / cyc, 3)
+        res["kernel_share_other_top"] = [[k, round(v.get("shader_cycles_per_step", 0.0) / step_cyc, 4)] for k, v in
                                          sorted(per.items(), key=lambda kv: -kv[1].get("shader_cycles_per_step", 0.0)) if train_family(k) == "other"][:8]
     res["leg_wall_s"] = time.perf_counter() - t0
     return res
@@ -886,11 +893,12 @@ def main():
     barrier()
     if rank == 0:
         emit_detail("full", result)
-        try:
-            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            json.dump(result, open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w"), indent=1)
-        except OSError:
-            pass
+        if not args.full_line and not args.no_extras:          # (the default run only: the child legs would overwrite it)
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                json.dump(result, open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w"), indent=1)
+            except OSError:
+                pass
         print(json.dumps(result if args.full_line else compact_line(result)))
     lt_dist.shutdown()
 

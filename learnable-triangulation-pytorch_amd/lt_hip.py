@@ -6,6 +6,13 @@ There is NO fallback: if the library is missing or a call fails, a RuntimeError 
 import ctypes as C
 import os
 
+# The HIP runtime maps every hipStream onto one of GPU_MAX_HW_QUEUES hardware queues (default 4); two streams that land on the same queue run one after the
+# other.  Measured (round 5, tools/concurrency_probe.py): two forwards of two model instances on two streams took exactly the sum of their times with the
+# default, and overlapped completely with 8 queues (B = 1 per forward: 8.2 -> 4.7 ms for both).  The training step (main + weight-gradient side stream +
+# RCCL's own streams) and concurrent inference requests want distinct queues, so ask for 8 unless the caller has decided otherwise.  Only effective when
+# this module is imported before the process's first HIP call (the variable is read when the runtime initialises).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
