@@ -544,6 +544,11 @@ class PlanBuilder:
         P, Cc = t2.shape[-1], res.shape[-1]
         if (Cc, P) != (1024, 256):
             return False
+        # one 96-row tile per workgroup and one workgroup per CU: below ~64 tiles the two launches (144-row tiles x 4 column tiles, two workgroups per CU)
+        # spread better -- measured (round 5, tools/batch_sweep_probe.py): 1 / 2 samples (24 / 48 tiles) -8 % / -2.5 % end to end with the seam kernel,
+        # 3 / 5 / 8 / 10 samples +1.5 % / +3.2 % / +4 % / +6.4 %
+        if t2.shape[0] * t2.shape[2] * t2.shape[3] < 64 * 96 and os.environ.get("LT_XR_ANY_SIZE") != "1":
+            return False
         return tuple(w_expand.shape) == (Cc, P, 1, 1) and tuple(w_reduce.shape) == (P, Cc, 1, 1)
 
     def expand_reduce(self, t2, res, w_expand, bn_expand, w_reduce, bn_reduce):
