@@ -764,7 +764,7 @@ def main():
             live = None
             if world == 1 and not args.no_pmc_leg and (not args.no_extras or args.force_pmc_leg):
                 live = pmc_leg(args)
-            for name in ([] if live else ["r04_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"]):
+            for name in ([] if live else ["r05_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"]):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                 except (OSError, ValueError):
