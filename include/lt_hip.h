@@ -481,6 +481,27 @@ typedef struct {
 int lt_bottleneck_fwd(const lt_bneck_desc* desc, const void* x, void* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The FIRST Bottleneck of ResNet layer1 -- the one with a `downsample` branch and stride 1 -- in one launch
+ * (mvn/models/pose_resnet.py:75-95 with downsample = conv1x1 + BatchNorm, built at :196-206):
+ *   t1 = relu(bn1(conv1x1(x)));  t2 = relu(bn2(conv3x3(t1), pad 1));  y = relu(bn3(conv1x1(t2)) + bn_d(conv1x1_d(x)))
+ * Like lt_bottleneck_fwd the two inner tensors stay in LDS; here the residual is not read but COMPUTED from the
+ * tile of x that is in LDS already (a second K = Cin GEMM of the output phase), and it is added in fp32 -- the four
+ * separate launches round the downsample branch to bf16 first.  x: N,H,W,Cin, y: N,H,W,C channels-last bf16;
+ * (Cin, P, C) = (64, 64, 256);  H % 8 == 0, W % 16 == 0.  weight[i]: lt_conv_pack_weights_t32 of the lt_conv_fwd
+ * packing of conv1 [P][Cin], conv2 [P][9 P], conv3 [C][P], downsample [C][Cin];  scale / shift [i]: the folded
+ * BatchNorm of that layer (ResNet convolutions carry no bias).
+ * -------------------------------------------------------------------------------------------*/
+typedef struct {
+    int32_t dtype;                       /* LT_BF16 */
+    int32_t N, H, W;
+    int32_t Cin, P, C;                   /* input width, bottleneck width, block width */
+    const void* weight[4];               /* conv1, conv2, conv3, downsample */
+    const float* scale[4];
+    const float* shift[4];
+} lt_bneck_ds_desc;
+int lt_bottleneck_ds_fwd(const lt_bneck_ds_desc* desc, const void* x, void* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The 1x1 EXPAND of one identity Bottleneck block and the 1x1 REDUCE of the next one in one launch
  * (mvn/models/pose_resnet.py:75-95, the seam between two consecutive blocks of a ResNet stage):
  *   y  = relu(bn3(conv1x1_expand(t2)) + residual)          C channels, written once

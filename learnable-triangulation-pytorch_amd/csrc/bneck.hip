@@ -532,6 +532,334 @@ int launch_bneck(const BneckArgs& a, hipStream_t s) {
     return LT_OK;
 }
 
+
+// ---- the FIRST Bottleneck of ResNet layer1 in one launch: 64 -> 64 -> 64 -> 256 with the 1x1 64 -> 256 downsample branch, stride 1 ----------------
+// (reference pose_resnet.py:75-95 with `downsample` = conv1x1 + bn, :196-206).  Same tile, same three phases as bneck_kernel; what differs:
+//   * x has 64 channels: its 10 x 18 halo is TWO 32-channel stages (23 KB) that stay in LDS for the whole kernel (no ring) -- phase 1 reads them as
+//     the reduce's operand, phase 3 reads the 128 centre pixels again as the operand of the downsample GEMM (K = 64);
+//   * the residual is not read from memory but computed: y = relu(bn3(W3 t2) + bnd(Wd x)), two accumulator sets per output block (the two branches
+//     have their own BatchNorm scale), combined in fp32 -- the separate launches round the downsample branch to bf16 before the add;
+//   * t1 has its own bytes, so phase 1's epilogue needs no barrier in front of it.
+// The four launches it replaces move 64 (x) + 256 + 64 + 64 + 64 + 64 + 256 (residual) + 256 channel-units per pixel, this one 64 + 256.
+struct BneckDsArgs {
+    const bf16_t* x;
+    bf16_t* y;
+    const bf16_t* w1;
+    const bf16_t* w2;
+    const bf16_t* w3;
+    const bf16_t* wd;
+    const float* scale[4];   // conv1, conv2, conv3, downsample
+    const float* shift[4];
+    int N, H, W, tiles_x, tiles_y;
+};
+
+template <int CIN, int P, int C>
+__global__ __launch_bounds__(256, 2) void bneck_ds_kernel(const BneckDsArgs a) {
+    typedef bf16_t T;
+    constexpr int TH = 8, TW = 16, HPI = TW + 2, HROWS = (TH + 2) * HPI;
+    constexpr int NPB = 4;
+    constexpr int NCB = P / 32, NOB = C / 32, G2 = P / 16, GD = CIN / 16, NK1 = CIN / 32;
+    constexpr int RB = 2 * P, NSL = P / 8;
+    constexpr int T1_BYTES = HROWS * RB, STAGE = HROWS * 64;
+    constexpr int XS_OFF = T1_BYTES, T2_OFF = XS_OFF + NK1 * STAGE;
+    constexpr int NPB1 = 3, NPB2 = 2, NOBW = NOB / 4;
+    static_assert(CIN == 64 && P == 64 && C == 256, "the first block of ResNet layer1");
+    static_assert(NCB == 2 && NSL == 8 && NOBW == 2, "wave roles below");
+    static_assert(XS_OFF % 256 == 0 && T2_OFF % 256 == 0, "the XOR / bank arguments assume 256-byte aligned regions");
+    auto fsw = [](int hp) -> int { return (hp >> 1) & 7; };
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page_b;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    int lin = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = lin & 7, j = lin >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int img = lin / tpi, rem = lin - img * tpi;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+    const T* __restrict__ x = a.x;
+
+    const int n31 = lane & 31, hk = lane >> 5;
+    const int cb = wave & 1, whalf = wave >> 1;
+    const int prr = n31 >> 4, pcc = ((n31 & 15) - 2 * prr) & 15;
+
+    // folded BatchNorm constants in 8 registers (see bneck_kernel): cst12 = [scale1 | shift1 | scale2 | shift2][32 channels of block cb],
+    // cst3 = [q][scale3 | shift3 | scale_d | shift_d][32 channels of block wave + 4 q] = 256 floats = one float4 per lane
+    float4 cst12, cst3;
+    {
+        const int l = lane & 31, arr = l >> 3, i4 = l & 7;
+        const float* t12 = arr == 0 ? a.scale[0] : arr == 1 ? a.shift[0] : arr == 2 ? a.scale[1] : a.shift[1];
+        cst12 = *(const float4*)(t12 + 32 * cb + 4 * i4);
+        const int f = 4 * lane, q = f >> 7, which = (f >> 5) & 3, c = f & 31;
+        const float* t3 = which == 0 ? a.scale[2] : which == 1 ? a.shift[2] : which == 2 ? a.scale[3] : a.shift[3];
+        cst3 = *(const float4*)(t3 + 32 * (wave + 4 * q) + c);
+    }
+    auto cget = [&](const float4& tb, int f) -> float {
+        const float v = (f & 3) == 0 ? tb.x : (f & 3) == 1 ? tb.y : (f & 3) == 2 ? tb.z : tb.w;
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), f >> 2));
+    };
+    auto csel = [&](const float4& tb, int base, int e) -> float {
+        const float lo = cget(tb, base + 16 * (e >> 3) + (e & 7)), hi = cget(tb, base + 16 * (e >> 3) + 8 + (e & 7));
+        return hk ? hi : lo;
+    };
+
+    // ================================================ phase 1: t1 = relu(bn1(W1 x)) on the halo =======================================
+    {
+        const int prow = lane >> 2;
+        const int kvlog = (lane & 3) ^ swz64_b(prow);
+        const T* w1l = a.w1 + (size_t)cb * 512;
+        const unsigned wlane = lane * 16;
+        V16 fa[NK1][2];
+#pragma unroll
+        for (int ks = 0; ks < NK1; ++ks) {
+            const T* p = w1l + (size_t)(2 * ks) * NCB * 512;
+            gload16b(fa[ks][0], p, wlane);
+            gload16b(fa[ks][1], p + NCB * 512, wlane);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int hp = 16 * (wave + 4 * i) + prow;
+            const int hr = hp / HPI, hc = hp - hr * HPI;
+            const int iy = y0 + hr, ix = x0 + hc;
+            const bool ok = (hp < HROWS) & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+            const int dbase = ok ? ((img * a.H + iy) * a.W + ix) * CIN + kvlog * 8 : -1;
+            if (hp < HROWS) {
+#pragma unroll
+                for (int ks = 0; ks < NK1; ++ks) {
+                    const void* src = dbase >= 0 ? (const void*)(x + (dbase + ks * 32)) : zero_page;
+                    dma16b(src, lds0 + XS_OFF + ks * STAGE + (wave + 4 * i) * 1024);
+                }
+            }
+        }
+        const int hb0 = 3 * whalf;
+        const unsigned fo0 = n31 * 64 + (((0 + hk) ^ swz64_b(n31)) << 4);
+        const unsigned fo1 = n31 * 64 + (((2 + hk) ^ swz64_b(n31)) << 4);
+        f32x16 acc[NPB1];
+#pragma unroll
+        for (int i = 0; i < NPB1; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // both stages of x (all four waves' pieces), W1, the constants
+#pragma unroll
+        for (int ks = 0; ks < NK1; ++ks) {
+            frag_ready_b(fa[ks][0]);
+            frag_ready_b(fa[ks][1]);
+            const unsigned rb = lds0 + XS_OFF + ks * STAGE + hb0 * 2048;
+            V16 b0[NPB1], b1[NPB1];
+#pragma unroll
+            for (int i = 0; i < NPB1; ++i) b0[i].u = *(const uint4*)((lptr_t)(size_t)(rb + fo0 + i * 2048));
+#pragma unroll
+            for (int i = 0; i < NPB1; ++i) b1[i].u = *(const uint4*)((lptr_t)(size_t)(rb + fo1 + i * 2048));
+#pragma unroll
+            for (int i = 0; i < NPB1; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][0].h, b0[i].h, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NPB1; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][1].h, b1[i].h, acc[i], 0, 0, 0);
+        }
+        float esc[16], esf[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            esc[e] = csel(cst12, 0, e);
+            esf[e] = csel(cst12, 32, e);
+        }
+#pragma unroll
+        for (int i = 0; i < NPB1; ++i) {
+            const int hp = 32 * (hb0 + i) + n31;
+            const int hr = hp / HPI, hc = hp - hr * HPI;
+            const int iy = y0 + hr, ix = x0 + hc;
+            const bool inimg = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+            if (hp < HROWS) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    unsigned o[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int e = 8 * q + 2 * d;
+                        const float v0 = fmaxf(acc[i][e] * esc[e] + esf[e], 0.f), v1 = fmaxf(acc[i][e + 1] * esc[e + 1] + esf[e + 1], 0.f);
+                        o[d] = inimg ? pack_bf16x2(v0, v1) : 0u;
+                    }
+                    const int slot = (4 * cb + 2 * q + hk) ^ fsw(hp);
+                    *(uint4*)((lptr_t)(size_t)(lds0 + hp * RB + slot * 16)) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 3's weight stream: per output block q (ob = wave + 4 q) GD units of the downsample (K blocks of x) and then G2 units of the expand
+    constexpr int NUQ = GD + G2, NU3 = NOBW * NUQ, WD3 = 6;
+    int poff[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+        poff[pb] = ((img * a.H + ty * TH + 2 * pb + prr) * a.W + tx * TW + pcc) * C + 8 * hk;
+    const T* wl3 = a.w3 + (size_t)lane * 8;
+    const T* wld = a.wd + (size_t)lane * 8;
+    auto load_w3 = [&](int u) -> V16 {
+        const int q = u / NUQ, k = u - q * NUQ;
+        V16 v;
+        if (k < GD) v.u = *(const uint4*)(wld + ((size_t)k * NOB + wave + 4 * q) * 512);
+        else v.u = *(const uint4*)(wl3 + ((size_t)(k - GD) * NOB + wave + 4 * q) * 512);
+        return v;
+    };
+    V16 wf3[WD3 + 1];
+
+    // ================================================ phase 2: t2 = relu(bn2(W2 * t1)) ================================================
+    {
+        const int pb0 = 2 * whalf;
+        const int bn = prr * HPI + pcc + 2 * HPI * pb0;
+        unsigned am[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) am[m] = lds0 + bn * RB + ((hk ^ fsw(bn + m)) << 4);
+        const T* wl = a.w2 + ((size_t)cb * 64 + lane) * 8;
+        auto load_w = [&](int u) -> V16 {
+            V16 v;
+            v.u = *(const uint4*)(wl + (size_t)u * NCB * 512);
+            return v;
+        };
+        constexpr int NU = 9 * G2, WD = 6;
+        V16 wf[WD + 1];
+#pragma unroll
+        for (int u = 0; u < WD; ++u) wf[u] = load_w(u);
+        f32x16 acc[NPB2];
+#pragma unroll
+        for (int i = 0; i < NPB2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        V16 xa[2][NPB2];
+        auto load_x = [&](auto uc, V16 (&dst)[NPB2]) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int tap = u / G2, g = u % G2, dy = tap / 3, dx = tap % 3;
+            static_for_b<0, NPB2>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int TT = dy * HPI + dx + 2 * HPI * i;
+                const unsigned ad = am[TT & 15] ^ (g << 5);
+                dst[i].u = *(const uint4*)((lptr_t)(size_t)(ad + TT * RB));
+            });
+        };
+        load_x(std::integral_constant<int, 0>{}, xa[0]);
+        static_for_b<0, NU>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if constexpr (u + WD < NU) wf[(u + WD) % (WD + 1)] = load_w(u + WD);
+            if constexpr (u + 1 < NU) load_x(std::integral_constant<int, u + 1>{}, xa[(u + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < NPB2; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % (WD + 1)].h, xa[u & 1][i].h, acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int u = 0; u < WD3; ++u) wf3[u] = load_w3(u);
+        __builtin_amdgcn_sched_barrier(0);
+
+        float esc[16], esf[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            esc[e] = csel(cst12, 64, e);
+            esf[e] = csel(cst12, 96, e);
+        }
+#pragma unroll
+        for (int i = 0; i < NPB2; ++i) {
+            const int px = 32 * (pb0 + i) + n31;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                unsigned o[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int e = 8 * q + 2 * d;
+                    o[d] = pack_bf16x2(fmaxf(acc[i][e] * esc[e] + esf[e], 0.f), fmaxf(acc[i][e + 1] * esc[e + 1] + esf[e + 1], 0.f));
+                }
+                const int slot = (4 * cb + 2 * q + hk) ^ fsw(n31);
+                *(uint4*)((lptr_t)(size_t)(lds0 + T2_OFF + px * RB + slot * 16)) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ================================================ phase 3: y = relu(bn3(W3 t2) + bnd(Wd x)) =======================================
+    {
+        const unsigned a2 = lds0 + T2_OFF + n31 * RB + ((hk ^ fsw(n31)) << 4);
+        unsigned xd[NPB][2];                                  // this lane's centre pixel of block pb in a stage of x: 16-byte slot 2 s + h, s = K block & 1
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb) {
+            const int hpc = (2 * pb + prr + 1) * HPI + pcc + 1;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) xd[pb][s2] = lds0 + XS_OFF + hpc * 64 + (((2 * s2 + hk) ^ swz64_b(hpc)) << 4);
+        }
+        f32x16 acc[NPB], accd[NPB];
+        static_for_b<0, NU3>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int q = u / NUQ, k = u % NUQ;
+            const int ob = wave + 4 * q;
+            if constexpr (k == 0) {
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { acc[pb][e] = 0.f; accd[pb][e] = 0.f; }
+            }
+            if constexpr (u + WD3 < NU3) wf3[(u + WD3) % (WD3 + 1)] = load_w3(u + WD3);
+            V16 xb[NPB];
+            if constexpr (k < GD) {
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb) xb[pb].u = *(const uint4*)((lptr_t)(size_t)(xd[pb][k & 1] + (k >> 1) * STAGE));
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb)
+                    accd[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf3[u % (WD3 + 1)].h, xb[pb].h, accd[pb], 0, 0, 0);
+            } else {
+                constexpr int g = k - GD;
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb) xb[pb].u = *(const uint4*)((lptr_t)(size_t)((a2 ^ (g << 5)) + pb * 32 * RB));
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb)
+                    acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf3[u % (WD3 + 1)].h, xb[pb].h, acc[pb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (k == NUQ - 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float esc[8], esf[8], dsc[8], dsf[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        esc[e] = csel(cst3, 128 * q, 8 * j + e);
+                        esf[e] = csel(cst3, 128 * q + 32, 8 * j + e);
+                        dsc[e] = csel(cst3, 128 * q + 64, 8 * j + e);
+                        dsf[e] = csel(cst3, 128 * q + 96, 8 * j + e);
+                    }
+#pragma unroll
+                    for (int pb = 0; pb < NPB; ++pb) {
+                        unsigned o[4];
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const int e = 2 * d;
+                            const float r0 = accd[pb][8 * j + e] * dsc[e] + dsf[e], r1 = accd[pb][8 * j + e + 1] * dsc[e + 1] + dsf[e + 1];
+                            const float v0 = fmaxf(acc[pb][8 * j + e] * esc[e] + esf[e] + r0, 0.f);
+                            const float v1 = fmaxf(acc[pb][8 * j + e + 1] * esc[e + 1] + esf[e + 1] + r1, 0.f);
+                            o[d] = pack_bf16x2(v0, v1);
+                        }
+                        *(uint4*)(a.y + poff[pb] + 32 * ob + 16 * j) = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+        });
+    }
+}
+
+int launch_bneck_ds(const BneckDsArgs& a, hipStream_t s) {
+    constexpr int lds = 180 * 128 + 2 * 180 * 64 + 128 * 128;   // t1 + the two stages of x + t2 = 62464 B
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    auto kern = bneck_ds_kernel<64, 64, 256>;
+    LT_OPT_IN_LDS(kern, lds);
+    const long long nblk = (long long)a.N * a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, s, a);
+    LT_CHECK_LAUNCH("lt_bottleneck_ds_fwd");
+    return LT_OK;
+}
+
 }  // namespace
 
 #ifdef LT_BNECK_TRACE
@@ -572,4 +900,30 @@ extern "C" int lt_bottleneck_fwd(const lt_bneck_desc* d, const void* x, void* y,
 #endif
     if (d->P == 64) return launch_bneck<256, 64, 4, LT_BNECK_HELD64>(a, s);
     return launch_bneck<512, 128, 3, LT_BNECK_HELD128>(a, s);
+}
+
+extern "C" int lt_bottleneck_ds_fwd(const lt_bneck_ds_desc* d, const void* x, void* y, void* stream) {
+    LT_REQUIRE(d && x && y, LT_ERR_INVALID, "lt_bottleneck_ds_fwd: null argument");
+    LT_REQUIRE(x != y, LT_ERR_INVALID, "lt_bottleneck_ds_fwd: in-place is not possible");
+    LT_REQUIRE(d->dtype == LT_BF16, LT_ERR_UNSUPPORTED, "lt_bottleneck_ds_fwd: bf16 only");
+    LT_REQUIRE(d->Cin == 64 && d->P == 64 && d->C == 256, LT_ERR_UNSUPPORTED,
+               "lt_bottleneck_ds_fwd: widths %d -> %d -> %d (64 -> 64 -> 256: the first block of ResNet layer1)", d->Cin, d->P, d->C);
+    LT_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->H % 8 == 0 && d->W % 16 == 0, LT_ERR_UNSUPPORTED,
+               "lt_bottleneck_ds_fwd: map %d x %d (8 x 16 pixel tiles)", d->H, d->W);
+    LT_REQUIRE((long long)d->N * d->H * d->W * d->C < (1ll << 31), LT_ERR_UNSUPPORTED, "lt_bottleneck_ds_fwd: 32-bit element offsets");
+    BneckDsArgs a;
+    a.x = (const bf16_t*)x;
+    a.y = (bf16_t*)y;
+    for (int i = 0; i < 4; ++i) {
+        LT_REQUIRE(d->weight[i] && d->scale[i] && d->shift[i], LT_ERR_INVALID, "lt_bottleneck_ds_fwd: layer %d: null weight / scale / shift", i);
+        a.scale[i] = d->scale[i];
+        a.shift[i] = d->shift[i];
+    }
+    a.w1 = (const bf16_t*)d->weight[0];
+    a.w2 = (const bf16_t*)d->weight[1];
+    a.w3 = (const bf16_t*)d->weight[2];
+    a.wd = (const bf16_t*)d->weight[3];
+    a.N = d->N; a.H = d->H; a.W = d->W;
+    a.tiles_x = d->W / 16; a.tiles_y = d->H / 8;
+    return launch_bneck_ds(a, (hipStream_t)stream);
 }

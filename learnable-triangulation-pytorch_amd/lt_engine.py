@@ -533,6 +533,64 @@ class PlanBuilder:
                   "conv", label, flops, nbytes, {"bneck": True, "specs": specs, "x": x, "y": y})
         return y
 
+    # ---- the first Bottleneck of ResNet layer1 (downsample branch, stride 1) in one launch --------------------------------------------------
+    def can_bottleneck_ds(self, x, convs, strides, w_down, stride_down):
+        """True when lt_bottleneck_ds_fwd covers the block: bf16 plan over build-time weights, 2D map, stride-1 convolutions 1x1 64->64, 3x3 64->64,
+        1x1 64->256 and a stride-1 1x1 64->256 downsample, H % 8 == 0 and W % 16 == 0 (LT_NO_BNECK_DS=1 or LT_NO_BNECK=1: off -- the A/B switches)."""
+        if (self.dtype != torch.bfloat16 or self.live_weights or self.tile_override or os.environ.get("LT_NO_BNECK") == "1" or
+                os.environ.get("LT_NO_BNECK_DS") == "1"):
+            return False
+        N, D, Hh, W, Cin = x.shape
+        if D != 1 or len(convs) != 3 or any(s != 1 for s in strides) or stride_down != 1:
+            return False
+        P, Cc = convs[0].shape[0], convs[2].shape[0]
+        if (Cin, P, Cc) != (64, 64, 256):
+            return False
+        if (tuple(convs[0].shape) != (P, Cin, 1, 1) or tuple(convs[1].shape) != (P, P, 3, 3) or tuple(convs[2].shape) != (Cc, P, 1, 1) or
+                tuple(w_down.shape) != (Cc, Cin, 1, 1)):
+            return False
+        return Hh % 8 == 0 and W % 16 == 0 and N * Hh * W * Cc < 2 ** 31
+
+    def bottleneck_ds(self, x, convs, bns, w_down, bn_down):
+        """relu(bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x)))))))) + bn_d(conv1x1_d(x))) in ONE launch (lt_bottleneck_ds_fwd): the two bottleneck-width
+        tensors stay in LDS and the downsample branch is computed from the tile of x that is there already.  Returns the output Act."""
+        assert self.can_bottleneck_ds(x, convs, (1, 1, 1), w_down, 1)
+        N, _, Hh, W, Cin = x.shape
+        P, Cc = convs[0].shape[0], convs[2].shape[0]
+        specs = []
+        shape = x.shape
+        for i, (w, bn) in enumerate(zip(convs, bns)):
+            spec = make_conv_spec(w, None, bn, shape, 1, 1 if i == 1 else 0, self.dtype, False, H.EPI_RELU_POST)
+            specs.append(spec)
+            shape = (N, 1, Hh, W, spec.Cout)
+        specs.append(make_conv_spec(w_down, None, bn_down, x.shape, 1, 0, self.dtype, False, 0))
+        y = self.alloc((N, 1, Hh, W, Cc))
+        d = H.BneckDsDesc()
+        d.dtype, d.N, d.H, d.W, d.Cin, d.P, d.C = self.code, N, Hh, W, Cin, P, Cc
+        lib = None if self.dry_run else H.lib()
+        flops = 0
+        for i, spec in enumerate(specs):
+            wdev = self.const(spec.phases[0].weight, self.dtype)
+            assert spec.cout_pad == spec.Cout and spec.k_pad == spec.phases[0].taps.shape[0] * spec.Cin, (spec.cout_pad, spec.k_pad)
+            assert not bool(spec.bias.any()), "ResNet convolutions carry no bias"
+            sc, sh = self.const(spec.scale), self.const(spec.shift)
+            wfr = torch.empty_like(wdev)
+            if not self.dry_run:
+                H.check(lib.lt_conv_pack_weights_t32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, spec.Cin, int(spec.phases[0].taps.shape[0]),
+                                                     wfr.data_ptr(), H.cur_stream()), "lt_conv_pack_weights_t32")
+            self.keep.append(wfr)
+            d.weight[i], d.scale[i], d.shift[i] = wfr.data_ptr(), sc.data_ptr(), sh.data_ptr()
+            flops += 2 * N * Hh * W * spec.Cout * spec.phases[0].taps.shape[0] * spec.Cin
+        self.keep.append(x.t)
+        self.keep.append(d)
+        self.flops += flops
+        esz = x.t.element_size()
+        nbytes = (x.t.numel() + y.t.numel()) * esz + sum(sp.phases[0].weight.numel() for sp in specs) * esz
+        label = "bneck-ds %d->%d->%d @%s" % (Cin, P, Cc, "x".join(str(v) for v in (N, 1, Hh, W)))
+        self._add(lambda s, d=d, xp=x.t.data_ptr(), yp=y.t.data_ptr(): H.check(lib.lt_bottleneck_ds_fwd(C.byref(d), xp, yp, s), "lt_bottleneck_ds_fwd"),
+                  "conv", label, flops, nbytes, {"bneck_ds": True, "specs": specs, "x": x, "y": y})
+        return y
+
     # ---- the seam between two identity Bottleneck blocks in one launch (ResNet layer3): expand of block i + reduce of block i + 1 -----------
     def can_expand_reduce(self, t2, res, w_expand, w_reduce):
         """True when lt_expand_reduce_fwd covers the seam: bf16 plan over build-time weights, 2D maps, 1x1 P -> C expand with a C-channel residual and

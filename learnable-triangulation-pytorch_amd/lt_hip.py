@@ -68,6 +68,11 @@ class BneckDesc(C.Structure):
                 ("weight", vp * 3), ("bias", vp * 3), ("scale", vp * 3), ("shift", vp * 3)]
 
 
+class BneckDsDesc(C.Structure):
+    _fields_ = [("dtype", i32), ("N", i32), ("H", i32), ("W", i32), ("Cin", i32), ("P", i32), ("C", i32),
+                ("weight", vp * 4), ("scale", vp * 4), ("shift", vp * 4)]
+
+
 class XrDesc(C.Structure):
     _fields_ = [("dtype", i32), ("C", i32), ("P", i32), ("M", C.c_int64), ("weight", vp * 2), ("scale", vp * 2), ("shift", vp * 2), ("consts", vp)]
 
@@ -85,6 +90,7 @@ SIGNATURES = {
     "lt_pwchain_fwd": (C.c_int, [C.POINTER(PwChainDesc), vp, vp, vp]),
     "lt_stem_pool_fwd": (C.c_int, [C.POINTER(StemDesc), vp, vp, vp]),
     "lt_bottleneck_fwd": (C.c_int, [C.POINTER(BneckDesc), vp, vp, vp]),
+    "lt_bottleneck_ds_fwd": (C.c_int, [C.POINTER(BneckDsDesc), vp, vp, vp]),
     "lt_expand_reduce_fwd": (C.c_int, [C.POINTER(XrDesc), vp, vp, vp, vp, vp]),
     "lt_stem_packed_bytes": (C.c_size_t, []),
     "lt_stem_pack_weights": (C.c_int, [vp, i32, vp, vp]),

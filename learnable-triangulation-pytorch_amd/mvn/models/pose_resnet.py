@@ -61,6 +61,12 @@ class ResidualBlock(nn.Module):
             convs = [self.conv1.weight, self.conv2.weight, self.conv3.weight]
             if b.can_bottleneck(x, convs, self.strides):
                 return b.bottleneck(x, convs, [bn_tuple(self.bn1), bn_tuple(self.bn2), bn_tuple(self.bn3)])
+        if (self.kind == "bottleneck" and self.downsample is not None and t1 is None and next_block is None and hasattr(b, "can_bottleneck_ds")):
+            # the first block of layer1 (downsample branch, stride 1) in bf16 plans: one launch, the residual branch computed from the tile of x in LDS
+            convs = [self.conv1.weight, self.conv2.weight, self.conv3.weight]
+            if b.can_bottleneck_ds(x, convs, self.strides, self.downsample[0].weight, self.downsample[0].stride[0]):
+                return b.bottleneck_ds(x, convs, [bn_tuple(self.bn1), bn_tuple(self.bn2), bn_tuple(self.bn3)], self.downsample[0].weight,
+                                       bn_tuple(self.downsample[1]))
         if t1 is not None or next_block is not None:
             assert self.is_identity_bottleneck()
             if t1 is None:

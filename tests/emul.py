@@ -81,6 +81,12 @@ def run_plan_on_cpu(plan):
             t1 = emulate_conv(s1, x).to(info["x"].t.dtype).float()
             t2 = emulate_conv(s2, t1).to(info["x"].t.dtype).float()
             info["y"].t.copy_(emulate_conv(s3, t2, x))
+        elif kind == "conv" and info.get("bneck_ds"):        # lt_bottleneck_ds_fwd: as above, the residual = the downsample branch of x, added in fp32 (not rounded)
+            x = info["x"].t.float().clone()
+            s1, s2, s3, sd = info["specs"]
+            t1 = emulate_conv(s1, x).to(info["x"].t.dtype).float()
+            t2 = emulate_conv(s2, t1).to(info["x"].t.dtype).float()
+            info["y"].t.copy_(emulate_conv(s3, t2, emulate_conv(sd, x)))
         elif kind == "conv" and info.get("xr"):              # lt_expand_reduce_fwd: expand (+ residual, ReLU) rounded to the plan dtype, then the next block's reduce
             s3, s1 = info["specs"]
             dt = info["x"].t.dtype

@@ -922,6 +922,60 @@ def test_bottleneck_fused(C, P, N, Hh, W, monkeypatch):
     assert float((y.float() - y3.float()).pow(2).mean().sqrt() / y3.float().pow(2).mean().sqrt()) < 2e-3
 
 
+@pytest.mark.parametrize("N,Hh,W", [(1, 8, 16), (3, 24, 32), (2, 16, 48), (9, 16, 16), (4, 96, 96)])
+def test_bottleneck_with_downsample_fused(N, Hh, W, monkeypatch):
+    """lt_bottleneck_ds_fwd (round 5; pose_resnet.py:75-95 with the `downsample` branch of :196-206: the first block of ResNet layer1, 64 -> 64 -> 256) against
+    (a) torch fp32 on bf16-rounded operands with the two inner tensors rounded to bf16 where the separate launches store them and the downsample branch
+    NOT rounded (the kernel adds it in fp32), (b) the four lt_conv_fwd launches it replaces (which do round the branch: one bf16 rounding apart).
+    One-tile maps (every halo pixel outside the image), several tiles per image, an odd image count (XCD remap), the benchmark's 96 x 96 map."""
+    Cin, P, C_ = 64, 64, 256
+    g = torch.Generator().manual_seed(7000 + N + Hh)
+    x = torch.relu(torch.randn(N, Cin, Hh, W, generator=g))       # the stem's output is a ReLU / max-pool of one
+    ws = [torch.randn(P, Cin, 1, 1, generator=g) / Cin ** 0.5, torch.randn(P, P, 3, 3, generator=g) / (9 * P) ** 0.5, torch.randn(C_, P, 1, 1, generator=g) / P ** 0.5]
+    wd = torch.randn(C_, Cin, 1, 1, generator=g) / Cin ** 0.5
+    bns, bnd = [_bn(P, g), _bn(P, g), _bn(C_, g)], _bn(C_, g)
+    x_cl = to_cl(x, None, torch.bfloat16)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("LT_NO_BNECK_DS", raising=False)
+        else:
+            monkeypatch.setenv("LT_NO_BNECK_DS", "1")
+        b = E.PlanBuilder(DEV, torch.bfloat16)
+        xa = E.Act(x_cl)
+        if fused:
+            assert b.can_bottleneck_ds(xa, ws, (1, 1, 1), wd, 1)
+            y = b.bottleneck_ds(xa, ws, bns, wd, bnd)
+        else:
+            assert not b.can_bottleneck_ds(xa, ws, (1, 1, 1), wd, 1)
+            r = b.conv(xa, wd, None, bnd)
+            t1 = b.conv(xa, ws[0], None, bns[0], relu=True)
+            t2 = b.conv(t1, ws[1], None, bns[1], pad=1, relu=True)
+            y = b.conv(t2, ws[2], None, bns[2], relu=True, residual=r)
+        plan = b.finish()
+        assert len(plan.ops) == (1 if fused else 4)
+        plan.run_eager(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return y.t
+    y = run(True)
+    assert y.data_ptr() != x_cl.data_ptr() and tuple(y.shape) == (N, 1, Hh, W, C_)
+    rd = bf16_round
+    xr = rd(x)
+    t1 = rd(torch.relu(_bn_ref(F.conv2d(xr, rd(ws[0])), bns[0])))
+    t2 = rd(torch.relu(_bn_ref(F.conv2d(t1, rd(ws[1]), None, 1, 1), bns[1])))
+    ref = torch.relu(_bn_ref(F.conv2d(t2, rd(ws[2])), bns[2]) + _bn_ref(F.conv2d(xr, rd(wd)), bnd))
+    name = "bneck_ds/%dx%dx%d" % (N, Hh, W)
+    check(name + "/vs_torch", from_cl(y, 2), ref, 1.5e-2)
+    y4 = run(False)
+    check(name + "/vs_four_launches", from_cl(y, 2), from_cl(y4, 2), 1.5e-2)
+    rms = float((y.float() - y4.float()).pow(2).mean().sqrt() / y4.float().pow(2).mean().sqrt())
+    record(name + "/rms_vs_four_launches", rms)
+    assert rms < 4e-3           # a structural mistake (one tap, one halo row, one K block of the branch) is far above the branch's bf16 rounding
+    e_f = float((from_cl(y, 2).float() - ref).pow(2).mean().sqrt()); e_4 = float((from_cl(y4, 2).float() - ref).pow(2).mean().sqrt())
+    record(name + "/rms_err_vs_torch fused | four launches", [e_f, e_4])
+    assert e_f <= e_4 * 1.05 + 1e-6   # adding the branch unrounded cannot be worse than rounding it first
+
+
 @pytest.mark.parametrize("N,Hh,W", [(2, 6, 6), (2, 24, 24), (8, 24, 24), (3, 12, 20)])
 def test_expand_reduce_seam_fused(N, Hh, W, monkeypatch):
     """lt_expand_reduce_fwd (round 5; pose_resnet.py:75-95, the seam between two identity blocks of layer3: expand + bn3 + residual + ReLU of block i, reduce +

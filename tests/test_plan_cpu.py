@@ -248,8 +248,8 @@ def test_identity_bottlenecks_are_recorded_as_one_launch_in_bf16_plans(monkeypat
         assert y.t.data_ptr() != inp.t.data_ptr()
     assert torch.equal(outs[True], outs[False])           # the interpreter rounds the inner tensors where the launches would store them
     monkeypatch.delenv("LT_NO_BNECK")
-    # what does NOT fuse: the first block of a level (downsample branch), fp32 plans, maps that are not whole tiles, layer3's width
-    for blk, shape, dt in ((m.layer1[0], (1, 1, 16, 32, 64), torch.bfloat16), (m.layer1[1], (1, 1, 16, 32, 256), torch.float32),
+    # what does NOT fuse: the first block of a strided level (downsample branch with stride 2), fp32 plans, maps that are not whole tiles, layer3's width
+    for blk, shape, dt in ((m.layer2[0], (1, 1, 16, 32, 256), torch.bfloat16), (m.layer1[1], (1, 1, 16, 32, 256), torch.float32),
                            (m.layer1[1], (1, 1, 12, 32, 256), torch.bfloat16), (m.layer3[1], (1, 1, 8, 16, 1024), torch.bfloat16)):
         b = E.PlanBuilder("cpu", dt, dry_run=True)
         blk.record(b, b.alloc(shape))
@@ -257,6 +257,53 @@ def test_identity_bottlenecks_are_recorded_as_one_launch_in_bf16_plans(monkeypat
     b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
     m.layer2[3].record(b, b.alloc((2, 1, 8, 16, 512)))
     assert [meta["label"] for _, meta in b.finish().ops] == ["bneck 512->128->512 @2x1x8x16"]
+
+
+def test_first_bottleneck_of_layer1_with_its_downsample_branch_is_one_launch_in_bf16_plans(monkeypatch):
+    """Round 5: the FIRST block of ResNet layer1 (64 -> 64 -> 256, stride 1, `downsample` = conv1x1 + bn: pose_resnet.py:75-95, :196-206) is ONE
+    lt_bottleneck_ds_fwd in bf16 plans.  It must be the function the four lt_conv_fwd launches compute, up to the one place where it is MORE exact:
+    the downsample branch is added in fp32 instead of being stored in bf16 first (so: equal within one bf16 rounding of the branch, and equal to the
+    fp32 module within the plan's rounding).  fp32 plans, ragged maps, LT_NO_BNECK_DS=1 and the strided first blocks of layer2-4 keep the launches."""
+    import lt_engine as E
+    from mvn.models.pose_resnet import PoseResNet
+    torch.manual_seed(13)
+    m = PoseResNet("bottleneck", [3, 4, 6, 3], 17).eval()
+    for bn in [mm for mm in m.modules() if isinstance(mm, torch.nn.BatchNorm2d)]:
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.1)
+    x = torch.randn(2, 1, 16, 32, 64)
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("LT_NO_BNECK_DS", "1")
+        b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
+        inp = b.alloc(tuple(x.shape)); inp.pooled = False
+        y = m.layer1[0].record(b, inp)
+        plan = b.finish()
+        labels = [meta["label"] for _, meta in plan.ops]
+        assert labels == (["bneck-ds 64->64->256 @2x1x16x32"] if fused else
+                          ["conv1x1 64->256 @2x1x16x32", "conv1x1 64->64 @2x1x16x32", "conv3x3 64->64 @2x1x16x32", "conv1x1 64->256 @2x1x16x32"]), labels
+        inp.t.copy_(x)
+        run_plan_on_cpu(plan)
+        outs[fused] = y.t.float().clone()
+    monkeypatch.delenv("LT_NO_BNECK_DS")
+    blk = m.layer1[0]
+    xb = x[:, 0].permute(0, 3, 1, 2).to(torch.bfloat16).float()
+    with torch.no_grad():
+        ref = torch.relu(blk.bn3(blk.conv3(torch.relu(blk.bn2(blk.conv2(torch.relu(blk.bn1(blk.conv1(xb)))))))) + blk.downsample(xb)).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    d_sep = float((outs[True] - outs[False]).abs().max())
+    assert d_sep <= 2.0 ** -7 * scale, (d_sep, scale)     # one bf16 rounding of the branch (relative 2^-9) plus one of the output
+    e_f, e_s = float((outs[True][:, 0] - ref).abs().max()), float((outs[False][:, 0] - ref).abs().max())
+    assert e_f <= 3e-2 * scale and e_f <= 1.5 * e_s + 1e-3, (e_f, e_s, scale)
+    for blk2, shape, dt, env in ((m.layer1[0], (1, 1, 16, 32, 64), torch.float32, None), (m.layer1[0], (1, 1, 12, 32, 64), torch.bfloat16, None),
+                                 (m.layer1[0], (1, 1, 16, 32, 64), torch.bfloat16, "LT_NO_BNECK"), (m.layer3[0], (1, 1, 16, 32, 512), torch.bfloat16, None)):
+        if env:
+            monkeypatch.setenv(env, "1")
+        b = E.PlanBuilder("cpu", dt, dry_run=True)
+        blk2.record(b, b.alloc(shape))
+        assert all(not meta["label"].startswith("bneck") for _, meta in b.finish().ops)
+        if env:
+            monkeypatch.delenv(env)
 
 
 def test_expand_reduce_seam_fusion_of_layer3_is_recorded_and_equals_the_separate_launches(monkeypatch):
