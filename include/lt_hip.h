@@ -146,6 +146,20 @@ enum { LT_TILE_AUTO = 0,
 
 int lt_conv_fwd(const lt_conv_desc* desc, const void* x, const float* bias, const float* scale, const float* shift,
                 const void* residual, void* y, void* stream);
+/* lt_conv_fwd whose residual is COMPUTED instead of read: y = relu_post((acc + bias) * scale + shift + W_skip . skip.x[same voxel]) -- the second
+ * convolution of a Res3DBlock whose skip connection is a 1x1x1 convolution + BatchNorm (mvn/models/v2v.py:20-42, the 16 -> 32 block at :76).  The caller
+ * folds the skip branch's BatchNorm scale into W_skip (fp32 product, then one bf16 rounding) and its (bias * scale + shift) into `shift`; the skip
+ * convolution's own launch, its Cout-channel output and the read of that tensor disappear.  Covered: bf16, 3x3x3 / stride 1 / pad 1, 32 -> 32 channels,
+ * skip.cin == 16, shapes the column-walk halo kernel takes (D % 4 == 0 with D >= 8, H % 8 == 0, W % 8 == 0, N * (H / 8) * (W / 8) a multiple of 8 and
+ * >= 256, no LT_EPI_RELU_PRE / LT_EPI_STORE_F32) -- anything else returns LT_ERR_UNSUPPORTED (there is no fallback: callers ask before they record).
+ * skip.x: N,D,H,W,cin channels-last bf16;  skip.weight_frag: lt_conv_pack_weights_t32 of [32][16] (ntaps 1, cin 16). */
+typedef struct lt_conv_skip {
+    const void* x;
+    int32_t cin;
+    const void* weight_frag;
+} lt_conv_skip;
+int lt_conv_skip_fwd(const lt_conv_desc* desc, const void* x, const float* bias, const float* scale, const float* shift,
+                     const lt_conv_skip* skip, void* y, void* stream);
 /* weight padding rule (every tile's N divides it): cout_pad = 16 if Cout <= 16, 32 if <= 32, 64 if <= 64,
  * else Cout rounded up to a multiple of 128; bias/scale/shift arrays hold cout_pad floats. */
 int lt_conv_cout_pad(int32_t cout);

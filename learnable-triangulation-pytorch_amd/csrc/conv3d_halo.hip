@@ -176,6 +176,8 @@ struct HaloArgs {
     int N, D, H, W, Cout, ldc, k_pad, flags;
     int tiles_d, tiles_h, tiles_w;   // per sample
     int xcd_pin;
+    const void* skip_x;   // lt_conv_skip_fwd (column-walk kernel only): the residual is W_skip . skip_x[voxel] (16 channels per voxel), or null
+    const void* skip_w;   // its weights in lt_conv_pack_weights_t32 order ([32][16] -> one fragment)
 };
 
 // per-column epilogue constants of the lane (column j*MF + lane % MF), loaded once per kernel, well before they are needed
@@ -963,7 +965,11 @@ __global__ __launch_bounds__(512) void conv3d_halo_persist_kernel(const HaloArgs
 //     units of tile i, out of a copy of the accumulators; the residual of tile i is requested in the middle of its own tap
 //     loop, after the pieces have consumed the previous one; tile coordinates advance by a stride (no divisions per tile).
 // F32OUT: LT_EPI_STORE_F32 (the mixed-precision training step) as its own instantiation -- the inference kernel keeps its registers and schedule.
-template <typename T, bool F32OUT>
+// SKIP: the residual is not read but COMPUTED -- the 1x1x1 skip convolution of a Res3DBlock whose channel count changes (v2v.py:33-42, 16 -> 32 at the
+// 64^3 level): one more MFMA per fragment on the 16 input channels of the lane's own voxel (a 16-byte load instead of the 32-byte residual), its
+// BatchNorm scale folded into the bf16 weights and its shift into `shift` by the caller.  The skip convolution's launch, its 32-channel output and that
+// tensor's read here all disappear (lt_conv_skip_fwd).
+template <typename T, bool F32OUT, bool SKIP>
 __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, const int total_cols) {
     constexpr int KS = 3, CIN = 32, CP = 32, TD = 4, TH = 8, TW = 8;
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, 9, 2> C;
@@ -1146,11 +1152,18 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
     const size_t vstep = (size_t)4 * a.W * ldc;          // fragment i -> th + 4
     const size_t dstep = (size_t)TD * a.H * a.W * ldc;   // next tile of the column
     const size_t rstep = has_res ? vstep : 0;            // without a residual every piece reads the zero page
+    constexpr int SKC = 16;                              // channels per voxel of the skip tensor
+    const size_t svoff0 = (((size_t)wave * a.H + (vl >> 3)) * a.W + (vl & 7)) * SKC + 8 * hh;
+    const size_t svstep = (size_t)4 * a.W * SKC, sdstep = (size_t)TD * a.H * a.W * SKC;
+    V16 wsk;
+    if constexpr (SKIP) wsk.u = *(const uint4*)((const T*)a.skip_w + (size_t)lane * 8);
 
     int n, h0, w0;
     col_of(blockIdx.x, n, h0, w0);
     size_t tbase = (((size_t)n * a.D * a.H + h0) * a.W + w0) * ldc + voff0;
+    size_t sbase = (((size_t)n * a.D * a.H + h0) * a.W + w0) * SKC + svoff0;
     size_t pbase = 0;                                    // output offset of the tile whose epilogue is pending
+    acc_t sacc;                                          // SKIP: W_skip . x_skip of the fragment whose pieces are being issued
 
     acc_t acc[SM], pacc[SM];
     uint4 rq[4], rqn[4];                                  // residual of the pending tile / of the tile being computed
@@ -1178,9 +1191,20 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
         });
         lds_read16<tap * C::SLAB>(fb[slot][0], bbase[g][0]);
     };
+    auto skip_mma = [&](auto ic) {                        // SKIP: fragment I of the pending tile (its 16 skip channels are in rq[I])
+        constexpr int I = decltype(ic)::value;
+        if constexpr (SKIP) {
+            V16 xs;
+            xs.u = rq[I];
+            acc_t z;
+#pragma unroll
+            for (int e = 0; e < NACC; ++e) z[e] = 0.f;
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wsk.h, xs.h, z, 0, 0, 0);
+        }
+    };
     auto epi_piece = [&](auto pc) {                       // piece p of the pending tile: fragment p / 2, 8-channel run p % 2
         constexpr int p = decltype(pc)::value, I = p >> 1, Q = p & 1;
-        const unsigned rr[4] = {rq[p].x | no_res, rq[p].y | no_res, rq[p].z | no_res, rq[p].w | no_res};
+        const unsigned rr[4] = {rq[SKIP ? 0 : p].x | no_res, rq[SKIP ? 0 : p].y | no_res, rq[SKIP ? 0 : p].z | no_res, rq[SKIP ? 0 : p].w | no_res};
         unsigned o[4];
         float vf[F32OUT ? 8 : 1];
 #pragma unroll
@@ -1188,8 +1212,8 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
             const int e = 8 * Q + 2 * d;
             float v0 = fmaf(pacc[I][e], esc[e], esf[e]);
             float v1 = fmaf(pacc[I][e + 1], esc[e + 1], esf[e + 1]);
-            v0 = epi_apply(v0, fl, __uint_as_float(rr[d] << 16));
-            v1 = epi_apply(v1, fl, __uint_as_float(rr[d] & 0xffff0000u));
+            v0 = epi_apply(v0, fl, SKIP ? sacc[e] : __uint_as_float(rr[d] << 16));
+            v1 = epi_apply(v1, fl, SKIP ? sacc[e + 1] : __uint_as_float(rr[d] & 0xffff0000u));
             if constexpr (F32OUT) { vf[2 * d] = v0; vf[2 * d + 1] = v1; }
             else o[d] = pack_bf16x2(v0, v1);
         }
@@ -1219,6 +1243,7 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
 #pragma unroll
             for (int i = 0; i < SM; ++i) Mma<T, MF>::run(acc[i], fb[slot][0], fa[slot][i]);   // D[co][voxel]: weights first
 #ifndef LT_ABL_NO_EPI
+            if constexpr (EPI && SKIP && (u == 0 || u == 12)) skip_mma(std::integral_constant<int, u / 12>{});   // two units in front of the pieces that use it
             if constexpr (EPI && u >= 2 && u < 26 && (u - 2) % 6 == 0) epi_piece(std::integral_constant<int, (u - 2) / 6>{});
 #endif
             if constexpr (u == 0) {
@@ -1228,17 +1253,32 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
                 // also count in lgkmcnt, which the fragment pipeline counts by hand
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 typedef const __attribute__((address_space(1))) u32x4* gq_t;
+                if constexpr (SKIP) {                            // the lane's own voxel of fragments 0 and 1: 8 of the 16 skip channels each (half hh)
+                    const unsigned long long sb = (unsigned long long)(size_t)((const T*)a.skip_x + sbase);
+                    static_for<0, 2>([&](auto pc) {
+                        constexpr int p = decltype(pc)::value;
+                        const u32x4 rv = *(gq_t)(sb + (p * svstep) * sizeof(T));
+                        rqn[p] = make_uint4(rv[0], rv[1], rv[2], rv[3]);
+                    });
+                } else {
                 const unsigned long long rb = has_res ? (unsigned long long)(size_t)((const T*)a.res + tbase) : zp_bits;
                 static_for<0, 4>([&](auto pc) {
                     constexpr int p = decltype(pc)::value;
                     const u32x4 rv = *(gq_t)(rb + ((p >> 1) * rstep + 16 * (p & 1)) * sizeof(T));
                     rqn[p] = make_uint4(rv[0], rv[1], rv[2], rv[3]);
                 });
+                }
             }
         });
     };
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the weight slabs (and the constants)
+    {   // the pointers the tile loop uses, in SGPRs HERE: left to itself hipcc fetches a.y from the kernel arguments right in front of the loop and puts the
+        // s_waitcnt lgkmcnt(0) for it in front of the first store INSIDE the loop -- where it drains the hand-counted fragment pipeline once per tile
+        const void* yp_ = a.y;
+        const void* sx_ = SKIP ? a.skip_x : a.res;
+        asm volatile("" ::"s"(yp_), "s"(sx_));
+    }
 #ifdef LT_TRACE
     long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
     const long long tr_begin = LT_CLKH();
@@ -1280,16 +1320,21 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
         pbase = tbase;
         ++sidx;
         tbase += dstep;
+        sbase += sdstep;
         if (++k == tpc) {                                // next column
             k = 0; ++sidx;
             if (++icol < ncol) {
                 col_of(blockIdx.x + icol * gridDim.x, n, h0, w0);
                 tbase = (((size_t)n * a.D * a.H + h0) * a.W + w0) * ldc + voff0;
+                sbase = (((size_t)n * a.D * a.H + h0) * a.W + w0) * SKC + svoff0;
             }
         }
         LT_TRC(6)
     }
-    static_for<0, 4>([&](auto pc) { epi_piece(pc); });   // the last tile's epilogue has nothing to hide under
+    static_for<0, 4>([&](auto pc) {                      // the last tile's epilogue has nothing to hide under
+        if constexpr ((decltype(pc)::value & 1) == 0) skip_mma(std::integral_constant<int, decltype(pc)::value / 2>{});
+        epi_piece(pc);
+    });
 #ifdef LT_TRACE
     if (wave == 0 && lane == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64) {   // same record as the persistent kernel
         long long* o = g_trace_h + (blockIdx.x >> 3) * 8;
@@ -1782,12 +1827,16 @@ int launch_halo_col(const HaloArgs& a, hipStream_t s) {
     const int n_cu = lt::device_cu_count8();
     const int total_cols = a.N * a.tiles_h * a.tiles_w;  // % 8 == 0 (checked by the caller)
     const int grid = total_cols < n_cu ? total_cols : n_cu;
-    if (a.flags & LT_EPI_STORE_F32) {
-        auto kern = conv3d_halo_col_kernel<T, true>;
+    if (a.skip_x) {
+        auto kern = conv3d_halo_col_kernel<T, false, true>;
+        LT_OPT_IN_LDS(kern, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, total_cols);
+    } else if (a.flags & LT_EPI_STORE_F32) {
+        auto kern = conv3d_halo_col_kernel<T, true, false>;
         LT_OPT_IN_LDS(kern, 160 * 1024);
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, total_cols);
     } else {
-        auto kern = conv3d_halo_col_kernel<T, false>;
+        auto kern = conv3d_halo_col_kernel<T, false, false>;
         LT_OPT_IN_LDS(kern, 160 * 1024);
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, s, a, total_cols);
     }
@@ -1834,7 +1883,9 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     a.N = c.N; a.D = c.D; a.H = c.H; a.W = c.W; a.Cout = c.Cout; a.ldc = c.ldc; a.k_pad = c.k_pad; a.flags = c.flags;
     a.tiles_d = c.D / 4; a.tiles_h = c.H / 8; a.tiles_w = c.W / 8;
     a.xcd_pin = (c.N % 8 == 0) ? 1 : 0;
+    a.skip_x = c.skip_x; a.skip_w = c.skip_w;
     const bool bf = dtype == LT_BF16, f8 = dtype == LT_FP8;
+    if (c.skip_x && (f32_out || c.res || (c.flags & LT_EPI_RELU_PRE) || !bf)) return LT_ERR_UNSUPPORTED;
 #define HALO_CASE_L(T_, KS_, CIN_, CP_, TPC_, NBUF_, PD_, LDR_)                                  \
     if (ks == KS_ && c.Cin == CIN_ && cout_pad == CP_) {                                        \
         int rc = launch_halo<T_, KS_, CIN_, CP_, 4, 8, 8, TPC_, NBUF_, PD_, LDR_>(a, s);        \
@@ -1855,10 +1906,12 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
             int rc = launch_halo_col<bf16_t>(a, s);
             return rc == LT_OK ? 1 : rc;
         }
+        if (c.skip_x) return LT_ERR_UNSUPPORTED;
         if (f32_out) return 0;
         int rc = launch_halo_persist<bf16_t, 32, 32>(a, s);
         return rc == LT_OK ? 1 : rc;
     }
+    if (c.skip_x) return LT_ERR_UNSUPPORTED;             // the computed residual exists in the column-walk kernel only
     if (f32_out) return 0;
     // halo-only LDS, weights as fragments from global memory (lt_conv_pack_weights_t32): 64 -> 64, 32 -> 64, 128 -> 128
     if (bf && ks == 3 && c.Cout == cout_pad && c.ldc % 8 == 0 && a.wfrag && !getenv("LT_HALO_NO_WREG")) {

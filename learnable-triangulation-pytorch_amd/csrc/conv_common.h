@@ -35,6 +35,8 @@ struct ConvArgs {
     int tiles_n;  // cout_pad / BN
     int stages;   // requested LDS-DMA ring depth (0 = auto)
     PhaseArg phase[LT_CONV_MAX_PHASES];
+    const void* skip_x;   // lt_conv_skip_fwd: the residual is computed as W_skip . skip_x[voxel] (conv3d_halo_col_kernel only), else null
+    const void* skip_w;
 };
 
 union V16 {

@@ -312,8 +312,8 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
 
 }  // namespace
 
-extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bias, const float* scale, const float* shift,
-                           const void* residual, void* y, void* stream) {
+static int conv_fwd_impl(const lt_conv_desc* d, const void* x, const float* bias, const float* scale, const float* shift,
+                         const void* residual, const lt_conv_skip* skip, void* y, void* stream) {
     LT_REQUIRE(d && x && y, LT_ERR_INVALID, "lt_conv_fwd: null argument");
     LT_REQUIRE(d->dtype == LT_F32 || d->dtype == LT_BF16 || d->dtype == LT_FP8, LT_ERR_INVALID, "lt_conv_fwd: bad dtype %d", d->dtype);
     const int vec = d->dtype == LT_F32 ? 4 : d->dtype == LT_BF16 ? 8 : 16;
@@ -345,6 +345,7 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bi
     a.OD = d->OD; a.OH = d->OH; a.OW = d->OW;
     a.osd = d->out_stride[0]; a.osh = d->out_stride[1]; a.osw = d->out_stride[2];
     a.Cout = d->Cout; a.ldc = d->ldc; a.k_pad = d->k_pad; a.flags = d->flags; a.M = (int)M; a.tiles_n = 1; a.stages = d->stages;
+    a.skip_x = skip ? skip->x : nullptr; a.skip_w = skip ? skip->weight_frag : nullptr;
     int max_taps = 0;
     for (int p = 0; p < d->nphase; ++p) {
         const lt_conv_phase& ph = d->phase[p];
@@ -358,6 +359,14 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bi
     }
     LT_REQUIRE(max_taps <= 2048, LT_ERR_UNSUPPORTED, "lt_conv_fwd: too many taps (%d)", max_taps);
     hipStream_t s = (hipStream_t)stream;
+    if (skip) {   // the computed residual exists in ONE kernel: fail loudly everywhere else
+        LT_REQUIRE(skip->x && skip->weight_frag && skip->cin == 16 && d->dtype == LT_BF16 && !residual && d->Cin == 32 && d->Cout == 32 && d->cout_pad == 32,
+                   LT_ERR_UNSUPPORTED, "lt_conv_skip_fwd: bf16 3x3x3 32 -> 32 with a 16-channel skip tensor only (cin %d, Cin %d, Cout %d)", skip->cin, d->Cin, d->Cout);
+        const int rc = conv3d_halo_try(LT_BF16, a, d->cout_pad, d->nphase, true, s);
+        LT_REQUIRE(rc == 1, rc < 0 ? rc : LT_ERR_UNSUPPORTED, "lt_conv_skip_fwd: this shape is not covered by the column-walk halo kernel (N %d, %d x %d x %d)",
+                   d->N, d->D, d->H, d->W);
+        return LT_OK;
+    }
     if (d->dtype == LT_F32) return dispatch<float>(a, d->cout_pad, d->nphase, max_taps, d->tile, s);
     if (d->dtype == LT_FP8) {
         // the 3^3 layers of the 64^3 / 32^3 levels: input halo in LDS (conv3d_halo.hip); bf16 stores only
@@ -370,6 +379,17 @@ extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bi
         return conv2_dispatch(LT_FP8, a, d->cout_pad, d->nphase, max_taps, d->tile, s);
     }
     return dispatch<bf16_t>(a, d->cout_pad, d->nphase, max_taps, d->tile, s);
+}
+
+extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bias, const float* scale, const float* shift,
+                           const void* residual, void* y, void* stream) {
+    return conv_fwd_impl(d, x, bias, scale, shift, residual, nullptr, y, stream);
+}
+
+extern "C" int lt_conv_skip_fwd(const lt_conv_desc* d, const void* x, const float* bias, const float* scale, const float* shift,
+                                const lt_conv_skip* skip, void* y, void* stream) {
+    LT_REQUIRE(skip, LT_ERR_INVALID, "lt_conv_skip_fwd: null skip descriptor");
+    return conv_fwd_impl(d, x, bias, scale, shift, nullptr, skip, y, stream);
 }
 
 extern "C" int lt_conv_cout_pad(int32_t cout) {

@@ -264,14 +264,47 @@ class PlanBuilder:
         self.last_info = info or {}        # lt_train.TrainTape reads the device buffers of the op it has just recorded
         self.ops.append((fn, meta))
 
+    def can_conv_skip(self, x_shape, weight, skip_shape, skip_weight):
+        """True when lt_conv_skip_fwd covers this convolution + computed residual: the second 3x3x3 convolution (32 -> 32) of a Res3DBlock whose skip
+        connection is a 1x1x1 convolution of a 16-channel tensor (v2v.py:20-42, :76), bf16 plan over build-time weights, on a shape the column-walk halo
+        kernel takes -- the conditions of conv3d_halo_try, mirrored (the C side has no fallback and fails loudly).  LT_NO_CONV_SKIP=1: off (A/B)."""
+        if (self.dtype != torch.bfloat16 or self.out_dtype != torch.bfloat16 or self.live_weights or self.tile_override or
+                any(os.environ.get(k) for k in ("LT_NO_CONV_SKIP", "LT_HALO_NO_COL", "LT_HALO_NO_PERSIST", "LT_CONV_NO_HALO"))):
+            return False
+        if tuple(weight.shape) != (32, 32, 3, 3, 3) or tuple(skip_weight.shape) != (32, 16, 1, 1, 1):
+            return False
+        N, D, Hh, W, Cin = x_shape
+        if Cin != 32 or tuple(skip_shape) != (N, D, Hh, W, 16) or D % 4 or Hh % 8 or W % 8 or D // 4 < 2:
+            return False
+        nblk, cols = N * (D // 4) * (Hh // 8) * (W // 8), N * (Hh // 8) * (W // 8)
+        return nblk >= 1024 and nblk % 8 == 0 and cols % 8 == 0 and cols >= 256 and N * D * Hh * W * 32 < 2 ** 31
+
     def conv(self, x, weight, bias=None, bn=None, stride=1, pad=0, transposed=False, relu=False, relu_pre=False,
-             residual=None, out_f32=False, out=None, sigmoid=False, output_padding=0, residual_f32=False):
+             residual=None, out_f32=False, out=None, sigmoid=False, output_padding=0, residual_f32=False, skip=None):
         """x: Act.  Returns the output Act [N, OD, OH, OW, Cout].  ``residual_f32`` (bf16 plans, with ``out_f32``): the residual is an fp32 tensor
-        (LT_EPI_RES_F32: the training tape's input-gradient accumulation)."""
+        (LT_EPI_RES_F32: the training tape's input-gradient accumulation).  ``skip`` = (Act, weight, bias, bn) of a 1x1x1 skip convolution whose output
+        is this convolution's residual (lt_conv_skip_fwd; only where ``can_conv_skip`` says so): the residual is computed inside the launch."""
         flags = ((H.EPI_RELU_POST if relu else 0) | (H.EPI_RELU_PRE if relu_pre else 0) | (H.EPI_STORE_F32 if out_f32 else 0)
                  | (H.EPI_SIGMOID if sigmoid else 0) | (H.EPI_RES_F32 if residual_f32 else 0))
         assert not residual_f32 or (out_f32 and residual is not None and self.dtype in (torch.bfloat16, torch.float8_e4m3fn))
         spec = make_conv_spec(weight, bias, bn, x.shape, stride, pad, self.dtype, transposed, flags, output_padding)
+        skip_info = None
+        if skip is not None:
+            sx, sw, sb, sbn = skip
+            assert residual is None and not relu_pre and not out_f32 and out is None and self.can_conv_skip(x.shape, weight, sx.shape, sw)
+            ss = make_conv_spec(sw, sb, sbn, sx.shape, 1, 0, self.dtype, False, 0)
+            assert ss.cout_pad == spec.cout_pad == 32
+            # the skip branch's BatchNorm: scale into its weights (fp32 product, ONE bf16 rounding), (bias * scale + shift) into this convolution's shift
+            wfold = (ss.phases[0].weight * ss.scale[:, None]).to(self.dtype)
+            spec.shift = spec.shift + ss.bias * ss.scale + ss.shift
+            wsk = self.const(wfold, self.dtype)
+            wfr = torch.empty(32 * 16, dtype=self.dtype, device=wsk.device)
+            if not self.dry_run:
+                H.check(H.lib().lt_conv_pack_weights_t32(wsk.data_ptr(), 32, ss.k_pad, 16, 1, wfr.data_ptr(), H.cur_stream()), "lt_conv_pack_weights_t32")
+            sk = H.ConvSkip()
+            sk.x, sk.cin, sk.weight_frag = sx.t.data_ptr(), 16, wfr.data_ptr()
+            self.keep += [wfr, sx.t, sk]
+            skip_info = {"x": sx, "w": wfold[:, :16].float(), "desc": sk}
         S = self.splitk_slices(spec, weight, transposed, out_f32, sigmoid, out)
         if S > 1:
             return self._conv_splitk(x, weight, spec, S, residual)
@@ -339,10 +372,20 @@ class PlanBuilder:
         esz = torch.empty((), dtype=self.dtype).element_size()
         nbytes = (x.t.numel() + y.t.numel() + (residual.t.numel() if residual is not None else 0)) * esz + \
             sum(p.weight.numel() for p in spec.phases) * esz
+        info = {"spec": spec, "x": x, "y": y, "res": residual, "wdev": wdevs, "bias_dev": bi, "scale_dev": sc, "shift_dev": sh}
+        if skip_info is not None:
+            macs += spec.N * spec.Do * spec.Ho * spec.Wo * spec.Cout * 16
+            self.flops += 2 * spec.N * spec.Do * spec.Ho * spec.Wo * spec.Cout * 16
+            nbytes += skip_info["x"].t.numel() * esz
+            info["skip"] = skip_info
+            self._add(lambda s, d=d, xp=x.t.data_ptr(), bip=bi.data_ptr(), scp=sc.data_ptr(), shp=sh.data_ptr(), sk=skip_info["desc"], yp=y.t.data_ptr():
+                      H.check(lib.lt_conv_skip_fwd(C.byref(d), xp, bip, scp, shp, C.byref(sk), yp, s), "lt_conv_skip_fwd"),
+                      "conv", label + " + skip conv1x1x1 16->32", 2 * macs, nbytes, info)
+            return y
         self._add(lambda s, d=d, xp=x.t.data_ptr(), bip=bi.data_ptr(), scp=sc.data_ptr(), shp=sh.data_ptr(),
                   rp=H.ptr(residual.t) if residual is not None else None, yp=y.t.data_ptr():
                   H.check(lib.lt_conv_fwd(C.byref(d), xp, bip, scp, shp, rp, yp, s), "lt_conv_fwd"),
-                  "conv", label, 2 * macs, nbytes, {"spec": spec, "x": x, "y": y, "res": residual, "wdev": wdevs, "bias_dev": bi, "scale_dev": sc, "shift_dev": sh})
+                  "conv", label, 2 * macs, nbytes, info)
         return y
 
     # ---- split-K for the tiny levels of V2V ---------------------------------------------------------------------------------------

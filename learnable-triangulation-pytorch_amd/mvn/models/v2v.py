@@ -40,6 +40,15 @@ class Res3DBlock(nn.Module):  # relu(BN(conv(relu(BN(conv x)))) + skip(x)) (refe
     def record(self, b, x):
         r = self.res_branch
         skip = x
+        if len(self.skip_con) and hasattr(b, "can_conv_skip") and b.can_conv_skip(tuple(x.shape[:-1]) + (r[0].weight.shape[0],), r[3].weight, x.shape,
+                                                                                   self.skip_con[0].weight):
+            # the 16 -> 32 block of the 64^3 level in bf16 plans: the skip convolution rides in the second convolution's launch (lt_conv_skip_fwd) --
+            # its own launch, its 32-channel output and the read of that tensor disappear
+            y = b.conv(x, r[0].weight, r[0].bias, bn_tuple(r[1]), stride=1, pad=1, relu=True)
+            z = b.conv(y, r[3].weight, r[3].bias, bn_tuple(r[4]), stride=1, pad=1, relu=True,
+                       skip=(x, self.skip_con[0].weight, self.skip_con[0].bias, bn_tuple(self.skip_con[1])))
+            b.release(y)
+            return z
         if len(self.skip_con):
             skip = b.conv(x, self.skip_con[0].weight, self.skip_con[0].bias, bn_tuple(self.skip_con[1]))
         y = b.conv(x, r[0].weight, r[0].bias, bn_tuple(r[1]), stride=1, pad=1, relu=True)

@@ -922,6 +922,82 @@ def test_bottleneck_fused(C, P, N, Hh, W, monkeypatch):
     assert float((y.float() - y3.float()).pow(2).mean().sqrt() / y3.float().pow(2).mean().sqrt()) < 2e-3
 
 
+@pytest.mark.parametrize("N,D,Hh,W", [(4, 16, 64, 64), (16, 8, 64, 32), (1, 64, 128, 128)])
+def test_conv3d_with_computed_skip_residual(N, D, Hh, W, monkeypatch):
+    """lt_conv_skip_fwd (round 5; v2v.py:20-42, the 16 -> 32 Res3DBlock of :76): relu(bn2(conv3x3x3(y)) + bn_s(conv1x1x1_s(x))) with the skip convolution computed
+    inside the second convolution's launch (column-walk halo kernel), against (a) torch fp32 on bf16-rounded operands with the skip branch's BatchNorm scale
+    folded into its weights before the ONE bf16 rounding -- what the plan builder does -- and (b) the two launches it replaces (skip convolution stored in bf16,
+    then read as the residual: one rounding apart).  Shapes: the smallest the column walk takes, a flat one (two tiles per column), one big sample."""
+    g = torch.Generator().manual_seed(8100 + N + D)
+    y = torch.relu(torch.randn(N, 32, D, Hh, W, generator=g))
+    x = torch.relu(torch.randn(N, 16, D, Hh, W, generator=g))
+    w = torch.randn(32, 32, 3, 3, 3, generator=g) / (27 * 32) ** 0.5
+    ws = torch.randn(32, 16, 1, 1, 1, generator=g) / 4.0
+    bias, bs = torch.randn(32, generator=g) * 0.1, torch.randn(32, generator=g) * 0.1
+    bn, bns = _bn(32, g), _bn(32, g)
+    ya, xa = E.Act(to_cl(y, None, torch.bfloat16)), E.Act(to_cl(x, None, torch.bfloat16))
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("LT_NO_CONV_SKIP", raising=False)
+        else:
+            monkeypatch.setenv("LT_NO_CONV_SKIP", "1")
+        b = E.PlanBuilder(DEV, torch.bfloat16)
+        assert b.can_conv_skip(ya.shape, w, xa.shape, ws) == fused
+        if fused:
+            z = b.conv(ya, w, bias, bn, pad=1, relu=True, skip=(xa, ws, bs, bns))
+        else:
+            r = b.conv(xa, ws, bs, bns)
+            z = b.conv(ya, w, bias, bn, pad=1, relu=True, residual=r)
+        plan = b.finish()
+        assert len(plan.ops) == (1 if fused else 2)
+        plan.run_eager(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return from_cl(z.t, 3)
+    zf = run(True)
+    rd = bf16_round
+    sc_s = bns[0] / torch.sqrt(bns[3] + 1e-5)
+    ws_fold = rd(ws * sc_s.view(-1, 1, 1, 1, 1))
+    skip_ref = F.conv3d(rd(x), ws_fold) + (bs * sc_s + bns[1] - bns[2] * sc_s).view(1, -1, 1, 1, 1)
+    ref = torch.relu(_bn_ref(F.conv3d(rd(y), rd(w), bias, 1, 1), bn) + skip_ref)
+    name = "conv_skip/%dx%dx%dx%d" % (N, D, Hh, W)
+    check(name + "/vs_torch", zf, ref, 1.5e-2)
+    z2 = run(False)
+    check(name + "/vs_two_launches", zf, z2, 2e-2)
+    rms = float((zf.float() - z2.float()).pow(2).mean().sqrt() / z2.float().pow(2).mean().sqrt())
+    record(name + "/rms_vs_two_launches", rms)
+    assert rms < 5e-3          # one tap / one K half / one fragment of the skip wrong is far above the branch's bf16 rounding
+    b = E.PlanBuilder(DEV, torch.bfloat16)   # shapes the column walk does not take keep the two launches: the builder must say so
+    assert not b.can_conv_skip((1, 16, 32, 32, 32), w, (1, 16, 32, 32, 16), ws) and not b.can_conv_skip((4, 4, 64, 64, 32), w, (4, 4, 64, 64, 16), ws)
+
+
+def test_conv_skip_refuses_what_it_does_not_cover():
+    """lt_conv_skip_fwd has no fallback kernel: a shape outside the column walk (4 columns of tiles) or another skip width must come back as
+    LT_ERR_UNSUPPORTED (-2, include/lt_hip.h), not as a silently different path."""
+    import ctypes as C
+    d = H.ConvDesc()
+    d.dtype = H.LT_BF16
+    d.N, d.D, d.H, d.W, d.Cin = 1, 8, 16, 16, 32
+    d.Do, d.Ho, d.Wo = 8, 16, 16
+    d.stride = H.i3((1, 1, 1)); d.pad = H.i3((1, 1, 1)); d.OD, d.OH, d.OW = 8, 16, 16; d.out_stride = H.i3((1, 1, 1))
+    d.Cout, d.ldc, d.cout_pad, d.k_pad = 32, 32, 32, 27 * 32
+    d.nphase, d.flags, d.tile, d.stages = 1, H.EPI_RELU_POST, 0, 0
+    wdev = torch.zeros(32, 27 * 32, dtype=torch.bfloat16, device=DEV)
+    taps = torch.tensor([(a, bb, c, ((a * 16 + bb) * 16 + c) * 32) for a in range(3) for bb in range(3) for c in range(3)], dtype=torch.int32, device=DEV)
+    d.phase[0].weight, d.phase[0].taps, d.phase[0].ntaps = wdev.data_ptr(), taps.data_ptr(), 27
+    xin = torch.zeros(1, 8, 16, 16, 32, dtype=torch.bfloat16, device=DEV)
+    sx = torch.zeros(1, 8, 16, 16, 16, dtype=torch.bfloat16, device=DEV)
+    wf = torch.zeros(512, dtype=torch.bfloat16, device=DEV)
+    y = torch.zeros(1, 8, 16, 16, 32, dtype=torch.bfloat16, device=DEV)
+    zero = torch.zeros(32, device=DEV); one = torch.ones(32, device=DEV)
+    for cin in (16, 32):
+        sk = H.ConvSkip()
+        sk.x, sk.cin, sk.weight_frag = sx.data_ptr(), cin, wf.data_ptr()
+        rc = H.lib().lt_conv_skip_fwd(C.byref(d), xin.data_ptr(), zero.data_ptr(), one.data_ptr(), zero.data_ptr(), C.byref(sk), y.data_ptr(), H.cur_stream())
+        assert rc == -2, rc
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("N,Hh,W", [(1, 8, 16), (3, 24, 32), (2, 16, 48), (9, 16, 16), (4, 96, 96)])
 def test_bottleneck_with_downsample_fused(N, Hh, W, monkeypatch):
     """lt_bottleneck_ds_fwd (round 5; pose_resnet.py:75-95 with the `downsample` branch of :196-206: the first block of ResNet layer1, 64 -> 64 -> 256) against

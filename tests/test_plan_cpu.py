@@ -306,6 +306,46 @@ def test_first_bottleneck_of_layer1_with_its_downsample_branch_is_one_launch_in_
             monkeypatch.delenv(env)
 
 
+def test_res3d_block_with_a_skip_convolution_records_the_skip_inside_the_second_convolution(monkeypatch):
+    """Round 5: the 16 -> 32 Res3DBlock of V2V's 64^3 level (v2v.py:20-42, :76) in bf16 plans, on shapes the column-walk halo kernel takes: two launches
+    (conv 16 -> 32, conv 32 -> 32 + computed skip: lt_conv_skip_fwd) instead of three.  The recorded block must be the function the three launches
+    compute up to the rounding of the skip branch (stored in bf16 there; BatchNorm scale folded into its bf16 weights and added in fp32 here), and equal
+    the fp32 module within the plan's rounding.  Small batches / volumes (too few tile columns), fp32 plans and LT_NO_CONV_SKIP=1 keep the three launches."""
+    import lt_engine as E
+    from mvn.models.v2v import Res3DBlock
+    torch.manual_seed(21)
+    blk = Res3DBlock(16, 32).eval()
+    for bn in [mm for mm in blk.modules() if isinstance(mm, torch.nn.BatchNorm3d)]:
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.1)
+    x = torch.relu(torch.randn(4, 16, 64, 64, 16))        # N, D, H, W, C: 256 columns of four tiles
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("LT_NO_CONV_SKIP", "1")
+        b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
+        inp = b.alloc(tuple(x.shape))
+        y = blk.record(b, inp)
+        plan = b.finish()
+        labels = [meta["label"] for _, meta in plan.ops]
+        assert labels == (["conv3x3x3 16->32 @4x16x64x64", "conv3x3x3 32->32 @4x16x64x64 + skip conv1x1x1 16->32"] if fused else
+                          ["conv1x1x1 16->32 @4x16x64x64", "conv3x3x3 16->32 @4x16x64x64", "conv3x3x3 32->32 @4x16x64x64"]), labels
+        inp.t.copy_(x)
+        run_plan_on_cpu(plan)
+        outs[fused] = y.t.float().clone()
+    monkeypatch.delenv("LT_NO_CONV_SKIP")
+    with torch.no_grad():
+        xb = x.to(torch.bfloat16).float().permute(0, 4, 1, 2, 3)
+        ref = torch.relu(blk.res_branch(xb) + blk.skip_con(xb)).permute(0, 2, 3, 4, 1)   # the container has no forward of its own (v2v.py:37-42)
+    scale = float(ref.abs().max())
+    assert float((outs[True] - outs[False]).abs().max()) <= 2.0 ** -6 * scale
+    e_f, e_s = float((outs[True] - ref).abs().max()), float((outs[False] - ref).abs().max())
+    assert e_f <= 3e-2 * scale and e_f <= 1.5 * e_s + 1e-3, (e_f, e_s, scale)
+    for shape, dt in (((1, 64, 64, 64, 16), torch.bfloat16), ((4, 16, 64, 64, 16), torch.float32), ((4, 4, 64, 64, 16), torch.bfloat16)):
+        b = E.PlanBuilder("cpu", dt, dry_run=True)
+        blk.record(b, b.alloc(shape))
+        assert len(b.finish().ops) == 3
+
+
 def test_expand_reduce_seam_fusion_of_layer3_is_recorded_and_equals_the_separate_launches(monkeypatch):
     """Round 5: bf16 plans run the seam between two identity Bottleneck blocks of ResNet layer3 (1024 / 256 wide) as ONE lt_expand_reduce_fwd -- the
     expand of block i (+ residual + ReLU) and the reduce of block i + 1.  The recorded chain must be the same function as the separate lt_conv_fwd
