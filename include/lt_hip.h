@@ -160,6 +160,22 @@ typedef struct lt_conv_skip {
 } lt_conv_skip;
 int lt_conv_skip_fwd(const lt_conv_desc* desc, const void* x, const float* bias, const float* scale, const float* shift,
                      const lt_conv_skip* skip, void* y, void* stream);
+/* A 1x1 convolution over the channel concatenation of TWO tensors, the second one optionally subsampled:
+ *   acc[m][co] = sum_{ci < Cin} x[m][ci] w[co][ci]  +  sum_{cj < second.cin} x2[n, oh * s, ow * s, cj] w[co][Cin + cj]        (m = (n, oh, ow))
+ * followed by lt_conv_fwd's epilogue.  It is the last 1x1 convolution of a Bottleneck block TOGETHER with the block's `downsample` branch
+ * (mvn/models/pose_resnet.py:75-95: out = bn3(conv3(t2)); residual = downsample(x); out += residual; relu -- the first blocks of layer2-4, whose
+ * downsample is a stride-2 1x1 convolution + BatchNorm of the block input): the caller folds both BatchNorm scales into the two weight blocks (fp32
+ * product, one bf16 rounding), passes scale = NULL and shift = shift3 + shift_d, and the downsample's launch, its C-channel output and the read of
+ * that tensor as the residual disappear.  desc: the pointwise convolution over x ([N][Ho][Wo][Cin], one phase, one tap) with k_pad = Cin + second.cin
+ * and weights [cout_pad][k_pad] = [w3 | w_d], ALSO given in fragment layout 3 (lt_conv_pack_weights32); bf16, Cin % 32 == 0, second.cin % 32 == 0,
+ * k_pad % 64 == 0, cout_pad % 256 == 0; second: x2 [N][H][W][cin] with H = stride * Ho, W = stride * Wo, stride 1 or 2.  Anything else:
+ * LT_ERR_UNSUPPORTED (one kernel, no fallback). */
+typedef struct lt_conv_cat2 {
+    const void* x;
+    int32_t cin, H, W, stride;
+} lt_conv_cat2;
+int lt_conv_cat2_fwd(const lt_conv_desc* desc, const void* x, const lt_conv_cat2* second, const float* bias, const float* scale, const float* shift,
+                     const void* residual, void* y, void* stream);
 /* weight padding rule (every tile's N divides it): cout_pad = 16 if Cout <= 16, 32 if <= 32, 64 if <= 64,
  * else Cout rounded up to a multiple of 128; bias/scale/shift arrays hold cout_pad floats. */
 int lt_conv_cout_pad(int32_t cout);

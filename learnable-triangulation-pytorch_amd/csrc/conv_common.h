@@ -37,6 +37,10 @@ struct ConvArgs {
     PhaseArg phase[LT_CONV_MAX_PHASES];
     const void* skip_x;   // lt_conv_skip_fwd: the residual is computed as W_skip . skip_x[voxel] (conv3d_halo_col_kernel only), else null
     const void* skip_w;
+    // lt_conv_cat2_fwd (conv_igemm7 MODE 3): a 1x1 convolution over the channel concatenation of TWO tensors -- K steps below Cin / 32 read x, the rest read
+    // x2 at pixel (n, oh * s2, ow * s2) of its H2 x W2 map (Cin2 channels per pixel); null = off
+    const void* x2;
+    int Cin2, H2, W2, s2;
 };
 
 union V16 {

@@ -313,7 +313,7 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
 }  // namespace
 
 static int conv_fwd_impl(const lt_conv_desc* d, const void* x, const float* bias, const float* scale, const float* shift,
-                         const void* residual, const lt_conv_skip* skip, void* y, void* stream) {
+                         const void* residual, const lt_conv_skip* skip, const lt_conv_cat2* cat2, void* y, void* stream) {
     LT_REQUIRE(d && x && y, LT_ERR_INVALID, "lt_conv_fwd: null argument");
     LT_REQUIRE(d->dtype == LT_F32 || d->dtype == LT_BF16 || d->dtype == LT_FP8, LT_ERR_INVALID, "lt_conv_fwd: bad dtype %d", d->dtype);
     const int vec = d->dtype == LT_F32 ? 4 : d->dtype == LT_BF16 ? 8 : 16;
@@ -346,6 +346,7 @@ static int conv_fwd_impl(const lt_conv_desc* d, const void* x, const float* bias
     a.osd = d->out_stride[0]; a.osh = d->out_stride[1]; a.osw = d->out_stride[2];
     a.Cout = d->Cout; a.ldc = d->ldc; a.k_pad = d->k_pad; a.flags = d->flags; a.M = (int)M; a.tiles_n = 1; a.stages = d->stages;
     a.skip_x = skip ? skip->x : nullptr; a.skip_w = skip ? skip->weight_frag : nullptr;
+    a.x2 = cat2 ? cat2->x : nullptr; a.Cin2 = cat2 ? cat2->cin : 0; a.H2 = cat2 ? cat2->H : 0; a.W2 = cat2 ? cat2->W : 0; a.s2 = cat2 ? cat2->stride : 0;
     int max_taps = 0;
     for (int p = 0; p < d->nphase; ++p) {
         const lt_conv_phase& ph = d->phase[p];
@@ -367,6 +368,20 @@ static int conv_fwd_impl(const lt_conv_desc* d, const void* x, const float* bias
                    d->N, d->D, d->H, d->W);
         return LT_OK;
     }
+    if (cat2) {   // one kernel (conv_igemm7, pointwise over two sources): fail loudly everywhere else
+        const bool pointwise = d->nphase == 1 && d->phase[0].ntaps == 1 && d->D == 1 && d->Do == 1 && d->OD == 1 && d->H == d->Ho && d->W == d->Wo &&
+                               d->OH == d->Ho && d->OW == d->Wo && d->stride[1] == 1 && d->stride[2] == 1 && d->pad[1] == 0 && d->pad[2] == 0 &&
+                               d->out_stride[1] == 1 && d->out_stride[2] == 1 && !d->phase[0].out_off[1] && !d->phase[0].out_off[2];
+        LT_REQUIRE(cat2->x && d->dtype == LT_BF16 && pointwise && d->Cin % 32 == 0 && cat2->cin % 32 == 0 && d->k_pad == d->Cin + cat2->cin && d->k_pad % 64 == 0 &&
+                       d->cout_pad % 256 == 0 && d->phase[0].weight_frag_layout == 3 && d->phase[0].weight_frag && (cat2->stride == 1 || cat2->stride == 2) &&
+                       cat2->H == d->Ho * cat2->stride && cat2->W == d->Wo * cat2->stride && !(d->flags & (LT_EPI_STORE_F32 | LT_EPI_SIGMOID)) &&
+                       (long long)d->N * cat2->H * cat2->W * cat2->cin < (1ll << 31),
+                   LT_ERR_UNSUPPORTED, "lt_conv_cat2_fwd: bf16 1x1 convolution, Cin %d + %d (multiples of 32, k_pad %d their sum), cout_pad %d (%% 256), fragment layout 3, "
+                   "second map %d x %d = stride %d x the output's", d->Cin, cat2->cin, d->k_pad, d->cout_pad, cat2->H, cat2->W, cat2->stride);
+        const int rc = conv7_try(a, d->cout_pad, max_taps, true, s);
+        LT_REQUIRE(rc == 1, rc < 0 ? rc : LT_ERR_UNSUPPORTED, "lt_conv_cat2_fwd: not covered by the 288 x 256 pointwise kernel");
+        return LT_OK;
+    }
     if (d->dtype == LT_F32) return dispatch<float>(a, d->cout_pad, d->nphase, max_taps, d->tile, s);
     if (d->dtype == LT_FP8) {
         // the 3^3 layers of the 64^3 / 32^3 levels: input halo in LDS (conv3d_halo.hip); bf16 stores only
@@ -383,13 +398,19 @@ static int conv_fwd_impl(const lt_conv_desc* d, const void* x, const float* bias
 
 extern "C" int lt_conv_fwd(const lt_conv_desc* d, const void* x, const float* bias, const float* scale, const float* shift,
                            const void* residual, void* y, void* stream) {
-    return conv_fwd_impl(d, x, bias, scale, shift, residual, nullptr, y, stream);
+    return conv_fwd_impl(d, x, bias, scale, shift, residual, nullptr, nullptr, y, stream);
+}
+
+extern "C" int lt_conv_cat2_fwd(const lt_conv_desc* d, const void* x, const lt_conv_cat2* second, const float* bias, const float* scale, const float* shift,
+                                const void* residual, void* y, void* stream) {
+    LT_REQUIRE(second, LT_ERR_INVALID, "lt_conv_cat2_fwd: null second-source descriptor");
+    return conv_fwd_impl(d, x, bias, scale, shift, residual, nullptr, second, y, stream);
 }
 
 extern "C" int lt_conv_skip_fwd(const lt_conv_desc* d, const void* x, const float* bias, const float* scale, const float* shift,
                                 const lt_conv_skip* skip, void* y, void* stream) {
     LT_REQUIRE(skip, LT_ERR_INVALID, "lt_conv_skip_fwd: null skip descriptor");
-    return conv_fwd_impl(d, x, bias, scale, shift, nullptr, skip, y, stream);
+    return conv_fwd_impl(d, x, bias, scale, shift, nullptr, skip, nullptr, y, stream);
 }
 
 extern "C" int lt_conv_cout_pad(int32_t cout) {

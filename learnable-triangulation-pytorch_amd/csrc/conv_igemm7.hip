@@ -101,7 +101,8 @@ __device__ __forceinline__ int swz64_7(int row) { return (0x78 >> (2 * ((row >> 
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void conv_igemm7_kernel(const ConvArgs a) {
     typedef bf16_t T;
-    constexpr bool PW = MODE == 1;
+    constexpr bool PW = MODE == 1 || MODE == 3;          // MODE 3: pointwise over TWO sources (ConvArgs::x2): the second one may be a strided map
+    constexpr bool PW2 = MODE == 3;
     constexpr int BM = 288, BN = 256, NW = 8, SM = 9, VEC = 8, BK = 32, ROWB = 64, NST = 6;
     constexpr int NPA = BM / 16;                          // 18 DMA pieces of 1 KiB per stage (16 rows of 64 B each)
     constexpr int A_IT = (NPA + NW - 1) / NW;             // 3 (waves 0, 1) / 2
@@ -138,15 +139,26 @@ __global__ __launch_bounds__(512, 2) void conv_igemm7_kernel(const ConvArgs a) {
     const int kv = (lane & 3) ^ swz64_7(prow);
     const bool a_tail = wave < NPA % NW;                 // waves 0, 1 own a third piece
     const int dps = (A_IT - 1) + (a_tail ? 1 : 0);       // 3 or 2 DMA pieces per wave and stage
-    int id0[PW ? 1 : A_IT], ih0[PW ? 1 : A_IT], iw0[PW ? 1 : A_IT], baseC[A_IT], cur[PW ? 1 : A_IT];
+    int id0[PW ? 1 : A_IT], ih0[PW ? 1 : A_IT], iw0[PW ? 1 : A_IT], baseC[A_IT], cur[PW ? 1 : A_IT], base2[PW2 ? A_IT : 1];
+    const T* __restrict__ x2 = (const T*)a.x2;
+    const int nk1 = a.Cin / BK;                          // PW2: K steps served by x
     if (!PW)
         for (int i = t; i < ph.ntaps; i += 64 * NW) s_taps[i] = ph.taps[i];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + 16 * (wave + NW * i) + prow;
         const bool own = i < A_IT - 1 || a_tail;
-        if (PW) baseC[i] = (own && m < a.M) ? m * a.Cin + kv * VEC : -1;
-        else if (own && m < a.M) {
+        if (PW) {
+            baseC[i] = (own && m < a.M) ? m * a.Cin + kv * VEC : -1;
+            if constexpr (PW2) {
+                base2[i] = -1;
+                if (own && m < a.M) {
+                    int n, od, oh, ow;
+                    decode_row(a, m, n, od, oh, ow);
+                    base2[i] = ((n * a.H2 + oh * a.s2) * a.W2 + ow * a.s2) * a.Cin2 + kv * VEC;
+                }
+            }
+        } else if (own && m < a.M) {
             int n, od, oh, ow;
             decode_row(a, m, n, od, oh, ow);
             id0[i] = od * a.sd - a.pd;
@@ -187,7 +199,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm7_kernel(const ConvArgs a) {
         constexpr int P = decltype(pc)::value;
         if (P == A_IT - 1 && !a_tail) return;
         const void* src;
-        if (PW) src = baseC[P] >= 0 ? (const void*)(x + (baseC[P] + ks * BK)) : zero_page;
+        if constexpr (PW2) src = baseC[P] < 0 ? zero_page : ks < nk1 ? (const void*)(x + (baseC[P] + ks * BK)) : (const void*)(x2 + (base2[P] + (ks - nk1) * BK));
+        else if constexpr (PW) src = baseC[P] >= 0 ? (const void*)(x + (baseC[P] + ks * BK)) : zero_page;
         else src = cur[P] >= 0 ? (const void*)(x + (cur[P] + c0s)) : zero_page;
         dma16(src, lds0 + sbuf + (wave + NW * P) * 1024);
     };
@@ -337,7 +350,8 @@ namespace lt {
 // 1 = launched, 0 = not applicable, < 0 = error.  Called by conv3_try where conv_igemm6's 288-row variant would run.
 int conv7_try(const ConvArgs& a, int cout_pad, int max_taps, bool pw, hipStream_t s) {
     if (!a.phase[0].wfrag32 || cout_pad % 256 || a.k_pad % 64) return 0;
-    const int rc = pw ? launch7<1>(a, cout_pad, max_taps, s) : launch7<2>(a, cout_pad, max_taps, s);
+    if (a.x2 && !pw) return 0;
+    const int rc = a.x2 ? launch7<3>(a, cout_pad, max_taps, s) : pw ? launch7<1>(a, cout_pad, max_taps, s) : launch7<2>(a, cout_pad, max_taps, s);
     return rc == LT_OK ? 1 : rc;
 }
 }  // namespace lt

@@ -388,6 +388,73 @@ class PlanBuilder:
                   "conv", label, 2 * macs, nbytes, info)
         return y
 
+    # ---- last 1x1 convolution of a Bottleneck + its downsample branch as ONE pointwise convolution over two sources ---------------------------------
+    def can_conv_cat2(self, t2_shape, w_expand, x_shape, w_down, stride_down):
+        """True when lt_conv_cat2_fwd covers  relu(bn3(conv1x1(t2)) + bn_d(conv1x1_d(x), stride s)): bf16 plan over build-time weights, 2D maps, both
+        channel counts multiples of 32 with a sum that is a multiple of 64, the block width a multiple of 256, s in (1, 2) and x's map exactly s times
+        t2's (LT_NO_CONV_CAT2=1: off; needs conv_igemm7, so LT_CONV_NO_V7=1 turns it off too)."""
+        if (self.dtype != torch.bfloat16 or self.out_dtype != torch.bfloat16 or self.live_weights or self.tile_override or
+                os.environ.get("LT_NO_CONV_CAT2") == "1" or os.environ.get("LT_CONV_NO_V7") == "1" or os.environ.get("LT_CONV_NO_V3") == "1"):
+            return False
+        N, D, Ho, Wo, P = t2_shape
+        if D != 1 or w_expand.dim() != 4 or w_down.dim() != 4 or tuple(w_expand.shape[2:]) != (1, 1) or tuple(w_down.shape[2:]) != (1, 1):
+            return False
+        Cc, Cin2 = w_expand.shape[0], w_down.shape[1]
+        if w_expand.shape[1] != P or w_down.shape[0] != Cc or stride_down not in (1, 2) or tuple(x_shape) != (N, 1, Ho * stride_down, Wo * stride_down, Cin2):
+            return False
+        if P % 32 or Cin2 % 32 or (P + Cin2) % 64 or Cc % 256 or P & (P - 1):
+            return False
+        return N * Ho * Wo * Cc < 2 ** 31 and N * x_shape[2] * x_shape[3] * Cin2 < 2 ** 31
+
+    def conv_cat2(self, t2, w_expand, bn_expand, x, w_down, bn_down, stride_down):
+        """relu(bn3(conv1x1(t2)) + bn_d(conv1x1_d(x), stride s)) as ONE launch (lt_conv_cat2_fwd): a pointwise convolution over the channel concatenation
+        [t2 | x at the strided pixels] with weights [s3 * w3 | s_d * w_d] (the two BatchNorm scales folded into the weights: fp32 product, one bf16
+        rounding) and shift = shift3 + shift_d.  The downsample's own launch, its output and the read of it as the residual disappear."""
+        assert self.can_conv_cat2(t2.shape, w_expand, x.shape, w_down, stride_down)
+        N, _, Ho, Wo, P = t2.shape
+        Cc, Cin2 = w_expand.shape[0], w_down.shape[1]
+        s3 = make_conv_spec(w_expand, None, bn_expand, t2.shape, 1, 0, self.dtype, False, H.EPI_RELU_POST)
+        sd = make_conv_spec(w_down, None, bn_down, x.shape, stride_down, 0, self.dtype, False, 0)
+        assert s3.cout_pad == sd.cout_pad == Cc and (s3.Do, s3.Ho, s3.Wo) == (sd.Do, sd.Ho, sd.Wo) == (1, Ho, Wo)
+        wcat = torch.cat([s3.phases[0].weight[:, :P] * s3.scale[:, None], sd.phases[0].weight[:, :Cin2] * sd.scale[:, None]], dim=1).to(self.dtype)
+        shift = (s3.bias * s3.scale + s3.shift) + (sd.bias * sd.scale + sd.shift)
+        kp = P + Cin2
+        spec = ConvSpec(N, 1, Ho, Wo, kp, 1, Ho, Wo, (1, 1, 1), (0, 0, 0), 1, Ho, Wo, (1, 1, 1), Cc, Cc, kp, H.EPI_RELU_POST,
+                        torch.zeros(Cc), torch.ones(Cc), shift)          # the convolution over the concatenated tensor (what the plan interpreter evaluates)
+        spec.phases.append(ConvPhaseSpec(wcat.float(), s3.phases[0].taps, (0, 0, 0)))
+        y = self.alloc((N, 1, Ho, Wo, Cc))
+        self.keep += [t2.t, x.t]
+        d = H.ConvDesc()
+        d.dtype = self.code
+        d.N, d.D, d.H, d.W, d.Cin = N, 1, Ho, Wo, P
+        d.Do, d.Ho, d.Wo = 1, Ho, Wo
+        d.stride = H.i3((1, 1, 1)); d.pad = H.i3((0, 0, 0))
+        d.OD, d.OH, d.OW = 1, Ho, Wo
+        d.out_stride = H.i3((1, 1, 1))
+        d.Cout, d.ldc, d.cout_pad, d.k_pad = Cc, Cc, Cc, kp
+        d.nphase, d.flags, d.tile, d.stages = 1, spec.flags, 0, 0
+        wdev = self.const(wcat, self.dtype)
+        tdev = self.const(s3.phases[0].taps)
+        wfr = torch.empty_like(wdev)
+        lib = None if self.dry_run else H.lib()
+        if not self.dry_run:
+            H.check(lib.lt_conv_pack_weights32(wdev.data_ptr(), Cc, kp, wfr.data_ptr(), H.cur_stream()), "lt_conv_pack_weights32")
+        d.phase[0].weight, d.phase[0].taps, d.phase[0].ntaps, d.phase[0].out_off = wdev.data_ptr(), tdev.data_ptr(), 1, H.i3((0, 0, 0))
+        d.phase[0].weight_frag, d.phase[0].weight_frag_layout = wfr.data_ptr(), 3
+        c2 = H.ConvCat2()
+        c2.x, c2.cin, c2.H, c2.W, c2.stride = x.t.data_ptr(), Cin2, x.shape[2], x.shape[3], stride_down
+        bi, sh = self.const(spec.bias), self.const(spec.shift)
+        self.keep += [wfr, d, c2]
+        macs = N * Ho * Wo * Cc * kp
+        self.flops += 2 * macs
+        esz = t2.t.element_size()
+        nbytes = (t2.t.numel() + N * Ho * Wo * Cin2 + y.t.numel() + wcat.numel()) * esz
+        label = "conv1x1 %d+%d->%d @%s (expand + stride-%d downsample)" % (P, Cin2, Cc, "x".join(str(v) for v in (N, 1, Ho, Wo)), stride_down)
+        self._add(lambda s, d=d, xp=t2.t.data_ptr(), c2=c2, bip=bi.data_ptr(), shp=sh.data_ptr(), yp=y.t.data_ptr():
+                  H.check(lib.lt_conv_cat2_fwd(C.byref(d), xp, C.byref(c2), bip, None, shp, None, yp, s), "lt_conv_cat2_fwd"),
+                  "conv", label, 2 * macs, nbytes, {"cat2": True, "spec": spec, "x": t2, "x2": x, "stride2": stride_down, "y": y})
+        return y
+
     # ---- split-K for the tiny levels of V2V ---------------------------------------------------------------------------------------
     def splitk_slices(self, spec, weight, transposed, out_f32, sigmoid, out):
         """Number of tap groups S the reduction of this convolution is cut into (1 = not split).  Taken for bf16 plans' 3 x 3 x 3 / stride 1

@@ -52,6 +52,10 @@ class ConvSkip(C.Structure):
     _fields_ = [("x", vp), ("cin", i32), ("weight_frag", vp)]
 
 
+class ConvCat2(C.Structure):
+    _fields_ = [("x", vp), ("cin", i32), ("H", i32), ("W", i32), ("stride", i32)]
+
+
 PWCHAIN_MAX = 3
 
 
@@ -88,6 +92,7 @@ SIGNATURES = {
     "lt_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "lt_conv_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
     "lt_conv_skip_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(ConvSkip), vp, vp]),
+    "lt_conv_cat2_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, C.POINTER(ConvCat2), vp, vp, vp, vp, vp, vp]),
     "lt_conv_cout_pad": (C.c_int, [i32]),
     "lt_conv_pack_weights": (C.c_int, [vp, i32, i32, vp, vp]),
     "lt_conv_pack_weights_t32": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),

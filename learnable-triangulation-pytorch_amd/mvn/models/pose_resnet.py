@@ -80,6 +80,17 @@ class ResidualBlock(nn.Module):
             y = b.conv(t2, self.conv3.weight, None, bn_tuple(self.bn3), stride=1, pad=0, relu=True, residual=x)
             b.release(t2)
             return (y, None) if next_block is not None else y
+        if self.kind == "bottleneck" and self.downsample is not None and hasattr(b, "can_conv_cat2"):
+            # first block of layer2-4 in bf16 plans: the expand and the (strided) downsample branch are ONE pointwise convolution over [t2 | x] (lt_conv_cat2_fwd)
+            ds, sds = self.downsample[0], self.downsample[0].stride[0]
+            Ho, Wo = (x.shape[2] - 1) // sds + 1, (x.shape[3] - 1) // sds + 1
+            if b.can_conv_cat2((x.shape[0], 1, Ho, Wo, self.conv3.weight.shape[1]), self.conv3.weight, x.shape, ds.weight, sds):
+                t1 = b.conv(x, self.conv1.weight, None, bn_tuple(self.bn1), stride=self.conv1.stride[0], pad=0, relu=True)
+                t2 = b.conv(t1, self.conv2.weight, None, bn_tuple(self.bn2), stride=self.conv2.stride[0], pad=1, relu=True)
+                b.release(t1)
+                y = b.conv_cat2(t2, self.conv3.weight, bn_tuple(self.bn3), x, ds.weight, bn_tuple(self.downsample[1]), sds)
+                b.release(t2)
+                return y
         res = x
         if self.downsample is not None:
             res = b.conv(x, self.downsample[0].weight, None, bn_tuple(self.downsample[1]), stride=self.downsample[0].stride[0], pad=0)

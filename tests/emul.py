@@ -93,6 +93,10 @@ def run_plan_on_cpu(plan):
             y = emulate_conv(s3, info["x"].t.float().clone(), info["res"].t.float().clone()).to(dt)
             info["y"].t.copy_(y)
             info["t1"].t.copy_(emulate_conv(s1, y.float()))
+        elif kind == "conv" and info.get("cat2"):            # lt_conv_cat2_fwd: a pointwise convolution over [x | x2 at the strided pixels] (weights: the scale-folded concatenation)
+            st = info["stride2"]
+            cat = torch.cat([info["x"].t.float(), info["x2"].t.float()[:, :, ::st, ::st, :]], dim=-1)
+            info["y"].t.copy_(emulate_conv(info["spec"], cat))
         elif kind == "conv" and info.get("skip"):            # lt_conv_skip_fwd: the residual is the (scale-folded, bf16-rounded) skip convolution of a second tensor, in fp32
             sk = info["skip"]
             res = sk["x"].t.float() @ sk["w"].t()

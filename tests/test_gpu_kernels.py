@@ -971,6 +971,47 @@ def test_conv3d_with_computed_skip_residual(N, D, Hh, W, monkeypatch):
     assert not b.can_conv_skip((1, 16, 32, 32, 32), w, (1, 16, 32, 32, 16), ws) and not b.can_conv_skip((4, 4, 64, 64, 32), w, (4, 4, 64, 64, 16), ws)
 
 
+@pytest.mark.parametrize("N,Ho,Wo,P,Cin2,Cc,st", [(2, 6, 10, 128, 256, 512, 2), (3, 24, 24, 256, 512, 1024, 2), (2, 12, 12, 512, 1024, 2048, 2), (1, 16, 32, 64, 64, 256, 1),
+                                                   (5, 13, 7, 128, 256, 512, 2)])
+def test_expand_plus_downsample_as_one_pointwise_convolution(N, Ho, Wo, P, Cin2, Cc, st, monkeypatch):
+    """lt_conv_cat2_fwd (round 5; pose_resnet.py:75-95 with the stride-2 `downsample` of :196-206 -- the first blocks of layer2 / 3 / 4, and the stride-1 one of
+    layer1): relu(bn3(conv1x1(t2)) + bn_d(conv1x1_d(x), stride s)) as one pointwise convolution over [t2 | x at the strided pixels], against (a) torch fp32 on
+    bf16-rounded operands with both BatchNorm scales folded into the weights before their ONE bf16 rounding (what the plan builder does) and (b) the two
+    launches it replaces.  Ragged tiles (120 / 455 rows), whole tiles, every layer's widths."""
+    g = torch.Generator().manual_seed(9100 + N + Ho + P)
+    t2 = torch.relu(torch.randn(N, P, Ho, Wo, generator=g))
+    x = torch.relu(torch.randn(N, Cin2, Ho * st, Wo * st, generator=g))
+    w3, wd = torch.randn(Cc, P, 1, 1, generator=g) / P ** 0.5, torch.randn(Cc, Cin2, 1, 1, generator=g) / Cin2 ** 0.5
+    bn3, bnd = _bn(Cc, g), _bn(Cc, g)
+    ta, xa = E.Act(to_cl(t2, None, torch.bfloat16)), E.Act(to_cl(x, None, torch.bfloat16))
+
+    def run(fused):
+        b = E.PlanBuilder(DEV, torch.bfloat16)
+        if fused:
+            assert b.can_conv_cat2(ta.shape, w3, xa.shape, wd, st)
+            y = b.conv_cat2(ta, w3, bn3, xa, wd, bnd, st)
+        else:
+            r = b.conv(xa, wd, None, bnd, stride=st)
+            y = b.conv(ta, w3, None, bn3, relu=True, residual=r)
+        plan = b.finish()
+        assert len(plan.ops) == (1 if fused else 2)
+        plan.run_eager(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return from_cl(y.t, 2)
+    yf = run(True)
+    rd = bf16_round
+    s3, sd = bn3[0] / torch.sqrt(bn3[3] + 1e-5), bnd[0] / torch.sqrt(bnd[3] + 1e-5)
+    ref = torch.relu(F.conv2d(rd(t2), rd(w3 * s3.view(-1, 1, 1, 1))) + F.conv2d(rd(x), rd(wd * sd.view(-1, 1, 1, 1)), None, st)
+                     + ((bn3[1] - bn3[2] * s3) + (bnd[1] - bnd[2] * sd)).view(1, -1, 1, 1))
+    name = "conv_cat2/%dx%dx%d/%d+%d_%d/s%d" % (N, Ho, Wo, P, Cin2, Cc, st)
+    check(name + "/vs_torch", yf, ref, 1.5e-2)
+    y2 = run(False)
+    check(name + "/vs_two_launches", yf, y2, 2.5e-2)
+    rms = float((yf.float() - y2.float()).pow(2).mean().sqrt() / y2.float().pow(2).mean().sqrt())
+    record(name + "/rms_vs_two_launches", rms)
+    assert rms < 6e-3          # a wrong pixel map / K split / weight block is far above the rounding of the branch and of the folded weights
+
+
 def test_conv_skip_refuses_what_it_does_not_cover():
     """lt_conv_skip_fwd has no fallback kernel: a shape outside the column walk (4 columns of tiles) or another skip width must come back as
     LT_ERR_UNSUPPORTED (-2, include/lt_hip.h), not as a silently different path."""
@@ -980,9 +1021,9 @@ def test_conv_skip_refuses_what_it_does_not_cover():
     d.N, d.D, d.H, d.W, d.Cin = 1, 8, 16, 16, 32
     d.Do, d.Ho, d.Wo = 8, 16, 16
     d.stride = H.i3((1, 1, 1)); d.pad = H.i3((1, 1, 1)); d.OD, d.OH, d.OW = 8, 16, 16; d.out_stride = H.i3((1, 1, 1))
-    d.Cout, d.ldc, d.cout_pad, d.k_pad = 32, 32, 32, 27 * 32
+    d.Cout, d.ldc, d.cout_pad, d.k_pad = 32, 32, 32, 896          # 27 taps x 32 channels, padded to whole 128-byte K steps
     d.nphase, d.flags, d.tile, d.stages = 1, H.EPI_RELU_POST, 0, 0
-    wdev = torch.zeros(32, 27 * 32, dtype=torch.bfloat16, device=DEV)
+    wdev = torch.zeros(32, 896, dtype=torch.bfloat16, device=DEV)
     taps = torch.tensor([(a, bb, c, ((a * 16 + bb) * 16 + c) * 32) for a in range(3) for bb in range(3) for c in range(3)], dtype=torch.int32, device=DEV)
     d.phase[0].weight, d.phase[0].taps, d.phase[0].ntaps = wdev.data_ptr(), taps.data_ptr(), 27
     xin = torch.zeros(1, 8, 16, 16, 32, dtype=torch.bfloat16, device=DEV)

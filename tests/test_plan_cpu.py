@@ -275,6 +275,7 @@ def test_first_bottleneck_of_layer1_with_its_downsample_branch_is_one_launch_in_
     for fused in (True, False):
         if not fused:
             monkeypatch.setenv("LT_NO_BNECK_DS", "1")
+            monkeypatch.setenv("LT_NO_CONV_CAT2", "1")       # (without it the block falls back to three launches: expand + downsample as one pointwise convolution)
         b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
         inp = b.alloc(tuple(x.shape)); inp.pooled = False
         y = m.layer1[0].record(b, inp)
@@ -286,6 +287,7 @@ def test_first_bottleneck_of_layer1_with_its_downsample_branch_is_one_launch_in_
         run_plan_on_cpu(plan)
         outs[fused] = y.t.float().clone()
     monkeypatch.delenv("LT_NO_BNECK_DS")
+    monkeypatch.delenv("LT_NO_CONV_CAT2")
     blk = m.layer1[0]
     xb = x[:, 0].permute(0, 3, 1, 2).to(torch.bfloat16).float()
     with torch.no_grad():
@@ -304,6 +306,47 @@ def test_first_bottleneck_of_layer1_with_its_downsample_branch_is_one_launch_in_
         assert all(not meta["label"].startswith("bneck") for _, meta in b.finish().ops)
         if env:
             monkeypatch.delenv(env)
+
+
+def test_first_blocks_of_layer2_to_4_fold_the_downsample_branch_into_the_expand(monkeypatch):
+    """Round 5: the first Bottleneck of ResNet layer2 / 3 / 4 (stride-2 `downsample` = conv1x1 + bn of the block input, pose_resnet.py:75-95, :196-206) records
+    its expand and its downsample branch as ONE pointwise convolution over [t2 | x at the strided pixels] (lt_conv_cat2_fwd) in bf16 plans: three launches
+    instead of four.  Same function as the four launches up to the rounding of the branch / of the scale-folded weights, equal to the fp32 module within the
+    plan's rounding; fp32 plans and LT_NO_CONV_CAT2=1 keep the four launches."""
+    import lt_engine as E
+    from mvn.models.pose_resnet import PoseResNet
+    torch.manual_seed(14)
+    m = PoseResNet("bottleneck", [3, 4, 6, 3], 17).eval()
+    for bn in [mm for mm in m.modules() if isinstance(mm, torch.nn.BatchNorm2d)]:
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.1)
+    for blk, cin, lab in ((m.layer2[0], 256, "conv1x1 128+256->512 @2x1x6x10 (expand + stride-2 downsample)"),
+                          (m.layer3[0], 512, "conv1x1 256+512->1024 @2x1x6x10 (expand + stride-2 downsample)"),
+                          (m.layer4[0], 1024, "conv1x1 512+1024->2048 @2x1x6x10 (expand + stride-2 downsample)")):
+        x = torch.relu(torch.randn(2, 1, 12, 20, cin))
+        outs = {}
+        for fused in (True, False):
+            if not fused:
+                monkeypatch.setenv("LT_NO_CONV_CAT2", "1")
+            b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
+            inp = b.alloc(tuple(x.shape))
+            y = blk.record(b, inp)
+            plan = b.finish()
+            labels = [meta["label"] for _, meta in plan.ops]
+            assert len(labels) == (3 if fused else 4) and (labels[-1] == lab) == fused, labels
+            inp.t.copy_(x)
+            run_plan_on_cpu(plan)
+            outs[fused] = y.t.float().clone()
+        monkeypatch.delenv("LT_NO_CONV_CAT2")
+        xb = x[:, 0].permute(0, 3, 1, 2).to(torch.bfloat16).float()
+        with torch.no_grad():
+            ref = torch.relu(blk.bn3(blk.conv3(torch.relu(blk.bn2(blk.conv2(torch.relu(blk.bn1(blk.conv1(xb)))))))) + blk.downsample(xb)).permute(0, 2, 3, 1)
+        scale = float(ref.abs().max())
+        assert float((outs[True] - outs[False]).abs().max()) <= 2.0 ** -5 * scale
+        e_f, e_s = float((outs[True][:, 0] - ref).abs().max()), float((outs[False][:, 0] - ref).abs().max())
+        assert e_f <= 3e-2 * scale and e_f <= 2.0 * e_s + 1e-3, (e_f, e_s, scale)
+        b = E.PlanBuilder("cpu", torch.float32, dry_run=True)
+        blk.record(b, b.alloc(tuple(x.shape)))
+        assert len(b.finish().ops) == 4
 
 
 def test_res3d_block_with_a_skip_convolution_records_the_skip_inside_the_second_convolution(monkeypatch):
