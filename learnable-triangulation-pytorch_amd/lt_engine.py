@@ -404,6 +404,10 @@ class PlanBuilder:
             return False
         if P % 32 or Cin2 % 32 or (P + Cin2) % 64 or Cc % 256 or P & (P - 1):
             return False
+        # one kernel with 288 x 256 tiles, one workgroup per CU: below ~200 tiles (lt_conv_fwd's own rule for that tile) the separate launches on
+        # smaller tiles fill the chip better (LT_CAT2_ANY_SIZE=1: always -- tests)
+        if -(-(N * Ho * Wo) // 288) * (Cc // 256) < 200 and os.environ.get("LT_CAT2_ANY_SIZE") != "1":
+            return False
         return N * Ho * Wo * Cc < 2 ** 31 and N * x_shape[2] * x_shape[3] * Cin2 < 2 ** 31
 
     def conv_cat2(self, t2, w_expand, bn_expand, x, w_down, bn_down, stride_down):

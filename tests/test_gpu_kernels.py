@@ -978,6 +978,7 @@ def test_expand_plus_downsample_as_one_pointwise_convolution(N, Ho, Wo, P, Cin2,
     layer1): relu(bn3(conv1x1(t2)) + bn_d(conv1x1_d(x), stride s)) as one pointwise convolution over [t2 | x at the strided pixels], against (a) torch fp32 on
     bf16-rounded operands with both BatchNorm scales folded into the weights before their ONE bf16 rounding (what the plan builder does) and (b) the two
     launches it replaces.  Ragged tiles (120 / 455 rows), whole tiles, every layer's widths."""
+    monkeypatch.setenv("LT_CAT2_ANY_SIZE", "1")      # the builder only takes this path from ~200 tiles on
     g = torch.Generator().manual_seed(9100 + N + Ho + P)
     t2 = torch.relu(torch.randn(N, P, Ho, Wo, generator=g))
     x = torch.relu(torch.randn(N, Cin2, Ho * st, Wo * st, generator=g))

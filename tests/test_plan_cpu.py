@@ -319,6 +319,10 @@ def test_first_blocks_of_layer2_to_4_fold_the_downsample_branch_into_the_expand(
     m = PoseResNet("bottleneck", [3, 4, 6, 3], 17).eval()
     for bn in [mm for mm in m.modules() if isinstance(mm, torch.nn.BatchNorm2d)]:
         bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.1)
+    b0 = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)      # by default only from ~200 tiles of 288 x 256 on (small batches spread better as separate launches)
+    w3, wd = m.layer2[0].conv3.weight, m.layer2[0].downsample[0].weight
+    assert not b0.can_conv_cat2((2, 1, 6, 10, 128), w3, (2, 1, 12, 20, 256), wd, 2) and b0.can_conv_cat2((20, 1, 48, 48, 128), w3, (20, 1, 96, 96, 256), wd, 2)
+    monkeypatch.setenv("LT_CAT2_ANY_SIZE", "1")
     for blk, cin, lab in ((m.layer2[0], 256, "conv1x1 128+256->512 @2x1x6x10 (expand + stride-2 downsample)"),
                           (m.layer3[0], 512, "conv1x1 256+512->1024 @2x1x6x10 (expand + stride-2 downsample)"),
                           (m.layer4[0], 1024, "conv1x1 512+1024->2048 @2x1x6x10 (expand + stride-2 downsample)")):
