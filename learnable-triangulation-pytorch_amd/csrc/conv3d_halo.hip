@@ -1360,16 +1360,19 @@ __global__ __launch_bounds__(512) void conv3d_halo_col_kernel(const HaloArgs a, 
 // Instantiated for 64 -> 64 (two Cout blocks: wave = (Cout half, pair of output planes), four voxel fragments), 32 -> 64 (same
 // roles, two K blocks) and 128 -> 128 (four Cout blocks: wave = Cout block, all eight voxel fragments; 256-byte voxels fill
 // LDS with the halo alone, one workgroup per CU with up to 512 registers per wave).
+// Round 5: also 16 -> 32 (the first 3^3 layer of V2V at 64^3: one Cout block, wave = output plane, two voxel fragments per weight fragment; a 23 KB halo and
+// 110 registers let four workgroups share a CU -- the one-tile loader-wave kernel it replaces there was latency-bound at 0.25 MFMA-busy).
 template <typename T, int CIN, int CP>
-__global__ __launch_bounds__(256, (CIN == 128 ? 1 : 2)) void conv3d_halo_wreg_kernel(const HaloArgs a) {
+__global__ __launch_bounds__(256, (CIN == 128 ? 1 : CIN == 16 ? 4 : 2)) void conv3d_halo_wreg_kernel(const HaloArgs a) {
     constexpr int KS = 3, TD = 4, TH = 8, TW = 8, G = CIN / 16, NB = CP / 32;
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, 3, 3> C;
-    static_assert(sizeof(T) == 2 && (NB == 2 || NB == 4) && (C::CINB == 64 || C::CINB == 128 || C::CINB == 256), "bf16; 32/64/128 -> 64/128");
+    static_assert(sizeof(T) == 2 && (NB == 1 || NB == 2 || NB == 4) && (C::CINB == 32 || C::CINB == 64 || C::CINB == 128 || C::CINB == 256),
+                  "bf16; 16/32/64/128 -> 32/64/128");
     static_assert(C::SW::FB == 0, "plane-independent swizzle");
     constexpr int PLANE_B = C::HH * C::PW * C::CINB;
     constexpr int NI_H = C::HALO_BYTES / 1024;
-    constexpr int FR = NB == 2 ? 4 : 8;                   // voxel fragments per wave
-    constexpr bool PRE_RES = FR == 4;                     // residual requested before the tap loop (register budget)
+    constexpr int FR = NB == 1 ? 2 : NB == 2 ? 4 : 8;     // voxel fragments per wave
+    constexpr bool PRE_RES = FR <= 4;                     // residual requested before the tap loop (register budget)
     // swizzle of the 16-byte vectors of a voxel: the searched ones for 64- and 128-byte voxels; 256-byte voxels start at bank 0
     // each, so the 16 lanes of a read phase (2 rows x 8 columns) must use 16 different slots: column & 7 | (row & 1) << 3
     auto wswz = [](int hh_, int hw_) -> int { return C::CINB == 256 ? ((hw_ & 7) | ((hh_ & 1) << 3)) : C::fswz(0, hh_, hw_); };
@@ -1412,8 +1415,8 @@ __global__ __launch_bounds__(256, (CIN == 128 ? 1 : 2)) void conv3d_halo_wreg_ke
     }
 
     // ---- roles ----
-    const int cb = NB == 2 ? (wave & 1) : wave;           // Cout block of 32
-    const int p0 = NB == 2 ? 2 * (wave >> 1) : 0;         // first output plane of this wave's fragments
+    const int cb = NB == 1 ? 0 : NB == 2 ? (wave & 1) : wave;             // Cout block of 32
+    const int p0 = NB == 1 ? wave : NB == 2 ? 2 * (wave >> 1) : 0;        // first output plane of this wave's fragments
     const int vl = lane & 31, hh = lane >> 5;
     // voxel-fragment addresses: fragment f = (plane p0 + f / 2, rows 4 (f & 1) + vl / 8, column vl % 8); tap (kd, kh, kw), K block g:
     //   (lp[kh*3+kw][f & 1] ^ (g << 5)) + (f / 2 + kd) planes
@@ -1917,6 +1920,7 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     if (bf && ks == 3 && c.Cout == cout_pad && c.ldc % 8 == 0 && a.wfrag && !getenv("LT_HALO_NO_WREG")) {
         int rc = 1;
         if (c.Cin == 64 && cout_pad == 64) rc = launch_halo_wreg<bf16_t, 64, 64>(a, s);
+        else if (c.Cin == 16 && cout_pad == 32 && !getenv("LT_HALO_NO_WREG16")) rc = launch_halo_wreg<bf16_t, 16, 32>(a, s);
         else if (c.Cin == 32 && cout_pad == 64) rc = launch_halo_wreg<bf16_t, 32, 64>(a, s);
         else if (c.Cin == 128 && cout_pad == 128) rc = launch_halo_wreg<bf16_t, 128, 128>(a, s);
         if (rc != 1) return rc == LT_OK ? 1 : rc;

@@ -352,9 +352,9 @@ class PlanBuilder:
                 self.keep.append(wfr)
                 d.phase[i].weight_frag, d.phase[i].weight_frag_layout = wfr.data_ptr(), layout
             elif (self.dtype == torch.bfloat16 and not self.dry_run and not transposed and x.shape[-1] == weight.shape[1]
-                  and tuple(weight.shape) in ((64, 64, 3, 3, 3), (64, 32, 3, 3, 3), (128, 128, 3, 3, 3))
+                  and tuple(weight.shape) in ((64, 64, 3, 3, 3), (64, 32, 3, 3, 3), (128, 128, 3, 3, 3), (32, 16, 3, 3, 3))
                   and spec.stride == (1, 1, 1) and spec.pad == (1, 1, 1)):
-                # 3x3x3 64 -> 64, 32 -> 64, 128 -> 128 (V2V): fragments of the transposed product for conv3d_halo_wreg_kernel
+                # 3x3x3 64 -> 64, 32 -> 64, 128 -> 128, 16 -> 32 (V2V): fragments of the transposed product for conv3d_halo_wreg_kernel
                 wfr = torch.empty_like(wdev)
                 H.check(H.lib().lt_conv_pack_weights_t32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, weight.shape[1], 27, wfr.data_ptr(),
                                                          H.cur_stream()), "lt_conv_pack_weights_t32")

@@ -758,10 +758,10 @@ def test_conv2d_3x3_256_256_layer3(N, H_):
 
 
 @pytest.mark.parametrize("wsrc", ["registers", "lds"])
-@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 64), (128, 128)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 64), (128, 128), (16, 32)])
 @pytest.mark.parametrize("N,sp", [(1, (8, 8, 16)), (3, (4, 16, 8)), (8, (8, 16, 16))])
 def test_conv3d_halo_64_64_weight_source(N, sp, cin, cout, wsrc, monkeypatch):
-    """3^3 64 -> 64 / 32 -> 64 / 128 -> 128 bf16: conv3d_halo_wreg_kernel (weights as fragments from global memory, halo-only LDS) and
+    """3^3 64 -> 64 / 32 -> 64 / 128 -> 128 / (round 5) 16 -> 32 bf16: conv3d_halo_wreg_kernel (weights as fragments from global memory, halo-only LDS) and
     the kernels it replaces (LT_HALO_NO_WREG=1: loader-wave halo kernel or implicit GEMM) vs torch: residual + ReLU, affine only;
     padding at every face."""
     if wsrc == "lds":
