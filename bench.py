@@ -269,7 +269,7 @@ def train_family(k):
         return "batchnorm+sums"
     if "wgrad" in k or k.startswith("pack_n8"):
         return "wgrad"
-    if k.startswith(("conv", "pwchain", "stem_pool", "bneck", "splitk")):
+    if k.startswith(("conv", "pwchain", "stem_pool", "bneck", "splitk", "xr_kernel")):
         return "conv fwd+dgrad"
     if k.startswith(("unproj", "coord_volumes")):
         return "unproject fwd+bwd"
@@ -777,7 +777,7 @@ def main():
                 pmc = live
                 src = "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ counters, three child runs of this command (%s; %.0f s)" % (
                     "eager launches, 3 forwards per pass", live["leg_wall_s"])
-            result["roofline"] = {"kernel": "conv family: conv_igemm2/3/6/7, bneck, conv3d_halo*, conv_pw, stem_pool, pwchain (all %d launches of one step)" % conv["launches"],
+            result["roofline"] = {"kernel": "conv family: conv_igemm2/3/6/7, bneck / bneck_ds, xr, conv3d_halo*, conv_pw, stem_pool, pwchain (all %d launches of one step)" % conv["launches"],
                                   "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                   "traffic": pmc.get("conv_family_bytes_per_step"), "traffic_source": src,
                                   "mfma_busy_frac": pmc.get("conv_family_mfma_busy_frac"),

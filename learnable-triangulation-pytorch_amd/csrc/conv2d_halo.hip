@@ -1,0 +1,209 @@
+// conv2d_halo_kernel: the 3x3 / stride 1 / pad 1 convolution 256 -> 256 of ResNet layer3's bottlenecks (reference mvn/models/pose_resnet.py:75-95, conv2 of
+// the 36 blocks of ResNet-152's third stage: 20 % of the forward) with the input HALO of a tile resident in LDS -- the 2D sibling of
+// conv3d_halo_wreg_kernel.
+//
+// Why (round 5): the implicit-GEMM kernel (conv_igemm7<2>) streams the im2col matrix through an LDS ring, i.e. every input pixel crosses L2 -> LDS nine
+// times (540 MB from the fabric per launch for a 75 MB tensor: profiles/r05_hbm_traffic_pmc.json) behind 72 barriers per tile, and runs at 0.40 MFMA-busy.
+// Here a workgroup owns TH rows x 24 columns of one image (24 x 24 maps: the 384 x 384 crops of the benchmark), DMAs the (TH + 2) x 26 pixel halo ONCE
+// (512 bytes per pixel, 16-byte slots XOR-swizzled by (column & 7) | (row & 1) << 3 on the source side: every ds_read_b128 of a 4 x 8 pixel fragment is
+// bank-conflict free for every tap), and then walks 9 taps x 16 K blocks with no barrier: per unit one weight fragment from global memory (fragment order
+// of the transposed product, lt_conv_pack_weights_t32; wave = one 32-channel output block) and one pixel fragment per 4 x 8 block from LDS at a
+// compile-time tap offset.  Transposed product with permuted weight rows: a lane ends up with two runs of 8 consecutive channels of ONE pixel and stores
+// them as 16-byte vectors straight from the accumulators (BatchNorm + ReLU folded in; this layer has no residual).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_common.h"
+
+using namespace lt;
+
+namespace {
+
+__device__ uint4 g_zero_page_2d[4];
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void dma16p(const void* src, unsigned lds_base) {
+    unsigned keep;
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_base)
+        : "memory");
+}
+
+template <int I0, int I1, typename F>
+__device__ __forceinline__ void static_for_p(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for_p<I0 + 1, I1>(f);
+    }
+}
+
+struct Halo2dArgs {
+    const bf16_t* x;
+    const bf16_t* wfrag;
+    bf16_t* y;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    int N, H, W, ldc, flags, tiles_h;
+};
+
+// TH = 8: six 4 x 8 pixel fragments per wave, 130 KB of halo, one workgroup per CU; TH = 4: three fragments, 78 KB, two workgroups per CU
+template <int TH>
+__global__ __launch_bounds__(512, (TH == 8 ? 1 : 2)) void conv2d_halo_kernel(const Halo2dArgs a) {
+    typedef bf16_t T;
+    constexpr int CIN = 256, CP = 256, TW = 24, G = CIN / 16, NB = CP / 32, PW = TW + 2, HH = TH + 2, PXB = CIN * 2;
+    constexpr int RG = TH / 4, CG = TW / 8, FR = RG * CG;
+    constexpr int HV = HH * PW, NI = HV * PXB / 1024;
+    static_assert(HV % 2 == 0 && PXB == 512 && NB == 8, "two pixels per DMA piece; eight waves = eight output blocks");
+    auto swz = [](int hh_, int hw_) -> int { return (hw_ & 7) | ((hh_ & 1) << 3); };
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    unsigned long long zp_bits = (unsigned long long)(size_t)g_zero_page_2d;
+    asm volatile("" : "+s"(zp_bits));
+    const void* const zero_page = (const void*)(size_t)zp_bits;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    int lin = blockIdx.x;
+    {   // XCD b % 8 walks one contiguous run of tiles: the tiles of an image (they share halo rows) meet in one L2
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = lin & 7, j = lin >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int n = lin / a.tiles_h, h0 = (lin - n * a.tiles_h) * TH;
+    const T* __restrict__ x = a.x + (size_t)n * a.H * a.W * CIN;
+
+    // ---- halo DMA: piece i = halo pixels 2 i, 2 i + 1; lane l -> pixel 2 i + l / 32, physical slot l % 32 holds logical slot (l % 32) ^ swz ----
+    for (int i = wave; i < NI; i += 8) {
+        const int hv = 2 * i + (lane >> 5), ps = lane & 31;
+        const int hh_ = hv / PW, hw_ = hv - hh_ * PW;
+        const int ih = h0 - 1 + hh_, iw = hw_ - 1;
+        const bool ok = ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+        const void* src = ok ? (const void*)(x + ((size_t)ih * a.W + iw) * CIN + (ps ^ swz(hh_, hw_)) * 8) : zero_page;
+        dma16p(src, lds0 + i * 1024);
+    }
+
+    // ---- roles: wave = output-channel block; fragment f = (row group i = f / CG, column group j = f % CG): pixel (4 i + vl / 8, 8 j + vl % 8) ----
+    const int cb = wave;
+    const int vl = lane & 31, hk = lane >> 5;
+    unsigned lp[9][RG];                                   // tap (kh, kw), row group i: + j * 8 pixels as an immediate, K block g as XOR (g << 5)
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+        const int th = 4 * i + (vl >> 3), tw = vl & 7;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                lp[kh * 3 + kw][i] = lds0 + ((th + kh) * PW + tw + kw) * PXB + ((hk ^ swz(th + kh, tw + kw)) << 4);
+    }
+    const T* wl = a.wfrag + ((size_t)cb * 64 + lane) * 8;    // unit u = tap * G + g -> fragment ((u * NB + cb) * 64 + lane) * 16 bytes
+    auto load_w = [&](int u) -> V16 {
+        V16 v;
+        v.u = *(const uint4*)(wl + (size_t)u * NB * 64 * 8);
+        return v;
+    };
+    constexpr int NU = 9 * G, WD = 6;
+    V16 wf[WD + 1];
+#pragma unroll
+    for (int u = 0; u < WD; ++u) wf[u] = load_w(u);
+
+    f32x16 acc[FR];
+#pragma unroll
+    for (int f = 0; f < FR; ++f)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
+
+    // the halo pieces are the oldest vector-memory operations of this wave: wait for everything once, the barrier publishes the image
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    V16 xa[2][FR];
+    auto load_x = [&](auto uc, V16 (&dst)[FR]) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int tap = u / G, g = u % G;
+        static_for_p<0, FR>([&](auto fc) {
+            constexpr int f = decltype(fc)::value, i = f / CG, j = f % CG;
+            dst[f].u = *(const uint4*)((lptr_t)(size_t)((lp[tap][i] ^ (g << 5)) + j * 8 * PXB));
+        });
+    };
+    load_x(std::integral_constant<int, 0>{}, xa[0]);
+    static_for_p<0, NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (u + WD < NU) wf[(u + WD) % (WD + 1)] = load_w(u + WD);
+        if constexpr (u + 1 < NU) load_x(std::integral_constant<int, u + 1>{}, xa[(u + 1) & 1]);
+#pragma unroll
+        for (int f = 0; f < FR; ++f)
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % (WD + 1)].h, xa[u & 1][f].h, acc[f], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+
+    // ---- epilogue from the accumulators: lane (pixel, h) holds channels 32 cb + 8 h + e (e < 8) and 32 cb + 16 + 8 h + (e - 8) ----
+    float esc[16], esf[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = 32 * cb + 16 * (e >> 3) + 8 * hk + (e & 7);
+        const float bi = a.bias ? a.bias[c] : 0.f, sc = a.scale ? a.scale[c] : 1.f, sf = a.shift ? a.shift[c] : 0.f;
+        esc[e] = sc; esf[e] = bi * sc + sf;
+    }
+    const EpiFloors fl = epi_floors(a.flags);
+#pragma unroll
+    for (int f = 0; f < FR; ++f) {
+        const int th = 4 * (f / CG) + (vl >> 3), tw = 8 * (f % CG) + (vl & 7);
+        bf16_t* yo = a.y + (((size_t)n * a.H + h0 + th) * a.W + tw) * a.ldc + 32 * cb + 8 * hk;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            unsigned o[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int e = 8 * q + 2 * d;
+                o[d] = pack_bf16x2(epi_apply(fmaf(acc[f][e], esc[e], esf[e]), fl, 0.f), epi_apply(fmaf(acc[f][e + 1], esc[e + 1], esf[e + 1]), fl, 0.f));
+            }
+            *(uint4*)(yo + 16 * q) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+template <int TH>
+int launch_halo2d(const Halo2dArgs& a0, hipStream_t s) {
+    Halo2dArgs a = a0;
+    a.tiles_h = a.H / TH;
+    constexpr int lds = (TH + 2) * 26 * 512;
+    static_assert(lds <= 160 * 1024, "halo fits LDS");
+    auto kern = conv2d_halo_kernel<TH>;
+    LT_OPT_IN_LDS(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * a.tiles_h)), dim3(512), lds, s, a);
+    LT_CHECK_LAUNCH("lt_conv_fwd(2D halo)");
+    return LT_OK;
+}
+
+}  // namespace
+
+namespace lt {
+
+// 1 = launched, 0 = not applicable (fall back), < 0 = error.  Takes: bf16 3x3 / stride 1 / pad 1, 256 -> 256 dense channels, 24-pixel-wide maps with
+// H % 8 == 0, no residual, plain bf16 store, weights given in the fragment order of the transposed product (weight_frag_layout 2).
+int conv2d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, hipStream_t s) {
+    const PhaseArg& p0 = c.phase[0];
+    if (dtype != LT_BF16 || nphase != 1 || !p0.wfrag_t || p0.ntaps != 9 || c.D != 1 || c.Do != 1 || c.OD != 1) return 0;
+    if (c.sh != 1 || c.sw != 1 || c.ph != 1 || c.pw != 1 || c.osh != 1 || c.osw != 1 || p0.ooh || p0.oow) return 0;
+    if (c.H != c.Ho || c.W != c.Wo || c.OH != c.Ho || c.OW != c.Wo || c.W != 24 || c.H % 8) return 0;
+    if (c.Cin != 256 || cout_pad != 256 || c.Cout != 256 || c.ldc % 8 || c.res || c.skip_x || c.x2) return 0;
+    if (c.flags & (LT_EPI_STORE_F32 | LT_EPI_SIGMOID)) return 0;
+    Halo2dArgs a;
+    a.x = (const bf16_t*)c.x; a.wfrag = (const bf16_t*)p0.wfrag_t; a.y = (bf16_t*)c.y;
+    a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
+    a.N = c.N; a.H = c.H; a.W = c.W; a.ldc = c.ldc; a.flags = c.flags; a.tiles_h = 0;
+    const char* th = getenv("LT_H2D_TH");                 // A/B: 4 = half-height tiles, two workgroups per CU
+    const int rc = (th && th[0] == '4') ? launch_halo2d<4>(a, s) : launch_halo2d<8>(a, s);
+    return rc == LT_OK ? 1 : rc;
+}
+
+}  // namespace lt

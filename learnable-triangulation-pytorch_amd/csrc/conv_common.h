@@ -126,6 +126,8 @@ int conv3_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, int max_ta
 int conv7_try(const ConvArgs& a, int cout_pad, int max_taps, bool pw, hipStream_t s);
 // conv_pw.hip (streaming kernel for single-tap phases: 1x1x1 convs, 2x2x2 stride-2 deconvs): 1 / 0 / < 0 as above
 int conv_pw_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, hipStream_t s);
+// conv2d_halo.hip (3x3 256 -> 256 on 24-wide maps, input halo in LDS, weights in layout 2): 1 / 0 / < 0 as above
+int conv2d_halo_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, hipStream_t s);
 // conv3d_halo.hip: 1 = launched, 0 = not applicable (fall back), < 0 = error
 int conv3d_halo_try(int dtype, const ConvArgs& a, int cout_pad, int nphase, bool forced, hipStream_t s);
 

@@ -279,6 +279,11 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
         if (rc < 0) return rc;
         if (rc == 1) return LT_OK;
     }
+    if (tile == LT_TILE_AUTO && !force_v1 && sizeof(T) == 2 && a.phase[0].wfrag_t) {   // ResNet layer3's 3x3 256 -> 256 with its weights in layout 2: 2D halo kernel
+        const int rc = conv2d_halo_try(LT_BF16, a, cout_pad, nphase, s);
+        if (rc < 0) return rc;
+        if (rc == 1) return LT_OK;
+    }
     static const bool no_v3 = getenv("LT_CONV_NO_V3") != nullptr;   // A/B switch
     if ((tile == LT_TILE_AUTO && !force_v1 && !no_v3) || tile == LT_TILE3_288) {
         const int rc = conv3_try(sizeof(T) == 4 ? LT_F32 : LT_BF16, a, cout_pad, nphase, max_taps, tile == LT_TILE3_288, s);

@@ -334,6 +334,17 @@ class PlanBuilder:
             # the 288 x 256 kernel); packed once, here
             if self.live_weights:
                 pass
+            elif (self.dtype == torch.bfloat16 and not self.dry_run and not transposed and tuple(weight.shape) == (256, 256, 3, 3) and x.shape[-1] == 256
+                  and spec.stride == (1, 1, 1) and spec.pad == (0, 1, 1) and spec.W == 24 and spec.H % 8 == 0 and residual is None and not out_f32 and not sigmoid
+                  and (spec.N * (spec.H // 8) >= 2 * 256 or os.environ.get("LT_H2D_ANY_SIZE") == "1") and os.environ.get("LT_CONV_NO_H2D") != "1"
+                  and not self.tile_override):
+                # ResNet layer3's 3x3 256 -> 256 on 24-wide maps, from two rounds of 8 x 24 tiles on: fragments of the transposed product for
+                # conv2d_halo_kernel (input halo resident in LDS; LT_CONV_NO_H2D=1 keeps conv_igemm7)
+                wfr = torch.empty_like(wdev)
+                H.check(H.lib().lt_conv_pack_weights_t32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, 256, 9, wfr.data_ptr(), H.cur_stream()),
+                        "lt_conv_pack_weights_t32")
+                self.keep.append(wfr)
+                d.phase[i].weight_frag, d.phase[i].weight_frag_layout = wfr.data_ptr(), 2
             elif self.dtype == torch.bfloat16 and not self.dry_run and spec.cout_pad % 256 == 0 and spec.k_pad % 64 == 0:
                 wfr = torch.empty_like(wdev)
                 # the 288-row layers get their weights in the fragment order of the 32x32x16 MFMA (conv_igemm7: +1 % end to end over
@@ -372,7 +383,7 @@ class PlanBuilder:
         esz = torch.empty((), dtype=self.dtype).element_size()
         nbytes = (x.t.numel() + y.t.numel() + (residual.t.numel() if residual is not None else 0)) * esz + \
             sum(p.weight.numel() for p in spec.phases) * esz
-        info = {"spec": spec, "x": x, "y": y, "res": residual, "wdev": wdevs, "bias_dev": bi, "scale_dev": sc, "shift_dev": sh}
+        info = {"spec": spec, "x": x, "y": y, "res": residual, "wdev": wdevs, "bias_dev": bi, "scale_dev": sc, "shift_dev": sh, "desc": d}
         if skip_info is not None:
             macs += spec.N * spec.Do * spec.Ho * spec.Wo * spec.Cout * 16
             self.flops += 2 * spec.N * spec.Do * spec.Ho * spec.Wo * spec.Cout * 16

@@ -757,6 +757,43 @@ def test_conv2d_3x3_256_256_layer3(N, H_):
     check("conv2d_3x3_256/N%d_H%d/res" % (N, H_), out2, torch.relu(conv + rd(res)), 1.5e-2)
 
 
+@pytest.mark.parametrize("th", ["8", "4"])
+@pytest.mark.parametrize("N,Hh", [(1, 8), (3, 24), (9, 16), (16, 24)])
+def test_conv2d_halo_3x3_256(N, Hh, th, monkeypatch):
+    """conv2d_halo_kernel (round 5): the 3x3 256 -> 256 convolution of ResNet layer3's bottlenecks (pose_resnet.py:75-95, conv2 + bn2 + relu) on 24-wide maps with
+    the input halo resident in LDS, 8 x 24 and 4 x 24 pixel tiles, vs torch on bf16-rounded operands and vs the implicit-GEMM kernel it replaces
+    (LT_CONV_NO_H2D=1).  One-tile images (every halo row outside), three tiles per image (halo rows shared across tiles), odd image counts (XCD remap)."""
+    monkeypatch.setenv("LT_H2D_ANY_SIZE", "1")
+    monkeypatch.setenv("LT_H2D_TH", th)
+    g = torch.Generator().manual_seed(4200 + N + Hh)
+    x = torch.relu(torch.randn(N, 256, Hh, 24, generator=g))
+    w = torch.randn(256, 256, 3, 3, generator=g) / (9 * 256) ** 0.5
+    bn = _bn(256, g)
+    rd = bf16_round
+    ref = torch.relu(_bn_ref(F.conv2d(rd(x), rd(w), None, 1, 1), bn))
+
+    def run(halo):
+        if halo:
+            monkeypatch.delenv("LT_CONV_NO_H2D", raising=False)
+        else:
+            monkeypatch.setenv("LT_CONV_NO_H2D", "1")
+        b = E.PlanBuilder(DEV, torch.bfloat16)
+        y = b.conv(E.Act(to_cl(x, None, torch.bfloat16)), w, None, bn, stride=1, pad=1, relu=True)
+        assert b.last_info["desc"].phase[0].weight_frag_layout == (2 if halo else 3)     # layout 2 = the halo kernel's fragment order: the dispatcher follows it
+        plan = b.finish()
+        plan.run_eager(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return from_cl(y.t, 2)
+    yh = run(True)
+    name = "conv2d_halo/N%d_H%d/th%s" % (N, Hh, th)
+    check(name + "/vs_torch", yh, ref, 1.5e-2)
+    yi = run(False)
+    check(name + "/vs_implicit_gemm", yh, yi, 1.5e-2)
+    rms = float((yh.float() - yi.float()).pow(2).mean().sqrt() / yi.float().pow(2).mean().sqrt())
+    record(name + "/rms_vs_implicit_gemm", rms)
+    assert rms < 2e-3          # same products in another summation order + one output rounding: a wrong tap / halo row / K block is far above
+
+
 @pytest.mark.parametrize("wsrc", ["registers", "lds"])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (32, 64), (128, 128), (16, 32)])
 @pytest.mark.parametrize("N,sp", [(1, (8, 8, 16)), (3, (4, 16, 8)), (8, (8, 16, 16))])

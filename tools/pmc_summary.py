@@ -51,8 +51,8 @@ def kernel_key(name):
 def family(k):
     if k.startswith(("conv_pack", "stem_pack")):
         return "setup"          # one-time weight packing at plan build, not part of a step
-    if k.startswith(("conv", "pwchain", "stem_pool", "bneck")):
-        return "conv"
+    if k.startswith(("conv", "pwchain", "stem_pool", "bneck", "xr_kernel")):   # (xr_kernel was missing from this list when round 5's first record was taken:
+        return "conv"                                                        #  its 27 GB per step were not in that record's `traffic`)
     if k.startswith("unproject"):
         return "unproject"
     if k.startswith(("sa3_", "softargmax3d")):
