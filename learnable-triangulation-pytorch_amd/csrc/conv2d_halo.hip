@@ -46,18 +46,26 @@ __device__ __forceinline__ void static_for_p(F&& f) {
     }
 }
 
+struct Halo2dPhase {
+    const bf16_t* wfrag;     // lt_conv_pack_weights_t32 of this phase's [256][k_pad] weights (k = tap * 256 + ci)
+    const int4* taps;        // lt_conv_phase.taps (device): (dd, dh, dw, element offset) per tap; input pixel of tap t for output pixel (h, w) = (h - pad_h + dh, w - pad_w + dw)
+    int ooh, oow;            // output offset of the phase (a stride-2 transposed convolution: the output parity)
+};
+
 struct Halo2dArgs {
     const bf16_t* x;
-    const bf16_t* wfrag;
     bf16_t* y;
     const float* bias;
     const float* scale;
     const float* shift;
-    int N, H, W, ldc, flags, tiles_h;
+    int N, H, W, OH, OW, osh, osw, ldc, flags, tiles_h, tiles_w, pad_h, pad_w;
+    Halo2dPhase ph[4];
 };
 
-// TH = 8: six 4 x 8 pixel fragments per wave, 130 KB of halo, one workgroup per CU; TH = 4: three fragments, 78 KB, two workgroups per CU
-template <int TH>
+// TH = 8: six 4 x 8 pixel fragments per wave, 130 KB of halo, one workgroup per CU; TH = 4: three fragments, 78 KB, two workgroups per CU.
+// NT taps per phase, NPH phases over the SAME halo: (9, 1) = the 3x3 convolution; (4, 4) = a 4x4 / stride-2 / pad-1 transposed convolution (the deconvolution
+// head, pose_resnet.py:208-233: four output parities of 2 x 2 taps each -- the halo is loaded once for all four, where the implicit GEMM ran four launches).
+template <int TH, int NT, int NPH>
 __global__ __launch_bounds__(512, (TH == 8 ? 1 : 2)) void conv2d_halo_kernel(const Halo2dArgs a) {
     typedef bf16_t T;
     constexpr int CIN = 256, CP = 256, TW = 24, G = CIN / 16, NB = CP / 32, PW = TW + 2, HH = TH + 2, PXB = CIN * 2;
@@ -79,14 +87,16 @@ __global__ __launch_bounds__(512, (TH == 8 ? 1 : 2)) void conv2d_halo_kernel(con
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = lin & 7, j = lin >> 3;
         lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    const int n = lin / a.tiles_h, h0 = (lin - n * a.tiles_h) * TH;
+    const int tpi = a.tiles_h * a.tiles_w;
+    const int n = lin / tpi, rem = lin - n * tpi;
+    const int h0 = (rem / a.tiles_w) * TH, w0 = (rem % a.tiles_w) * TW;
     const T* __restrict__ x = a.x + (size_t)n * a.H * a.W * CIN;
 
     // ---- halo DMA: piece i = halo pixels 2 i, 2 i + 1; lane l -> pixel 2 i + l / 32, physical slot l % 32 holds logical slot (l % 32) ^ swz ----
     for (int i = wave; i < NI; i += 8) {
         const int hv = 2 * i + (lane >> 5), ps = lane & 31;
         const int hh_ = hv / PW, hw_ = hv - hh_ * PW;
-        const int ih = h0 - 1 + hh_, iw = hw_ - 1;
+        const int ih = h0 - 1 + hh_, iw = w0 - 1 + hw_;
         const bool ok = ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
         const void* src = ok ? (const void*)(x + ((size_t)ih * a.W + iw) * CIN + (ps ^ swz(hh_, hw_)) * 8) : zero_page;
         dma16p(src, lds0 + i * 1024);
@@ -95,91 +105,123 @@ __global__ __launch_bounds__(512, (TH == 8 ? 1 : 2)) void conv2d_halo_kernel(con
     // ---- roles: wave = output-channel block; fragment f = (row group i = f / CG, column group j = f % CG): pixel (4 i + vl / 8, 8 j + vl % 8) ----
     const int cb = wave;
     const int vl = lane & 31, hk = lane >> 5;
-    unsigned lp[9][RG];                                   // tap (kh, kw), row group i: + j * 8 pixels as an immediate, K block g as XOR (g << 5)
-#pragma unroll
-    for (int i = 0; i < RG; ++i) {
-        const int th = 4 * i + (vl >> 3), tw = vl & 7;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-                lp[kh * 3 + kw][i] = lds0 + ((th + kh) * PW + tw + kw) * PXB + ((hk ^ swz(th + kh, tw + kw)) << 4);
-    }
-    const T* wl = a.wfrag + ((size_t)cb * 64 + lane) * 8;    // unit u = tap * G + g -> fragment ((u * NB + cb) * 64 + lane) * 16 bytes
-    auto load_w = [&](int u) -> V16 {
+    constexpr int NU = NT * G, WD = 7, NS = WD + 1;       // weight fragments: requested WD units ahead, straight through the phases (NU % NS == 0)
+    static_assert(NU % NS == 0, "the fragment ring must close at a phase boundary");
+    auto wptr = [&](int p) -> const T* { return a.ph[p].wfrag + ((size_t)cb * 64 + lane) * 8; };
+    auto load_w = [&](int p, int u) -> V16 {             // unit u = tap * G + g of phase p -> fragment ((u * NB + cb) * 64 + lane) * 16 bytes
         V16 v;
-        v.u = *(const uint4*)(wl + (size_t)u * NB * 64 * 8);
+        v.u = *(const uint4*)(wptr(p) + (size_t)u * NB * 64 * 8);
         return v;
     };
-    constexpr int NU = 9 * G, WD = 6;
-    V16 wf[WD + 1];
+    V16 wf[NS];
 #pragma unroll
-    for (int u = 0; u < WD; ++u) wf[u] = load_w(u);
+    for (int u = 0; u < WD; ++u) wf[u] = load_w(0, u);
 
-    f32x16 acc[FR];
+    // epilogue constants: with several phases they are fetched once, in front of the tap loops (32 registers); the single-phase kernel fetches them behind
+    // its tap loop instead (it has the registers of one more weight fragment in flight there)
+    float esc[16], esf[16];
+    auto load_consts = [&]() {
 #pragma unroll
-    for (int f = 0; f < FR; ++f)
+        for (int e = 0; e < 16; ++e) {
+            const int c = 32 * cb + 16 * (e >> 3) + 8 * hk + (e & 7);
+            const float bi = a.bias ? a.bias[c] : 0.f, sc = a.scale ? a.scale[c] : 1.f, sf = a.shift ? a.shift[c] : 0.f;
+            esc[e] = sc; esf[e] = bi * sc + sf;
+        }
+    };
+    if constexpr (NPH > 1) load_consts();
+    const EpiFloors fl = epi_floors(a.flags);
+    // every phase's taps, fetched ONCE and in front of the barrier, as wave-uniform halo offsets (row * PW + column of the tap for output pixel (0, 0)): inside
+    // the phase loop they were vector loads with a vmcnt(0) each, queued behind the previous phase's stores (one exposed round trip per tap and phase)
+    int tapo[NPH][NT];
+    {
+        int4 tv[NPH][NT];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
+        for (int p = 0; p < NPH; ++p)
+#pragma unroll
+            for (int tp = 0; tp < NT; ++tp) tv[p][tp] = a.ph[p].taps[tp];        // all requests first: one wait, not one round trip per tap
+        bool bad = false;
+#pragma unroll
+        for (int p = 0; p < NPH; ++p)
+#pragma unroll
+            for (int tp = 0; tp < NT; ++tp) {
+                const int dh = tv[p][tp].y - a.pad_h, dw = tv[p][tp].z - a.pad_w;
+                bad |= (tv[p][tp].x != 0) | (dh < -1) | (dh > 1) | (dw < -1) | (dw > 1);
+                tapo[p][tp] = __builtin_amdgcn_readfirstlane((1 + dh) * 32 + (1 + dw));   // row offset * 32 + column offset (decoded below)
+            }
+        if (bad) __builtin_trap();                        // a tap outside the one-pixel halo: not this kernel's problem class (fail loudly)
+    }
 
     // the halo pieces are the oldest vector-memory operations of this wave: wait for everything once, the barrier publishes the image
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
-    V16 xa[2][FR];
-    auto load_x = [&](auto uc, V16 (&dst)[FR]) {
-        constexpr int u = decltype(uc)::value;
-        constexpr int tap = u / G, g = u % G;
-        static_for_p<0, FR>([&](auto fc) {
-            constexpr int f = decltype(fc)::value, i = f / CG, j = f % CG;
-            dst[f].u = *(const uint4*)((lptr_t)(size_t)((lp[tap][i] ^ (g << 5)) + j * 8 * PXB));
-        });
-    };
-    load_x(std::integral_constant<int, 0>{}, xa[0]);
-    static_for_p<0, NU>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        if constexpr (u + WD < NU) wf[(u + WD) % (WD + 1)] = load_w(u + WD);
-        if constexpr (u + 1 < NU) load_x(std::integral_constant<int, u + 1>{}, xa[(u + 1) & 1]);
+    static_for_p<0, NPH>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        unsigned lp[NT][RG];                              // tap t, row group i: + j * 8 pixels as an immediate, K block g as XOR (g << 5)
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            const int th = 4 * i + (vl >> 3), tw = vl & 7;
+#pragma unroll
+            for (int tp = 0; tp < NT; ++tp) {
+                const int row = th + (tapo[p][tp] >> 5), col = tw + (tapo[p][tp] & 31);
+                lp[tp][i] = lds0 + (row * PW + col) * PXB + ((hk ^ swz(row, col)) << 4);
+            }
+        }
+        f32x16 acc[FR];
 #pragma unroll
         for (int f = 0; f < FR; ++f)
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % (WD + 1)].h, xa[u & 1][f].h, acc[f], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    });
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
+        V16 xa[2][FR];
+        auto load_x = [&](auto uc, V16 (&dst)[FR]) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int tap = u / G, g = u % G;
+            static_for_p<0, FR>([&](auto fc) {
+                constexpr int f = decltype(fc)::value, i = f / CG, j = f % CG;
+                dst[f].u = *(const uint4*)((lptr_t)(size_t)((lp[tap][i] ^ (g << 5)) + j * 8 * PXB));
+            });
+        };
+        load_x(std::integral_constant<int, 0>{}, xa[0]);
+        static_for_p<0, NU>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if constexpr (u + WD < NU) wf[(u + WD) % NS] = load_w(p, u + WD);
+            else if constexpr (p + 1 < NPH) wf[(u + WD) % NS] = load_w(p + 1, u + WD - NU);    // the next phase's first fragments, under this phase's tail
+            if constexpr (u + 1 < NU) load_x(std::integral_constant<int, u + 1>{}, xa[(u + 1) & 1]);
+#pragma unroll
+            for (int f = 0; f < FR; ++f)
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % NS].h, xa[u & 1][f].h, acc[f], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
 
-    // ---- epilogue from the accumulators: lane (pixel, h) holds channels 32 cb + 8 h + e (e < 8) and 32 cb + 16 + 8 h + (e - 8) ----
-    float esc[16], esf[16];
+        // ---- epilogue from the accumulators: lane (pixel, h) holds channels 32 cb + 8 h + e (e < 8) and 32 cb + 16 + 8 h + (e - 8) ----
+        if constexpr (NPH == 1) load_consts();
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int c = 32 * cb + 16 * (e >> 3) + 8 * hk + (e & 7);
-        const float bi = a.bias ? a.bias[c] : 0.f, sc = a.scale ? a.scale[c] : 1.f, sf = a.shift ? a.shift[c] : 0.f;
-        esc[e] = sc; esf[e] = bi * sc + sf;
-    }
-    const EpiFloors fl = epi_floors(a.flags);
+        for (int f = 0; f < FR; ++f) {
+            const int th = 4 * (f / CG) + (vl >> 3), tw = 8 * (f % CG) + (vl & 7);
+            bf16_t* yo = a.y + (((size_t)n * a.OH + (h0 + th) * a.osh + a.ph[p].ooh) * a.OW + (w0 + tw) * a.osw + a.ph[p].oow) * a.ldc + 32 * cb + 8 * hk;
 #pragma unroll
-    for (int f = 0; f < FR; ++f) {
-        const int th = 4 * (f / CG) + (vl >> 3), tw = 8 * (f % CG) + (vl & 7);
-        bf16_t* yo = a.y + (((size_t)n * a.H + h0 + th) * a.W + tw) * a.ldc + 32 * cb + 8 * hk;
+            for (int q = 0; q < 2; ++q) {
+                unsigned o[4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            unsigned o[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int e = 8 * q + 2 * d;
-                o[d] = pack_bf16x2(epi_apply(fmaf(acc[f][e], esc[e], esf[e]), fl, 0.f), epi_apply(fmaf(acc[f][e + 1], esc[e + 1], esf[e + 1]), fl, 0.f));
+                for (int d = 0; d < 4; ++d) {
+                    const int e = 8 * q + 2 * d;
+                    o[d] = pack_bf16x2(epi_apply(fmaf(acc[f][e], esc[e], esf[e]), fl, 0.f), epi_apply(fmaf(acc[f][e + 1], esc[e + 1], esf[e + 1]), fl, 0.f));
+                }
+                *(uint4*)(yo + 16 * q) = make_uint4(o[0], o[1], o[2], o[3]);
             }
-            *(uint4*)(yo + 16 * q) = make_uint4(o[0], o[1], o[2], o[3]);
         }
-    }
+    });
 }
 
-template <int TH>
+template <int TH, int NT, int NPH>
 int launch_halo2d(const Halo2dArgs& a0, hipStream_t s) {
     Halo2dArgs a = a0;
     a.tiles_h = a.H / TH;
+    a.tiles_w = a.W / 24;
     constexpr int lds = (TH + 2) * 26 * 512;
     static_assert(lds <= 160 * 1024, "halo fits LDS");
-    auto kern = conv2d_halo_kernel<TH>;
+    auto kern = conv2d_halo_kernel<TH, NT, NPH>;
     LT_OPT_IN_LDS(kern, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * a.tiles_h)), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * a.tiles_h * a.tiles_w)), dim3(512), lds, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(2D halo)");
     return LT_OK;
 }
@@ -188,21 +230,35 @@ int launch_halo2d(const Halo2dArgs& a0, hipStream_t s) {
 
 namespace lt {
 
-// 1 = launched, 0 = not applicable (fall back), < 0 = error.  Takes: bf16 3x3 / stride 1 / pad 1, 256 -> 256 dense channels, 24-pixel-wide maps with
-// H % 8 == 0, no residual, plain bf16 store, weights given in the fragment order of the transposed product (weight_frag_layout 2).
+// 1 = launched, 0 = not applicable (fall back), < 0 = error.  Takes: bf16, 256 -> 256 dense channels, maps whose width is a multiple of 24 and whose
+// height is a multiple of 8, iteration space == input grid, every tap within one pixel of the output pixel, no residual, plain bf16 store, weights of every
+// phase in the fragment order of the transposed product (weight_frag_layout 2); one phase of nine taps (3x3 / stride 1 / pad 1) or four phases of four
+// taps with output stride 2 (4x4 / stride 2 / pad 1 transposed).
 int conv2d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, hipStream_t s) {
-    const PhaseArg& p0 = c.phase[0];
-    if (dtype != LT_BF16 || nphase != 1 || !p0.wfrag_t || p0.ntaps != 9 || c.D != 1 || c.Do != 1 || c.OD != 1) return 0;
-    if (c.sh != 1 || c.sw != 1 || c.ph != 1 || c.pw != 1 || c.osh != 1 || c.osw != 1 || p0.ooh || p0.oow) return 0;
-    if (c.H != c.Ho || c.W != c.Wo || c.OH != c.Ho || c.OW != c.Wo || c.W != 24 || c.H % 8) return 0;
+    if (dtype != LT_BF16 || (nphase != 1 && nphase != 4) || c.D != 1 || c.Do != 1 || c.OD != 1) return 0;
+    if (c.sh != 1 || c.sw != 1 || c.H != c.Ho || c.W != c.Wo || c.W % 24 || c.H % 8) return 0;
     if (c.Cin != 256 || cout_pad != 256 || c.Cout != 256 || c.ldc % 8 || c.res || c.skip_x || c.x2) return 0;
     if (c.flags & (LT_EPI_STORE_F32 | LT_EPI_SIGMOID)) return 0;
+    const int nt = nphase == 1 ? 9 : 4;
+    // the taps live in device memory: their range is checked by the kernel (it traps); here the geometry that implies it -- a "same" 3x3 (pad 1) or the
+    // 2 x 2-tap parities of a 4x4 / stride-2 / pad-1 transposed convolution (recorded with pad 0 and signed tap offsets)
+    if (c.pd != 0) return 0;
+    if (nphase == 1 && (c.osh != 1 || c.osw != 1 || c.OH != c.Ho || c.OW != c.Wo || c.ph != 1 || c.pw != 1)) return 0;
+    if (nphase == 4 && (c.osh != 2 || c.osw != 2 || c.OH != 2 * c.Ho || c.OW != 2 * c.Wo || c.ph != 0 || c.pw != 0)) return 0;
     Halo2dArgs a;
-    a.x = (const bf16_t*)c.x; a.wfrag = (const bf16_t*)p0.wfrag_t; a.y = (bf16_t*)c.y;
+    for (int p = 0; p < nphase; ++p) {
+        const PhaseArg& ph = c.phase[p];
+        if (!ph.wfrag_t || ph.ntaps != nt || ph.ood) return 0;
+        a.ph[p].wfrag = (const bf16_t*)ph.wfrag_t; a.ph[p].taps = ph.taps; a.ph[p].ooh = ph.ooh; a.ph[p].oow = ph.oow;
+    }
+    a.x = (const bf16_t*)c.x; a.y = (bf16_t*)c.y;
     a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
-    a.N = c.N; a.H = c.H; a.W = c.W; a.ldc = c.ldc; a.flags = c.flags; a.tiles_h = 0;
+    a.N = c.N; a.H = c.H; a.W = c.W; a.OH = c.OH; a.OW = c.OW; a.osh = c.osh; a.osw = c.osw; a.ldc = c.ldc; a.flags = c.flags; a.tiles_h = a.tiles_w = 0;
+    a.pad_h = c.ph; a.pad_w = c.pw;
     const char* th = getenv("LT_H2D_TH");                 // A/B: 4 = half-height tiles, two workgroups per CU
-    const int rc = (th && th[0] == '4') ? launch_halo2d<4>(a, s) : launch_halo2d<8>(a, s);
+    int rc;
+    if (nphase == 1) rc = (th && th[0] == '4') ? launch_halo2d<4, 9, 1>(a, s) : launch_halo2d<8, 9, 1>(a, s);
+    else rc = launch_halo2d<8, 4, 4>(a, s);
     return rc == LT_OK ? 1 : rc;
 }
 

@@ -794,6 +794,41 @@ def test_conv2d_halo_3x3_256(N, Hh, th, monkeypatch):
     assert rms < 2e-3          # same products in another summation order + one output rounding: a wrong tap / halo row / K block is far above
 
 
+@pytest.mark.parametrize("N,Hh,W", [(1, 8, 24), (3, 24, 24), (2, 16, 48), (5, 48, 48)])
+def test_deconv4x4_256_halo(N, Hh, W, monkeypatch):
+    """conv2d_halo_kernel<8, 4, 4> (round 5): the 4x4 / stride-2 / pad-1 transposed convolutions 256 -> 256 of the deconvolution head (pose_resnet.py:208-233,
+    + BatchNorm + ReLU) as four output parities of 2 x 2 taps over ONE input halo, vs torch on bf16-rounded operands and vs the four implicit-GEMM launches it
+    replaces (LT_DECONV_NO_H2D=1).  One-tile maps, 24- and 48-wide maps (two column tiles per row), odd image counts."""
+    monkeypatch.setenv("LT_H2D_ANY_SIZE", "1")
+    g = torch.Generator().manual_seed(4300 + N + Hh + W)
+    x = torch.relu(torch.randn(N, 256, Hh, W, generator=g))
+    w = torch.randn(256, 256, 4, 4, generator=g) / (4 * 256) ** 0.5
+    bn = _bn(256, g)
+    rd = bf16_round
+    ref = torch.relu(_bn_ref(F.conv_transpose2d(rd(x), rd(w), None, 2, 1), bn))
+
+    def run(halo):
+        if halo:
+            monkeypatch.delenv("LT_DECONV_NO_H2D", raising=False)
+        else:
+            monkeypatch.setenv("LT_DECONV_NO_H2D", "1")
+        b = E.PlanBuilder(DEV, torch.bfloat16)
+        y = b.conv(E.Act(to_cl(x, None, torch.bfloat16)), w, None, bn, stride=2, pad=1, transposed=True, relu=True)
+        assert all(b.last_info["desc"].phase[i].weight_frag_layout == (2 if halo else 3) for i in range(4))
+        plan = b.finish()
+        plan.run_eager(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return from_cl(y.t, 2)
+    yh = run(True)
+    name = "deconv4x4_halo/N%d_%dx%d" % (N, Hh, W)
+    check(name + "/vs_torch", yh, ref, 1.5e-2)
+    yi = run(False)
+    check(name + "/vs_implicit_gemm", yh, yi, 1.5e-2)
+    rms = float((yh.float() - yi.float()).pow(2).mean().sqrt() / yi.float().pow(2).mean().sqrt())
+    record(name + "/rms_vs_implicit_gemm", rms)
+    assert rms < 2e-3
+
+
 @pytest.mark.parametrize("wsrc", ["registers", "lds"])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (32, 64), (128, 128), (16, 32)])
 @pytest.mark.parametrize("N,sp", [(1, (8, 8, 16)), (3, (4, 16, 8)), (8, (8, 16, 16))])
