@@ -105,7 +105,10 @@ __global__ __launch_bounds__(512, (TH == 8 ? 1 : 2)) void conv2d_halo_kernel(con
     // ---- roles: wave = output-channel block; fragment f = (row group i = f / CG, column group j = f % CG): pixel (4 i + vl / 8, 8 j + vl % 8) ----
     const int cb = wave;
     const int vl = lane & 31, hk = lane >> 5;
-    constexpr int NU = NT * G, WD = 7, NS = WD + 1;       // weight fragments: requested WD units ahead, straight through the phases (NU % NS == 0)
+#ifndef LT_H2D_WD
+#define LT_H2D_WD 7
+#endif
+    constexpr int NU = NT * G, WD = LT_H2D_WD, NS = WD + 1;   // weight fragments: requested WD units ahead, straight through the phases (NU % NS == 0)
     static_assert(NU % NS == 0, "the fragment ring must close at a phase boundary");
     auto wptr = [&](int p) -> const T* { return a.ph[p].wfrag + ((size_t)cb * 64 + lane) * 8; };
     auto load_w = [&](int p, int u) -> V16 {             // unit u = tap * G + g of phase p -> fragment ((u * NB + cb) * 64 + lane) * 16 bytes
@@ -171,7 +174,11 @@ __global__ __launch_bounds__(512, (TH == 8 ? 1 : 2)) void conv2d_halo_kernel(con
         for (int f = 0; f < FR; ++f)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
-        V16 xa[2][FR];
+#ifndef LT_H2D_XLOOK
+#define LT_H2D_XLOOK 1
+#endif
+        constexpr int XL = LT_H2D_XLOOK, XS = XL + 1;       // pixel fragments are read XL units ahead of the MFMAs that use them (-DLT_H2D_XLOOK=n: A/B builds)
+        V16 xa[XS][FR];
         auto load_x = [&](auto uc, V16 (&dst)[FR]) {
             constexpr int u = decltype(uc)::value;
             constexpr int tap = u / G, g = u % G;
@@ -180,15 +187,15 @@ __global__ __launch_bounds__(512, (TH == 8 ? 1 : 2)) void conv2d_halo_kernel(con
                 dst[f].u = *(const uint4*)((lptr_t)(size_t)((lp[tap][i] ^ (g << 5)) + j * 8 * PXB));
             });
         };
-        load_x(std::integral_constant<int, 0>{}, xa[0]);
+        static_for_p<0, XL>([&](auto uc) { load_x(uc, xa[decltype(uc)::value % XS]); });
         static_for_p<0, NU>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             if constexpr (u + WD < NU) wf[(u + WD) % NS] = load_w(p, u + WD);
             else if constexpr (p + 1 < NPH) wf[(u + WD) % NS] = load_w(p + 1, u + WD - NU);    // the next phase's first fragments, under this phase's tail
-            if constexpr (u + 1 < NU) load_x(std::integral_constant<int, u + 1>{}, xa[(u + 1) & 1]);
+            if constexpr (u + XL < NU) load_x(std::integral_constant<int, u + XL>{}, xa[(u + XL) % XS]);
 #pragma unroll
             for (int f = 0; f < FR; ++f)
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % NS].h, xa[u & 1][f].h, acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u % NS].h, xa[u % XS][f].h, acc[f], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
 

@@ -23,6 +23,6 @@ a=load('gpurun_out/lab_ops_base.json')
 for v in sys.argv[1:]:
     b=load('gpurun_out/lab_ops_%s.json'%v)
     rows=sorted(((b[k][1]-a[k][1],k) for k in b if k in a))
-    print("==", v, "total %+.3f ms"%sum(r[0] for r in rows))
+    print("==", v, "total %+.3f ms"%sum(r[0] for r in rows)); [print("   %s: %.1f -> %.1f us"%(k[:44], 1e3*a[k][1]/a[k][0], 1e3*b[k][1]/b[k][0])) for k in b if k in a and (k.startswith("conv3x3 256->256 @256") or k.startswith("deconv4x4 256->256"))]
     for d,k in rows[:5]+rows[-3:]: print("%+.3f ms  %-55s n=%d  %.1f -> %.1f us"%(d,k[:55],b[k][0],1e3*a[k][1]/a[k][0],1e3*b[k][1]/b[k][0]))
 PY
