@@ -100,7 +100,9 @@ typedef struct lt_conv_phase {
     const void* weight_frag; /* optional (NULL = none): the same bf16 weights in an MFMA fragment order, so that a kernel can read
                                 its weight operand with coalesced loads instead of staging it through LDS */
     int32_t weight_frag_layout; /* 0 = none; 1 = lt_conv_pack_weights (Cout % 256 == 0 layers, 288 x 256 / 144 x 256 kernels on the 16x16x32 MFMA);
-                                   2 = lt_conv_pack_weights_t32 (3x3x3 64->64 / 32->64 / 128->128 halo kernel);
+                                   2 = lt_conv_pack_weights_t32 (3x3x3 64->64 / 32->64 / 128->128 / 16->32 halo kernel; round 5: the 2D halo kernel for 256->256
+                                       layers on maps of 24 n x 8 m pixels -- 3x3 / stride 1 / pad 1, or the four 2 x 2-tap phases of a 4x4 / stride-2 /
+                                       pad-1 transposed convolution, every phase packed with its own ntaps; taps must lie within one pixel of the output pixel);
                                    3 = lt_conv_pack_weights32 (288 x 256 kernel on the 32x32x16 MFMA) */
 } lt_conv_phase;
 

@@ -336,13 +336,14 @@ class PlanBuilder:
                 pass
             elif (self.dtype == torch.bfloat16 and not self.dry_run and x.shape[-1] == 256 and spec.D == 1 and spec.W % 24 == 0 and spec.H % 8 == 0
                   and residual is None and not out_f32 and not sigmoid and not self.tile_override and os.environ.get("LT_CONV_NO_H2D") != "1"
-                  and (spec.N * (spec.H // 8) * (spec.W // 24) >= (256 if transposed else 512) or os.environ.get("LT_H2D_ANY_SIZE") == "1")
+                  and (spec.N * (spec.H // 8) * (spec.W // 24) >= 60 or os.environ.get("LT_H2D_ANY_SIZE") == "1")
                   and ((not transposed and tuple(weight.shape) == (256, 256, 3, 3) and spec.stride == (1, 1, 1) and spec.pad == (0, 1, 1) and spec.W == 24) or
                        (transposed and tuple(weight.shape) == (256, 256, 4, 4) and len(spec.phases) == 4 and os.environ.get("LT_DECONV_NO_H2D") != "1"))):
                 # ResNet layer3's 3x3 256 -> 256 on 24-wide maps and the 4x4 / stride-2 transposed convolutions 256 -> 256 of the head (four parities of
-                # 2 x 2 taps), from two rounds of 8 x 24 tiles on (one round for the transposed ones: one launch there replaces four): fragments of the
-                # transposed product for conv2d_halo_kernel (input halo resident in LDS; LT_CONV_NO_H2D=1 keeps conv_igemm7, LT_DECONV_NO_H2D=1 only for
-                # the transposed ones)
+                # 2 x 2 taps), from 60 tiles of 8 x 24 pixels on (= 5 samples of 4 views; measured with the threshold off: 799.9 -> 811.3 samples/s at 5 samples,
+                # 1145 -> 1172 at 10, 1406 -> 1428 at 32 -- a tile is a ~40 us serial chain, so a handful of them loses to the small implicit-GEMM tiles):
+                # fragments of the transposed product for conv2d_halo_kernel (input halo resident in LDS; LT_CONV_NO_H2D=1 keeps conv_igemm7,
+                # LT_DECONV_NO_H2D=1 only for the transposed ones)
                 wfr = torch.empty_like(wdev)
                 H.check(H.lib().lt_conv_pack_weights_t32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, 256, int(ph.taps.shape[0]), wfr.data_ptr(), H.cur_stream()),
                         "lt_conv_pack_weights_t32")
