@@ -262,9 +262,14 @@ int conv2d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, hipS
     a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
     a.N = c.N; a.H = c.H; a.W = c.W; a.OH = c.OH; a.OW = c.OW; a.osh = c.osh; a.osw = c.osw; a.ldc = c.ldc; a.flags = c.flags; a.tiles_h = a.tiles_w = 0;
     a.pad_h = c.ph; a.pad_w = c.pw;
-    const char* th = getenv("LT_H2D_TH");                 // A/B: 4 = half-height tiles, two workgroups per CU
+    // 8-row tiles (one workgroup per CU, every weight fragment feeds six MFMAs) from half a round of them on; below that the 4-row tiles (twice as many
+    // workgroups) halve the time of the single round -- measured end to end (forward, samples/s, 8-row -> 4-row): 5 samples (60 tiles of 8 rows) 808 -> 871,
+    // 10 samples (120) 1167 -> 1219, 16 samples (192) 1325 -> 1307, 64 samples (768) 1418 -> 1399 (LT_H2D_TH=4 / 8 forces one)
+    const char* th = getenv("LT_H2D_TH");
+    const long long tiles8 = (long long)c.N * (c.H / 8) * (c.W / 24);
+    const bool th4 = th ? th[0] == '4' : tiles8 <= 128;
     int rc;
-    if (nphase == 1) rc = (th && th[0] == '4') ? launch_halo2d<4, 9, 1>(a, s) : launch_halo2d<8, 9, 1>(a, s);
+    if (nphase == 1) rc = th4 ? launch_halo2d<4, 9, 1>(a, s) : launch_halo2d<8, 9, 1>(a, s);
     else rc = launch_halo2d<8, 4, 4>(a, s);
     return rc == LT_OK ? 1 : rc;
 }
