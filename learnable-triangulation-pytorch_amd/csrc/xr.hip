@@ -94,10 +94,12 @@ __device__ __forceinline__ void static_for_x(F&& f) {
 
 // FULL: every tile of the launch is complete (no row checks anywhere: a wave-uniform run-time switch made hipcc merge its counter state at the join and wait
 // vmcnt(0), a per-store condition made it park the rows in scratch); the ragged last tile of a tensor runs as a second one-tile launch with FULL = false.
-template <int C, int P, bool FULL>
+// NPB: pixel blocks of 32 per tile.  3 (96 pixels: 147456 rows of the benchmark = 6 whole rounds of 256 tiles) is the throughput shape -- every weight fragment
+// feeds three MFMAs; 2 and 1 are for small batches, where 96-pixel tiles leave CUs without a tile (20 images = 120 tiles).
+template <int C, int P, bool FULL, int NPB>
 __global__ __launch_bounds__(512, 2) void xr_kernel(const XrArgs a) {
     typedef bf16_t T;
-    constexpr int NPB = 3, TM = 32 * NPB;                    // 96 pixels per tile (147456 rows of the benchmark = 6 whole rounds of 256 tiles)
+    constexpr int TM = 32 * NPB;
     constexpr int CH = 128, NCH = C / CH;                    // expand output channels per chunk / chunks
     constexpr int G3 = P / 16, G1 = CH / 16;                 // K blocks of the expand / of one chunk of the reduce
     constexpr int NOB3 = C / 32, NOB1 = P / 32;              // 32-channel output blocks of the two weight matrices
@@ -357,21 +359,32 @@ extern "C" int lt_expand_reduce_fwd(const lt_xr_desc* d, const void* t2, const v
     LT_REQUIRE(!d->consts || ((size_t)d->consts % 16 == 0), LT_ERR_INVALID, "lt_expand_reduce_fwd: consts must be 16-byte aligned");
     a.M = (int)d->M;
     LT_REQUIRE(d->M < (1ll << 31) - 256, LT_ERR_UNSUPPORTED, "lt_expand_reduce_fwd: row count");
-    constexpr int TMH = 96, lds = TMH * 512 + 2 * TMH * 256 + (2 * 1024 + 2 * 256) * 4;
-    const long long nfull = d->M / TMH;
-    if (nfull > 0) {
-        auto kern = xr_kernel<1024, 256, true>;
-        LT_OPT_IN_LDS(kern, lds);
-        a.tile0 = 0;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nfull), dim3(512), lds, (hipStream_t)stream, a);
-        LT_CHECK_LAUNCH("lt_expand_reduce_fwd");
-    }
-    if (d->M % TMH) {
-        auto kern = xr_kernel<1024, 256, false>;
-        LT_OPT_IN_LDS(kern, lds);
-        a.tile0 = (int)nfull;
-        hipLaunchKernelGGL(kern, dim3(1), dim3(512), lds, (hipStream_t)stream, a);
-        LT_CHECK_LAUNCH("lt_expand_reduce_fwd(ragged tile)");
-    }
-    return LT_OK;
+    // tile height: 96 pixels once they fill most of the chip; 64 / 32 when 96-pixel tiles would leave CUs idle -- measured (forward samples/s with 96 / 64 / 32
+    // pixels): 2 samples (48 tiles of 96) 446 / 461 / 470, 5 samples (120) 857 / 876 / 836, 10 samples (240) 1186 / 1135 / 1122 (LT_XR_NPB=1|2|3 forces one)
+    const char* e = getenv("LT_XR_NPB");
+    const long long t96 = (d->M + 95) / 96;
+    const int npb = e ? (e[0] - '0') : (t96 >= 224 ? 3 : t96 >= 112 ? 2 : 1);
+    LT_REQUIRE(npb >= 1 && npb <= 3, LT_ERR_INVALID, "lt_expand_reduce_fwd: LT_XR_NPB=%s", e ? e : "?");
+    auto run = [&](auto npbc) -> int {
+        constexpr int NPBH = decltype(npbc)::value, TMH = 32 * NPBH, lds = TMH * 512 + 2 * TMH * 256 + (2 * 1024 + 2 * 256) * 4;
+        const long long nfull = d->M / TMH;
+        if (nfull > 0) {
+            auto kern = xr_kernel<1024, 256, true, NPBH>;
+            LT_OPT_IN_LDS(kern, lds);
+            a.tile0 = 0;
+            hipLaunchKernelGGL(kern, dim3((unsigned)nfull), dim3(512), lds, (hipStream_t)stream, a);
+            LT_CHECK_LAUNCH("lt_expand_reduce_fwd");
+        }
+        if (d->M % TMH) {
+            auto kern = xr_kernel<1024, 256, false, NPBH>;
+            LT_OPT_IN_LDS(kern, lds);
+            a.tile0 = (int)nfull;
+            hipLaunchKernelGGL(kern, dim3(1), dim3(512), lds, (hipStream_t)stream, a);
+            LT_CHECK_LAUNCH("lt_expand_reduce_fwd(ragged tile)");
+        }
+        return LT_OK;
+    };
+    if (npb == 3) return run(std::integral_constant<int, 3>{});
+    if (npb == 2) return run(std::integral_constant<int, 2>{});
+    return run(std::integral_constant<int, 1>{});
 }

@@ -731,10 +731,11 @@ class PlanBuilder:
         P, Cc = t2.shape[-1], res.shape[-1]
         if (Cc, P) != (1024, 256):
             return False
-        # one 96-row tile per workgroup and one workgroup per CU: below ~64 tiles the two launches (144-row tiles x 4 column tiles, two workgroups per CU)
-        # spread better -- measured (round 5, tools/batch_sweep_probe.py): 1 / 2 samples (24 / 48 tiles) -8 % / -2.5 % end to end with the seam kernel,
-        # 3 / 5 / 8 / 10 samples +1.5 % / +3.2 % / +4 % / +6.4 %
-        if t2.shape[0] * t2.shape[2] * t2.shape[3] < 64 * 96 and os.environ.get("LT_XR_ANY_SIZE") != "1":
+        # one tile per workgroup and one workgroup per CU.  With 96-row tiles only, 1 / 2 samples (24 / 48 tiles) lost 8 % / 2.5 % end to end to the two
+        # launches (144-row tiles x 4 column tiles, two workgroups per CU) and the builder fused from 64 tiles on; the launcher now picks 64- and 32-row tiles
+        # for small row counts (measured, forward samples/s, 96 / 64 / 32-row tiles / two launches: 1 sample 277 / 286 / 297 / 301, 2 samples 446 / 461 / 470 /
+        # 454, 5 samples 857 / 876 / 836 / 827, 10 samples 1186 / 1135 / 1122 / 1104), so the seam is fused from 2 samples = 36 tiles of 96 rows on
+        if t2.shape[0] * t2.shape[2] * t2.shape[3] < 36 * 96 and os.environ.get("LT_XR_ANY_SIZE") != "1":
             return False
         return tuple(w_expand.shape) == (Cc, P, 1, 1) and tuple(w_reduce.shape) == (P, Cc, 1, 1)
 

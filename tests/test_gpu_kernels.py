@@ -1166,8 +1166,9 @@ def test_bottleneck_with_downsample_fused(N, Hh, W, monkeypatch):
     assert e_f <= e_4 * 1.05 + 1e-6   # adding the branch unrounded cannot be worse than rounding it first
 
 
+@pytest.mark.parametrize("npb", ["3", "2", "1"])
 @pytest.mark.parametrize("N,Hh,W", [(2, 6, 6), (2, 24, 24), (8, 24, 24), (3, 12, 20)])
-def test_expand_reduce_seam_fused(N, Hh, W, monkeypatch):
+def test_expand_reduce_seam_fused(N, Hh, W, npb, monkeypatch):
     """lt_expand_reduce_fwd (round 5; pose_resnet.py:75-95, the seam between two identity blocks of layer3: expand + bn3 + residual + ReLU of block i, reduce +
     bn1 + ReLU of block i + 1) against (a) torch fp32 on bf16-rounded operands with y rounded to bf16 where the expand stores it, (b) the two lt_conv_fwd
     launches it replaces.  72 rows (one ragged 128-row tile), 1152 and 4608 rows (whole tiles, several per XCD), 720 rows (5.6 tiles: ragged tail, odd count)."""
@@ -1180,6 +1181,7 @@ def test_expand_reduce_seam_fused(N, Hh, W, monkeypatch):
     t2_cl, res_cl = to_cl(t2, None, torch.bfloat16), to_cl(res, None, torch.bfloat16)
 
     monkeypatch.setenv("LT_XR_ANY_SIZE", "1")          # the plan builder only picks the seam kernel from 64 tiles on; the kernel itself takes any row count
+    monkeypatch.setenv("LT_XR_NPB", npb)               # tiles of 96 / 64 / 32 pixels (the launcher picks by row count: these shapes would all get 32)
 
     def run(fused):
         if fused:

@@ -405,7 +405,7 @@ def test_expand_reduce_seam_fusion_of_layer3_is_recorded_and_equals_the_separate
     for bn in [mm for mm in m.modules() if isinstance(mm, torch.nn.BatchNorm2d)]:
         bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.data.uniform_(0.2, 0.6); bn.bias.data.normal_(0, 0.1)
     x = torch.randn(2, 1, 6, 6, 1024)                      # 72 GEMM rows: one ragged tile
-    b0 = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)          # by default the builder only fuses from 64 tiles of 96 rows on (small batches spread better as two launches)
+    b0 = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)          # by default the builder only fuses from 36 tiles of 96 rows (2 samples of 4 views) on: below, the two launches spread better
     assert not b0.can_expand_reduce(b0.alloc((2, 1, 6, 6, 256)), b0.alloc((2, 1, 6, 6, 1024)), m.layer3[1].conv3.weight, m.layer3[2].conv1.weight)
     assert b0.can_expand_reduce(b0.alloc((12, 1, 24, 24, 256)), b0.alloc((12, 1, 24, 24, 1024)), m.layer3[1].conv3.weight, m.layer3[2].conv1.weight)
     monkeypatch.setenv("LT_XR_ANY_SIZE", "1")
