@@ -59,6 +59,7 @@ struct Halo2dArgs {
     const float* scale;
     const float* shift;
     int N, H, W, OH, OW, osh, osw, ldc, flags, tiles_h, tiles_w, pad_h, pad_w;
+    int tile0;               // first tile of this launch (a ragged last round runs as a second launch of half-height tiles)
     Halo2dPhase ph[4];
 };
 
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(512, (TH == 8 ? 1 : 2)) void conv2d_halo_kernel(con
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = lin & 7, j = lin >> 3;
         lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
+    lin += a.tile0;
     const int tpi = a.tiles_h * a.tiles_w;
     const int n = lin / tpi, rem = lin - n * tpi;
     const int h0 = (rem / a.tiles_w) * TH, w0 = (rem % a.tiles_w) * TW;
@@ -219,16 +221,21 @@ __global__ __launch_bounds__(512, (TH == 8 ? 1 : 2)) void conv2d_halo_kernel(con
     });
 }
 
+// tiles [first, first + count) of the TH-row tiling of the whole tensor (count < 0: all of them)
 template <int TH, int NT, int NPH>
-int launch_halo2d(const Halo2dArgs& a0, hipStream_t s) {
+int launch_halo2d(const Halo2dArgs& a0, hipStream_t s, long long first = 0, long long count = -1) {
     Halo2dArgs a = a0;
     a.tiles_h = a.H / TH;
     a.tiles_w = a.W / 24;
+    const long long total = (long long)a.N * a.tiles_h * a.tiles_w;
+    if (count < 0) count = total - first;
+    if (count <= 0) return LT_OK;
+    a.tile0 = (int)first;
     constexpr int lds = (TH + 2) * 26 * 512;
     static_assert(lds <= 160 * 1024, "halo fits LDS");
     auto kern = conv2d_halo_kernel<TH, NT, NPH>;
     LT_OPT_IN_LDS(kern, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * a.tiles_h * a.tiles_w)), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(512), lds, s, a);
     LT_CHECK_LAUNCH("lt_conv_fwd(2D halo)");
     return LT_OK;
 }
@@ -261,7 +268,7 @@ int conv2d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, hipS
     a.x = (const bf16_t*)c.x; a.y = (bf16_t*)c.y;
     a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
     a.N = c.N; a.H = c.H; a.W = c.W; a.OH = c.OH; a.OW = c.OW; a.osh = c.osh; a.osw = c.osw; a.ldc = c.ldc; a.flags = c.flags; a.tiles_h = a.tiles_w = 0;
-    a.pad_h = c.ph; a.pad_w = c.pw;
+    a.pad_h = c.ph; a.pad_w = c.pw; a.tile0 = 0;
     // 8-row tiles (one workgroup per CU, every weight fragment feeds six MFMAs) from half a round of them on; below that the 4-row tiles (twice as many
     // workgroups) halve the time of the single round -- measured end to end (forward, samples/s, 8-row -> 4-row): 5 samples (60 tiles of 8 rows) 808 -> 871,
     // 10 samples (120) 1167 -> 1219, 16 samples (192) 1325 -> 1307, 64 samples (768) 1418 -> 1399 (LT_H2D_TH=4 / 8 forces one)
@@ -269,8 +276,20 @@ int conv2d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, hipS
     const long long tiles8 = (long long)c.N * (c.H / 8) * (c.W / 24);
     const bool th4 = th ? th[0] == '4' : tiles8 <= 128;
     int rc;
-    if (nphase == 1) rc = th4 ? launch_halo2d<4, 9, 1>(a, s) : launch_halo2d<8, 9, 1>(a, s);
-    else rc = launch_halo2d<8, 4, 4>(a, s);
+    if (nphase != 1) rc = launch_halo2d<8, 4, 4>(a, s);
+    else if (th4) rc = launch_halo2d<4, 9, 1>(a, s);
+    else {
+        // whole rounds of 8-row tiles (one workgroup per CU), and a ragged last round of at most half the CUs as 4-row tiles in a second launch: its
+        // workgroups are half as long, so the tail costs half a round instead of a whole one (128 images = 384 tiles: 256 + 2 x 128)
+        const int n_cu = lt::device_cu_count8();
+        const long long rem = tiles8 % n_cu;
+        // (the split point must be a whole row of tiles, so that 8-row tile t and the 4-row tiles 2 t, 2 t + 1 cover the same pixels)
+        const bool split = !th && tiles8 > n_cu && rem > 0 && 2 * rem <= n_cu && (tiles8 - rem) % (c.W / 24) == 0 && !getenv("LT_H2D_NO_TAIL4");
+        if (split) {
+            rc = launch_halo2d<8, 9, 1>(a, s, 0, tiles8 - rem);
+            if (rc == LT_OK) rc = launch_halo2d<4, 9, 1>(a, s, 2 * (tiles8 - rem), 2 * rem);
+        } else rc = launch_halo2d<8, 9, 1>(a, s);
+    }
     return rc == LT_OK ? 1 : rc;
 }
 

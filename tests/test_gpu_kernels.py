@@ -794,6 +794,38 @@ def test_conv2d_halo_3x3_256(N, Hh, th, monkeypatch):
     assert rms < 2e-3          # same products in another summation order + one output rounding: a wrong tap / halo row / K block is far above
 
 
+def test_conv2d_halo_ragged_last_round_runs_as_half_height_tiles(monkeypatch):
+    """128 images of 24 x 24 (the 32-sample forward, config 4 at 16 samples): 384 tiles of 8 rows = one round of 256 + 128; the tail runs as 256 tiles of 4 rows
+    in a second launch (half a round instead of a whole one).  Same result as the single launch (LT_H2D_NO_TAIL4=1) BIT FOR BIT -- the tile height does not
+    change a pixel's summation order -- and as torch on a sample of images."""
+    monkeypatch.setenv("LT_H2D_ANY_SIZE", "1")
+    monkeypatch.delenv("LT_H2D_TH", raising=False)
+    g = torch.Generator().manual_seed(4242)
+    N = 128
+    x = torch.relu(torch.randn(N, 256, 24, 24, generator=g))
+    w = torch.randn(256, 256, 3, 3, generator=g) / (9 * 256) ** 0.5
+    bn = _bn(256, g)
+    x_cl = to_cl(x, None, torch.bfloat16)
+
+    def run(tail4):
+        if tail4:
+            monkeypatch.delenv("LT_H2D_NO_TAIL4", raising=False)
+        else:
+            monkeypatch.setenv("LT_H2D_NO_TAIL4", "1")
+        b = E.PlanBuilder(DEV, torch.bfloat16)
+        y = b.conv(E.Act(x_cl), w, None, bn, stride=1, pad=1, relu=True)
+        assert b.last_info["desc"].phase[0].weight_frag_layout == 2
+        b.finish().run_eager(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return y.t.clone()
+    ya, yb = run(True), run(False)
+    assert torch.equal(ya, yb)
+    rd = bf16_round
+    for i in (0, 85, 86, 127):          # images on both sides of the split (tile 256 = image 85, rows 8-15)
+        ref = torch.relu(_bn_ref(F.conv2d(rd(x[i:i + 1]), rd(w), None, 1, 1), bn))
+        check("conv2d_halo/tail4/image%d" % i, from_cl(ya[i:i + 1], 2), ref, 1.5e-2)
+
+
 @pytest.mark.parametrize("N,Hh,W", [(1, 8, 24), (3, 24, 24), (2, 16, 48), (5, 48, 48)])
 def test_deconv4x4_256_halo(N, Hh, W, monkeypatch):
     """conv2d_halo_kernel<8, 4, 4> (round 5): the 4x4 / stride-2 / pad-1 transposed convolutions 256 -> 256 of the deconvolution head (pose_resnet.py:208-233,
