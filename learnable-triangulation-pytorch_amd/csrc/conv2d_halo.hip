@@ -7,9 +7,13 @@
 // Here a workgroup owns TH rows x 24 columns of one image (24 x 24 maps: the 384 x 384 crops of the benchmark), DMAs the (TH + 2) x 26 pixel halo ONCE
 // (512 bytes per pixel, 16-byte slots XOR-swizzled by (column & 7) | (row & 1) << 3 on the source side: every ds_read_b128 of a 4 x 8 pixel fragment is
 // bank-conflict free for every tap), and then walks 9 taps x 16 K blocks with no barrier: per unit one weight fragment from global memory (fragment order
-// of the transposed product, lt_conv_pack_weights_t32; wave = one 32-channel output block) and one pixel fragment per 4 x 8 block from LDS at a
-// compile-time tap offset.  Transposed product with permuted weight rows: a lane ends up with two runs of 8 consecutive channels of ONE pixel and stores
-// them as 16-byte vectors straight from the accumulators (BatchNorm + ReLU folded in; this layer has no residual).
+// of the transposed product, lt_conv_pack_weights_t32; wave = one 32-channel output block) and one pixel fragment per 4 x 8 block from LDS at the tap's
+// offset (the taps come from the descriptor's tap table, read once per launch: one address register per tap and row group).  Transposed product with permuted
+// weight rows: a lane ends up with two runs of 8 consecutive channels of ONE pixel and stores them as 16-byte vectors straight from the accumulators
+// (BatchNorm + ReLU folded in; these layers have no residual).
+// The same kernel runs the 4x4 / stride-2 / pad-1 transposed convolutions 256 -> 256 of the deconvolution head (pose_resnet.py:208-233): their four output
+// parities are four phases of 2 x 2 taps over the same halo -- one launch, the halo loaded once, the weight ring running through the phase boundaries.
+// Tile heights: 8 rows (one workgroup per CU) for throughput, 4 rows (two per CU) below half a round of 8-row tiles and for a ragged last round.
 #include <stdlib.h>
 
 #include <type_traits>
