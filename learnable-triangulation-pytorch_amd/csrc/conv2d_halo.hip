@@ -1,5 +1,5 @@
 // conv2d_halo_kernel: the 3x3 / stride 1 / pad 1 convolution 256 -> 256 of ResNet layer3's bottlenecks (reference mvn/models/pose_resnet.py:75-95, conv2 of
-// the 36 blocks of ResNet-152's third stage: 20 % of the forward) with the input HALO of a tile resident in LDS -- the 2D sibling of
+// the 35 stride-1 blocks of ResNet-152's third stage (the first block strides its 3x3): 20 % of the forward) with the input HALO of a tile resident in LDS -- the 2D sibling of
 // conv3d_halo_wreg_kernel.
 //
 // Why (round 5): the implicit-GEMM kernel (conv_igemm7<2>) streams the im2col matrix through an LDS ring, i.e. every input pixel crosses L2 -> LDS nine

@@ -446,3 +446,29 @@ def test_expand_reduce_seam_fusion_of_layer3_is_recorded_and_equals_the_separate
         m.record(b, b.alloc((1, 1, 64, 64, E.min_cin_of(dt))), False)
         labels = [meta["label"] for _, meta in b.finish().ops]
         assert sum(l.startswith("xr ") for l in labels) == want, (dt, [l for l in labels if l.startswith("xr ")])
+
+
+def test_benchmark_model_plan_records_the_round5_fusions():
+    """The launch structure of the benchmark's model (BASELINE config 2: ResNet-152, 4 views of 384 x 384, 64^3 voxels) as a bf16 plan at 8 samples, recorded
+    dry: layer1's first block as one launch, 9 whole identity bottlenecks in layer1 / layer2, 34 expand + reduce seams in layer3, the first blocks of layer2 / 3
+    with expand + strided downsample as one pointwise convolution (layer4's 128 rows x 8 column tiles stay below that kernel's size rule at 8 samples), V2V's
+    16 -> 32 block with its skip convolution inside the second convolution, the pointwise tail as one chain -- and nothing of it in an fp32 plan."""
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    cfg = synth.vol_config(152, 64, "softmax")
+    m = VolumetricTriangulationNet(cfg, device="cpu")
+    m.eval()
+    counts = {}
+    for dt in (torch.bfloat16, torch.float32):
+        m.compute_dtype = dt
+        P = m._build_plan(8 if dt == torch.bfloat16 else 1, 4, 384, 384, "cpu", dry_run=True)
+        labels = [meta["label"] for _, meta in P["plan"].ops]
+        counts[dt] = {"launches": len(labels), "xr": sum(l.startswith("xr ") for l in labels), "bneck": sum(l.startswith("bneck ") for l in labels),
+                      "bneck-ds": sum(l.startswith("bneck-ds") for l in labels), "cat2": sum("downsample)" in l for l in labels),
+                      "skip": sum("+ skip conv1x1x1" in l for l in labels), "pwchain": sum(l.startswith("pwchain") for l in labels),
+                      "conv3x3 256->256": sum(l.startswith("conv3x3 256->256 @") for l in labels)}
+        del P
+    b, f = counts[torch.bfloat16], counts[torch.float32]
+    assert (b["xr"], b["bneck"], b["bneck-ds"], b["cat2"], b["skip"], b["pwchain"]) == (34, 9, 1, 2, 1, 1), b
+    assert b["conv3x3 256->256"] == 36              # layer3's 36 blocks: 35 stride-1 ones (the 2D halo kernel on the GPU) + the strided one of the first block
+    assert (f["xr"], f["bneck"], f["bneck-ds"], f["cat2"], f["skip"], f["pwchain"]) == (0, 0, 0, 0, 0, 0), f
+    assert b["launches"] <= f["launches"] - 40, (b["launches"], f["launches"])        # 177 against 220 when this was written
