@@ -540,8 +540,10 @@ int lt_bottleneck_ds_fwd(const lt_bneck_ds_desc* desc, const void* x, void* y, v
  *   t1 = relu(bn1'(conv1x1_reduce'(y)))                    P channels, the next block's first activation
  * The reduce consumes y from LDS while the tile is there: the C-channel tensor is not read back from memory.
  * y is rounded to bf16 exactly where the expand's own launch would store it (the reduce sees those values).
- * t2 [M][P], residual / y [M][C], t1 [M][P]: channels-last bf16, M = N * H * W GEMM rows (any M: 128-row
- * tiles, the last one masked);  (C, P) = (1024, 256): the identity blocks of ResNet layer3.
+ * t2 [M][P], residual / y [M][C], t1 [M][P]: channels-last bf16, M = N * H * W GEMM rows (any M: tiles of
+ * 96 / 64 / 32 rows, chosen by M against the device's CU count -- 96 from 7/8 of a round of 96-row tiles on,
+ * 64 from 7/16; LT_XR_NPB=3|2|1 forces one -- and a ragged last tile as a second one-workgroup launch with
+ * row checks);  (C, P) = (1024, 256): the identity blocks of ResNet layer3.
  * weight[0]: lt_conv_pack_weights_t32 of the expand's lt_conv_fwd packing [C][P] (ntaps 1, cin P);
  * weight[1]: the same of the reduce's [P][C] (ntaps 1, cin C);  scale / shift [i]: the folded BatchNorm of
  * layer i (C / P floats), applied as acc * scale + shift (ResNet convolutions carry no bias).

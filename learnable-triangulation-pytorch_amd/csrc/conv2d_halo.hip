@@ -276,16 +276,16 @@ int conv2d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, hipS
     // 8-row tiles (one workgroup per CU, every weight fragment feeds six MFMAs) from half a round of them on; below that the 4-row tiles (twice as many
     // workgroups) halve the time of the single round -- measured end to end (forward, samples/s, 8-row -> 4-row): 5 samples (60 tiles of 8 rows) 808 -> 871,
     // 10 samples (120) 1167 -> 1219, 16 samples (192) 1325 -> 1307, 64 samples (768) 1418 -> 1399 (LT_H2D_TH=4 / 8 forces one)
-    const char* th = getenv("LT_H2D_TH");
+    const char* th = getenv("LT_H2D_TH");                       // A/B switches are read per launch CALL (tests flip them in-process); graph replays never get here
     const long long tiles8 = (long long)c.N * (c.H / 8) * (c.W / 24);
-    const bool th4 = th ? th[0] == '4' : tiles8 <= 128;
+    const int n_cu = lt::device_cu_count8();
+    const bool th4 = th ? th[0] == '4' : tiles8 <= n_cu / 2;   // half a round of 8-row tiles (128 on the 256-CU part)
     int rc;
     if (nphase != 1) rc = launch_halo2d<8, 4, 4>(a, s);
     else if (th4) rc = launch_halo2d<4, 9, 1>(a, s);
     else {
         // whole rounds of 8-row tiles (one workgroup per CU), and a ragged last round of at most half the CUs as 4-row tiles in a second launch: its
         // workgroups are half as long, so the tail costs half a round instead of a whole one (128 images = 384 tiles: 256 + 2 x 128)
-        const int n_cu = lt::device_cu_count8();
         const long long rem = tiles8 % n_cu;
         // (the split point must be a whole row of tiles, so that 8-row tile t and the 4-row tiles 2 t, 2 t + 1 cover the same pixels)
         const bool split = !th && tiles8 > n_cu && rem > 0 && 2 * rem <= n_cu && (tiles8 - rem) % (c.W / 24) == 0 && !getenv("LT_H2D_NO_TAIL4");

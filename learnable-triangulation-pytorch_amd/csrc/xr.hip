@@ -127,8 +127,11 @@ __global__ __launch_bounds__(512, 2) void xr_kernel(const XrArgs a) {
 
     // ---- once: the BatchNorm constants of both layers into LDS ----
     if (a.consts) {                                           // [sc3 | sh3 | sc1 | sh1] back to back: ten 1 KiB LDS-DMA pieces, no register round trip
+        // issued by the EXPANDER waves only: an LDS-DMA counts in vmcnt, and only those waves wait vmcnt(0) in front of the first barrier (the reducers wait
+        // lgkmcnt(0) there -- a piece issued by a reducer could still be in flight when an expander reads sh3 in the chunk-0 epilogue: ADVICE r5)
         constexpr int NPC = (2 * C + 2 * P) * 4 / 1024;
-        for (int p = wave; p < NPC; p += 8) dma16x((const void*)((const char*)a.consts + p * 1024 + lane * 16), lds0 + CST_OFF + p * 1024);
+        if (wave < 4)
+            for (int p = wave; p < NPC; p += 4) dma16x((const void*)((const char*)a.consts + p * 1024 + lane * 16), lds0 + CST_OFF + p * 1024);
     } else {
         for (int i = t; i < 2 * C + 2 * P; i += 512)
             cst[i] = i < C ? a.sc3[i] : i < 2 * C ? a.sh3[i - C] : i < 2 * C + P ? a.sc1[i - 2 * C] : a.sh1[i - 2 * C - P];
@@ -361,9 +364,10 @@ extern "C" int lt_expand_reduce_fwd(const lt_xr_desc* d, const void* t2, const v
     LT_REQUIRE(d->M < (1ll << 31) - 256, LT_ERR_UNSUPPORTED, "lt_expand_reduce_fwd: row count");
     // tile height: 96 pixels once they fill most of the chip; 64 / 32 when 96-pixel tiles would leave CUs idle -- measured (forward samples/s with 96 / 64 / 32
     // pixels): 2 samples (48 tiles of 96) 446 / 461 / 470, 5 samples (120) 857 / 876 / 836, 10 samples (240) 1186 / 1135 / 1122 (LT_XR_NPB=1|2|3 forces one)
-    const char* e = getenv("LT_XR_NPB");
+    const char* e = getenv("LT_XR_NPB");                        // A/B switch, read per launch CALL (the tests flip it in-process); a replayed hipGraph never gets here
     const long long t96 = (d->M + 95) / 96;
-    const int npb = e ? (e[0] - '0') : (t96 >= 224 ? 3 : t96 >= 112 ? 2 : 1);
+    const int ncu = device_cu_count8();                         // thresholds in CUs: 7/8 and 7/16 of the chip (224 / 112 tiles on the 256-CU part)
+    const int npb = e ? (e[0] - '0') : (t96 >= ncu * 7 / 8 ? 3 : t96 >= ncu * 7 / 16 ? 2 : 1);
     LT_REQUIRE(npb >= 1 && npb <= 3, LT_ERR_INVALID, "lt_expand_reduce_fwd: LT_XR_NPB=%s", e ? e : "?");
     auto run = [&](auto npbc) -> int {
         constexpr int NPBH = decltype(npbc)::value, TMH = 32 * NPBH, lds = TMH * 512 + 2 * TMH * 256 + (2 * 1024 + 2 * 256) * 4;

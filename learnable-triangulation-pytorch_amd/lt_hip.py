@@ -11,7 +11,26 @@ import os
 # default, and overlapped completely with 8 queues (B = 1 per forward: 8.2 -> 4.7 ms for both).  The training step (main + weight-gradient side stream +
 # RCCL's own streams) and concurrent inference requests want distinct queues, so ask for 8 unless the caller has decided otherwise.  Only effective when
 # this module is imported before the process's first HIP call (the variable is read when the runtime initialises).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Opt-out: LT_KEEP_HW_QUEUES=1 leaves the variable alone (a host application that manages its own runtime configuration); an explicit GPU_MAX_HW_QUEUES in
+# the environment always wins.  If HIP was initialised before this import the variable can no longer take effect: say so instead of failing silently
+# (INTEGRATION.md "Process-wide settings").
+import sys
+import warnings
+
+
+def _request_hw_queues():
+    if os.environ.get("LT_KEEP_HW_QUEUES") == "1" or "GPU_MAX_HW_QUEUES" in os.environ:
+        return
+    t = sys.modules.get("torch")
+    if t is not None and t.cuda.is_initialized():
+        warnings.warn("lt_hip: HIP is already initialised, GPU_MAX_HW_QUEUES=8 cannot take effect any more (streams may share hardware queues: the "
+                      "training step's side stream and concurrent forwards then serialise).  Import lt_hip before the first CUDA/HIP call or export "
+                      "GPU_MAX_HW_QUEUES=8 yourself; LT_KEEP_HW_QUEUES=1 silences this.", RuntimeWarning, stacklevel=3)
+        return
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
+
+_request_hw_queues()
 
 import torch
 
