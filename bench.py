@@ -313,6 +313,12 @@ def _train_short(t):
     if rf.get("traffic"):
         o["traffic_gb"] = _r(rf["traffic"] / 1e9)
         o["mfma_busy_frac"] = _r(rf.get("mfma_busy_frac"), 3)
+    rc = t.get("rccl") or {}
+    if t.get("n_gpus", 1) > 1:          # an N-GPU training line diagnoses itself: per-rank rates, replicas, what the exchange left exposed behind the backward
+        o["per_rank"] = [_r(v, 3) for v in t.get("per_rank_samples_per_s", [])]
+        for k in ("replicas_identical_after_training", "gradient_buckets_per_step", "allreduce_window_ms_per_step", "backward_main_stream_ms", "exposed_behind_main_stream_ms"):
+            if rc.get(k) is not None:
+                o[k] = _r(rc[k], 4) if isinstance(rc[k], float) else rc[k]
     if t.get("kernel_share"):          # the four families that carry the step; the rest (and the recording-step note) stays in the full record
         o["kernel_share"] = {k: v for k, v in list(t["kernel_share"].items())[:4]}
     return o
@@ -607,6 +613,105 @@ def train_leg(args, model, dev, world, rank, barrier, images, batch, workload):
     lt_dist.shutdown()
 
 
+def preflight(args, world, rank, local):
+    """``bench.py --gpus N --preflight``: make the first N-GPU run on hardware boring.  Three checks, each through the process group the timed runs use,
+    one JSON line from rank 0 (``ok`` = all of them passed), then exit:
+      1. census -- an all-reduce of ones counts the ranks, an all-gather collects every rank's device (name / PCI bus id): N ranks on N DISTINCT devices;
+      2. one 64 MB fp32 all-reduce, timed (two warm-ups, three timed; max over ranks): algorithmic and bus bandwidth 2 (N - 1) / N x bytes / t -- an xGMI ring is
+         per-link bound (~153 GB/s per link, MI355X guide), so a healthy 8-GPU node shows a few hundred GB/s here and a mis-routed one (PCIe) ~20;
+      3. one data-parallel training step (reference train.py:450-460: DistributedDataParallel semantics through lt_dist.GradReducer -- rank 0's weights
+         broadcast, per-rank batches, bucketed gradient all-reduce overlapped with the backward, Adam): finite loss, ``replicas_identical`` afterwards.
+    --stub-cpu runs the same three checks over gloo with a stand-in model (tests/test_distributed_cpu.py)."""
+    import lt_dist
+    stub = args.stub_cpu
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if torch.cuda.device_count() <= local:
+            raise RuntimeError("rank %d needs cuda:%d but only %d GPU(s) are visible" % (rank, local, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    sync = (lambda: None) if stub else torch.cuda.synchronize
+    comm = lt_dist.comm_info(dev)
+    devices = comm.get("devices") or []
+    census_ok = comm.get("nranks") == world and (stub or world == 1 or len(set(devices)) == world)
+    # ---- one 64 MB all-reduce, timed
+    n = (64 << 20) // 4
+    buf = torch.ones(n, dtype=torch.float32, device=dev)
+    times = []
+    for it in range(5):
+        sync(); lt_dist.barrier(); sync()
+        t0 = time.perf_counter()
+        if world > 1:
+            torch.distributed.all_reduce(buf)
+        sync()
+        dt = lt_dist.max_over_ranks(time.perf_counter() - t0, dev)
+        if it >= 2:
+            times.append(dt)
+        buf.fill_(1.0)
+    t_ar = sorted(times)[len(times) // 2]
+    allreduce = {"bytes": 4 * n, "ms": 1e3 * t_ar, "algorithmic_gb_per_s": 4 * n / t_ar / 1e9 if world > 1 else None,
+                 "bus_gb_per_s": (2 * (world - 1) / world) * 4 * n / t_ar / 1e9 if world > 1 else None}
+    # ---- one data-parallel training step
+    torch.manual_seed(100 + rank)          # the ranks START different on purpose: attach() has to make them identical
+    step_info = {}
+    if stub:
+        net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.BatchNorm1d(256), torch.nn.Linear(256, 64))
+        red = lt_dist.GradReducer(bucket_bytes=32 << 10).attach(net) if world > 1 else None
+        x = torch.randn(8, 64, generator=torch.Generator().manual_seed(7 + rank))
+        loss = net(x).pow(2).mean()
+        loss.backward()
+        arena = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        if red is not None:
+            for o in range(0, arena.numel(), 8192):
+                red.reduce_inplace(arena[o:o + 8192])
+            red.wait_all()
+        o = 0
+        with torch.no_grad():
+            for p in net.parameters():
+                p.sub_(1e-3 * arena[o:o + p.numel()].view(p.shape)); o += p.numel()
+        step_info = {"loss": float(loss), "model": "stand-in (Linear + BatchNorm1d + Linear)"}
+        model = net
+    else:
+        import lt_train
+        from mvn.models import loss as L
+        pre = argparse.Namespace(**vars(args))
+        pre.layers, pre.volume = 50, 32          # a small member of the family (ResNet-50, 32^3 voxels, 2 samples of 4 x 256^2): seconds, same code path
+        B, image = 2, 256
+        model = make_bench_model(pre, dev)
+        model.to(dev); model.train(); model.train_precision = "act16"
+        red = model.grad_reducer = lt_dist.GradReducer().attach(model) if world > 1 else None
+        images_cpu, batch, _ = synthetic_batch(B, args.views, image, 1000 + rank)
+        images = images_cpu.to(dev)
+        opt = lt_train.Adam([{"params": list(model.parameters())}], lr=1e-4)
+        gt = (torch.as_tensor(np.asarray(batch["pred_keypoints_3d"]))[:, :, :3].float()).to(dev)
+        val = torch.ones(B, 17, 1, device=dev)
+        np.random.seed(1234 + rank)
+        t0 = time.perf_counter()
+        kp, _, vols, _, _, cvs, _ = model(images, None, batch)
+        loss = L.KeypointsMAELoss()(kp * 0.1, gt * 0.1, val) + 0.01 * L.VolumetricCELoss()(cvs, vols, gt, val)
+        opt.zero_grad(); loss.backward(); opt.step()
+        sync()
+        step_info = {"loss": float(loss), "model": "ResNet-50 backbone, 32^3 voxels, 2 samples x %d views x %dx%d per rank, act16" % (args.views, image, image),
+                     "record_and_step_s": time.perf_counter() - t0}
+        plan = next(iter(model.__dict__.get("_train_plans", {}).values()), None)
+        bt = plan.tape.backward_timing() if plan is not None and plan.tape is not None else None
+        if bt:
+            step_info.update(bt)
+    step_info["loss_finite_on_every_rank"] = lt_dist.sum_over_ranks(1.0 if np.isfinite(step_info["loss"]) else 0.0, dev) == world
+    if world > 1:
+        step_info["replicas_identical_after_training"] = bool(red.replicas_identical(model, buffers=False))
+        step_info.update(red.stats())
+    ok = bool(census_ok and step_info["loss_finite_on_every_rank"] and (world == 1 or step_info["replicas_identical_after_training"]))
+    lt_dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "preflight", "ok": ok, "n_gpus": world, "backend": comm.get("backend"), "rccl": comm, "census_ok": bool(census_ok),
+                          "allreduce_64MB": allreduce, "train_step": step_info, "self_launched": os.environ.get("LT_BENCH_SELF_LAUNCHED") == "1"}))
+    lt_dist.shutdown()
+    if not ok:
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -641,6 +746,8 @@ def main():
     ap.add_argument("--fp32-parity-batch", type=int, default=0, help="with --no-extras: also run this many samples through the exact-fp32 kernel set and report their "
                     "parity (the config-4 child leg of the default run: the driver line then shows config 4 inside the tolerance)")
     ap.add_argument("--stub-cpu", action="store_true", help="TEST ONLY: gloo backend, no GPU, step() is a sleep (exercises launcher + timing plumbing)")
+    ap.add_argument("--preflight", action="store_true", help="N-GPU sanity run before a scaling session (VERDICT r5 'next' 7): communicator census (ranks, distinct "
+                    "devices, RCCL version), ONE timed 64 MB all-reduce, ONE data-parallel training step with the replicas checked identical, then exit with its own JSON line")
     args = ap.parse_args()
     if not args.batch:
         # 64 samples (256 images) per GPU per step from round 4 on: two full rounds of 288-row tiles on the 256 CUs and half the per-sample share of the
@@ -659,6 +766,9 @@ def main():
     c4 = (args.views, args.volume, args.layers) == (8, 128, 152)
     workload = "%svolumetric-softmax forward, %d views %dx%d, %d^3 voxel cube, ResNet-%d, random-init weights" % (
         "BASELINE config 2: " if c2 else "BASELINE config 4: " if c4 else "", args.views, args.image, args.image, args.volume, args.layers)
+
+    if args.preflight:
+        return preflight(args, world, rank, local)
 
     if args.stub_cpu:       # launcher / collective plumbing without a GPU (tests/test_distributed_cpu.py)
         dev = torch.device("cpu")

@@ -283,6 +283,15 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
         const int rc = conv2d_halo_try(LT_BF16, a, cout_pad, nphase, s);
         if (rc < 0) return rc;
         if (rc == 1) return LT_OK;
+        // a 2D layer whose weights were packed in layout 2 has NO layout-1 / -3 fragments: the generic tiles would still compute it (from the plain
+        // [cout][k] weights) at a fraction of the rate, silently.  The plan builder's gate mirrors conv2d_halo_try's predicate; a mismatch is a bug: say so
+        // (ADVICE r5).  (3D layers carry layout-2 fragments for conv3d_halo_wreg_kernel, whose siblings above take them when it declines.)
+        if (a.D == 1 && a.Do == 1 && a.OD == 1) {
+            set_error("lt_conv_fwd: 2D layer with weight_frag_layout 2 (conv2d_halo_kernel) but the halo kernel does not cover it: Cin %d, Cout %d, ldc %d, "
+                      "%d x %d -> %d x %d, stride %d, pad %d, %d phase(s), flags 0x%x%s", a.Cin, a.Cout, a.ldc, a.H, a.W, a.OH, a.OW, a.sh, a.ph, nphase, a.flags,
+                      a.res ? ", residual" : "");
+            return LT_ERR_UNSUPPORTED;
+        }
     }
     static const bool no_v3 = getenv("LT_CONV_NO_V3") != nullptr;   // A/B switch
     if ((tile == LT_TILE_AUTO && !force_v1 && !no_v3) || tile == LT_TILE3_288) {

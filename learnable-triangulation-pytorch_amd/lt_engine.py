@@ -225,6 +225,11 @@ class PlanBuilder:
         # copy in MFMA fragment order may be packed at build time (a kernel reading one would compute with the build-time values), and no split-K
         # pair (two ops per convolution) is recorded
         self.live_weights = False
+        # round 6: with live weights, STILL pack the fragment-order copies (from whatever the build-time tensor holds) and hand each one out as
+        # info["wfrag"] = [(phase, fragment tensor, pack(src_ptr, dst_ptr))]: the tape composes the pack's permutation with its own index map and gathers
+        # the live Parameter straight into the fragment layout every step, so the training forward / input gradients run the kernels of the inference
+        # forward (conv2d_halo, conv_igemm6/7, conv3d_halo_wreg) instead of the generic tiles
+        self.live_frag = False
         self.flops = 0         # 2*MAC of the recorded convolutions
         self.bytes_alloc = 0
         self.ntail = 0         # trailing ops kept out of the captured graph (PlanBuilder.custom(tail=True))
@@ -323,7 +328,7 @@ class PlanBuilder:
         d.out_stride = H.i3(spec.out_stride)
         d.Cout, d.ldc, d.cout_pad, d.k_pad = spec.Cout, spec.Cout, spec.cout_pad, spec.k_pad
         d.nphase, d.flags, d.tile, d.stages = len(spec.phases), spec.flags, self.tile_override, self.stages
-        wdevs = []
+        wdevs, wfrags = [], []
         for i, ph in enumerate(spec.phases):
             wdev = self.const(ph.weight, self.dtype)
             wdevs.append(wdev)
@@ -332,22 +337,30 @@ class PlanBuilder:
             d.phase[i].ntaps = ph.taps.shape[0]; d.phase[i].out_off = H.i3(ph.out_off)
             # wide bf16 layers also get their weights in MFMA fragment order (B operand read straight from global memory by
             # the 288 x 256 kernel); packed once, here
-            if self.live_weights:
+            if self.live_weights and not self.live_frag:
                 pass
             elif (self.dtype == torch.bfloat16 and not self.dry_run and x.shape[-1] == 256 and spec.D == 1 and spec.W % 24 == 0 and spec.H % 8 == 0
                   and residual is None and not out_f32 and not sigmoid and not self.tile_override and os.environ.get("LT_CONV_NO_H2D") != "1"
+                  and spec.Cout == spec.cout_pad == 256 and d.ldc % 8 == 0 and not any(os.environ.get(k) for k in ("LT_CONV_V1",))
                   and (spec.N * (spec.H // 8) * (spec.W // 24) >= 60 or os.environ.get("LT_H2D_ANY_SIZE") == "1")
-                  and ((not transposed and tuple(weight.shape) == (256, 256, 3, 3) and spec.stride == (1, 1, 1) and spec.pad == (0, 1, 1) and spec.W == 24) or
-                       (transposed and tuple(weight.shape) == (256, 256, 4, 4) and len(spec.phases) == 4 and os.environ.get("LT_DECONV_NO_H2D") != "1"))):
+                  # conv2d_halo_try's predicate, mirrored (the dispatcher fails loudly on a layout-2 2D layer the kernel declines): a "same" 3x3 / stride 1 /
+                  # pad 1, or the four 2 x 2-tap parities of a 4x4 / stride 2 / pad 1 / output_padding 0 transposed convolution that doubles the map
+                  and ((not transposed and tuple(weight.shape) == (256, 256, 3, 3) and spec.stride == (1, 1, 1) and spec.pad == (0, 1, 1) and spec.W == 24
+                        and (spec.OH, spec.OW) == (spec.Ho, spec.Wo) == (spec.H, spec.W) and spec.out_stride == (1, 1, 1)) or
+                       (transposed and tuple(weight.shape) == (256, 256, 4, 4) and len(spec.phases) == 4 and os.environ.get("LT_DECONV_NO_H2D") != "1"
+                        and output_padding == 0 and spec.out_stride == (1, 2, 2) and (spec.OH, spec.OW) == (2 * spec.H, 2 * spec.W)
+                        and all(int(p.taps.shape[0]) == 4 for p in spec.phases)))):
                 # ResNet layer3's 3x3 256 -> 256 on 24-wide maps and the 4x4 / stride-2 transposed convolutions 256 -> 256 of the head (four parities of
                 # 2 x 2 taps), from 60 tiles of 8 x 24 pixels on (= 5 samples of 4 views; measured with the threshold off: 799.9 -> 811.3 samples/s at 5 samples,
                 # 1145 -> 1172 at 10, 1406 -> 1428 at 32 -- a tile is a ~40 us serial chain, so a handful of them loses to the small implicit-GEMM tiles):
                 # fragments of the transposed product for conv2d_halo_kernel (input halo resident in LDS; LT_CONV_NO_H2D=1 keeps conv_igemm7,
                 # LT_DECONV_NO_H2D=1 only for the transposed ones)
                 wfr = torch.empty_like(wdev)
-                H.check(H.lib().lt_conv_pack_weights_t32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, 256, int(ph.taps.shape[0]), wfr.data_ptr(), H.cur_stream()),
-                        "lt_conv_pack_weights_t32")
+                pack = lambda sp, dp, a=(spec.cout_pad, spec.k_pad, 256, int(ph.taps.shape[0])): H.check(
+                    H.lib().lt_conv_pack_weights_t32(sp, a[0], a[1], a[2], a[3], dp, H.cur_stream()), "lt_conv_pack_weights_t32")
+                pack(wdev.data_ptr(), wfr.data_ptr())
                 self.keep.append(wfr)
+                wfrags.append((i, wfr, pack))
                 d.phase[i].weight_frag, d.phase[i].weight_frag_layout = wfr.data_ptr(), 2
             elif self.dtype == torch.bfloat16 and not self.dry_run and spec.cout_pad % 256 == 0 and spec.k_pad % 64 == 0:
                 wfr = torch.empty_like(wdev)
@@ -357,23 +370,27 @@ class PlanBuilder:
                 # 16x16x32 order (measured: conv_igemm7 103.6 vs 85.6 us on 256->1024)
                 short_pw = all(k == 1 for k in weight.shape[2:]) and spec.k_pad <= 256 and not transposed
                 if os.environ.get("LT_CONV_NO_V7") != "1" and not short_pw:
-                    H.check(H.lib().lt_conv_pack_weights32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, wfr.data_ptr(), H.cur_stream()),
-                            "lt_conv_pack_weights32")
+                    pack = lambda sp, dp, a=(spec.cout_pad, spec.k_pad): H.check(H.lib().lt_conv_pack_weights32(sp, a[0], a[1], dp, H.cur_stream()),
+                                                                                 "lt_conv_pack_weights32")
                     layout = 3
                 else:
-                    H.check(H.lib().lt_conv_pack_weights(wdev.data_ptr(), spec.cout_pad, spec.k_pad, wfr.data_ptr(), H.cur_stream()),
-                            "lt_conv_pack_weights")
+                    pack = lambda sp, dp, a=(spec.cout_pad, spec.k_pad): H.check(H.lib().lt_conv_pack_weights(sp, a[0], a[1], dp, H.cur_stream()),
+                                                                                 "lt_conv_pack_weights")
                     layout = 1
+                pack(wdev.data_ptr(), wfr.data_ptr())
                 self.keep.append(wfr)
+                wfrags.append((i, wfr, pack))
                 d.phase[i].weight_frag, d.phase[i].weight_frag_layout = wfr.data_ptr(), layout
             elif (self.dtype == torch.bfloat16 and not self.dry_run and not transposed and x.shape[-1] == weight.shape[1]
                   and tuple(weight.shape) in ((64, 64, 3, 3, 3), (64, 32, 3, 3, 3), (128, 128, 3, 3, 3), (32, 16, 3, 3, 3))
                   and spec.stride == (1, 1, 1) and spec.pad == (1, 1, 1)):
                 # 3x3x3 64 -> 64, 32 -> 64, 128 -> 128, 16 -> 32 (V2V): fragments of the transposed product for conv3d_halo_wreg_kernel
                 wfr = torch.empty_like(wdev)
-                H.check(H.lib().lt_conv_pack_weights_t32(wdev.data_ptr(), spec.cout_pad, spec.k_pad, weight.shape[1], 27, wfr.data_ptr(),
-                                                         H.cur_stream()), "lt_conv_pack_weights_t32")
+                pack = lambda sp, dp, a=(spec.cout_pad, spec.k_pad, int(weight.shape[1])): H.check(
+                    H.lib().lt_conv_pack_weights_t32(sp, a[0], a[1], a[2], 27, dp, H.cur_stream()), "lt_conv_pack_weights_t32")
+                pack(wdev.data_ptr(), wfr.data_ptr())
                 self.keep.append(wfr)
+                wfrags.append((i, wfr, pack))
                 d.phase[i].weight_frag, d.phase[i].weight_frag_layout = wfr.data_ptr(), 2
         bi, sc, sh = self.const(spec.bias), self.const(spec.scale), self.const(spec.shift)
         self.keep.append(d)
@@ -387,7 +404,7 @@ class PlanBuilder:
         esz = torch.empty((), dtype=self.dtype).element_size()
         nbytes = (x.t.numel() + y.t.numel() + (residual.t.numel() if residual is not None else 0)) * esz + \
             sum(p.weight.numel() for p in spec.phases) * esz
-        info = {"spec": spec, "x": x, "y": y, "res": residual, "wdev": wdevs, "bias_dev": bi, "scale_dev": sc, "shift_dev": sh, "desc": d}
+        info = {"spec": spec, "x": x, "y": y, "res": residual, "wdev": wdevs, "bias_dev": bi, "scale_dev": sc, "shift_dev": sh, "desc": d, "wfrag": wfrags}
         if skip_info is not None:
             macs += spec.N * spec.Do * spec.Ho * spec.Wo * spec.Cout * 16
             self.flops += 2 * spec.N * spec.Do * spec.Ho * spec.Wo * spec.Cout * 16

@@ -62,6 +62,10 @@ class TrainTape:
         self.pbh = E.PlanBuilder(device, torch.bfloat16) if self.mixed else None
         if self.pbh is not None:
             self.pbh.live_weights = True
+            # round 6 (VERDICT r5 "next" 2 iv): the 16-bit step's convolutions read bf16 and store bf16 through their ordinary epilogues, so the fragment-order /
+            # halo kernels of the inference forward apply -- given their weights in fragment order EVERY step: the builder packs the fragment copies as in
+            # inference and the tape gathers the live Parameter straight into them through the composed index map (_frag_index_map).  LT_TRAIN_NO_FRAG=1: off (A/B)
+            self.pbh.live_frag = self.act16 and os.environ.get("LT_TRAIN_NO_FRAG") is None
         # mixed precision, opt-in (LT_TRAIN_Y16=1): the output of a convolution that feeds a BatchNorm is STORED in bf16 -- its statistics, the
         # normalisation and the BatchNorm backward read 2 bytes instead of 4, and every bf16 kernel of the forward applies (fp32 stores are
         # restricted to the generic one and the column walk); BatchNorm's output, the gradients and everything else stay fp32.  Measured: the
@@ -263,6 +267,21 @@ class TrainTape:
             self.batched[id(fn)] = True
             (self.fwd_jobs if self._cur is self.fwd_ops else self.bwd_jobs).append((src, imap, dst, n))
 
+    def _frag_index_map(self, plain, pack):
+        """Index map of a fragment-order weight copy: ``plain`` is the layer's [cout_pad][k_pad] matrix of (1 + flat Parameter index), 0 = padding (what the
+        gather of the plain GEMM layout uses); ``pack(src_ptr, dst_ptr)`` is the device routine that permutes a bf16 matrix of that shape into the fragment
+        order.  The permutation is taken FROM the routine: the indices go through it as three byte planes (0..255 are exact in bf16), so whatever order a
+        kernel's packer defines, the gather reproduces it -- no host restatement of any fragment layout."""
+        idx = plain.round().to(torch.int64).contiguous()
+        assert int(idx.max()) < (1 << 24)
+        out = torch.zeros(idx.numel(), dtype=torch.int64, device=self.device)
+        for sh in (0, 8, 16):
+            src = ((idx >> sh) & 255).to(torch.bfloat16).to(self.device).contiguous()
+            dst = torch.zeros_like(src)
+            pack(src.data_ptr(), dst.data_ptr())
+            out += dst.reshape(-1).float().round().to(torch.int64) << sh
+        return (out - 1).to(torch.int32)
+
     def _cast(self, src, dst):
         n = src.numel()
         self.keep += [src, dst]
@@ -302,6 +321,9 @@ class TrainTape:
             for ph, wdev in zip(spec_idx.phases, info["wdev"]):
                 assert tuple(ph.weight.shape) == tuple(wdev.shape)
                 self._gather(wparam, (ph.weight.round().to(torch.int32) - 1).contiguous().to(self.device), wdev, "w")      # fp32 Parameter -> bf16 GEMM layout
+            for pi, wfr, pack in info.get("wfrag", ()):          # ... and into the fragment-order copy the fast kernels read (live_frag)
+                self._gather(wparam, self._frag_index_map(spec_idx.phases[pi].weight, pack), wfr.reshape(-1), "w")
+                self.n_frag_layers = getattr(self, "n_frag_layers", 0) + 1
             if bias is not None:
                 bi = info["bias_dev"]
                 bmap = torch.full((bi.numel(),), -1, dtype=torch.int32)

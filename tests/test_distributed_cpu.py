@@ -118,6 +118,18 @@ def test_bench_eight_ranks_the_drivers_scaling_shape():
     assert c["gradient_buckets_per_step"] == -(-nparam // 8192) and c["gradient_bytes_per_step"] == 4 * nparam
 
 
+def test_bench_preflight_two_ranks():
+    """`bench.py --gpus N --preflight` (VERDICT r5 "next" 7): the sanity run in front of a scaling session -- communicator census, one timed 64 MB all-reduce,
+    one data-parallel training step with the replicas checked identical -- over gloo with the stand-in model; same launcher and collectives as on RCCL."""
+    res = _run_bench(["--gpus", "2", "--preflight", "--stub-cpu"])
+    assert res["metric"] == "preflight" and res["ok"] is True and res["n_gpus"] == 2 and res["self_launched"] is True
+    assert res["census_ok"] is True and res["rccl"]["nranks"] == 2 and len(set(res["rccl"]["devices"])) == 2
+    ar = res["allreduce_64MB"]
+    assert ar["bytes"] == 64 << 20 and ar["ms"] > 0 and ar["bus_gb_per_s"] > 0 and abs(ar["bus_gb_per_s"] - ar["algorithmic_gb_per_s"]) < 1e-9      # 2 (N - 1) / N = 1 at N = 2
+    st = res["train_step"]
+    assert st["loss_finite_on_every_rank"] is True and st["replicas_identical_after_training"] is True and st["gradient_buckets_per_step"] >= 1
+
+
 def test_bench_under_torchrun_env_does_not_relaunch():
     """The driver's way: torch.distributed.run starts the ranks; bench.py must then NOT launch again."""
     import json

@@ -362,6 +362,73 @@ def test_tape_layer_gradients(case, mode, mixed):
         check(tag + " db", pg[bp].cpu(), bd.grad, T2)
 
 
+FRAG_CASES = [  # nd, Cin, Cout, k, pad, transposed, N, spatial -- shapes whose bf16 inference kernels read fragment-order weights
+    (2, 256, 256, 3, 1, False, 20, (24, 24)),        # conv2d_halo_kernel (60 tiles of 8 x 24 pixels), forward AND input gradient (the flipped filter has the same shape)
+    (2, 256, 1024, 1, 0, False, 32, (24, 24)),       # 288 / 144-row fragment-order kernels (conv_igemm6: short K), input gradient 1024 -> 256 (conv_igemm7)
+    (2, 256, 256, 4, 1, True, 20, (24, 24)),         # the head's 4x4 / stride-2 transposed convolution: four parities over one halo
+    (3, 64, 64, 3, 1, False, 2, (32, 32, 32)),       # conv3d_halo_wreg_kernel
+    (3, 16, 32, 3, 1, False, 1, (64, 64, 64)),       # ... its 16 -> 32 instantiation (forward; the 32 -> 16 input gradient has no fragment kernel)
+]
+
+
+@pytest.mark.parametrize("case", FRAG_CASES, ids=lambda c: "nd%d_%dto%d_k%d%s_N%d" % (c[0], c[1], c[2], c[3], "_T" if c[5] else "", c[6]))
+def test_tape_live_fragment_weights(case, monkeypatch):
+    """Round 6 (VERDICT r5 "next" 2 iv): the 16-bit training tape gathers the LIVE Parameters straight into the fragment-order copies the fast inference
+    kernels read (PlanBuilder.live_frag + TrainTape._frag_index_map), so its forward / input gradients leave the generic tiles.  Checked here: (a) the
+    gathered fragment copy equals the device packer applied to the gathered plain copy BIT FOR BIT, at record time and after the weights have changed;
+    (b) forward and input gradient against torch on the bf16-rounded operands, and against the same tape with the fragments off (LT_TRAIN_NO_FRAG=1)."""
+    import lt_engine as E
+    import lt_train
+    nd, Cin, Cout, k, p, tr, N, sp = case
+    g = torch.Generator().manual_seed(Cin + 3 * Cout + k)
+    bf = torch.bfloat16
+    x = torch.randn(N, Cin, *sp, generator=g).to(bf).float()
+    wshape = (Cin, Cout) if tr else (Cout, Cin)
+    w = (torch.randn(*wshape, *([k] * nd), generator=g) * (1.0 / np.sqrt(Cin * k ** nd))).to(bf).float()
+    conv = {(2, False): F.conv2d, (3, False): F.conv3d, (2, True): F.conv_transpose2d}[(nd, tr)]
+    s = 2 if tr else 1
+    xr = x.clone().requires_grad_(True)
+    y = conv(xr, w, None, stride=s, padding=p)
+    dz = torch.randn(y.shape, generator=g).to(bf).float()
+    (y * dz).sum().backward()
+    outs = {}
+    for mode in ("frag", "plain"):
+        if mode == "plain":
+            monkeypatch.setenv("LT_TRAIN_NO_FRAG", "1")
+        wp = torch.nn.Parameter(w.to(DEV))
+        tape = lt_train.TrainTape(DEV, params=[wp], mixed=True, act16=True)
+        xa = E.Act(to_cl(x, None, bf))
+        z = tape.conv(xa, wp, None, None, stride=s, pad=p, transposed=tr)
+        if mode == "frag":
+            assert getattr(tape, "n_frag_layers", 0) >= 1, "no fragment-order copy was recorded for this shape"
+            info = tape.pbh.last_info
+            for pi, wfr, pack in info["wfrag"]:
+                ref = torch.zeros_like(wfr); pack(info["wdev"][pi].data_ptr(), ref.data_ptr())
+                assert torch.equal(ref.view(torch.int16), wfr.view(torch.int16)), "gathered fragments != pack(gathered plain layout)"
+        else:
+            assert getattr(tape, "n_frag_layers", 0) == 0
+        tape.seed(z, to_cl(dz, None, bf))
+        tape.run_backward()
+        outs[mode] = (from_cl(z.t, nd).clone(), from_cl(tape.grad_of(xa), nd).clone())
+        if mode == "frag":          # the weights change in place (an optimiser step): the replay must see them in BOTH layouts
+            n0 = tape.n_frag_layers
+            with torch.no_grad():
+                wp.mul_(-0.5)
+            tape.run_forward()
+            torch.cuda.synchronize()
+            for pi, wfr, pack in info["wfrag"]:
+                ref = torch.zeros_like(wfr); pack(info["wdev"][pi].data_ptr(), ref.data_ptr())
+                assert torch.equal(ref.view(torch.int16), wfr.view(torch.int16))
+            z2 = from_cl(z.t, nd)
+            check("train/live fragments nd%d %d->%d k%d%s: forward after an in-place weight update" % (nd, Cin, Cout, k, " T" if tr else ""), z2, -0.5 * y.detach(), 1.5e-2)
+            record("train/live fragments nd%d %d->%d k%d%s: fragment-order copies (forward + input gradient)" % (nd, Cin, Cout, k, " T" if tr else ""), n0)
+    tag = "train/live fragments nd%d %d->%d k%d%s N%d" % (nd, Cin, Cout, k, " T" if tr else "", N)
+    check(tag + " z vs torch", outs["frag"][0], y.detach(), 1.5e-2)
+    check(tag + " dx vs torch", outs["frag"][1], xr.grad, 1.5e-2)
+    check(tag + " z vs the generic tiles", outs["frag"][0], outs["plain"][0], 1.5e-2)
+    check(tag + " dx vs the generic tiles", outs["frag"][1], outs["plain"][1], 1.5e-2)
+
+
 W16_CASES = [  # N, (D, H, W), Cin, Cout, k (taps per dim), stride, pad
     (11, (1, 9, 7), 64, 96, (1, 1, 1), 1, 0),        # pointwise, two octet groups with a ragged second one, Cout not a multiple of 32
     (8, (1, 10, 12), 32, 64, (1, 3, 3), 1, 1),       # 2D 3x3

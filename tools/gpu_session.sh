@@ -12,6 +12,14 @@ STAGES="${@:-tests bench prof}"
 echo "== stages: $STAGES" | tee $OUT/session.log
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9" | head -4 | tee -a $OUT/session.log
 nproc | tee -a $OUT/session.log
+# on a box with >= 2 GPUs the N-rank path comes FIRST (VERDICT r5 "next" 7: it has never run on hardware): the two-rank RCCL test, then the preflight
+NGPU=$(python -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 0)
+if [ "${NGPU:-0}" -ge 2 ]; then
+  timeout 900 python -m pytest tests/test_gpu_train.py -m gpu -q --tb=short -p no:cacheprovider -k "two_ranks_rccl" > $OUT/test_two_ranks_rccl.log 2>&1
+  echo "two-rank RCCL test rc=$?" | tee -a $OUT/session.log; tail -3 $OUT/test_two_ranks_rccl.log | tee -a $OUT/session.log
+  timeout 900 python bench.py --gpus $NGPU --preflight > $OUT/preflight.json 2> $OUT/preflight.err
+  echo "preflight ($NGPU GPUs) rc=$?" | tee -a $OUT/session.log; cat $OUT/preflight.json | tee -a $OUT/session.log
+fi
 for s in $STAGES; do
 case $s in
 tests)
