@@ -698,7 +698,10 @@ def main():
         # round 6: the benchmark shape at B = 8 (32 images): the smallest batch at which the bf16 plan records the kernels the timed forward is made of --
         # conv2d_halo_kernel (from 20 images), the layer3 seam kernel, bneck_ds, cat2 (forced on in its test) -- so that they run under a REFERENCE golden
         # with a joint gate in mm (tests/test_gpu_models.py::test_volumetric_forward_bf16_deviation); stride 8 keeps the fixture at ~2.5 MB
-        run_vol_case(mvn, "c2_b8_sharp", 152, 8, 4, 384, 64, "softmax", sharpen=True, seed=11, stride=8)
+        # gain 150, not the x250 of c2_sharp: with this seed's weights x250 puts the soft-argmax into the near-argmax regime SURVEY section 7 says not to gate
+        # on (largest probability 0.07-0.24 per sample against c2_sharp's 7e-3; the REFERENCE then deviates from itself by 1.2e-4 between 1 and 8 threads --
+        # measured -- i.e. by more than the 1e-4 gate); x150: largest probability ~1e-2, the reference's own thread-count noise < 5e-5
+        run_vol_case(mvn, "c2_b8_sharp", 152, 8, 4, 384, 64, "softmax", sharpen=150.0, seed=11, stride=8)
     if "train" in which:
         print("[train]"); gen_train(mvn)
     if "train_frozen" in which:

@@ -1198,7 +1198,7 @@ def test_bottleneck_with_downsample_fused(N, Hh, W, monkeypatch):
     assert e_f <= e_4 * 1.05 + 1e-6   # adding the branch unrounded cannot be worse than rounding it first
 
 
-@pytest.mark.parametrize("npb", ["3", "2", "1"])
+@pytest.mark.parametrize("npb", ["4", "3", "2", "1"])
 @pytest.mark.parametrize("N,Hh,W", [(2, 6, 6), (2, 24, 24), (8, 24, 24), (3, 12, 20)])
 def test_expand_reduce_seam_fused(N, Hh, W, npb, monkeypatch):
     """lt_expand_reduce_fwd (round 5; pose_resnet.py:75-95, the seam between two identity blocks of layer3: expand + bn3 + residual + ReLU of block i, reduce +
