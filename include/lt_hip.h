@@ -181,6 +181,12 @@ int lt_conv_cat2_fwd(const lt_conv_desc* desc, const void* x, const lt_conv_cat2
 /* weight padding rule (every tile's N divides it): cout_pad = 16 if Cout <= 16, 32 if <= 32, 64 if <= 64,
  * else Cout rounded up to a multiple of 128; bias/scale/shift arrays hold cout_pad floats. */
 int lt_conv_cout_pad(int32_t cout);
+/* Samples per launch of lt_conv_fwd / lt_conv_skip_fwd / lt_conv_cat2_fwd for tensors of `per_sample` elements per sample (the largest of input,
+ * output, second source).  The kernels index ONE launch with 32-bit element offsets; the entry points accept any batch and walk batches beyond 2^31
+ * elements per tensor in chunks of this many samples, every per-sample pointer advanced in 64 bits (BASELINE config 4 at 32 samples per GPU --
+ * 32 x 128^3 voxels x 32 channels = 2^31 elements -- is one call; reference: mvn/models/triangulation.py:245-355 has no such limit).  Returns N
+ * when the whole batch fits, a multiple of 8 where possible otherwise, 0 when a single sample is too large. */
+int32_t lt_conv_chunk_samples(int32_t N, int64_t per_sample);
 
 /* max pooling, channels-last, window k / stride s / zero-size padding p per dim (padding never wins):
  * F.max_pool2d(x,3,2,1) (pose_resnet.py:297) and F.max_pool3d(x,2,2) (v2v.py:51) */

@@ -285,8 +285,9 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
         if (rc == 1) return LT_OK;
         // a 2D layer whose weights were packed in layout 2 has NO layout-1 / -3 fragments: the generic tiles would still compute it (from the plain
         // [cout][k] weights) at a fraction of the rate, silently.  The plan builder's gate mirrors conv2d_halo_try's predicate; a mismatch is a bug: say so
-        // (ADVICE r5).  (3D layers carry layout-2 fragments for conv3d_halo_wreg_kernel, whose siblings above take them when it declines.)
-        if (a.D == 1 && a.Do == 1 && a.OD == 1) {
+        // (ADVICE r5).  (3D layers carry layout-2 fragments for conv3d_halo_wreg_kernel, whose siblings above take them when it declines -- a 3^3 layer on a
+        // volume of ONE voxel plane, V2V's deepest level in small test volumes, has D == 1 too: the 2D signature is 256 -> 256 with 9 or 4 taps.)
+        if (a.D == 1 && a.Do == 1 && a.OD == 1 && a.Cin == 256 && cout_pad == 256 && (a.phase[0].ntaps == 9 || a.phase[0].ntaps == 4)) {
             set_error("lt_conv_fwd: 2D layer with weight_frag_layout 2 (conv2d_halo_kernel) but the halo kernel does not cover it: Cin %d, Cout %d, ldc %d, "
                       "%d x %d -> %d x %d, stride %d, pad %d, %d phase(s), flags 0x%x%s", a.Cin, a.Cout, a.ldc, a.H, a.W, a.OH, a.OW, a.sh, a.ph, nphase, a.flags,
                       a.res ? ", residual" : "");
@@ -326,10 +327,52 @@ int dispatch(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int tile
 
 }  // namespace
 
+// Samples per launch of a convolution whose tensors have ``per_sample`` elements per sample (the largest of input, output, second source): the kernels index
+// one LAUNCH with 32-bit element offsets, the entry point walks larger batches in sample chunks with 64-bit base pointers (round 6).  All of N when it
+// fits; else equal-sized chunks, multiples of 8 samples where possible (the halo / column-walk kernels pin samples to XCDs).  0: one sample alone is too large.
+extern "C" int32_t lt_conv_chunk_samples(int32_t N, int64_t per_sample) {
+    const long long lim = (1ll << 31) - 1;
+    if (N < 1 || per_sample < 1 || per_sample > lim) return 0;
+    if ((long long)N * per_sample <= lim) return N;
+    long long nmax = lim / per_sample;
+    if (nmax >= 8) nmax &= ~7ll;
+    const long long chunks = (N + nmax - 1) / nmax;
+    long long nc = (N + chunks - 1) / chunks;
+    if (nc > 8 && (nc & 7) && ((nc + 7) & ~7ll) <= nmax) nc = (nc + 7) & ~7ll;
+    return (int32_t)nc;
+}
+
 static int conv_fwd_impl(const lt_conv_desc* d, const void* x, const float* bias, const float* scale, const float* shift,
                          const void* residual, const lt_conv_skip* skip, const lt_conv_cat2* cat2, void* y, void* stream) {
     LT_REQUIRE(d && x && y, LT_ERR_INVALID, "lt_conv_fwd: null argument");
     LT_REQUIRE(d->dtype == LT_F32 || d->dtype == LT_BF16 || d->dtype == LT_FP8, LT_ERR_INVALID, "lt_conv_fwd: bad dtype %d", d->dtype);
+    {
+        // ---- batches beyond 2^31 elements per tensor (BASELINE config 4 at 32 samples: 32 x 128^3 x 32 channels = 2^31 exactly): sample chunks, each a launch
+        // of the same descriptor over fewer samples with every per-sample pointer advanced in 64 bits; results identical (samples are independent units)
+        const long long in_s = (long long)d->D * d->H * d->W * d->Cin, out_s = (long long)d->OD * d->OH * d->OW * d->ldc;
+        const long long x2_s = cat2 ? (long long)cat2->H * cat2->W * cat2->cin : 0;
+        long long big = in_s > out_s ? in_s : out_s;
+        if (x2_s > big) big = x2_s;
+        if (d->N > 1 && big > 0 && (long long)d->N * big >= (1ll << 31)) {
+            const int nc = lt_conv_chunk_samples(d->N, big);
+            LT_REQUIRE(nc >= 1, LT_ERR_UNSUPPORTED, "lt_conv_fwd: one sample has %lld elements: beyond 32-bit element offsets", big);
+            const size_t ex = d->dtype == LT_F32 ? 4 : d->dtype == LT_BF16 ? 2 : 1;
+            const size_t ey = (d->flags & LT_EPI_STORE_F32) ? 4 : (d->dtype == LT_F32 ? 4 : 2);
+            const size_t er = (d->flags & LT_EPI_RES_F32) ? 4 : (d->dtype == LT_F32 ? 4 : 2);
+            for (int n0 = 0; n0 < d->N; n0 += nc) {
+                lt_conv_desc dd = *d;
+                dd.N = d->N - n0 < nc ? d->N - n0 : nc;
+                lt_conv_skip sk; lt_conv_cat2 c2;
+                if (skip) { sk = *skip; sk.x = (const char*)skip->x + (size_t)n0 * d->D * d->H * d->W * skip->cin * 2; }
+                if (cat2) { c2 = *cat2; c2.x = (const char*)cat2->x + (size_t)n0 * x2_s * 2; }
+                const int rc = conv_fwd_impl(&dd, (const char*)x + (size_t)n0 * in_s * ex, bias, scale, shift,
+                                             residual ? (const char*)residual + (size_t)n0 * out_s * er : nullptr, skip ? &sk : nullptr, cat2 ? &c2 : nullptr,
+                                             (char*)y + (size_t)n0 * out_s * ey, stream);
+                if (rc != LT_OK) return rc;
+            }
+            return LT_OK;
+        }
+    }
     const int vec = d->dtype == LT_F32 ? 4 : d->dtype == LT_BF16 ? 8 : 16;
     LT_REQUIRE(d->dtype != LT_FP8 || (!(d->flags & LT_EPI_SIGMOID) &&
                                       (((d->flags & LT_EPI_STORE_F32) && (!residual || (d->flags & LT_EPI_RES_F32))) ||

@@ -368,7 +368,7 @@ extern "C" int lt_expand_reduce_fwd(const lt_xr_desc* d, const void* t2, const v
     const long long t96 = (d->M + 95) / 96;
     const int ncu = device_cu_count8();                         // thresholds in CUs: 7/8 and 7/16 of the chip (224 / 112 tiles on the 256-CU part)
     const int npb = e ? (e[0] - '0') : (t96 >= ncu * 7 / 8 ? 3 : t96 >= ncu * 7 / 16 ? 2 : 1);
-    LT_REQUIRE(npb >= 1 && npb <= 4, LT_ERR_INVALID, "lt_expand_reduce_fwd: LT_XR_NPB=%s", e ? e : "?");
+    LT_REQUIRE(npb >= 1 && npb <= 3, LT_ERR_INVALID, "lt_expand_reduce_fwd: LT_XR_NPB=%s", e ? e : "?");
     auto run = [&](auto npbc) -> int {
         constexpr int NPBH = decltype(npbc)::value, TMH = 32 * NPBH, lds = TMH * 512 + 2 * TMH * 256 + (2 * 1024 + 2 * 256) * 4;
         const long long nfull = d->M / TMH;
@@ -388,8 +388,9 @@ extern "C" int lt_expand_reduce_fwd(const lt_xr_desc* d, const void* t2, const v
         }
         return LT_OK;
     };
-    // (round 6 experiment, LT_XR_NPB=4 only: 128-pixel tiles -- every weight fragment feeds four MFMAs instead of three, 138 KB of LDS)
-    if (npb == 4) return run(std::integral_constant<int, 4>{});
+    // (round 6, measured and removed: 128-pixel tiles -- NPB = 4, every weight fragment feeds four MFMAs instead of three, 138 KB of LDS, 4.5 rounds of the chip
+    //  at 256 images -- 292 vs 213 us per seam, 1372 / 1395 vs 1464 / 1490 samples/s in two interleaved runs: the accumulators of a fourth pixel block do not
+    //  fit beside the 15-deep weight ring (256 VGPRs, 26 spilled), and the spill traffic sits on the vector-memory path the kernel is bound by)
     if (npb == 3) return run(std::integral_constant<int, 3>{});
     if (npb == 2) return run(std::integral_constant<int, 2>{});
     return run(std::integral_constant<int, 1>{});

@@ -34,6 +34,24 @@ def cout_pad_of(cout):
     return (cout + 127) // 128 * 128
 
 
+def conv_chunk_samples(N, per_sample):
+    """lt_conv_chunk_samples (include/lt_hip.h) restated: samples per launch of a convolution over tensors of ``per_sample`` elements per sample -- all of
+    N while N * per_sample < 2^31, else equal chunks (multiples of 8 where possible) walked by the C entry point with 64-bit base pointers."""
+    lim = (1 << 31) - 1
+    if N < 1 or per_sample < 1 or per_sample > lim:
+        return 0
+    if N * per_sample <= lim:
+        return N
+    nmax = lim // per_sample
+    if nmax >= 8:
+        nmax &= ~7
+    chunks = -(-N // nmax)
+    nc = -(-N // chunks)
+    if nc > 8 and (nc & 7) and ((nc + 7) & ~7) <= nmax:
+        nc = (nc + 7) & ~7
+    return nc
+
+
 def k_step_of(dtype):
     return 128 // torch.empty((), dtype=dtype).element_size()  # elements per 128-byte K step: 32 fp32 / 64 bf16 / 128 fp8
 
@@ -281,8 +299,15 @@ class PlanBuilder:
         N, D, Hh, W, Cin = x_shape
         if Cin != 32 or tuple(skip_shape) != (N, D, Hh, W, 16) or D % 4 or Hh % 8 or W % 8 or D // 4 < 2:
             return False
-        nblk, cols = N * (D // 4) * (Hh // 8) * (W // 8), N * (Hh // 8) * (W // 8)
-        return nblk >= 1024 and nblk % 8 == 0 and cols % 8 == 0 and cols >= 256 and N * D * Hh * W * 32 < 2 ** 31
+        # batches beyond 2^31 elements run as sample chunks inside the C entry point (round 6): EVERY chunk has to satisfy the kernel's conditions
+        nc = conv_chunk_samples(N, D * Hh * W * 32)
+        if nc < 1:
+            return False
+        for n in {nc, N - (N - 1) // nc * nc}:          # the full chunks and the last one
+            nblk, cols = n * (D // 4) * (Hh // 8) * (W // 8), n * (Hh // 8) * (W // 8)
+            if not (nblk >= 1024 and nblk % 8 == 0 and cols % 8 == 0 and cols >= 256):
+                return False
+        return True
 
     def conv(self, x, weight, bias=None, bn=None, stride=1, pad=0, transposed=False, relu=False, relu_pre=False,
              residual=None, out_f32=False, out=None, sigmoid=False, output_padding=0, residual_f32=False, skip=None):

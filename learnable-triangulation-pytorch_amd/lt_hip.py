@@ -113,6 +113,7 @@ SIGNATURES = {
     "lt_conv_skip_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, vp, vp, vp, C.POINTER(ConvSkip), vp, vp]),
     "lt_conv_cat2_fwd": (C.c_int, [C.POINTER(ConvDesc), vp, C.POINTER(ConvCat2), vp, vp, vp, vp, vp, vp]),
     "lt_conv_cout_pad": (C.c_int, [i32]),
+    "lt_conv_chunk_samples": (i32, [i32, i64]),
     "lt_conv_pack_weights": (C.c_int, [vp, i32, i32, vp, vp]),
     "lt_conv_pack_weights_t32": (C.c_int, [vp, i32, i32, i32, i32, vp, vp]),
     "lt_conv_pack_weights32": (C.c_int, [vp, i32, i32, vp, vp]),

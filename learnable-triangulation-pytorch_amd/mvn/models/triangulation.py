@@ -30,7 +30,8 @@ from mvn.utils import multiview, op, volumetric
 
 
 GEO_RING = 4          # pinned geometry staging slots per plan (forwards the host may run ahead of the GPU)
-MAX_LAUNCH_ELEMS = 2 ** 31   # liblt_hip indexes activations with 32-bit element offsets (conv_igemm.hip guard)
+MAX_LAUNCH_ELEMS = 2 ** 31   # ONE SAMPLE's largest activation: liblt_hip's convolution kernels index a launch with 32-bit element offsets; batches beyond that
+                             # are walked in sample chunks INSIDE lt_conv_fwd (64-bit base pointers, round 6), the other kernels of the path index in 64 bits
 
 
 def _bn_in_train_mode(m):
@@ -487,11 +488,13 @@ class VolumetricTriangulationNet(_PlannedNet):
 
     # ---------------------------------------------------------------------------------------
     def max_samples_per_launch(self, NV, Hh, W):
-        """Largest per-launch batch: every activation must stay below 2^31 elements (32-bit element offsets in liblt_hip).  The
-        widest ones are the 32-channel V^3 volume and the 64-channel half-resolution map behind the stem."""
+        """Largest batch of ONE plan.  Since round 6 a plan covers any batch: tensors beyond 2^31 elements (BASELINE config 4 at 32 samples: 32 x 128^3 voxels x
+        32 channels = 2^31) are walked in sample chunks inside the convolution entry points (lt_conv_chunk_samples, 64-bit base pointers; the gather, pooling,
+        pointwise-chain and soft-argmax kernels index in 64 bits), so the only remaining bound is a single SAMPLE whose widest activation exceeds 32-bit
+        offsets -- then 1, and liblt_hip refuses the launch loudly."""
         V = self.volume_size
         per_sample = max(32 * V ** 3, NV * 64 * ((Hh + 1) // 2) * ((W + 1) // 2), NV * 256 * ((Hh + 3) // 4) * ((W + 3) // 4))
-        return max(1, (MAX_LAUNCH_ELEMS - 1) // per_sample)
+        return (1 << 30) if per_sample < MAX_LAUNCH_ELEMS else 1
 
     def forward(self, images, proj_matricies, batch):
         """images (B,NV,3,H,W) fp32 on the GPU; ``proj_matricies`` is ignored exactly as in the reference
@@ -499,8 +502,8 @@ class VolumetricTriangulationNet(_PlannedNet):
         ``pred_keypoints_3d`` or ``keypoints_3d``).  Returns the reference's 7-tuple (:355).
 
         Asynchronous like the reference's CUDA forward: nothing here waits for the GPU (results are ordered on the current
-        stream).  Batches beyond ``max_samples_per_launch`` (BASELINE config 4: 32 samples of 128^3 voxels are exactly 2^31
-        elements) run as consecutive sub-batches of one plan."""
+        stream).  One plan per batch shape whatever its size: BASELINE config 4 at 32 samples (2^31 elements per 32-channel volume) is ONE plan and one
+        captured graph -- the convolution entry points walk such tensors in sample chunks (``max_samples_per_launch``)."""
         H.require_gpu(images, "images")
         if _bn_in_train_mode(self):          # any BatchNorm module in train(): the training step (modules left in eval() keep frozen statistics)
             return self._forward_train(images, batch)

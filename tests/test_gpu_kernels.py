@@ -1198,7 +1198,7 @@ def test_bottleneck_with_downsample_fused(N, Hh, W, monkeypatch):
     assert e_f <= e_4 * 1.05 + 1e-6   # adding the branch unrounded cannot be worse than rounding it first
 
 
-@pytest.mark.parametrize("npb", ["4", "3", "2", "1"])
+@pytest.mark.parametrize("npb", ["3", "2", "1"])
 @pytest.mark.parametrize("N,Hh,W", [(2, 6, 6), (2, 24, 24), (8, 24, 24), (3, 12, 20)])
 def test_expand_reduce_seam_fused(N, Hh, W, npb, monkeypatch):
     """lt_expand_reduce_fwd (round 5; pose_resnet.py:75-95, the seam between two identity blocks of layer3: expand + bn3 + residual + ReLU of block i, reduce +
@@ -1248,3 +1248,73 @@ def test_expand_reduce_seam_fused(N, Hh, W, npb, monkeypatch):
         record(name + "/%s rms_vs_two_launches" % nm, rms)
         check(name + "/%s vs_two_launches" % nm, from_cl(a_, 2), from_cl(b_, 2), 1.5e-2)
         assert rms < 2e-3, (nm, rms)          # bf16 rounding noise; a structural mistake (one K block, one channel run) is far above this
+
+
+@pytest.mark.parametrize("kind", ["col_walk_residual", "deconv2_residual", "skip_conv"])
+def test_conv_beyond_32_bit_element_offsets(kind):
+    """Round 6 ("64-bit element offsets"): lt_conv_fwd / lt_conv_skip_fwd over tensors of >= 2^31 ELEMENTS -- BASELINE config 4 at 32 samples
+    per GPU: 32 x 128^3 voxels x 32 channels = 2^31 exactly -- in ONE call.  The kernels index a launch with 32-bit offsets; the entry point walks the batch in
+    sample chunks (lt_conv_chunk_samples: here 2 x 16) with every per-sample pointer -- input, output, residual, the skip source -- advanced in 64 bits.
+    Checked against the same layer run by hand on the two halves (bit-identical: same kernel, same tiles), and a spot check of the last sample against
+    torch on the bf16-rounded operands (a wrong base pointer would read another sample)."""
+    N, V = 32, 128
+    g = torch.Generator().manual_seed(77)
+    bf = torch.bfloat16
+    lib = H.lib()
+    assert lib.lt_conv_chunk_samples(N, V ** 3 * 32) == 16
+
+    def big(shape):          # random bf16 tensor on the device without a 4-byte staging copy of the whole thing
+        t = torch.empty(shape, dtype=bf, device=DEV)
+        for n in range(shape[0]):
+            t[n] = torch.randn(shape[1:], generator=g).to(bf).to(DEV) if n in (0, 15, 16, 31) else t[n - 1].roll(1, 0)
+        return t
+    if kind == "deconv2_residual":       # V2V's last upsampling: 64 -> 32 channels, 64^3 -> 128^3, the skip tensor added in the epilogue (2^31 output elements)
+        x = big((N, V // 2, V // 2, V // 2, 64))
+        w = torch.randn(64, 32, 2, 2, 2, generator=g) * 0.05
+        kw = dict(stride=2, pad=0, transposed=True, relu=True)
+        oshape = (N, V, V, V, 32)
+    else:                                # 3x3x3 32 -> 32 at 128^3 (input AND output 2^31 elements), residual or computed skip branch
+        x = big((N, V, V, V, 32))
+        w = torch.randn(32, 32, 3, 3, 3, generator=g) * 0.03
+        kw = dict(stride=1, pad=1, relu=True)
+        oshape = (N, V, V, V, 32)
+    bn = _bn(32, g)
+    res = big(oshape) if kind != "skip_conv" else None
+    sx = big((N, V, V, V, 16)) if kind == "skip_conv" else None
+    sw, sbn = torch.randn(32, 16, 1, 1, 1, generator=g) * 0.1, _bn(32, g)
+    assert x.numel() >= 2 ** 31 or oshape[0] * oshape[1] * oshape[2] * oshape[3] * oshape[4] >= 2 ** 31
+
+    def run(sl):
+        b = E.PlanBuilder(DEV, bf)
+        xa = E.Act(x[sl])
+        if kind == "skip_conv":
+            sa = E.Act(sx[sl])
+            assert b.can_conv_skip(xa.shape, w, sa.shape, sw)
+            y = b.conv(xa, w, None, bn, skip=(sa, sw, None, sbn), **kw)
+        else:
+            y = b.conv(xa, w, None, bn, residual=E.Act(res[sl]), **kw)
+        b.finish().run_eager(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return y.t
+    y = run(slice(0, N))
+    for lo in (0, 16):
+        yh = run(slice(lo, lo + 16))
+        assert torch.equal(y[lo:lo + 16].view(torch.int16), yh.view(torch.int16)), "one call over 2^31 elements != the two halves (%s, samples %d..)" % (kind, lo)
+        del yh
+    # the last sample against torch (fp32 on the bf16-rounded operands), one 32^3 corner of it
+    n = N - 1
+    xs = x[n].float().cpu().permute(3, 0, 1, 2)[None]
+    if kind == "deconv2_residual":
+        ref = F.conv_transpose3d(xs[:, :, :16, :16, :16], bf16_round(w), stride=2)
+        ref = torch.relu(_bn_ref(ref, bn) + res[n, :32, :32, :32].float().cpu().permute(3, 0, 1, 2)[None])
+        got = y[n, :32, :32, :32].float().cpu().permute(3, 0, 1, 2)[None]
+        check("conv > 2^31 elements/%s last sample vs torch" % kind, got, ref, 1.5e-2)
+    else:
+        ref = _bn_ref(F.conv3d(xs[:, :, :34, :34, :34], bf16_round(w), padding=1), bn)[:, :, :32, :32, :32]
+        if kind == "skip_conv":
+            ref = ref + _bn_ref(F.conv3d(sx[n, :32, :32, :32].float().cpu().permute(3, 0, 1, 2)[None], bf16_round(sw)), sbn)
+        else:
+            ref = ref + res[n, :32, :32, :32].float().cpu().permute(3, 0, 1, 2)[None]
+        # (rows / planes 0..31 of the corner: their 3^3 windows lie inside the 34^3 crop except at the volume's own border, which both sides zero-pad)
+        got = y[n, :32, :32, :32].float().cpu().permute(3, 0, 1, 2)[None]
+        check("conv > 2^31 elements/%s last sample vs torch" % kind, got[:, :, :32, :32, :32], torch.relu(ref), 1.5e-2)

@@ -144,7 +144,7 @@ BF16_GATES = {                  # measured (round 6, session 1): see the comment
     "c2_default": (0.0037, 0.0075, 0.0251, 0.0172, 0.00115),      # 0.0024 mm, 0.0050 mm, 1.67e-2, 1.14e-2, 7.6e-4
     "c2_sharp": (5.3, 44.1, 0.0251, 0.0186, 0.0801),              # 3.51 mm, 29.4 mm (one joint of a near-argmax volume), 1.67e-2, 1.24e-2, 5.34e-2
     "c2_b4": (2.51, 8.7, 0.0281, 0.0197, 0.0756),                 # 1.67 mm, 5.79 mm, 1.87e-2, 1.31e-2, 5.04e-2
-    "c2_b8_sharp": (None, None, None, None, None),
+    "c2_b8_sharp": (1.10, 5.35, 0.0282, 0.0172, 0.0726),          # 0.73 mm, 3.57 mm, 1.88e-2, 1.14e-2, 4.84e-2 (the larger of the plain and the all-cat2 run)
     "c4_sharp": (2.41, 7.93, 0.0257, 0.0253, 0.0972),             # 1.60 mm, 5.28 mm, 1.71e-2, 1.68e-2, 6.47e-2
 }
 
@@ -334,6 +334,38 @@ def test_panoptic_shape_8_views_128_cube():
     record("8 views / 128^3: volumes bf16 vs fp32 (max|d|/max|ref|)", rel_err(outs["bf16"][2], outs["f32"][2]))
     assert torch.isfinite(kp16).all() and float((kp16 - kp32).norm(dim=-1).mean()) < 0.1
     assert float((outs["bf16"][2].sum(dim=(2, 3, 4)) - 1).abs().max()) < 1e-3
+
+
+def test_config4_at_32_samples_is_one_plan():
+    """BASELINE config 4 (8 views, 128^3 voxels) at 32 samples per step: the 32-channel volumes have exactly 2^31 elements.  Until round 5 forward() cut such a
+    batch into sub-batches of the MODEL; now it is one plan (one captured graph), and the convolution entry points walk the oversize tensors in sample chunks
+    with 64-bit base pointers.  fp32 kernels (the arithmetic that is exact up to summation order), ResNet-18 backbone to keep it short, sharpened
+    weights: every sample of the 32 equals the same sample run in a batch of 16 -- joints 1e-4 relative, features 1e-5 and softmaxed volumes 1e-4 of max (SURVEY 8d's gates)."""
+    import warnings
+    from mvn.models.triangulation import VolumetricTriangulationNet
+    B, NV, V = 32, 8, 128
+    cfg = synth.vol_config(18, V, "softmax", 1.0)
+    sd = synth.make_state_dict(spec.vol_net_spec(18, 17), seed=12, sharpen=157.0, basic_block=True)
+    inp = synth.make_inputs(B, NV, 128, seed=12)
+    images = inp["images"].to(DEV)
+    m = VolumetricTriangulationNet(cfg, device=DEV); m.load_state_dict(sd); m.eval(); m.compute_dtype = torch.float32
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # the old path announced its sub-batches with a warning: there must be none
+        o32 = m(images, None, {"cameras": _cameras(inp, B), "pred_keypoints_3d": inp["pred_keypoints_3d"]})
+    assert len(m._plans) == 1 and list(m._plans)[0][0] == B, "32 samples must be ONE plan"
+    kp32, f32_, v32 = o32[0].clone(), o32[1].clone(), o32[2]
+    assert torch.isfinite(kp32).all() and tuple(v32.shape) == (B, 17, V, V, V)
+    worst = 0.0
+    for lo in (0, 16):
+        o16 = m(images[lo:lo + 16], None, {"cameras": _cameras(inp, 16), "pred_keypoints_3d": inp["pred_keypoints_3d"][lo:lo + 16]})
+        rel = float(((o16[0] - kp32[lo:lo + 16]).abs() / kp32[lo:lo + 16].abs().clamp(min=1.0)).max())
+        worst = max(worst, rel)
+        assert rel <= 1e-4, "samples %d..: joints of the 32-sample call differ from the 16-sample call by %.3e" % (lo, rel)
+        fe = float((o16[1] - f32_[lo:lo + 16]).abs().max() / f32_.abs().max())
+        ve = max(float((o16[2][i] - v32[lo + i]).abs().max()) for i in range(16)) / float(v32.max())
+        assert fe <= 1e-5 and ve <= 1e-4, (fe, ve)
+        del o16
+    record("config 4 at 32 samples (one plan, conv entry points chunk the 2^31-element tensors) vs 16-sample calls: joints max rel", worst)
 
 
 @pytest.mark.parametrize("nl,hw", [(50, 128), (18, 64)])

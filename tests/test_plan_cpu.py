@@ -170,13 +170,25 @@ def test_plan_cache_fingerprint_and_lru():
     assert m.weights_fingerprint() == fp
 
 
-def test_sub_batching_limit():
-    """BASELINE config 4 at 32 samples is exactly 2^31 elements per 32-channel volume: forward() splits such batches."""
+def test_batches_beyond_32_bit_offsets_are_one_plan():
+    """BASELINE config 4 at 32 samples is exactly 2^31 elements per 32-channel volume.  Until round 5 forward() split such batches into sub-batches of the
+    model; since round 6 the convolution entry points walk them in sample chunks with 64-bit base pointers (lt_conv_chunk_samples) and a plan covers any
+    batch.  Here: the model no longer splits, and the host restatement of the chunk rule (used by the builder's gates) equals the library's."""
+    import lt_engine as E
+    import lt_hip as H
     from mvn.models.triangulation import VolumetricTriangulationNet
     m = VolumetricTriangulationNet(synth.vol_config(18, 128), device="cpu")
-    assert m.max_samples_per_launch(8, 384, 384) == 31
-    m64 = VolumetricTriangulationNet(synth.vol_config(18, 64), device="cpu")
-    assert m64.max_samples_per_launch(4, 384, 384) == 227     # bounded by the 256-channel quarter-resolution maps of 4 views
+    assert m.max_samples_per_launch(8, 384, 384) >= 1 << 20
+    lib = H.lib()
+    for N, per in ((32, 32 * 128 ** 3), (31, 32 * 128 ** 3), (64, 32 * 128 ** 3), (33, 32 * 128 ** 3), (5, 1 << 30), (7, (1 << 31) - 1), (3, 1 << 31), (1, 100),
+                   (256, 64 * 192 * 192), (1000, 256 * 96 * 96), (20, 3 * 10 ** 8)):
+        assert E.conv_chunk_samples(N, per) == lib.lt_conv_chunk_samples(N, per), (N, per)
+    assert E.conv_chunk_samples(32, 32 * 128 ** 3) == 16 and E.conv_chunk_samples(64, 32 * 128 ** 3) == 24 and E.conv_chunk_samples(31, 32 * 128 ** 3) == 31
+    assert E.conv_chunk_samples(33, 32 * 128 ** 3) == 24          # 24 + 9 (24 = the largest multiple of 8 below 31.99 samples of 2^26 elements)
+    assert E.conv_chunk_samples(3, 1 << 31) == 0                  # one sample alone is too large
+    b = E.PlanBuilder("cpu", torch.bfloat16, dry_run=True)
+    w, sw = torch.zeros(32, 32, 3, 3, 3), torch.zeros(32, 16, 1, 1, 1)
+    assert b.can_conv_skip((32, 128, 128, 128, 32), w, (32, 128, 128, 128, 16), sw)          # two chunks of 16 samples, each a shape the column-walk kernel takes
 
 
 def test_splitk_tiny_volume_convolutions_are_recorded_and_equal_the_unsplit_convolution():
