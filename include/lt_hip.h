@@ -579,6 +579,71 @@ int lt_event_record(void* ev, void* stream);
 int lt_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
 int lt_event_destroy(void* ev);
 
+/* ---------------------------------------------------------------------------------------------
+ * PLAN-LEVEL entry points ("whole-network plan entry points that own pre-packed weights and a hipGraph"; round 6).
+ * Everything the Python host does between the reference's module API and the kernel-level calls above lives behind these four symbols, so that a
+ * host in any language can run the timed forward: layer -> kernel selection with every batch threshold (fused stem, whole-bottleneck launches, the
+ * layer3 seam kernel, conv_cat2, the 2D / 3D halo kernels by weight layout, split-K of the tiny V2V levels, the pointwise tail), the eval-BatchNorm fold
+ * as ATen evaluates it, weight packing (GEMM layout, MFMA fragment orders, parity phases of the stride-2 transposed convolutions), buffer reuse, the
+ * fp64 camera algebra of the reference's forward, and the captured hipGraph.
+ *
+ * lt_plan_create_vol  = VolumetricTriangulationNet.__init__ + load_state_dict + the first forward's plan recording
+ *                       (mvn/models/triangulation.py:204-242, mvn/models/pose_resnet.py:177-377, mvn/models/v2v.py:142-180).
+ *   weights: the reference's state_dict -- names as torch writes them ("backbone.layer3.0.conv1.weight", "volume_net.front_layers.0.block.0.bias", ...;
+ *   a leading "module." is stripped like train.py:408-410), HOST fp32 arrays in torch's layout; keys the volumetric path does not use
+ *   (backbone.final_layer.*, num_batches_tracked) are ignored; a missing key is LT_ERR_INVALID with its name.  The arrays are read during this call only.
+ *   One plan = one input shape (B, NV, H, W) and one element type: LT_F32 (exact-fp32 MFMA: the kernel set that meets the 1e-4 joint tolerance) or
+ *   LT_BF16 (the throughput set).  Allocates device memory (hipMalloc) that lt_plan_destroy frees.
+ * lt_plan_forward_vol = VolumetricTriangulationNet.forward (triangulation.py:245-355) for inference (eval-mode BatchNorm).
+ *   images: DEVICE (B, NV, 3, H, W) fp32, the reference's input tensor.  Cameras: HOST fp64 K (B, NV, 3, 3) at IMAGE resolution, R (B, NV, 3, 3),
+ *   t (B, NV, 3) -- batch['cameras'][view][sample] of the reference (datasets/utils.py:26), sample-major here; the call rescales K to the heatmap
+ *   resolution and forms K [R | t] in fp64 like Camera.update_after_resize / .projection (multiview.py:33-52).  base_points: HOST (B, 3) fp64, the
+ *   pelvis the cuboid is centred on (triangulation.py:284-296: batch['pred_keypoints_3d'][b][6] for kind 'mpii').  rot: HOST (B, 9) fp64 row-major
+ *   cuboid rotations (triangulation.py:318-328) or NULL = identity (what eval mode draws).
+ *   Outputs, DEVICE fp32, written on `stream`: keypoints_3d (B, J, 3) [required]; volumes (B, J, V, V, V) softmaxed / ReLU'd (NULL: kept in a plan
+ *   buffer); features (B, NV, 32, h, w) or NULL; coord_volumes (B, V, V, V, 3) or NULL; vol_confidences (B, NV, 32) RAW head outputs or NULL (only for
+ *   LT_AGG_CONF / LT_AGG_CONF_NORM plans; the reference returns them divided by their sum over views for 'conf_norm').  cuboids / base_points of the
+ *   reference's 7-tuple are host values the caller already has.  Asynchronous; the first call captures the hipGraph (use_graph), later calls replay it.
+ *   stream == NULL with use_graph: the legacy default stream cannot be captured, so the forward runs on a stream the plan owns, ordered behind the default
+ *   stream's earlier work and in front of its later work by events.  Not thread-safe per plan (one forward of a plan at a time).
+ * -------------------------------------------------------------------------------------------*/
+typedef struct lt_plan lt_plan;
+typedef struct lt_named_tensor {
+    const char* name;        /* state_dict key */
+    const float* data;       /* HOST fp32, contiguous, torch's layout (Conv: [Cout][Cin][k..]; ConvTranspose: [Cin][Cout][k..]; Linear: [out][in]) */
+    int32_t ndim;            /* 1 .. 5 */
+    int64_t shape[5];
+} lt_named_tensor;
+typedef struct lt_vol_plan_config {
+    int32_t dtype;                        /* LT_F32 | LT_BF16 */
+    int32_t num_layers;                   /* config.model.backbone.num_layers: 18 | 34 | 50 | 101 | 152 */
+    int32_t style_caffe;                  /* config.model.backbone.style == "caffe" */
+    int32_t num_joints;                   /* 17 */
+    int32_t B, NV, H, W;                  /* samples, views per sample, image size */
+    int32_t volume_size;                  /* config.model.volume_size (64) */
+    double cuboid_side;                   /* config.model.cuboid_side (2500.0 mm) */
+    double volume_multiplier;             /* config.model.volume_multiplier */
+    int32_t volume_softmax;               /* config.model.volume_softmax */
+    int32_t aggregation;                  /* LT_AGG_* of config.model.volume_aggregation_method */
+    int32_t transfer_cmu_to_human36m;     /* config.model.transfer_cmu_to_human36m (triangulation.py:336-339) */
+    int32_t use_graph;                    /* capture the forward into a hipGraph at the first call and replay it */
+} lt_vol_plan_config;
+typedef struct lt_plan_info_t {
+    int32_t launches;                     /* ops of one forward (pre + captured + tail) */
+    int32_t heatmap_h, heatmap_w;         /* h, w of the feature maps (H / 4, W / 4) */
+    double flops;                         /* 2 * MAC of the recorded convolutions */
+    int64_t bytes_allocated;              /* device memory owned by the plan */
+    int32_t n_expand_reduce, n_bottleneck, n_bottleneck_ds, n_conv_cat2, n_conv2d_halo, n_pwchain, n_stem_pool, n_splitk, n_conv_skip;   /* which fused kernels it recorded */
+    int32_t graph_captured;
+    const float* logits;                  /* V2V logits (fp32; planar (B, J, V, V, V) when logits_planar, else channels-last (B, V, V, V, J)): valid after a forward, for tests */
+    int32_t logits_planar;
+} lt_plan_info_t;
+int lt_plan_create_vol(const lt_vol_plan_config* cfg, const lt_named_tensor* weights, int32_t nweights, lt_plan** plan_out);
+int lt_plan_forward_vol(lt_plan* plan, const float* images, const double* K_host, const double* R_host, const double* t_host, const double* base_points_host,
+                        const double* rot_host, float* keypoints_3d, float* volumes, float* features, float* coord_volumes, float* vol_confidences, void* stream);
+int lt_plan_info(const lt_plan* plan, lt_plan_info_t* info);
+void lt_plan_destroy(lt_plan* plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -230,6 +230,7 @@ struct lt_plan {
     std::deque<lt_xr_desc> xr_descs;
     hipGraphExec_t graph = nullptr;
     bool captured = false;
+    hipStream_t own_stream = nullptr; hipEvent_t own_ev[2] = {nullptr, nullptr};          // stream == NULL with use_graph: the legacy default stream cannot be captured
     // per-call pointers the pre / tail ops read
     const float* cur_images = nullptr;
     float* out_kp = nullptr; float* out_probs = nullptr; float* out_feats = nullptr;
@@ -244,6 +245,8 @@ struct lt_plan {
 
     ~lt_plan() {
         if (graph) (void)hipGraphExecDestroy(graph);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+        for (int i = 0; i < 2; ++i) if (own_ev[i]) (void)hipEventDestroy(own_ev[i]);
         for (void* p : allocs) (void)hipFree(p);
         for (int i = 0; i < GEO_RING; ++i) { if (geo_host[i]) (void)hipHostFree(geo_host[i]); if (geo_ev[i]) (void)hipEventDestroy(geo_ev[i]); }
     }
@@ -982,7 +985,7 @@ struct lt_plan {
         for (int i = 0; i < GEO_RING; ++i) { PL_HIP(hipHostMalloc((void**)&geo_host[i], n_geo * 4, hipHostMallocDefault)); }
         void* c; PL_TRY(dev_alloc((size_t)B * V * V * V * 3 * 4, &c)); coords = (float*)c;
         PL_TRY(alloc(B, V, V, V, 32, es, vol));
-        const float step = (float)(cfg.cuboid_side / (V - 1));          // float(np.float32(side / (V - 1))): the fp64 quotient rounded once
+        const float step = (float)(cfg.cuboid_side / (double)(V - 1));          // float(np.float32(side / (V - 1))): the fp64 quotient rounded once
         {
             const int dt = dtype, agg = cfg.aggregation, cmu = cfg.transfer_cmu_to_human36m ? 1 : 0, h = hm_h, w = hm_w;
             const float* gp = geo_dev; const size_t op = o_pos, oc = o_cen, orr = o_rot;
@@ -1000,7 +1003,7 @@ struct lt_plan {
             ops.push_back([=](hipStream_t s) { return self->out_feats ? lt_nhwc_to_nchw_f32(dt, fp, self->out_feats, B * NV, 32, h * w, 32, s) : LT_OK; });
         }
         {   // tail op 2: soft-argmax straight into the caller's tensors
-            const float mult = cfg.volume_multiplier; const int sm = cfg.volume_softmax ? 1 : 0, cl = logits.planar ? 0 : 1;
+            const float mult = (float)cfg.volume_multiplier; const int sm = cfg.volume_softmax ? 1 : 0, cl = logits.planar ? 0 : 1;
             const float* lp = (const float*)logits.p; const float* cp = coords; void* ws = sa_ws; lt_plan* self = this;
             float* kpd = kp; float* prd = probs;
             ops.push_back([=](hipStream_t s) {
@@ -1066,6 +1069,16 @@ extern "C" int lt_plan_forward_vol(lt_plan* p, const float* images, const double
                                    void* stream) {
     LT_REQUIRE(p && images && K_host && R_host && t_host && base_points_host && keypoints_3d, LT_ERR_INVALID, "lt_plan_forward_vol: null argument");
     hipStream_t st = (hipStream_t)stream;
+    const bool detour = st == nullptr && p->cfg.use_graph;
+    if (detour) {          // the plan's own stream, ordered behind what the default stream has queued so far
+        if (!p->own_stream) {
+            PL_HIP(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) PL_HIP(hipEventCreateWithFlags(&p->own_ev[i], hipEventDisableTiming));
+        }
+        PL_HIP(hipEventRecord(p->own_ev[0], nullptr));
+        PL_HIP(hipStreamWaitEvent(p->own_stream, p->own_ev[0], 0));
+        st = p->own_stream;
+    }
     const int B = p->cfg.B, NV = p->cfg.NV, V = p->cfg.volume_size;
     // ---- host geometry in fp64 like the reference (triangulation.py:272-296): Camera.update_after_resize to the heatmap resolution, projection = K [R | t];
     // cuboid position = base - side / 2; rotation about the vertical axis (identity in eval mode); one pinned block, one H2D copy
@@ -1103,6 +1116,10 @@ extern "C" int lt_plan_forward_vol(lt_plan* p, const float* images, const double
         LT_REQUIRE(!p->volc.null(), LT_ERR_INVALID, "lt_plan_forward_vol: vol_confidences asked of a plan without the confidence head (aggregation %d)", p->cfg.aggregation);
         PL_HIP(hipMemcpyAsync(vol_confidences, p->volc.p, (size_t)B * NV * 32 * 4, hipMemcpyDeviceToDevice, st));          // RAW sigmoid outputs; 'conf_norm' divides by their sum over views
     }
+    if (detour) {          // ... and in front of what the default stream gets next
+        PL_HIP(hipEventRecord(p->own_ev[1], st));
+        PL_HIP(hipStreamWaitEvent(nullptr, p->own_ev[1], 0));
+    }
     return LT_OK;
 }
 
@@ -1116,7 +1133,6 @@ extern "C" int lt_plan_info(const lt_plan* p, lt_plan_info_t* info) {
     info->n_conv2d_halo = p->n_halo2d; info->n_pwchain = p->n_pwchain; info->n_stem_pool = p->n_stem; info->n_splitk = p->n_splitk; info->n_conv_skip = p->n_conv_skip;
     info->graph_captured = p->captured ? 1 : 0;
     info->logits = (const float*)p->logits.p; info->logits_planar = p->logits.planar ? 1 : 0;
-    info->unprojected = p->vol.p;
     return LT_OK;
 }
 

@@ -104,8 +104,28 @@ class XrDesc(C.Structure):
     _fields_ = [("dtype", i32), ("C", i32), ("P", i32), ("M", C.c_int64), ("weight", vp * 2), ("scale", vp * 2), ("shift", vp * 2), ("consts", vp)]
 
 
+class NamedTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", vp), ("ndim", i32), ("shape", C.c_int64 * 5)]
+
+
+class VolPlanConfig(C.Structure):
+    _fields_ = [("dtype", i32), ("num_layers", i32), ("style_caffe", i32), ("num_joints", i32), ("B", i32), ("NV", i32), ("H", i32), ("W", i32),
+                ("volume_size", i32), ("cuboid_side", C.c_double), ("volume_multiplier", C.c_double), ("volume_softmax", i32), ("aggregation", i32),
+                ("transfer_cmu_to_human36m", i32), ("use_graph", i32)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("launches", i32), ("heatmap_h", i32), ("heatmap_w", i32), ("flops", C.c_double), ("bytes_allocated", C.c_int64),
+                ("n_expand_reduce", i32), ("n_bottleneck", i32), ("n_bottleneck_ds", i32), ("n_conv_cat2", i32), ("n_conv2d_halo", i32), ("n_pwchain", i32),
+                ("n_stem_pool", i32), ("n_splitk", i32), ("n_conv_skip", i32), ("graph_captured", i32), ("logits", vp), ("logits_planar", i32)]
+
+
 # symbol -> (restype, argtypes); must list every symbol include/lt_hip.h declares
 SIGNATURES = {
+    "lt_plan_create_vol": (C.c_int, [C.POINTER(VolPlanConfig), C.POINTER(NamedTensor), i32, C.POINTER(vp)]),
+    "lt_plan_forward_vol": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "lt_plan_info": (C.c_int, [vp, C.POINTER(PlanInfo)]),
+    "lt_plan_destroy": (None, [vp]),
     "lt_last_error": (C.c_char_p, []),
     "lt_abi_version": (C.c_int, []),
     "lt_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
