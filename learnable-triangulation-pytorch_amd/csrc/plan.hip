@@ -384,7 +384,7 @@ struct lt_plan {
             // the skip branch's BatchNorm: scale into its weights (fp32 product, ONE bf16 rounding), (bias * scale + shift) into this convolution's shift
             std::vector<float> wf((size_t)32 * ss.k_pad);
             for (int co = 0; co < 32; ++co) for (int k = 0; k < ss.k_pad; ++k) wf[(size_t)co * ss.k_pad + k] = ss.ph[0].w[(size_t)co * ss.k_pad + k] * ss.scale[co];
-            for (int co = 0; co < 32; ++co) { const float bs = ss.bias[co] * ss.scale[co]; const float t = bs + ss.shift[co]; sp.shift[co] = sp.shift[co] + t; }
+            for (int co = 0; co < 32; ++co) { const float bs = ss.bias[co] * ss.scale[co]; const float t = sp.shift[co] + bs; sp.shift[co] = t + ss.shift[co]; }          // Python's order: (shift + bias * scale) + shift_skip
             const void* wsk; PL_TRY(upload_w(wf, &wsk));
             const void* wfr; PL_TRY(pack_frag(wsk, 32 * 16, 2, 32, ss.k_pad, 16, 1, &wfr));
             skip_descs.emplace_back();

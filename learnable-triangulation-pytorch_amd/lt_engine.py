@@ -106,11 +106,14 @@ def fold_bn(cout, bias, bn, cout_pad):
     if bias is not None:
         bi[:cout] = bias.detach().float().cpu()
     if bn is not None:
-        g, b, m, v = (t.detach().float().cpu() for t in bn)
-        invstd = 1.0 / torch.sqrt(v + BN_EPS)
-        alpha = invstd * g
-        sc[:cout] = alpha
-        sh[:cout] = b - m * alpha
+        # numpy fp32, not torch: ATen's eval BatchNorm computes 1 / std::sqrt(var + eps) per channel with the scalar (correctly rounded) square root, and so does
+        # the C host of the plan-level ABI (csrc/plan.hip: fold_bn); torch's VECTORISED CPU sqrt differs from the IEEE result in ~0.5 % of the elements
+        # (measured, round 6), which made the two hosts' plans differ in the last bit of some scales.  numpy's float32 sqrt / divide / multiply are IEEE.
+        g, b, m, v = (t.detach().float().cpu().numpy() for t in bn)
+        invstd = (np.float32(1.0) / np.sqrt(v + np.float32(BN_EPS))).astype(np.float32)
+        alpha = (invstd * g).astype(np.float32)
+        sc[:cout] = torch.from_numpy(alpha)
+        sh[:cout] = torch.from_numpy((b - (m * alpha).astype(np.float32)).astype(np.float32))
     return bi, sc, sh
 
 
