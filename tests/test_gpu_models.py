@@ -136,16 +136,20 @@ def test_volumetric_forward_vs_reference_golden(golden_dir, tag):
     check(tag + "/v2v logits", _sub(logits, s), g["logits_sub"], 2e-5)
 
 
-# bf16 throughput mode against the REFERENCE's stored outputs: per-fixture gates at 1.5 x the figures measured in round 6 (profiles/r06_parity_report.json,
-# VERDICT r5 "next" 1a: the 60 mm "same skeleton, not garbage" bound this replaces said nothing about the kernels).  Per tag:
+# bf16 throughput mode against the REFERENCE's stored outputs: per-fixture gates (VERDICT r5 "next" 1a: the 60 mm "same skeleton, not garbage" bound this
+# replaces said nothing about the kernels).  Round 6 measured every figure TWICE with the same kernel set: once with the BatchNorm fold's constants from torch's
+# vectorised sqrt, once from the IEEE sqrt (a last-bit change of ~0.5 % of the scales, lt_engine.fold_bn).  Through 152 bf16 layers and a sharpened
+# soft-argmax that moved the single-fixture figures by up to +53 % (small_softmax max abs 0.45 -> 0.69 mm, c4_sharp MPJPE 1.60 -> 2.19 mm) and others down
+# (c2_sharp 3.51 -> 3.19 mm): the deviation of a bf16 forward from the fp32 reference is itself a noisy quantity.  Gates: 1.5 x the LARGER of the two measurements
+# (profiles/r06_parity_report.json holds the final run).  Per tag:
 # (joints MPJPE mm, joints max abs mm, features max|d|/max|ref|, V2V logits max|d|/max|ref|, softmaxed volumes max|d|/max|ref|)
-BF16_GATES = {                  # measured (round 6, session 1): see the comment of each row
-    "small_softmax": (0.29, 0.68, 0.018, 0.0135, 0.035),          # 0.193 mm, 0.448 mm, 1.17e-2, 8.98e-3, 2.28e-2
-    "c2_default": (0.0037, 0.0075, 0.0251, 0.0172, 0.00115),      # 0.0024 mm, 0.0050 mm, 1.67e-2, 1.14e-2, 7.6e-4
-    "c2_sharp": (5.3, 44.1, 0.0251, 0.0186, 0.0801),              # 3.51 mm, 29.4 mm (one joint of a near-argmax volume), 1.67e-2, 1.24e-2, 5.34e-2
-    "c2_b4": (2.51, 8.7, 0.0281, 0.0197, 0.0756),                 # 1.67 mm, 5.79 mm, 1.87e-2, 1.31e-2, 5.04e-2
-    "c2_b8_sharp": (1.10, 5.35, 0.0282, 0.0172, 0.0726),          # 0.73 mm, 3.57 mm, 1.88e-2, 1.14e-2, 4.84e-2 (the larger of the plain and the all-cat2 run)
-    "c4_sharp": (2.41, 7.93, 0.0257, 0.0253, 0.0972),             # 1.60 mm, 5.28 mm, 1.71e-2, 1.68e-2, 6.47e-2
+BF16_GATES = {                  # the two measurements behind each row
+    "small_softmax": (0.405, 1.03, 0.0177, 0.0135, 0.0444),       # 0.193 | 0.270 mm, 0.448 | 0.688 mm, 1.17e-2, 8.98e-3 | 8.75e-3, 2.28e-2 | 2.96e-2
+    "c2_default": (0.0037, 0.0075, 0.0262, 0.0172, 0.00115),      # 0.0024 | 0.0023 mm, 0.0050 | 0.0035 mm, 1.67e-2 | 1.75e-2, 1.14e-2 | 1.08e-2, 7.6e-4 | 7.3e-4
+    "c2_sharp": (5.26, 44.1, 0.0262, 0.0186, 0.104),              # 3.51 | 3.19 mm, 29.4 | 24.1 mm (one joint of a near-argmax volume), 1.75e-2, 1.24e-2 | 1.18e-2, 5.3e-2 | 6.9e-2
+    "c2_b4": (2.51, 11.4, 0.0281, 0.0223, 0.0833),                # 1.67 | 1.49 mm, 5.79 | 7.56 mm, 1.87e-2 | 1.75e-2, 1.31e-2 | 1.49e-2, 5.0e-2 | 5.6e-2
+    "c2_b8_sharp": (1.10, 5.6, 0.0283, 0.0172, 0.118),            # 0.73 | 0.64 mm, 3.57 | 3.73 mm, 1.88e-2 | 1.81e-2, 1.14e-2 | 1.02e-2, 4.8e-2 | 7.9e-2 (plain and all-cat2 runs)
+    "c4_sharp": (3.28, 12.1, 0.0257, 0.0284, 0.098),              # 1.60 | 2.19 mm, 5.28 | 8.06 mm, 1.71e-2 | 1.65e-2, 1.68e-2 | 1.89e-2, 6.5e-2 | 6.5e-2
 }
 
 
@@ -184,7 +188,7 @@ def _bf16_vs_reference(golden_dir, tag, monkeypatch=None, env=()):
     record(name + "/bf16 plan kernels", kernels)
     assert np.isfinite(kp.cpu().numpy()).all()
     for what, got, gate in zip(("MPJPE mm", "max abs mm", "features", "logits", "volumes"), (mpjpe, mabs, e_f, e_l, e_v), BF16_GATES[tag]):
-        assert gate is None or got <= gate, "%s: %s = %.4g > gate %.4g (1.5 x the round-6 measurement)" % (name, what, got, gate)
+        assert gate is None or got <= gate, "%s: %s = %.4g > gate %.4g (1.5 x the larger of the two round-6 measurements)" % (name, what, got, gate)
     return kernels
 
 
@@ -253,9 +257,9 @@ def _dev_err(a, ref):
 
 
 # the timed kernel set against the fp32 parity kernels at the benchmark's batch, SHARPENED weights (what bench.py times): gates at 1.5 x the round-6
-# measurement (profiles/r06_parity_report.json).  Per batch: (MPJPE mm, max abs mm, features max-rel, features rms, logits max-rel, logits rms, volumes max-rel)
-BENCH_SHAPE_GATES = {32: (4.33, 34.7, 0.0267, 0.0187, 0.0210, 0.0111, 0.0676),          # 2.88 mm, 23.1 mm, 1.78e-2, 1.24e-2, 1.39e-2, 7.4e-3, 4.5e-2
-                     64: (4.37, 33.6, 0.0267, 0.0187, 0.0206, 0.0111, 0.105)}           # 2.91 mm, 22.4 mm, 1.77e-2, 1.24e-2, 1.37e-2, 7.4e-3, 7.0e-2
+# measurement -- the larger of the two described at BF16_GATES (profiles/r06_parity_report.json).  Per batch: (MPJPE mm, max abs mm, features max-rel, features rms, logits max-rel, logits rms, volumes max-rel)
+BENCH_SHAPE_GATES = {32: (4.33, 43.4, 0.0319, 0.0187, 0.0210, 0.0111, 0.089),          # 2.88 | 2.86 mm, 23.1 | 28.9 mm, 1.78e-2 | 2.12e-2, 1.24e-2, 1.39e-2, 7.4e-3, 4.5e-2 | 5.9e-2
+                     64: (4.37, 48.2, 0.0315, 0.0187, 0.0206, 0.0111, 0.105)}          # 2.91 | 2.87 mm, 22.4 | 32.1 mm, 1.77e-2 | 2.10e-2, 1.24e-2, 1.37e-2 | 1.30e-2, 7.4e-3, 7.0e-2 | 6.5e-2
 
 
 @pytest.mark.parametrize("B", [32, 64])
