@@ -102,6 +102,7 @@ struct UnprojArgs {
     void* out;
     int B, NV, C, h, w, v0, v1, v2, agg;
     int bricked;        // 4x4x16 bricks (v0%4 == v1%4 == v2%16 == 0) or linear 256-voxel chunks
+    int blocked;        // bricks walked in 32^3-voxel super-blocks (8 x 8 x 2 bricks) instead of in raster order -- see brick_of()
     int chunks;         // workgroups per sample
     int xcd_pin;        // B % 8 == 0
     // lt_unproject_grid_fwd: the voxel centres are COMPUTED (voxel_coord) from the cuboid description instead of read, and written to
@@ -109,6 +110,30 @@ struct UnprojArgs {
     const float* g_pos; const float* g_center; const float* g_rot;
     float g_step; int g_cmu; float* coords_out;
 };
+
+// Brick (bi, bj, bk) of chunk c of a sample.  Raster order (k fastest) makes every 4-voxel i-slab of bricks sweep the WHOLE projected cube in every view:
+// at 8 views the per-slab working set (2.7 MB of feature rows) plus the output stream does not fit the 4 MB L2 of the XCD the sample is pinned to, and the
+// next slab -- which projects 2 pixels next to this one -- finds its rows evicted: PMC traffic 1.33 x the algorithmic bytes at BASELINE config 4 (rounds 4-5,
+// unexplained there).  Blocked order (round 6): consecutive chunks fill one 32^3-voxel super-block (8 x 8 x 2 bricks = 128 workgroups, about what one XCD
+// runs at a time), whose footprint is ~20 x 20 pixels per view; a pixel row is re-read once per super-block along the view's depth direction instead of
+// once per slab.  Per-voxel arithmetic is untouched: results are bit-identical.  Measured at config 4, 16 samples (live PMC, profiles/r06_ab_unproject_brick_order.log):
+// 3.48 -> 2.80 GB per launch = 1.33 -> 1.07 x the algorithmic 2.63 GB; the kernel's TIME does not move (3.62-3.67 ms either way: it is issue-bound, not
+// traffic-bound); config 2 (4 views: 2.4 MB of maps, they fit): 1.10 -> 1.07 ms.
+__device__ __forceinline__ void brick_of(const UnprojArgs& a, int chunk, int& bi, int& bj, int& bk) {
+    const int nk = a.v2 >> 4, nj = a.v1 >> 2;
+    if (a.blocked) {
+        const int g = chunk >> 7, l = chunk & 127;
+        const int ngk = nk >> 1, ngj = nj >> 3;
+        const int gk = g % ngk, gj = (g / ngk) % ngj, gi = g / (ngk * ngj);
+        bk = (gk * 2 + (l & 1)) << 4;
+        bj = (gj * 8 + ((l >> 1) & 7)) << 2;
+        bi = (gi * 8 + (l >> 4)) << 2;
+    } else {
+        bk = (chunk % nk) << 4;
+        bj = ((chunk / nk) % nj) << 2;
+        bi = (chunk / (nk * nj)) << 2;
+    }
+}
 
 // fp32 (parity) mode keeps IEEE divisions / expf; bf16 (throughput) mode uses v_rcp_f32 / v_exp_f32: the kernel was
 // issue-bound (PMC: SQ_WAIT_INST_ANY 40 %, ~50 IEEE divisions + 32 expf per lane-item), not memory-bound.
@@ -178,12 +203,7 @@ __global__ __launch_bounds__(256) void unproject_kernel(const UnprojArgs a) {
     const float* coords = a.coords + (long long)b * nvox * 3;
     T* out = (T*)a.out + (long long)b * nvox * a.C;
     int bi = 0, bj = 0, bk = 0;
-    if (a.bricked) {
-        const int nk = a.v2 >> 4, nj = a.v1 >> 2;
-        bk = (chunk % nk) << 4;
-        bj = ((chunk / nk) % nj) << 2;
-        bi = (chunk / (nk * nj)) << 2;
-    }
+    if (a.bricked) brick_of(a, chunk, bi, bj, bk);
     const int items = 256 * tpv;
     for (int q = threadIdx.x; q < items; q += 256) {
         const int vb = q / tpv;            // voxel within the chunk, 0..255
@@ -292,6 +312,9 @@ template <int Q>
 __device__ __forceinline__ float quad_bcast_f(float v) { return __int_as_float(quad_bcast_i<Q>(__float_as_int(v))); }
 __device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
 
+// (round 6, measured and not kept: the 8-view instantiation takes 152 VGPRs = 3 waves per SIMD; capped at 128 = 4 waves with __launch_bounds__(256, 4) --
+//  4 registers of loop invariants in scratch -- it ran 3.72-3.75 ms against 3.62-3.67 ms at BASELINE config 4, and with MORE memory traffic (3.09 vs 2.80 GB):
+//  the kernel is bound by VALU issue + the gather path together (valu_issue_frac 0.44-0.45), and a fourth wave adds neither.)
 template <int NVL, bool GRID>
 __global__ __launch_bounds__(256) void unproject_qn_kernel(const UnprojArgs a) {
     typedef bf16_t T;
@@ -310,8 +333,8 @@ __global__ __launch_bounds__(256) void unproject_qn_kernel(const UnprojArgs a) {
     const float* coords = GRID ? nullptr : a.coords + (long long)b * nvox * 3;
     float* coords_out = (GRID && a.coords_out) ? a.coords_out + (long long)b * nvox * 3 : nullptr;
     T* out = (T*)a.out + (long long)b * nvox * C;
-    const int nk = a.v2 >> 4, nj = a.v1 >> 2;
-    const int bk = (chunk % nk) << 4, bj = ((chunk / nk) % nj) << 2, bi = (chunk / (nk * nj)) << 2;
+    int bi, bj, bk;
+    brick_of(a, chunk, bi, bj, bk);
     const int t = threadIdx.x, qv = t & 3;               // qv: the views this lane projects into (qv, qv + 4) AND its 8-channel vector
     const int h = a.h, w = a.w;
     float P[NVL][12];
@@ -443,6 +466,7 @@ namespace {
 int unproject_dispatch(UnprojArgs& a, int dtype, bool grid, hipStream_t st) {
     const long long nvox = (long long)a.v0 * a.v1 * a.v2;
     a.bricked = (a.v0 % 4 == 0 && a.v1 % 4 == 0 && a.v2 % 16 == 0) ? 1 : 0;
+    a.blocked = (a.bricked && a.v0 % 32 == 0 && a.v1 % 32 == 0 && a.v2 % 32 == 0 && !getenv("LT_UNPROJ_RASTER")) ? 1 : 0;          // LT_UNPROJ_RASTER=1: the old order (A/B)
     a.chunks = (int)cdiv(nvox, 256);
     a.xcd_pin = (a.B % 8 == 0) ? 1 : 0;
     LT_REQUIRE((long long)a.B * a.chunks < (1ll << 31), LT_ERR_UNSUPPORTED, "lt_unproject_fwd: grid too large");
