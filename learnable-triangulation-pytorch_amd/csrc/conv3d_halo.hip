@@ -164,6 +164,38 @@ __device__ __forceinline__ void wait_vmcnt_h(int n) {
 #define LT_HMMA(c_, a_, b_) Mma<T, MF>::run(c_, a_, b_)
 #endif
 
+// All MFMAs of one tap for a wave's SM x SN accumulator blocks over G fragment groups.  bf16: one MFMA per (group, block).  fp32 (round 6): a 16-byte
+// fragment is FOUR exact-fp32 MFMAs (K pairs e = 0 .. 3); issued back to back on one accumulator they wait for each other (~10 % below the issue rate,
+// measured in conv_igemm2's K loop: 4740 cycles for 64 MFMAs of 64) -- the K pair goes outermost, so that consecutive MFMAs write different blocks.  The
+// summation order of every accumulator is unchanged (results are bit-identical).  -DLT_FP32_NO_PIPE: the old order (A/B builds).
+template <typename T, int MF, int SM, int SN, int G, typename ACC, typename FA, typename FB>
+__device__ __forceinline__ void mma_tap_blocks(ACC (&acc)[SM][SN], const FA& fa, const FB& fb) {
+#if !defined(LT_ABL_NO_MMA)
+#if !defined(LT_FP32_NO_PIPE)
+    if constexpr (sizeof(T) == 4 && SM * SN > 1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < SM; ++i)
+#pragma unroll
+                    for (int j = 0; j < SN; ++j) {
+                        if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][i].f[e], fb[g][j].f[e], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g][i].f[e], fb[g][j].f[e], acc[i][j], 0, 0, 0);
+                    }
+        return;
+    }
+#endif
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < SM; ++i)
+#pragma unroll
+            for (int j = 0; j < SN; ++j) Mma<T, MF>::run(acc[i][j], fa[g][i], fb[g][j]);
+#endif
+}
+
 struct HaloArgs {
     const void* x;
     const void* w;      // [cout_pad][k_pad], k = tap*Cin + ci (the lt_conv_fwd packing)
@@ -520,12 +552,7 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
 #pragma unroll
                 for (int j = 0; j < SN; ++j) frag_ready(fb[TJ][g][j]);
             }
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int i = 0; i < SM; ++i)
-#pragma unroll
-                    for (int j = 0; j < SN; ++j) LT_HMMA(acc[i][j], fa[TJ][g][i], fb[TJ][g][j]);
+            mma_tap_blocks<T, MF, SM, SN, G>(acc, fa[TJ], fb[TJ]);
         };
         // LAST_ (compile time): no chunk follows.  Two copies of the chunk body instead of a uniform branch around the
         // cross-chunk loads, so that the number of reads in flight at every wait is a compile-time constant.
@@ -642,12 +669,7 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
                 if (tap < C::NTAPS) {
                     if (tj + 1 < TPC && tap + 1 < C::NTAPS) load_tap(tj + 1, (tj + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-                    for (int g = 0; g < G; ++g)
-    #pragma unroll
-                        for (int i = 0; i < SM; ++i)
-    #pragma unroll
-                            for (int j = 0; j < SN; ++j) LT_HMMA(acc[i][j], fa[tj & 1][g][i], fb[tj & 1][g][j]);
+                    mma_tap_blocks<T, MF, SM, SN, G>(acc, fa[tj & 1], fb[tj & 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (ACC64 && ((tap & LT_ACC64_MASK) == LT_ACC64_MASK || tap + 1 == C::NTAPS)) {
     #pragma unroll

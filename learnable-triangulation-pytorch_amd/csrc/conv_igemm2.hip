@@ -106,6 +106,13 @@ __device__ __forceinline__ float epi_act(float v, const EpiFloors& fl, float r, 
     return v;
 }
 
+// one exact-fp32 MFMA on one operand value per lane (32x32x2 / 16x16x4); only instantiated for T = float
+template <int MF, typename ACC>
+__device__ __forceinline__ ACC mfma_f32_k2(float a, float b, ACC c) {
+    if constexpr (MF == 32) return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int MF, int NST, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
     constexpr bool PW = MODE == 1;   // pointwise: rows contiguous, no taps
@@ -350,6 +357,11 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
 #else
     constexpr bool UPFRONT = true;
 #endif
+#ifdef LT_FP32_NO_PIPE
+    constexpr bool PIPE32 = false;
+#else
+    constexpr bool PIPE32 = ACC64 && UPFRONT;
+#endif
 #ifdef LT_TRACE
 #define LT_TR0 const long long tr0 = LT_CLK(); if (ks > 0) tr_cmp += tr0 - tr_prev;
 #define LT_TR1 const long long tr1 = LT_CLK(); tr_vm += tr1 - tr0;
@@ -366,6 +378,11 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
 #else
 #define LT_MMA_RUN(c_, a_, b_) Mma<T, MF>::run(c_, a_, b_)
 #endif
+    /* fp32 (round 6): the 128 x 128 tile holds 64 accumulators + 64 fp64 sums per lane = 320 registers, i.e. ONE wave per SIMD, and an exact-fp32 MFMA   \
+       occupies the matrix pipe for 64 cycles: everything the wave issues BETWEEN two MFMAs is free, everything it issues before the first or after the    \
+       last one of a K step is exposed (shader-clock trace, 256 images, 3x3 256 -> 256: 5490 cycles per K step for 4096 of MFMA -- 620 DMA issue, ~700      \
+       around the fragment groups and the fp64 flush, 130 wait + barrier).  PIPE32: the next stage's DMA pieces go out one by one behind the MFMA blocks   \
+       of the first half of the step, and a flush step folds block b - 1 into its fp64 sums behind the MFMAs of block b.  -DLT_FP32_NO_PIPE: the old order. */ \
 #define LT_KSTEP(MORE_)                                                                                              \
     {                                                                                                                \
         LT_TR0                                                                                                       \
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
         LT_TR1                                                                                                       \
         block_barrier(); /* everybody's stage-ks DMAs landed, everybody is done reading stage ks-1 */                \
         LT_TR2                                                                                                       \
-        if (MORE_ && UPFRONT) stage(ks + NST - 1, (ks + NST - 1) % NST, 0, NPIECE);                                  \
+        if (MORE_ && UPFRONT && !PIPE32) stage(ks + NST - 1, (ks + NST - 1) % NST, 0, NPIECE);                       \
         LT_TR3                                                                                                       \
         const int buf = ks % NST;                                                                                    \
         const unsigned char* pa = smem + buf * STAGE + a_base;                                                       \
@@ -385,6 +402,30 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
             _Pragma("unroll") for (int j = 0; j < SN; ++j) fb[slot][j].u = *(const uint4*)(pb + j * MF * ROW_BYTES + foff[g]); \
         };                                                                                                           \
         load_group(0, 0);                                                                                            \
+        if constexpr (PIPE32) {                                                                                      \
+            const bool flush_ = (ks & LT_ACC64_MASK) == LT_ACC64_MASK || ks + 1 == nk;                               \
+            constexpr int NU_ = G * 4, NUH_ = (NU_ / 2 >= NPIECE) ? NU_ / 2 : NU_;                                    \
+            _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                          \
+                if (g + 1 < G) load_group(g + 1, (g + 1) & 1);                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                                   \
+                /* K pair e of the fragment OUTERMOST: consecutive MFMAs write different accumulator blocks (a block is revisited every NB_ MFMAs), so no    \
+                   MFMA waits for the one in front of it -- four dependent 32x32x2 MFMAs in a row ran ~10 % below the issue rate (trace: 4740 cycles for     \
+                   64 MFMAs of 64) -- and the DMA pieces sit between rounds of independent MFMAs */                                                           \
+                _Pragma("unroll") for (int e4 = 0; e4 < 4; ++e4) {                                                   \
+                    const int unit = g * 4 + e4;                                                                     \
+                    _Pragma("unroll") for (int i = 0; i < SM; ++i)                                                   \
+                        _Pragma("unroll") for (int j = 0; j < SN; ++j)                                               \
+                            acc[i][j] = mfma_f32_k2<MF>(fa[g & 1][i].f[e4], fb[g & 1][j].f[e4], acc[i][j]);          \
+                    if (MORE_ && unit < NUH_) stage(ks + NST - 1, (ks + NST - 1) % NST, unit * NPIECE / NUH_, (unit + 1) * NPIECE / NUH_); \
+                    __builtin_amdgcn_sched_barrier(0);                                                               \
+                }                                                                                                    \
+            }                                                                                                        \
+            if (flush_) {                                                                                            \
+                _Pragma("unroll") for (int i = 0; i < SM; ++i)                                                       \
+                    _Pragma("unroll") for (int j = 0; j < SN; ++j)                                                   \
+                        _Pragma("unroll") for (int e = 0; e < NACC; ++e) { dacc[i][j][e] += (double)acc[i][j][e]; acc[i][j][e] = 0.f; } \
+            }                                                                                                        \
+        } else {                                                                                                     \
         _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                              \
             if (g + 1 < G) load_group(g + 1, (g + 1) & 1);                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -403,6 +444,7 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(const ConvArgs a) {
                         dacc[i][j][e] += (double)acc[i][j][e];                                                       \
                         acc[i][j][e] = 0.f;                                                                          \
                     }                                                                                                \
+        }                                                                                                            \
         }                                                                                                            \
     }
 #ifdef LT_TRACE
