@@ -98,6 +98,8 @@ template <int KS, int CINB, int MF> struct HaloSwz { static constexpr int FA = 0
 template <> struct HaloSwz<7, 64, 16> { static constexpr int FA = 0, FB = 0, FC = 0, FSH = 0, PAD = 1; };
 template <> struct HaloSwz<3, 128, 32> { static constexpr int FA = 3, FB = 0, FC = 2, FSH = 1, PAD = 1; };
 template <> struct HaloSwz<3, 32, 32> { static constexpr int FA = 0, FB = 0, FC = 0, FSH = 2, PAD = 4; };
+// (7, 32 B, 32x32) -- round 6: the input gradient of V2V's 7^3 front layer, 16 -> 32 -- takes the default: the 7^3 tap loop needs a swizzle that depends on kw only,
+// and the best of those is 2-way conflicted (tools/halo_bank_search.py: 2.0 for every kw-only candidate; the conflict-free ones mix in kh)
 
 template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF>
 struct HaloCfg {
@@ -1978,6 +1980,9 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
             return rc == LT_OK ? 1 : rc;
         }
         HALO_CASE(bf16_t, 7, 32, 16, 7, 4, 2)
+        // round 6: 7^3 16 -> 32 = the INPUT GRADIENT of the front layer in the 16-bit training step (the flipped / transposed filter): it ran on the generic
+        // 256 x 32 implicit-GEMM tile with four taps per 128-byte K step (1.78 ms at 8 samples, 4.2 % of the step's kernel time); LT_HALO_NO_D7=1: that tile again (A/B)
+        if (!getenv("LT_HALO_NO_D7")) { HALO_CASE(bf16_t, 7, 16, 32, 7, 4, 2) }
     } else {
         HALO_CASE(float, 3, 32, 32, 3, 3, 1)
         HALO_CASE(float, 3, 16, 32, 9, 2, 1)

@@ -1318,3 +1318,26 @@ def test_conv_beyond_32_bit_element_offsets(kind):
         # (rows / planes 0..31 of the corner: their 3^3 windows lie inside the 34^3 crop except at the volume's own border, which both sides zero-pad)
         got = y[n, :32, :32, :32].float().cpu().permute(3, 0, 1, 2)[None]
         check("conv > 2^31 elements/%s last sample vs torch" % kind, got[:, :, :32, :32, :32], torch.relu(ref), 1.5e-2)
+
+
+@pytest.mark.parametrize("N,sp", [(1, (8, 8, 16)), (3, (12, 16, 24))])
+def test_conv3d_halo_7x7x7_16_to_32_the_front_layers_input_gradient(N, sp, monkeypatch):
+    """Round 6: 7^3 16 -> 32 (the INPUT GRADIENT of V2V's front layer in the 16-bit training step, v2v.py:146: the flipped / transposed filter of the 32 -> 16
+    convolution) on the halo kernel instead of the generic 256 x 32 implicit-GEMM tile (four taps per K step: 1.78 ms at 8 samples).  Against torch on the
+    bf16-rounded operands, with and without a residual (the input gradient that is already there rides in the epilogue), and against the generic tile."""
+    g = torch.Generator().manual_seed(N * 7 + sp[0])
+    cin, cout, k = 16, 32, 7
+    x = torch.randn(N, cin, *sp, generator=g)
+    w = torch.randn(cout, cin, k, k, k, generator=g) * (1.0 / (cin * k ** 3) ** 0.5)
+    res = torch.randn(N, cout, *sp, generator=g)
+    rd = bf16_round
+    conv = F.conv3d(rd(x), rd(w), None, 1, 3)
+    out = run_conv(x, w, None, None, 1, 3, torch.bfloat16, H.TILE_HALO, residual=res)          # LT_TILE_HALO: fails loudly if no halo kernel takes the shape
+    check("conv3d_halo 7^3 16->32/N%d/res" % N, out, conv + rd(res), 1.5e-2)
+    out2 = run_conv(x, w, None, None, 1, 3, torch.bfloat16, 0)
+    check("conv3d_halo 7^3 16->32/N%d/plain" % N, out2, conv, 1.5e-2)
+    monkeypatch.setenv("LT_HALO_NO_D7", "1")
+    out3 = run_conv(x, w, None, None, 1, 3, torch.bfloat16, 0)
+    rms = float((out2 - out3).pow(2).mean().sqrt() / out3.pow(2).mean().sqrt())
+    record("conv3d_halo 7^3 16->32/N%d rms vs the generic tile" % N, rms)
+    assert rms < 2e-3, rms
