@@ -241,6 +241,12 @@ def pmc_leg(args, timeout_s=90, train=False, keep_per_kernel=False):
     cyc = sum(v.get("shader_cycles_per_step", 0.0) for v in res["per_kernel"].values())
     res["all_kernels_mfma_busy_frac"] = mf / cyc if cyc else None
     res["all_kernels_bytes_per_step"] = res["total_fetch_bytes_per_step"] + res["total_write_bytes_per_step"]
+    if train:
+        # the STEP's traffic: what the recording step does once (weight packing, index maps, uploads: family "setup+copies") is not part of a replayed step and is
+        # reported next to it (round 6; until round 5 it was averaged in: ~3 GB then, ~17 GB with the fragment-order index maps)
+        setup = sum(v.get("fetch_bytes_per_step_corrected", 0.0) + v.get("write_bytes_per_step", 0.0) for k, v in res["per_kernel"].items() if train_family(k) == "setup+copies")
+        res["recording_step_setup_bytes"] = setup * nsteps
+        res["all_kernels_bytes_per_step"] -= setup
     per = res.pop("per_kernel", None)
     if keep_per_kernel:
         res["per_kernel"] = per
@@ -263,8 +269,11 @@ def pmc_leg(args, timeout_s=90, train=False, keep_per_kernel=False):
 
 def train_family(k):
     """Kernel name (tools/pmc_summary.kernel_key) -> family of the training step's kernel-time split."""
-    if k.startswith(("conv_pack", "stem_pack", "pack_w", "__amd_rocclr")):
-        return "setup+copies"          # weight packing / index maps / uploads of the RECORDING step (the passes profile 3 steps, the first one records) and runtime copies
+    if k.startswith(("conv_pack", "stem_pack", "pack_w", "__amd_rocclr", "at::native", "void at::native")):
+        # weight packing / index maps / uploads of the RECORDING step (the passes profile 3 steps, the first one records) and runtime copies.  torch's own
+        # elementwise kernels belong here: the recording step builds its index maps with them (round 6: the fragment-order maps go through the device packers
+        # as byte planes -- ~350 launches, once); a replayed step runs ~20 tiny ones (the reference's loss expressions on (B, 17, 3) tensors)
+        return "setup+copies"
     if k.startswith(("bn_", "colsum", "channel_sum")):
         return "batchnorm+sums"
     if "wgrad" in k or k.startswith("pack_n8"):
