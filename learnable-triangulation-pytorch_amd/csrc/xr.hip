@@ -367,7 +367,11 @@ extern "C" int lt_expand_reduce_fwd(const lt_xr_desc* d, const void* t2, const v
     const char* e = getenv("LT_XR_NPB");                        // A/B switch, read per launch CALL (the tests flip it in-process); a replayed hipGraph never gets here
     const long long t96 = (d->M + 95) / 96;
     const int ncu = device_cu_count8();                         // thresholds in CUs: 7/8 and 7/16 of the chip (224 / 112 tiles on the 256-CU part)
-    const int npb = e ? (e[0] - '0') : (t96 >= ncu * 7 / 8 ? 3 : t96 >= ncu * 7 / 16 ? 2 : 1);
+    // (round 6: between those points the tile that still fits ONE round of the chip wins -- 8 / 9 samples = 288 / 324 tiles of 64 rows spill into a second round,
+    //  their 192 / 216 tiles of 96 rows do not: 1057 -> 1113 / 1063 -> 1115 samples/s; 6 / 7 samples = 216 / 252 tiles of 64 rows fit: 985 vs 962, 1079 vs 1064;
+    //  profiles/r06_ab_xr_tile_height_6_to_9_samples.log)
+    const long long t64 = (d->M + 63) / 64, t32 = (d->M + 31) / 32;
+    const int npb = e ? (e[0] - '0') : (t96 >= ncu * 7 / 8 ? 3 : t96 >= ncu * 7 / 16 ? (t64 <= ncu ? 2 : 3) : (t32 <= ncu ? 1 : 2));
     LT_REQUIRE(npb >= 1 && npb <= 3, LT_ERR_INVALID, "lt_expand_reduce_fwd: LT_XR_NPB=%s", e ? e : "?");
     auto run = [&](auto npbc) -> int {
         constexpr int NPBH = decltype(npbc)::value, TMH = 32 * NPBH, lds = TMH * 512 + 2 * TMH * 256 + (2 * 1024 + 2 * 256) * 4;
