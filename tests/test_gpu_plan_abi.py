@@ -198,3 +198,33 @@ def test_plan_abi_equals_the_python_hosts_plan_bit_for_bit(tag, dtype):
         assert P.info.launches == npy + (1 if dtype == torch.float32 else 0)          # the fp32 C plan counts its image layout pass (the Python host launches it outside its plan)
     finally:
         P.close()
+
+
+def test_plan_abi_runs_in_a_process_that_never_imports_the_python_host(golden_dir):
+    """The proof that the plan level needs nothing of the Python host: a FRESH interpreter builds the c2_sharp plan (ResNet-152, 4 x 384^2, 64^3) through
+    lt_plan_* and checks its joints against the reference's stored output at the fp32 gate -- and at the end neither ``lt_engine`` nor any ``mvn`` module has
+    been imported into that process (this test session itself imports them for other tests)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, os
+import numpy as np, torch
+root = %r
+for p in (root, os.path.join(root, "learnable-triangulation-pytorch_amd"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import test_gpu_plan_abi as T
+g = np.load(os.path.join(%r, "vol_c2_sharp.npz"))
+P = T.CPlan("c2_sharp", torch.float32)
+o = P.forward()
+kp = o["kp"].cpu().double().numpy()
+rel = float((np.abs(kp - g["kp_fp64"]) / np.maximum(np.abs(g["kp_fp64"]), 1.0)).max())
+P.close()
+host = sorted(m for m in sys.modules if m == "lt_engine" or m == "lt_train" or m == "mvn" or m.startswith("mvn."))
+print("REL %%.3e HOST %%s" %% (rel, host))
+assert rel <= 1e-4 and not host
+''' % (root, golden_dir)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("REL")][0]
+    record("plan-abi c2_sharp in a process without lt_engine / mvn: joints max rel vs the exact value | host modules imported", line)
