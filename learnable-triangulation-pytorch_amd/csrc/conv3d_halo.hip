@@ -341,10 +341,18 @@ __device__ __forceinline__ void halo_epilogue(unsigned char* smem, const HaloArg
 
 // LDR: eight waves, waves 4-7 are loaders (halo + weight chunk ring, nothing else); waves 0-3 then issue no DMA and wait on
 // no vmcnt inside the tap loop (same idea as the 7^3 and the persistent kernels; non-ring path only)
-template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF, int PD, bool LDR>
+// NPH > 1 (round 6, fp32 7^3 32 -> 16): CHANNEL PHASES.  The tensor has CIN * NPH channels per voxel; the halo tile of all of them does not fit LDS
+// (10 x 14 x 14 voxels x 128 B = 245 KB), the tile of CIN of them does (123 KB, the byte geometry of the bf16 kernel).  The kernel walks all taps over
+// channels [0, CIN), reloads the halo image with channels [CIN, 2 CIN) and walks the taps again; the accumulators live across the phases.  Every input
+// voxel enters LDS once per tile and phase -- on the generic 256 x 16 tile it crossed L2 -> LDS once per TAP (343 times), and the eight-piece DMA issue
+// per K step cost as much as its 32 MFMAs (51 % of the fp32 MFMA peak).
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF, int PD, bool LDR, int NPH = 1>
 __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const HaloArgs a) {
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF> C;
     static_assert(!LDR || PD == 1, "loader waves: non-ring path");
+    static_assert(NPH == 1 || !LDR, "channel phases: no loader waves");
+    constexpr int XLD = CIN * NPH;                       // channels per voxel of the tensor (and per tap of a weight row)
+    int cph = 0;                                         // the channel phase whose halo / weight images are in LDS (or on their way)
     constexpr bool ACC64 = sizeof(T) == 4;
     constexpr int MF = C::MF, SM = C::SM, SN = C::SN, G = C::G, NACC = C::NACC, NVV = C::NVV, VPR = C::VPR, CINB = C::CINB;
     typedef typename Mma<T, MF>::acc_t acc_t;
@@ -384,24 +392,26 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
     const int d0 = (tix / (a.tiles_w * a.tiles_h)) * TD;
     constexpr int P = KS / 2;
 
-    const T* __restrict__ x = (const T*)a.x + (size_t)n * a.D * a.H * a.W * CIN;
+    const T* __restrict__ x = (const T*)a.x + (size_t)n * a.D * a.H * a.W * XLD;
     const T* __restrict__ w = (const T*)a.w;
 
     // ---- halo DMA: vector q = hv*NVV + pv, wave-instruction i covers q in [64 i, 64 i + 64) ----
     constexpr int NI_H = C::HALO_BYTES / 1024;
+    auto issue_halo = [&]() {
 #ifndef LT_ABL_NO_A   // -DLT_ABL_*: timing ablations for profiling builds (results are WRONG with any of them)
-    if (do_dma)
-    for (int i = dw; i < NI_H; i += 4) {
-        const int q = i * 64 + lane;
-        const int hv = q / NVV, pv = q % NVV;
-        const int hw_ = hv % C::PW, hh_ = (hv / C::PW) % C::HH, hd_ = hv / (C::PW * C::HH);
-        const int lv = pv ^ C::fswz(hd_, hh_, hw_);
-        const int id = d0 - P + hd_, ih = h0 - P + hh_, iw = w0 - P + hw_;
-        const bool ok = hv < C::HV && hw_ < C::HW && ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
-        const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * CIN + lv * C::VEC) : zero_page;
-        dma16h(src, lds0 + i * 1024);
-    }
+        for (int i = dw; i < NI_H; i += 4) {
+            const int q = i * 64 + lane;
+            const int hv = q / NVV, pv = q % NVV;
+            const int hw_ = hv % C::PW, hh_ = (hv / C::PW) % C::HH, hd_ = hv / (C::PW * C::HH);
+            const int lv = pv ^ C::fswz(hd_, hh_, hw_);
+            const int id = d0 - P + hd_, ih = h0 - P + hh_, iw = w0 - P + hw_;
+            const bool ok = hv < C::HV && hw_ < C::HW && ((unsigned)id < (unsigned)a.D) & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W);
+            const void* src = ok ? (const void*)(x + (((size_t)id * a.H + ih) * a.W + iw) * XLD + cph * CIN + lv * C::VEC) : zero_page;
+            dma16h(src, lds0 + i * 1024);
+        }
 #endif
+    };
+    if (do_dma) issue_halo();
     // ---- weight chunk DMA: vector q = (tap_in_chunk*CP + col)*NVV + pv ----
     constexpr int NI_W = C::WCH / 1024;
     auto stage_w = [&](int ch, int buf) {
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
             const int tap = ch * TPC + tj;
             const int lv = pv ^ ((-(col / VPR)) & (NVV - 1));
             const bool ok = tj < TPC && tap < C::NTAPS;
-            const void* src = ok ? (const void*)(w + (size_t)col * a.k_pad + tap * CIN + lv * C::VEC) : zero_page;
+            const void* src = ok ? (const void*)(w + (size_t)col * a.k_pad + tap * XLD + cph * CIN + lv * C::VEC) : zero_page;
             dma16h(src, lds0 + C::HALO_BYTES + buf * C::WCH + i * 1024);
         }
     };
@@ -588,6 +598,15 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
             }                                                                                                           \
         });                                                                                                             \
     }
+        for (int phase = 0; phase < NPH; ++phase) {
+        if (NPH > 1 && phase) {          // next channel phase: every wave is done with the halo / weight images, then the same start-up as above
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            cph = phase;
+            issue_halo();
+#pragma unroll
+            for (int c = 0; c < NBUF - 1; ++c)
+                if (c < C::NCH) stage_w(c, c);
+        }
         // prologue: the first PD taps of chunk 0 (needs the halo and chunk 0: same wait as the loop's first barrier)
         {
             int younger = C::NCH - 2;
@@ -600,8 +619,18 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
         int ch = 0;
         for (; ch < C::NCH - 1; ++ch) LT_HALO_RING_CHUNK(false)
         LT_HALO_RING_CHUNK(true)
+        }
 #undef LT_HALO_RING_CHUNK
     } else {
+        for (int phase = 0; phase < NPH; ++phase) {
+        if (NPH > 1 && phase) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            cph = phase;
+            issue_halo();
+#pragma unroll
+            for (int c = 0; c < NBUF - 1; ++c)
+                if (c < C::NCH) stage_w(c, c);
+        }
         for (int ch = 0; ch < C::NCH; ++ch) {
             // chunk ch (and, the first time, the halo issued before it) must have landed; up to NBUF-2 younger chunks stay in flight
             int younger = C::NCH - 1 - ch;
@@ -686,6 +715,7 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
                     }
                 }
             }
+        }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done with the halo / weight images
@@ -1871,11 +1901,11 @@ int launch_halo_col(const HaloArgs& a, hipStream_t s) {
     return LT_OK;
 }
 
-template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF, int PD, bool LDR>
+template <typename T, int KS, int CIN, int CP, int TD, int TH, int TW, int TPC, int NBUF, int PD, bool LDR, int NPH = 1>
 int launch_halo(const HaloArgs& a, hipStream_t s) {
     typedef HaloCfg<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF> C;
     static_assert(C::LDS_BYTES <= 160 * 1024, "halo tile does not fit LDS");
-    auto kern = conv3d_halo_kernel<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF, PD, LDR>;
+    auto kern = conv3d_halo_kernel<T, KS, CIN, CP, TD, TH, TW, TPC, NBUF, PD, LDR, NPH>;
     LT_OPT_IN_LDS(kern, 160 * 1024);
     const long long nblk = (long long)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(LDR ? 512 : 256), C::LDS_BYTES, s, a);
@@ -1986,6 +2016,16 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
     } else {
         HALO_CASE(float, 3, 32, 32, 3, 3, 1)
         HALO_CASE(float, 3, 16, 32, 9, 2, 1)
+        // round 6: the 7^3 layers of the exact-fp32 kernel set.  32 -> 16 (V2V's front layer, 18 % of the fp32 forward on the generic 256 x 16 tile at 51 % of
+        // the fp32 MFMA peak): two channel phases of 16 over a 123 KB halo image (NPH = 2, see the kernel).  16 -> 32 (its input gradient in the fp32
+        // training step): one phase, one-tap lookahead, two weight buffers (151 KB).  LT_HALO_NO_F7=1: the generic tiles again (A/B).
+        if (ks == 7 && !getenv("LT_HALO_NO_F7")) {
+            if (c.Cin == 32 && cout_pad == 16) {
+                int rc = launch_halo<float, 7, 16, 16, 4, 8, 8, 7, 4, 2, false, 2>(a, s);
+                return rc == LT_OK ? 1 : rc;
+            }
+            HALO_CASE(float, 7, 16, 32, 7, 2, 1)
+        }
     }
 #undef HALO_CASE
 #undef HALO_CASE_L

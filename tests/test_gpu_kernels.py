@@ -466,6 +466,11 @@ HALO_CASES = {  # name: (N, cin, cout, k, (D,H,W), dtypes)
     "halo_3x3_32_32_persist_xcdpin": (8, 32, 32, 3, (16, 32, 64), ("bf16",)),
     # 7^3 at a size with several tiles per CU (fragment ring across weight chunks)
     "halo_7x7_32_16_big": (1, 32, 16, 7, (32, 32, 32), ("bf16",)),
+    # round 6: the 7^3 layers of the exact-fp32 kernel set -- 32 -> 16 in two channel phases of 16 (the halo image of 32 fp32 channels does not fit LDS),
+    # 16 -> 32 (the front layer's input gradient in the fp32 training step); one tile per axis and several, every face padded
+    "halo_7x7_32_16_f32": (1, 32, 16, 7, (8, 16, 8), ("f32",)),
+    "halo_7x7_32_16_f32_big": (2, 32, 16, 7, (16, 24, 32), ("f32",)),
+    "halo_7x7_16_32_f32": (1, 16, 32, 7, (8, 16, 16), ("f32",)),
 }
 
 
@@ -487,6 +492,13 @@ def test_conv3d_halo_kernel(case):
         check("conv3d_halo/%s/%s" % (case, dname), out, ref, 2e-5 if dtype == torch.float32 else 1.5e-2)
         out2 = run_conv(x, w, bias, bn, 1, k // 2, dtype, 0, relu=True, residual=res)   # AUTO (generic or halo) agrees
         check("conv3d_auto/%s/%s" % (case, dname), out2, ref, 2e-5 if dtype == torch.float32 else 1.5e-2)
+        if case.endswith("_f32_big"):          # the generic tile (LT_HALO_NO_F7=1, read per call) computes the same sums in another order
+            os.environ["LT_HALO_NO_F7"] = "1"
+            try:
+                out4 = run_conv(x, w, bias, bn, 1, k // 2, dtype, 0, relu=True, residual=res)
+            finally:
+                del os.environ["LT_HALO_NO_F7"]
+            check("conv3d_halo vs generic/%s" % case, out, out4, 2e-6)
         if "persist" in case:   # no residual, no ReLU: the epilogue without prefetched vectors
             ref3 = _bn_ref(F.conv3d(rd(x), rd(w), bias, 1, k // 2), bn)
             out3 = run_conv(x, w, bias, bn, 1, k // 2, dtype, H.TILE_HALO, relu=False, residual=None)

@@ -137,7 +137,8 @@ def test_plan_abi_fp32_vs_reference_golden(golden_dir, tag):
             scale = np.abs(g["kp_fp64"]).max(axis=(1, 2), keepdims=True)
             rel64, rel = np.abs(kp - g["kp_fp64"]) / scale, np.abs(kp - g["kp"]) / scale
         record("plan-abi " + tag + "/joints fp32: max rel vs the exact soft-argmax of the reference's logits", float(rel64.max()))
-        assert rel64.max() <= 1e-4 and rel.max() <= 1e-4 + self_rel, (float(rel64.max()), float(rel.max()), self_rel)
+        order_rel = float(g["ref_order_rel"]) if "ref_order_rel" in g.files else 0.0          # the reference's own fp32 order noise where the fixture stores it (tests/test_gpu_models.py)
+        assert rel64.max() <= 1e-4 + order_rel and rel.max() <= 1e-4 + self_rel + order_rel, (float(rel64.max()), float(rel.max()), self_rel, order_rel)
         o2 = P.forward(g["thetas"] if c["rotate"] else None)          # the second call replays the captured graph
         assert P.info.graph_captured == 1 and torch.equal(o2["kp"], o["kp"]) and torch.equal(o2["vols"], o["vols"])
         assert P.info.n_expand_reduce == 0 and P.info.n_bottleneck == 0 and P.info.n_stem_pool == 0          # fp32 plans record no bf16-only fusion

@@ -32,4 +32,13 @@ print("copies in the last step:", sum(pairs.values()), "total us %.1f" % sum(dur
 for k, c in pairs.most_common(25):
     print("  %4d x %7.1f us  after %-60s before %s" % (c, dur[k], k[0], k[1]))
 print("grid / workgroup / stream:", sizes.most_common(12))
+tot = collections.defaultdict(lambda: [0, 0.0])
+for r in seg:
+    n = r["Kernel_Name"]; n = n[n.find("::") + 2:] if n.startswith("void (anonymous") or n.startswith("(anonymous") else n
+    t = tot[n[:70]]; t[0] += 1; t[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+wall = (max(int(r["End_Timestamp"]) for r in seg) - min(int(r["Start_Timestamp"]) for r in seg)) / 1e3
+ksum = sum(v[1] for v in tot.values())
+print("last step: wall %.1f us, summed kernel time %.1f us" % (wall, ksum))
+for n, (c, t) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:45]:
+    print("  %5d x %9.1f us  %5.2f %%  %s" % (c, t, 100 * t / ksum, n))
 PY
