@@ -352,6 +352,9 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
     static_assert(!LDR || PD == 1, "loader waves: non-ring path");
     static_assert(NPH == 1 || !LDR, "channel phases: no loader waves");
     constexpr int XLD = CIN * NPH;                       // channels per voxel of the tensor (and per tap of a weight row)
+    // fp64 flush of the fp32 accumulators: every 4 taps of 32 channels = after 128 products; the 16-channel 7^3 kernels flush every 8 taps -- the same 128
+    // products (the 16 cvt + 16 v_add_f64 of a flush next to the 16 MFMAs of a 16-channel tap cost 10 % at every fourth tap)
+    constexpr int AMASK = (sizeof(T) == 4 && KS == 7 && CIN <= 16) ? 2 * LT_ACC64_MASK + 1 : LT_ACC64_MASK;
     int cph = 0;                                         // the channel phase whose halo / weight images are in LDS (or on their way)
     constexpr bool ACC64 = sizeof(T) == 4;
     constexpr int MF = C::MF, SM = C::SM, SN = C::SN, G = C::G, NACC = C::NACC, NVV = C::NVV, VPR = C::VPR, CINB = C::CINB;
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
             else if constexpr (!LAST_) load_ring(coff_n, wb_n, std::integral_constant<int, (tj + PD) % TPC>{});         \
             lgkm_wait<ahead * RPT>();                                                                                   \
             mma_tap(tjc);                                                                                               \
-            if (ACC64 && (((ch * TPC + tj) & LT_ACC64_MASK) == LT_ACC64_MASK || ch * TPC + tj + 1 == C::NTAPS)) {                               \
+            if (ACC64 && (((ch * TPC + tj) & AMASK) == AMASK || ch * TPC + tj + 1 == C::NTAPS)) {                                               \
                 _Pragma("unroll") for (int i = 0; i < SM; ++i)                                                          \
                     _Pragma("unroll") for (int j = 0; j < SN; ++j)                                                      \
                         _Pragma("unroll") for (int e = 0; e < NACC; ++e) {                                              \
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
                     __builtin_amdgcn_sched_barrier(0);
                     mma_tap_blocks<T, MF, SM, SN, G>(acc, fa[tj & 1], fb[tj & 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (ACC64 && ((tap & LT_ACC64_MASK) == LT_ACC64_MASK || tap + 1 == C::NTAPS)) {
+                    if (ACC64 && ((tap & AMASK) == AMASK || tap + 1 == C::NTAPS)) {
     #pragma unroll
                         for (int i = 0; i < SM; ++i)
     #pragma unroll

@@ -126,8 +126,8 @@ def test_volumetric_forward_vs_reference_golden(golden_dir, tag):
     record(tag + "/reference's own fp32 reduction error (max rel)", self_rel)
     # ref_order_rel (stored with c2_b8_sharp, round 6): how far the exact soft-argmax of the REFERENCE's logits moves when only the order of the reference's
     # fp32 sums changes (1 thread vs 8; oracle/make_golden.py, oracle/ref_noise.py) -- 3.0e-5 on that fixture, whose 408 coordinates with a 1 mm floor make it
-    # the tightest of the set: the exact-fp32 kernels measured 0.80e-4 with one K order of V2V's 7^3 layer and 1.01e-4 with another order of the SAME products
-    # (the two-phase halo kernel).  The reference's logits are defined up to that noise, so the strict gate widens by it where it was measured (0 elsewhere).
+    # the tightest of the set: the exact-fp32 kernels measured 0.80e-4 with one K order of V2V's 7^3 layer, 1.01e-4 and 1.05e-4 with two other orders of the SAME
+    # products (the two-phase halo kernel flushing to fp64 every 4 / every 8 taps).  The reference's logits are defined up to that noise, so the strict gate widens by it where it was measured (0 elsewhere).
     order_rel = float(g["ref_order_rel"]) if "ref_order_rel" in g.files else 0.0
     if order_rel:
         record(tag + "/reference's own fp32 ORDER noise, 1 vs 8 threads (max rel of the exact soft-argmax of its logits)", order_rel)
