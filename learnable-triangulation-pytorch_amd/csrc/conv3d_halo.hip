@@ -352,9 +352,9 @@ __global__ __launch_bounds__(LDR ? 512 : 256) void conv3d_halo_kernel(const Halo
     static_assert(!LDR || PD == 1, "loader waves: non-ring path");
     static_assert(NPH == 1 || !LDR, "channel phases: no loader waves");
     constexpr int XLD = CIN * NPH;                       // channels per voxel of the tensor (and per tap of a weight row)
-    // fp64 flush of the fp32 accumulators: every 4 taps of 32 channels = after 128 products; the 16-channel 7^3 kernels flush every 8 taps -- the same 128
+    // fp64 flush of the fp32 accumulators: every 4 taps of 32 channels = after 128 products; the 16-channel 7^3 and two-phase kernels flush every 8 taps -- the same 128
     // products (the 16 cvt + 16 v_add_f64 of a flush next to the 16 MFMAs of a 16-channel tap cost 10 % at every fourth tap)
-    constexpr int AMASK = (sizeof(T) == 4 && KS == 7 && CIN <= 16) ? 2 * LT_ACC64_MASK + 1 : LT_ACC64_MASK;
+    constexpr int AMASK = (sizeof(T) == 4 && CIN <= 16 && (KS == 7 || NPH > 1)) ? 2 * LT_ACC64_MASK + 1 : LT_ACC64_MASK;
     int cph = 0;                                         // the channel phase whose halo / weight images are in LDS (or on their way)
     constexpr bool ACC64 = sizeof(T) == 4;
     constexpr int MF = C::MF, SM = C::SM, SN = C::SN, G = C::G, NACC = C::NACC, NVV = C::NVV, VPR = C::VPR, CINB = C::CINB;
@@ -2017,6 +2017,17 @@ int conv3d_halo_try(int dtype, const ConvArgs& c, int cout_pad, int nphase, bool
         // 256 x 32 implicit-GEMM tile with four taps per 128-byte K step (1.78 ms at 8 samples, 4.2 % of the step's kernel time); LT_HALO_NO_D7=1: that tile again (A/B)
         if (!getenv("LT_HALO_NO_D7")) { HALO_CASE(bf16_t, 7, 16, 32, 7, 4, 2) }
     } else {
+        // round 6: 3^3 32 -> 32 (nine layers at 64^3, 23 % of the exact-fp32 forward) in two channel phases of 16: 38 KB of halo + 18 KB of weight ring instead of
+        // 77 + 36 KB -> TWO workgroups per CU = two waves per SIMD, so that one tile's halo load, chunk barriers, fp64 flushes and epilogue run under the other
+        // tile's MFMAs (with one workgroup per CU all of that was exposed: 59 % of the fp32 MFMA peak).  LT_HALO_F3=1: the one-phase kernel; =9: plane chunks
+        {
+            const char* f3 = getenv("LT_HALO_F3");
+            if (ks == 3 && c.Cin == 32 && cout_pad == 32 && !(f3 && f3[0] == '1')) {
+                int rc = (f3 && f3[0] == '9') ? launch_halo<float, 3, 16, 32, 4, 8, 8, 9, 2, 1, false, 2>(a, s)
+                                              : launch_halo<float, 3, 16, 32, 4, 8, 8, 3, 3, 1, false, 2>(a, s);
+                return rc == LT_OK ? 1 : rc;
+            }
+        }
         HALO_CASE(float, 3, 32, 32, 3, 3, 1)
         HALO_CASE(float, 3, 16, 32, 9, 2, 1)
         // round 6: the 7^3 layers of the exact-fp32 kernel set.  32 -> 16 (V2V's front layer, 18 % of the fp32 forward on the generic 256 x 16 tile at 51 % of
