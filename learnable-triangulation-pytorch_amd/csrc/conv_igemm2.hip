@@ -661,6 +661,9 @@ int dispatch2(const ConvArgs& a, int cout_pad, int nphase, int max_taps, int til
         else if (cout_pad <= 64) tile = blocks(128, 64) >= minblk ? LT_TILE2_128x64 : LT_TILE2_64x64;
         else if (pw && a.k_pad <= 256 && blocks(128, 64) >= minblk) tile = LT_TILE2_128x64;   // short-K expand convs: epilogue-bound,
         // more and smaller workgroups overlap stores with loads (measured 171 vs 204 us on 64->256 at 96^2, 111 vs 120 on 128->512)
+        // exact-fp32 (round 6): the 128 x 128 tile is ONE wave per SIMD (320 registers), the 128 x 64 tile two to three.  Measured at 256 images
+        // (tools/conv_bench.py --dtype fp32): 1x1 1024 -> 256 712 -> 656 us, 1x1 512 -> 128 785 -> 682, 3x3 128 -> 128 1614 -> 1565; 3x3 256 -> 256 stays (1503 vs 1553)
+        else if (sizeof(T) == 4 && (pw || cout_pad <= 128) && blocks(128, 64) >= minblk) tile = LT_TILE2_128x64;
         else tile = blocks(128, 128) >= minblk ? LT_TILE2_128x128 : (blocks(128, 64) >= minblk ? LT_TILE2_128x64 : LT_TILE2_64x64);
     }
     // uniform-tap path: every 128-byte K step lies inside one tap
