@@ -34,6 +34,7 @@ def shapes(B):
         ("rn deconv 256->256 @48", 2, NV, 256, 256, 4, 2, 1, (48, 48), True),
         ("v2v 3^3 32->32 @64", 3, B, 32, 32, 3, 1, 1, (64, 64, 64), False),
         ("v2v 7^3 32->16 @64", 3, B, 32, 16, 7, 1, 3, (64, 64, 64), False),
+        ("v2v 7^3 16->32 @64 (the front layer's input gradient)", 3, B, 16, 32, 7, 1, 3, (64, 64, 64), False),
         ("v2v 3^3 64->64 @32", 3, B, 64, 64, 3, 1, 1, (32, 32, 32), False),
         ("v2v 3^3 128->128 @16", 3, B, 128, 128, 3, 1, 1, (16, 16, 16), False),
         ("v2v 3^3 128->128 @4", 3, B, 128, 128, 3, 1, 1, (4, 4, 4), False),
