@@ -31,8 +31,12 @@ Besides the driver contract the line carries
 import argparse
 import json
 import os
+import re
+import shutil
 import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -354,6 +358,8 @@ def compact_line(res):
                            "traffic_source": "live rocprofv3 --pmc" if (rf.get("traffic_source") or "").startswith("measured in this run") else rf.get("traffic_source"),
                            "mfma_busy_frac": _r(rf.get("mfma_busy_frac"), 3), "flop_per_step": rf["flop_per_step"], "ms_in_kernel": _r(rf["ms_per_step_in_kernel"]),
                            "end_to_end_frac": _r(rf["end_to_end_frac"])}
+        if rf.get("sclk_mhz"):
+            out["roofline"].update(sclk_mhz=rf["sclk_mhz"], power_w=rf.get("power_w"))
     hb = res.get("roofline_hbm")
     if hb:
         out["roofline_hbm"] = {k: {kk: _r(v.get(kk)) for kk in ("achieved", "frac", "bytes_per_step", "traffic", "ms_per_step_in_kernel", "valu_issue_frac", "lane_insts_per_voxel") if v.get(kk) is not None}
@@ -401,6 +407,66 @@ def emit_detail(name, rec):
         sys.stderr.flush()
     except Exception:
         pass
+
+
+class ClockSampler:
+    """Shader clock and socket power DURING the timed steps (rank 0 of a 1-GPU run): ``rocm-smi --showclocks --showpower`` polled ~5 times a second by a shell
+    loop in its own process (no GIL, no HIP calls in this one), every sample stamped with the wall clock; ``window(t0, t1)`` averages those that fell inside
+    the timed region.  Why it is on the line: the bf16 forward runs at the socket power limit and the clock settles near 2.09 GHz -- 0.87 of the 2.4 GHz the
+    MFMA peaks assume (profiles/r06_clock_power_bf16_fp32.log) -- so ``roofline.frac`` is read next to the clock it was measured at.  Never fails the run."""
+
+    def __init__(self, device_index):
+        self.proc, self.path = None, None
+        smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        if not os.path.exists(smi):
+            return
+        try:
+            fd, self.path = tempfile.mkstemp(prefix="lt_clk_", suffix=".log")
+            os.close(fd)
+            # a sample counts only when BOTH stamps -- before and after rocm-smi ran (it takes ~0.2 s) -- lie inside the window
+            loop = ("while :; do echo \"T $(date +%%s.%%N)\"; %s -d %d --showclocks --showpower 2>/dev/null | grep -E 'sclk|Power'; echo \"E $(date +%%s.%%N)\"; sleep 0.1; done > %s" % (
+                smi, device_index, self.path))
+            self.proc = subprocess.Popen(["bash", "-c", loop], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, preexec_fn=os.setsid)
+        except Exception:
+            self.proc = None
+
+    def stop(self):
+        if self.proc is not None:
+            try:
+                os.killpg(os.getpgid(self.proc.pid), 15)          # the exact process group started above
+                self.proc.wait(timeout=5)
+            except Exception:
+                pass
+            self.proc = None
+
+    def window(self, t0, t1):
+        self.stop()
+        if not self.path:
+            return None
+        try:
+            sclk, power, t, cur = [], [], None, [None, None]
+            for line in open(self.path):
+                if line.startswith("T "):
+                    t, cur = float(line.split()[1]), [None, None]
+                elif line.startswith("E "):
+                    if t is not None and t >= t0 and float(line.split()[1]) <= t1 and cur[0] is not None:
+                        sclk.append(cur[0])
+                        if cur[1] is not None:
+                            power.append(cur[1])
+                    t = None
+                else:
+                    m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", line)
+                    if m:
+                        cur[0] = int(m.group(1))
+                    m = re.search(r"Power \(W\): ([\d.]+)", line)
+                    if m:
+                        cur[1] = float(m.group(1))
+            os.unlink(self.path)
+            if not sclk:
+                return None
+            return {"sclk_mhz": round(sum(sclk) / len(sclk)), "power_w": round(sum(power) / len(power)) if power else None, "samples": len(sclk)}
+        except Exception:
+            return None
 
 
 def time_steps(step, n, barrier):
@@ -857,9 +923,13 @@ def main():
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.preroll_s:
         out = step(); torch.cuda.synchronize()
+    sampler = ClockSampler(local) if (world == 1 and rank == 0 and os.environ.get("LT_BENCH_NO_CLOCKS") != "1") else None
     for _ in range(args.warmup):
         out = step()
+    t_w0 = time.time()
     dt_local, out = time_steps(step, args.steps, barrier)
+    t_w1 = time.time()
+    clocks = sampler.window(t_w0, t_w1) if sampler else None
     value, total_samples, dt = lt_dist.job_throughput(B * args.steps, dt_local, dev)   # all ranks' samples / slowest rank
     per_rank = lt_dist.gather_floats(B * args.steps / dt_local, dev)
     assert torch.isfinite(out[0]).all()
@@ -915,6 +985,10 @@ def main():
                                   "algorithmic_bytes_per_step": conv["bytes"],
                                   "traffic_over_algorithmic": (pmc["conv_family_bytes_per_step"] / conv["bytes"]) if (pmc.get("conv_family_bytes_per_step") and conv["bytes"]) else None,
                                   "end_to_end_frac": conv["flops"] / (1e-3 * result["ms_per_step"]) / 1e12 / peak}
+            if clocks:
+                # the clock the chip held during the timed steps (socket power next to it): peak x sclk / 2400 is the roof at THAT clock
+                result["roofline"].update(sclk_mhz=clocks["sclk_mhz"], power_w=clocks["power_w"], clock_samples=clocks["samples"],
+                                          frac_at_measured_clock=(ach / (peak * clocks["sclk_mhz"] / 2400.0)) if clocks["sclk_mhz"] else None)
             hb = {}
             for k in ("unproject", "softargmax3d", "coord_volumes"):
                 if k in fam:
