@@ -87,3 +87,33 @@ def test_compact_line_fits_the_drivers_tail_and_keeps_every_headline_figure():
     # a failed leg stays visible as an error, not as a crash of the line
     full["config4"] = {"error": "timed out after 600 s", "argv": []}
     assert bench.compact_line(full)["config4"] == {"error": "timed out after 600 s"}
+
+
+def test_clock_sampler_counts_only_reads_inside_the_timed_window(tmp_path):
+    """Round 6: bench.ClockSampler -- rocm-smi is polled by a shell loop that stamps every read before (T) and after (E); window(t0, t1) averages the reads
+    that BEGAN and ENDED inside the timed region (a read that ends after the last step sees the idling chip), survives a missing rocm-smi / an empty log,
+    and the two figures ride on the compact line next to roofline.frac."""
+    import bench
+    s = bench.ClockSampler.__new__(bench.ClockSampler)
+    s.proc, s.path = None, str(tmp_path / "clk.log")
+
+    def read(t, e, mhz, w):
+        return "T %.3f\nGPU[0]\t\t: sclk clock level: 1: (%dMhz)\nGPU[0]\t\t: Current Socket Graphics Package Power (W): %.1f\nE %.3f\n" % (t, mhz, w, e)
+    open(s.path, "w").write(read(99.0, 99.2, 2400, 300.0) +           # before the window (clocks not settled)
+                            read(100.1, 100.3, 2100, 1370.0) + read(100.5, 100.7, 2080, 1366.0) +
+                            read(100.9, 101.15, 900, 400.0) +        # began inside, ended after the last step: idle chip
+                            "T 101.3\n")                             # the loop was killed mid-read
+    r = s.window(100.0, 101.0)
+    assert r == {"sclk_mhz": 2090, "power_w": 1368, "samples": 2}
+    assert not os.path.exists(s.path)                                 # the temporary log is removed
+    s2 = bench.ClockSampler.__new__(bench.ClockSampler)
+    s2.proc, s2.path = None, str(tmp_path / "empty.log")
+    open(s2.path, "w").write("T 100.2\nE 100.4\n")                    # rocm-smi printed nothing (no such device)
+    assert s2.window(100.0, 101.0) is None
+    s3 = bench.ClockSampler.__new__(bench.ClockSampler)
+    s3.proc, s3.path = None, None                                     # rocm-smi not installed
+    assert s3.window(0.0, 1.0) is None
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_bf16_full_record.json")))
+    full["roofline"].update(sclk_mhz=2090, power_w=1368)
+    c = bench.compact_line(full)
+    assert c["roofline"]["sclk_mhz"] == 2090 and c["roofline"]["power_w"] == 1368 and len(json.dumps(c)) <= 4096
