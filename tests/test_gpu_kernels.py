@@ -471,6 +471,8 @@ HALO_CASES = {  # name: (N, cin, cout, k, (D,H,W), dtypes)
     "halo_7x7_32_16_f32": (1, 32, 16, 7, (8, 16, 8), ("f32",)),
     "halo_7x7_32_16_f32_big": (2, 32, 16, 7, (16, 24, 32), ("f32",)),
     "halo_7x7_16_32_f32": (1, 16, 32, 7, (8, 16, 16), ("f32",)),
+    # 3^3 32 -> 32 in two channel phases (two workgroups per CU), XCD-pinned samples, against the one-phase kernel (LT_HALO_F3=1)
+    "halo_3x3_32_32_f32_xcdpin": (8, 32, 32, 3, (8, 16, 16), ("f32",)),
 }
 
 
@@ -499,6 +501,13 @@ def test_conv3d_halo_kernel(case):
             finally:
                 del os.environ["LT_HALO_NO_F7"]
             check("conv3d_halo vs generic/%s" % case, out, out4, 2e-6)
+        if case == "halo_3x3_32_32_f32_xcdpin":
+            os.environ["LT_HALO_F3"] = "1"
+            try:
+                out5 = run_conv(x, w, bias, bn, 1, k // 2, dtype, H.TILE_HALO, relu=True, residual=res)
+            finally:
+                del os.environ["LT_HALO_F3"]
+            check("conv3d_halo two phases vs one/%s" % case, out, out5, 2e-6)
         if "persist" in case:   # no residual, no ReLU: the epilogue without prefetched vectors
             ref3 = _bn_ref(F.conv3d(rd(x), rd(w), bias, 1, k // 2), bn)
             out3 = run_conv(x, w, bias, bn, 1, k // 2, dtype, H.TILE_HALO, relu=False, residual=None)
